@@ -1,0 +1,563 @@
+/*
+ * pss_oracle.c -- CPU restatement of the PySubstringSearch hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the shipped package
+ * (pysubstringsearch_amd/) may link, load or call this file.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and only as
+ * the checker the HIP path is compared against.
+ *
+ * What is restated (reference file:line under /root/reference):
+ *   - suffix-array contract        src/libsais/libsais.h:57-65, libsais.c:6597-6610
+ *   - Writer::new                  src/lib.rs:50-65
+ *   - Writer::add_entries_from_file_lines  src/lib.rs:67-86  (+ bstr for_byte_line)
+ *   - Writer::add_entry            src/lib.rs:88-103
+ *   - Writer::dump_data            src/lib.rs:105-124   (chunk record layout)
+ *   - Writer::finalize             src/lib.rs:126-135
+ *   - Reader::new                  src/lib.rs:162-199
+ *   - Reader::search               src/lib.rs:201-287   (two binary searches,
+ *                                   newline scan, per-chunk dedupe on line start)
+ *   - Reader.search_multiple       pysubstringsearch/__init__.py:61-73
+ *
+ * Parity pinning: the suffix-array routine here is an independent O(n log n)
+ * prefix-doubling sort (NOT libsais); it is checked byte-for-byte against the
+ * real libsais compiled from /root/reference into oracle/_ref/ (see
+ * oracle/Makefile, tests/test_oracle.py).  The container + search restatement
+ * is pinned by the reference's own seven tests, re-expressed as data in
+ * tests/golden/reference_cases.json.  Behaviour no reference test covers
+ * (file ingest CR/LF rule, Vec growth quirk, multi-chunk) is labelled
+ * "parity unpinned" where it is restated below.
+ */
+#include <errno.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_OK 0
+#define ORC_EINVAL (-1)
+#define ORC_ENOMEM (-2)
+#define ORC_EIO (-3)
+#define ORC_ETOOBIG (-4)
+
+/* ------------------------------------------------------------------------ */
+/* Suffix array: prefix doubling with two-pass counting sort per round.       */
+/* Contract of libsais() (libsais.h:57-65; libsais.c:6597-6610): SA is the    */
+/* permutation of 0..n-1 ordering suffixes by unsigned bytes, a proper prefix */
+/* sorting first; returns 0, -1 (bad args) or -2 (allocation failure); n==0   */
+/* writes nothing, n==1 writes SA[0]=0.  An optional external builder (the    */
+/* real libsais from oracle/_ref) can be plugged in for large inputs.         */
+/* ------------------------------------------------------------------------ */
+
+typedef int32_t (*orc_sa_fn)(const uint8_t *, int32_t *, int32_t, int32_t, int32_t *);
+static orc_sa_fn g_external_sa = NULL;
+
+/* Route SA construction of the container writer through the real libsais
+ * (fn = address of `libsais` in oracle/_ref/libsais.so); NULL restores the
+ * restatement.  Signature = lib.rs:14-22. */
+void orc_set_external_sa(void *fn) { g_external_sa = (orc_sa_fn)fn; }
+
+int32_t orc_sa_build(const uint8_t *T, int32_t *SA, int32_t n)
+{
+    if (T == NULL || SA == NULL || n < 0) return ORC_EINVAL;
+    if (n < 2) {
+        if (n == 1) SA[0] = 0;
+        return ORC_OK;
+    }
+    /* rank[i] in 1..n ; rank of "past the end" is 0 (shorter suffix first). */
+    size_t N = (size_t)n;
+    int32_t *rank = (int32_t *)malloc((N + 1) * sizeof(int32_t));
+    int32_t *tmp = (int32_t *)malloc((N + 1) * sizeof(int32_t));
+    int32_t *sa2 = (int32_t *)malloc(N * sizeof(int32_t));
+    int32_t *cnt = (int32_t *)malloc((N + 2) * sizeof(int32_t));
+    if (!rank || !tmp || !sa2 || !cnt) {
+        free(rank); free(tmp); free(sa2); free(cnt);
+        return ORC_ENOMEM;
+    }
+    /* round 0: counting sort on the first byte */
+    {
+        int32_t c[257];
+        memset(c, 0, sizeof c);
+        for (size_t i = 0; i < N; i++) c[T[i] + 1]++;
+        for (int k = 0; k < 256; k++) c[k + 1] += c[k];
+        int32_t start[256];
+        for (int k = 0; k < 256; k++) start[k] = c[k];
+        for (size_t i = 0; i < N; i++) SA[c[T[i]]++] = (int32_t)i;
+        for (size_t i = 0; i < N; i++) rank[i] = start[T[i]] + 1; /* head pos + 1 */
+    }
+    for (size_t h = 1;; h <<= 1) {
+        /* key = (rank[i], rank2[i]) with rank2 = rank[i+h] or 0 past the end.
+         * LSD: stable counting sort by rank2, then by rank. */
+#define RANK2(i) (((size_t)(i) + h < N) ? rank[(size_t)(i) + h] : 0)
+        memset(cnt, 0, (N + 2) * sizeof(int32_t));
+        for (size_t i = 0; i < N; i++) cnt[RANK2(i) + 1]++;
+        for (size_t k = 0; k <= N; k++) cnt[k + 1] += cnt[k];
+        for (size_t i = 0; i < N; i++) sa2[cnt[RANK2(i)]++] = (int32_t)i;
+        memset(cnt, 0, (N + 2) * sizeof(int32_t));
+        for (size_t i = 0; i < N; i++) cnt[rank[i] + 1]++;
+        for (size_t k = 0; k <= N; k++) cnt[k + 1] += cnt[k];
+        for (size_t j = 0; j < N; j++) { int32_t i = sa2[j]; SA[cnt[rank[i]]++] = i; }
+        /* re-rank: rank = (position of group head) + 1 */
+        int all_unique = 1;
+        tmp[SA[0]] = 1;
+        int32_t head = 0;
+        for (size_t j = 1; j < N; j++) {
+            int32_t a = SA[j - 1], b = SA[j];
+            if (rank[a] != rank[b] || RANK2(a) != RANK2(b)) head = (int32_t)j;
+            else all_unique = 0;
+            tmp[b] = head + 1;
+        }
+#undef RANK2
+        memcpy(rank, tmp, N * sizeof(int32_t));
+        if (all_unique || h >= N) break;
+    }
+    free(rank); free(tmp); free(sa2); free(cnt);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Writer (lib.rs:42-144)                                                     */
+/* ------------------------------------------------------------------------ */
+
+typedef struct orc_writer {
+    FILE *fp;          /* BufWriter<File>, lib.rs:44 */
+    uint8_t *buf;      /* Vec<u8> buffer, lib.rs:45 */
+    size_t len;
+    size_t cap;        /* Vec capacity == chunk limit, lib.rs:62,75,92,96 */
+    size_t alloc;      /* bytes actually malloc'ed (lazy; not observable) */
+} orc_writer;
+
+/* Rust `Vec<u8>` amortised growth (std RawVec::grow_amortized): when a push /
+ * extend needs more room, new_cap = max(8, max(2*cap, len+additional)).  The
+ * reference uses the Vec capacity as its chunk limit (lib.rs:75,92,96), so an
+ * over-long entry silently raises the limit.  Parity unpinned: no reference
+ * test reaches this; restated from the Rust standard library's documented rule. */
+static int orc_reserve(orc_writer *w, size_t additional)
+{
+    if (w->cap - w->len < additional) {
+        size_t need = w->len + additional;
+        size_t nc = w->cap * 2;
+        if (nc < need) nc = need;
+        if (nc < 8) nc = 8;
+        w->cap = nc;
+    }
+    size_t need = w->len + additional;
+    if (need > w->alloc) {
+        size_t na = w->alloc ? w->alloc : 4096;
+        while (na < need) na *= 2;
+        uint8_t *nb = (uint8_t *)realloc(w->buf, na);
+        if (!nb) return ORC_ENOMEM;
+        w->buf = nb;
+        w->alloc = na;
+    }
+    return ORC_OK;
+}
+
+/* lib.rs:50-65: File::create truncates; default limit 512 MiB.
+ * max_chunk_len < 0 means "None". */
+int orc_writer_open(const char *path, int64_t max_chunk_len, orc_writer **out)
+{
+    if (!path || !out) return ORC_EINVAL;
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return ORC_EIO;
+    orc_writer *w = (orc_writer *)calloc(1, sizeof *w);
+    if (!w) { fclose(fp); return ORC_ENOMEM; }
+    w->fp = fp;
+    w->cap = max_chunk_len < 0 ? (size_t)512 * 1024 * 1024 : (size_t)max_chunk_len;
+    *out = w;
+    return ORC_OK;
+}
+
+static void put_u32le(uint8_t *p, uint32_t v)
+{
+    p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
+}
+
+/* lib.rs:105-124: u32le data_len | data | u32le 4*n | n x i32le. */
+int orc_writer_dump(orc_writer *w)
+{
+    if (w->len == 0) return ORC_OK;
+    uint8_t hdr[4];
+    put_u32le(hdr, (uint32_t)w->len);
+    if (fwrite(hdr, 1, 4, w->fp) != 4) return ORC_EIO;
+    if (fwrite(w->buf, 1, w->len, w->fp) != w->len) return ORC_EIO;
+    int32_t *sa = (int32_t *)malloc(w->len * sizeof(int32_t));
+    if (!sa) return ORC_ENOMEM;
+    int32_t rc = g_external_sa ? g_external_sa(w->buf, sa, (int32_t)w->len, 0, NULL)
+                               : orc_sa_build(w->buf, sa, (int32_t)w->len);
+    if (rc != 0) { free(sa); return ORC_ENOMEM; }
+    put_u32le(hdr, (uint32_t)(w->len * 4));
+    if (fwrite(hdr, 1, 4, w->fp) != 4) { free(sa); return ORC_EIO; }
+    /* host is little-endian (checked in tests): raw i32 == i32le */
+    if (fwrite(sa, 4, w->len, w->fp) != w->len) { free(sa); return ORC_EIO; }
+    free(sa);
+    w->len = 0;
+    return ORC_OK;
+}
+
+/* lib.rs:88-103 */
+int orc_writer_add_entry(orc_writer *w, const uint8_t *text, size_t tlen)
+{
+    if (tlen > w->cap) return ORC_ETOOBIG; /* "entry is too big", lib.rs:92-94 */
+    if (w->len + tlen + 1 > w->cap) {
+        int rc = orc_writer_dump(w);
+        if (rc) return rc;
+    }
+    int rc = orc_reserve(w, tlen);
+    if (rc) return rc;
+    memcpy(w->buf + w->len, text, tlen);
+    w->len += tlen;
+    rc = orc_reserve(w, 1);
+    if (rc) return rc;
+    w->buf[w->len++] = '\n';
+    return ORC_OK;
+}
+
+/* lib.rs:67-86.  Line rule = bstr 0.2 `for_byte_line` (dependency not vendored
+ * under /root/reference; Cargo.toml pins "0.2"): split after each '\n'; strip
+ * that '\n' and, only then, one preceding '\r'; a final unterminated line is
+ * delivered unchanged; an empty file yields no line.  No "too big" check and
+ * no UTF-8 validation on this path.  Parity unpinned (no reference test). */
+int orc_writer_add_file_lines(orc_writer *w, const char *path)
+{
+    FILE *in = fopen(path, "rb");
+    if (!in) return ORC_EIO;
+    size_t lcap = 1 << 16, llen = 0;
+    uint8_t *line = (uint8_t *)malloc(lcap);
+    if (!line) { fclose(in); return ORC_ENOMEM; }
+    int rc = ORC_OK;
+    int c;
+    int have = 0;
+    for (;;) {
+        c = fgetc(in);
+        if (c != EOF) {
+            have = 1;
+            if (llen == lcap) {
+                lcap *= 2;
+                uint8_t *nl = (uint8_t *)realloc(line, lcap);
+                if (!nl) { rc = ORC_ENOMEM; break; }
+                line = nl;
+            }
+            line[llen++] = (uint8_t)c;
+            if (c != '\n') continue;
+        }
+        if (!have) break;
+        size_t l = llen;
+        if (l && line[l - 1] == '\n') {
+            l--;
+            if (l && line[l - 1] == '\r') l--;
+        }
+        if (w->len + l + 1 > w->cap) {
+            rc = orc_writer_dump(w);
+            if (rc) break;
+        }
+        rc = orc_reserve(w, l);
+        if (rc) break;
+        memcpy(w->buf + w->len, line, l);
+        w->len += l;
+        rc = orc_reserve(w, 1);
+        if (rc) break;
+        w->buf[w->len++] = '\n';
+        llen = 0;
+        have = 0;
+        if (c == EOF) break;
+    }
+    if (ferror(in)) rc = ORC_EIO;
+    free(line);
+    fclose(in);
+    return rc;
+}
+
+/* lib.rs:126-135 */
+int orc_writer_finalize(orc_writer *w)
+{
+    if (w->len) {
+        int rc = orc_writer_dump(w);
+        if (rc) return rc;
+    }
+    if (fflush(w->fp) != 0) return ORC_EIO;
+    return ORC_OK;
+}
+
+/* Drop, lib.rs:138-144 */
+int orc_writer_close(orc_writer *w)
+{
+    if (!w) return ORC_OK;
+    int rc = orc_writer_finalize(w);
+    if (fclose(w->fp) != 0 && rc == ORC_OK) rc = ORC_EIO;
+    free(w->buf);
+    free(w);
+    return rc;
+}
+
+size_t orc_writer_capacity(const orc_writer *w) { return w->cap; }
+
+/* ------------------------------------------------------------------------ */
+/* Reader (lib.rs:146-288)                                                    */
+/* ------------------------------------------------------------------------ */
+
+typedef struct orc_chunk {
+    uint8_t *data;     /* SubIndex.data, lib.rs:147 */
+    size_t dlen;
+    int32_t *sa;       /* the reference leaves this on disk (lib.rs:179-182);
+                          values are identical, only the access path differs */
+    size_t n_sa;
+} orc_chunk;
+
+typedef struct orc_reader {
+    orc_chunk *chunks;
+    size_t n_chunks;
+} orc_reader;
+
+typedef struct orc_result {
+    uint8_t *bytes;      /* concatenated entries */
+    uint64_t *offsets;   /* n_entries + 1 */
+    size_t n_entries;
+    size_t bytes_len, bytes_cap, ent_cap;
+} orc_result;
+
+static uint32_t get_u32le(const uint8_t *p)
+{
+    return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+}
+
+void orc_reader_close(orc_reader *r)
+{
+    if (!r) return;
+    for (size_t i = 0; i < r->n_chunks; i++) { free(r->chunks[i].data); free(r->chunks[i].sa); }
+    free(r->chunks);
+    free(r);
+}
+
+/* lib.rs:162-199; truncated file -> UnexpectedEof -> OSError */
+int orc_reader_open(const char *path, orc_reader **out)
+{
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return ORC_EIO;
+    if (fseeko(fp, 0, SEEK_END) != 0) { fclose(fp); return ORC_EIO; }
+    uint64_t flen = (uint64_t)ftello(fp);
+    fseeko(fp, 0, SEEK_SET);
+    orc_reader *r = (orc_reader *)calloc(1, sizeof *r);
+    if (!r) { fclose(fp); return ORC_ENOMEM; }
+    uint64_t bytes_read = 0;
+    int rc = ORC_OK;
+    while (bytes_read < flen) {
+        uint8_t hdr[4];
+        if (fread(hdr, 1, 4, fp) != 4) { rc = ORC_EIO; errno = EIO; break; }
+        uint32_t dlen = get_u32le(hdr);
+        orc_chunk ch;
+        memset(&ch, 0, sizeof ch);
+        ch.data = (uint8_t *)malloc(dlen ? dlen : 1);
+        if (!ch.data) { rc = ORC_ENOMEM; break; }
+        if (fread(ch.data, 1, dlen, fp) != dlen) { free(ch.data); rc = ORC_EIO; errno = EIO; break; }
+        ch.dlen = dlen;
+        if (fread(hdr, 1, 4, fp) != 4) { free(ch.data); rc = ORC_EIO; errno = EIO; break; }
+        uint32_t slen = get_u32le(hdr);
+        ch.sa = (int32_t *)malloc(slen ? slen : 4);
+        if (!ch.sa) { free(ch.data); rc = ORC_ENOMEM; break; }
+        /* the reference only seeks past the SA (lib.rs:182); a short file is
+         * detected there lazily.  We read it, and report short files here. */
+        if (fread(ch.sa, 1, slen, fp) != slen) { free(ch.data); free(ch.sa); rc = ORC_EIO; errno = EIO; break; }
+        ch.n_sa = slen / 4;
+        bytes_read += 8 + (uint64_t)dlen + slen;
+        orc_chunk *nc = (orc_chunk *)realloc(r->chunks, (r->n_chunks + 1) * sizeof(orc_chunk));
+        if (!nc) { free(ch.data); free(ch.sa); rc = ORC_ENOMEM; break; }
+        r->chunks = nc;
+        r->chunks[r->n_chunks++] = ch;
+    }
+    fclose(fp);
+    if (rc) { orc_reader_close(r); return rc; }
+    *out = r;
+    return ORC_OK;
+}
+
+size_t orc_reader_num_chunks(const orc_reader *r) { return r->n_chunks; }
+
+static int res_push(orc_result *res, const uint8_t *p, size_t l)
+{
+    if (res->n_entries + 2 > res->ent_cap) {
+        size_t nc = res->ent_cap ? res->ent_cap * 2 : 64;
+        uint64_t *no = (uint64_t *)realloc(res->offsets, nc * sizeof(uint64_t));
+        if (!no) return ORC_ENOMEM;
+        res->offsets = no;
+        res->ent_cap = nc;
+    }
+    if (res->bytes_len + l > res->bytes_cap) {
+        size_t nc = res->bytes_cap ? res->bytes_cap : 4096;
+        while (nc < res->bytes_len + l) nc *= 2;
+        uint8_t *nb = (uint8_t *)realloc(res->bytes, nc);
+        if (!nb) return ORC_ENOMEM;
+        res->bytes = nb;
+        res->bytes_cap = nc;
+    }
+    if (res->n_entries == 0) res->offsets[0] = 0;
+    memcpy(res->bytes + res->bytes_len, p, l);
+    res->bytes_len += l;
+    res->offsets[++res->n_entries] = res->bytes_len;
+    return ORC_OK;
+}
+
+/* slice `pat` vs suffix `line`: Rust `<[u8]>::cmp` (unsigned, shorter first) */
+static int slice_cmp(const uint8_t *a, size_t al, const uint8_t *b, size_t bl)
+{
+    size_t m = al < bl ? al : bl;
+    int c = m ? memcmp(a, b, m) : 0;
+    if (c) return c;
+    return (al > bl) - (al < bl);
+}
+
+static int u64_cmp(const void *a, const void *b)
+{
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return (x > y) - (x < y);
+}
+
+/* lib.rs:209-278 for one chunk.  Offsets below are SA *element* indices; the
+ * reference works on byte offsets = 4*index + file start, with the same
+ * midpoint: left + ((right-left)/4/2*4)  ==  4*(l + (r-l)/2). */
+static int search_chunk(const orc_chunk *ch, const uint8_t *pat, size_t plen, orc_result *res)
+{
+    if (ch->n_sa == 0) return ORC_OK;
+    int64_t left = 0, right = (int64_t)ch->n_sa - 1;
+    int64_t start = -1, end = -1;
+    while (left <= right) {                                   /* lib.rs:212-230 */
+        int64_t mid = left + (right - left) / 2;
+        size_t di = (size_t)ch->sa[mid];
+        const uint8_t *line = ch->data + di;
+        size_t ll = ch->dlen - di;
+        if (ll >= plen && memcmp(line, pat, plen) == 0) { start = mid; right = mid - 1; }
+        else {
+            int c = slice_cmp(pat, plen, line, ll);
+            if (c < 0) right = mid - 1; else if (c > 0) left = mid + 1;
+        }
+    }
+    if (start < 0) return ORC_OK;                             /* lib.rs:231-233 */
+    right = (int64_t)ch->n_sa - 1;                            /* lib.rs:235 */
+    while (left <= right) {                                   /* lib.rs:236-252 */
+        int64_t mid = left + (right - left) / 2;
+        size_t di = (size_t)ch->sa[mid];
+        const uint8_t *line = ch->data + di;
+        size_t ll = ch->dlen - di;
+        if (ll >= plen && memcmp(line, pat, plen) == 0) { end = mid; left = mid + 1; }
+        else {
+            int c = slice_cmp(pat, plen, line, ll);
+            if (c < 0) right = mid - 1; else if (c > 0) left = mid + 1;
+        }
+    }
+    /* lib.rs:262-278: AHashSet<line_tail> dedupe, emission in SA order of the
+     * first hit.  A set is order-free; we keep first-hit order with a sorted
+     * scratch list of seen line starts (results compared as multisets). */
+    size_t nh = (size_t)(end - start + 1);
+    uint64_t *seen = (uint64_t *)malloc(nh * sizeof(uint64_t));
+    uint64_t *order = (uint64_t *)malloc(nh * 2 * sizeof(uint64_t));
+    if (!seen || !order) { free(seen); free(order); return ORC_ENOMEM; }
+    for (size_t k = 0; k < nh; k++) {
+        size_t di = (size_t)ch->sa[start + (int64_t)k];
+        const uint8_t *nl = (const uint8_t *)memchr(ch->data + di, '\n', ch->dlen - di);
+        size_t line_head = nl ? (size_t)(nl - ch->data) : ch->dlen - 1;   /* lib.rs:266-269 */
+        size_t line_tail = 0;                                              /* lib.rs:270-273 */
+        for (size_t p = di; p > 0; p--) if (ch->data[p - 1] == '\n') { line_tail = p; break; }
+        seen[k] = (uint64_t)line_tail;
+        order[2 * k] = (uint64_t)line_tail;
+        order[2 * k + 1] = (uint64_t)line_head;
+    }
+    /* first-occurrence filter: sort a copy, then mark */
+    uint64_t *sorted = (uint64_t *)malloc(nh * sizeof(uint64_t));
+    if (!sorted) { free(seen); free(order); return ORC_ENOMEM; }
+    memcpy(sorted, seen, nh * sizeof(uint64_t));
+    qsort(sorted, nh, sizeof(uint64_t), u64_cmp);
+    size_t nu = 0;
+    for (size_t k = 0; k < nh; k++) if (k == 0 || sorted[k] != sorted[k - 1]) sorted[nu++] = sorted[k];
+    uint8_t *used = (uint8_t *)calloc(nu ? nu : 1, 1);
+    int rc = used ? ORC_OK : ORC_ENOMEM;
+    for (size_t k = 0; k < nh && rc == ORC_OK; k++) {
+        uint64_t key = seen[k];
+        uint64_t *f = (uint64_t *)bsearch(&key, sorted, nu, sizeof(uint64_t), u64_cmp);
+        size_t ix = (size_t)(f - sorted);
+        if (used[ix]) continue;
+        used[ix] = 1;
+        rc = res_push(res, ch->data + order[2 * k], (size_t)(order[2 * k + 1] - order[2 * k]));
+    }
+    free(used); free(sorted); free(seen); free(order);
+    return rc;
+}
+
+/* Reader::search over all chunks (lib.rs:201-287; inter-chunk order is
+ * nondeterministic in the reference, chunk order here). */
+int orc_reader_search(const orc_reader *r, const uint8_t *pat, size_t plen, orc_result **out)
+{
+    orc_result *res = (orc_result *)calloc(1, sizeof *res);
+    if (!res) return ORC_ENOMEM;
+    for (size_t c = 0; c < r->n_chunks; c++) {
+        int rc = search_chunk(&r->chunks[c], pat, plen, res);
+        if (rc) { free(res->bytes); free(res->offsets); free(res); return rc; }
+    }
+    *out = res;
+    return ORC_OK;
+}
+
+/* search_multiple (__init__.py:61-73): results of each query concatenated in
+ * query order; `counts[q]` receives the number of entries of query q. */
+int orc_reader_search_multiple(const orc_reader *r, const uint8_t *qbytes, const uint64_t *qoff,
+                               uint32_t nq, uint64_t *counts, orc_result **out)
+{
+    orc_result *res = (orc_result *)calloc(1, sizeof *res);
+    if (!res) return ORC_ENOMEM;
+    for (uint32_t q = 0; q < nq; q++) {
+        size_t before = res->n_entries;
+        for (size_t c = 0; c < r->n_chunks; c++) {
+            int rc = search_chunk(&r->chunks[c], qbytes + qoff[q], (size_t)(qoff[q + 1] - qoff[q]), res);
+            if (rc) { free(res->bytes); free(res->offsets); free(res); return rc; }
+        }
+        if (counts) counts[q] = res->n_entries - before;
+    }
+    *out = res;
+    return ORC_OK;
+}
+
+size_t orc_result_count(const orc_result *res) { return res->n_entries; }
+const uint64_t *orc_result_offsets(const orc_result *res)
+{
+    static const uint64_t zero = 0;
+    return res->n_entries ? res->offsets : &zero;
+}
+const uint8_t *orc_result_bytes(const orc_result *res) { return res->bytes; }
+void orc_result_free(orc_result *res)
+{
+    if (!res) return;
+    free(res->bytes); free(res->offsets); free(res);
+}
+
+/* Access for tests: chunk text and SA of a parsed index. */
+const uint8_t *orc_reader_chunk_data(const orc_reader *r, size_t c, size_t *len)
+{
+    *len = r->chunks[c].dlen;
+    return r->chunks[c].data;
+}
+const int32_t *orc_reader_chunk_sa(const orc_reader *r, size_t c, size_t *n)
+{
+    *n = r->chunks[c].n_sa;
+    return r->chunks[c].sa;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Synthetic corpora; integer-only, so the C, HIP    */
+/* and Python generators agree bit for bit.                                   */
+/* ------------------------------------------------------------------------ */
+static inline uint64_t xs64(uint64_t *s)
+{
+    uint64_t x = *s;
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    *s = x;
+    return x;
+}
+
+void orc_gen_lines(uint8_t *out, size_t n, uint64_t chunk_index)
+{
+    static const char ALPHA[] = "abcdefghijklmnopqrstuvwxyz0123456789 .";
+    uint64_t s = 88172645463325252ULL + chunk_index;
+    for (size_t i = 0; i < n; i++) {
+        uint32_t r = (uint32_t)(xs64(&s) >> 32);
+        out[i] = (r % 40 == 0) ? '\n' : (uint8_t)ALPHA[(r >> 8) % 38];
+    }
+    if (n) out[n - 1] = '\n';
+}
