@@ -1,0 +1,163 @@
+/*
+ * pss.h -- C ABI of libpss.so, the MI355X (gfx950) engine behind the
+ * pysubstringsearch Writer/Reader API.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes, returns an
+ * int status (0 = ok, negative = error, see PSS_E*) and never throws or aborts.
+ * Each declaration cites the reference interface (file:line under the
+ * upstream tree, Intsights/PySubstringSearch v0.7.1) it replaces.  The
+ * reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Handles are not thread-safe: one thread per handle at a time (the reference's
+ * pyclass methods take `&mut self`, src/lib.rs:67,88,105,126,201).
+ *
+ * There is no CPU fallback: every compute entry point fails with PSS_EDEVICE
+ * when no HIP device is usable.
+ */
+#ifndef PSS_H
+#define PSS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSS_OK 0
+#define PSS_EINVAL (-1)   /* bad arguments            (libsais.c:6599-6602 returns -1) */
+#define PSS_ENOMEM (-2)   /* host/device allocation   (libsais.c:6505-6507 returns -2) */
+#define PSS_EIO (-3)      /* I/O error, errno is set  (io::Error -> OSError, src/lib.rs:55,71,112-118) */
+#define PSS_ETOOBIG (-4)  /* "entry is too big"       (src/lib.rs:92-94 -> ValueError) */
+#define PSS_EDEVICE (-5)  /* HIP runtime error / no device */
+#define PSS_EFORMAT (-6)  /* malformed or truncated .idx (UnexpectedEof in src/lib.rs:175-179) */
+
+typedef struct pss_writer pss_writer;
+typedef struct pss_reader pss_reader;
+typedef struct pss_result pss_result;
+
+/* ---- library ---------------------------------------------------------- */
+
+/* Number of visible HIP devices (0 when none / runtime unusable). */
+int pss_device_count(void);
+
+/* Copies the calling thread's last error message into buf (NUL-terminated,
+ * truncated to cap); returns the untruncated length. */
+size_t pss_last_error(char *buf, size_t cap);
+
+/* ---- suffix-array builder seam ----------------------------------------- */
+
+/* Per-build statistics (filled when `stats` is non-NULL). */
+typedef struct pss_sa_stats {
+    uint32_t sigma;            /* distinct byte values in the text */
+    uint32_t code_bits;        /* bits per recoded symbol (b) */
+    uint32_t key_chars;        /* symbols packed into the initial 64-bit key (h0) */
+    uint32_t initial_passes;   /* radix passes of the initial key sort */
+    uint32_t rounds;           /* prefix-doubling rounds executed after it */
+    uint32_t round_passes;     /* radix passes summed over all rounds */
+    uint64_t sum_active;       /* sum over rounds of suffixes still unresolved */
+    uint64_t sort_elems;       /* sum over every radix pass of elements moved */
+    double ms_total;           /* device time of the whole build (HIP events) */
+    double ms_sort;            /* device time inside radix passes (profile mode only) */
+    uint64_t sort_launches;    /* radix-pass kernel launches */
+} pss_sa_stats;
+
+/*
+ * Drop-in for `libsais(T, SA, n, 0, NULL)` as called by
+ * construct_suffix_array (src/lib.rs:24-40; contract src/libsais/libsais.h:57-65,
+ * src/libsais/libsais.c:6597-6610): SA[0..n) becomes the permutation of 0..n-1
+ * that orders the suffixes of T by unsigned bytes, a proper prefix first.
+ * n == 0 writes nothing, n == 1 writes SA[0] = 0.  T and SA are HOST pointers;
+ * the text is uploaded, sorted on `device` and the result copied back.
+ * Returns 0, PSS_EINVAL (NULL pointers, n < 0), PSS_ENOMEM or PSS_EDEVICE.
+ */
+int32_t pss_sa_build(const uint8_t *T, int32_t *SA, int32_t n, int32_t device);
+
+/* Same, with T and SA already resident in the HBM of `device` (T must be
+ * readable for n bytes, SA writable for n int32).  `flags` bit 0 = profile
+ * mode (per-pass HIP events, fills ms_sort).  This is the timed region of
+ * bench.py: inputs resident, no PCIe. */
+int32_t pss_sa_build_device(const void *d_T, void *d_SA, int32_t n, int32_t device,
+                            uint32_t flags, pss_sa_stats *stats);
+
+/* ---- Writer (src/lib.rs:42-144; pysubstringsearch/__init__.py:6-41) ----- */
+
+/* Writer::new, src/lib.rs:50-65.  Creates/truncates `path`.  max_chunk_len < 0
+ * means None (512 MiB, src/lib.rs:57).  Suffix arrays are built on `device`. */
+int pss_writer_open(const char *path, int64_t max_chunk_len, int32_t device, pss_writer **out);
+/* Writer::add_entry, src/lib.rs:88-103.  PSS_ETOOBIG when len > limit. */
+int pss_writer_add_entry(pss_writer *w, const uint8_t *text, uint64_t len);
+/* Writer::add_entries_from_file_lines, src/lib.rs:67-86 (bstr for_byte_line rule). */
+int pss_writer_add_file_lines(pss_writer *w, const char *path);
+/* Writer::dump_data, src/lib.rs:105-124: emits u32le len | data | u32le 4n | n x i32le. */
+int pss_writer_dump(pss_writer *w);
+/* Writer::finalize, src/lib.rs:126-135. */
+int pss_writer_finalize(pss_writer *w);
+/* Drop for Writer, src/lib.rs:138-144: finalize, close the file, free. */
+int pss_writer_close(pss_writer *w);
+/* Current chunk limit (Vec capacity in the reference, src/lib.rs:62,75,92,96). */
+uint64_t pss_writer_chunk_limit(const pss_writer *w);
+
+/* ---- Reader (src/lib.rs:146-288; pysubstringsearch/__init__.py:44-73) --- */
+
+/* Reader::new, src/lib.rs:162-199.  Parses the chunk records of `path` and
+ * makes the text AND suffix array of every chunk c with
+ * c % shard_count == shard_index resident in the HBM of `device`
+ * (shard_index 0, shard_count 1 = whole file). */
+int pss_reader_open(const char *path, int32_t device, int32_t shard_index, int32_t shard_count,
+                    pss_reader **out);
+/* An empty reader on `device`, to be filled with pss_reader_add_chunk_device
+ * (Writer -> Reader hand-off through HBM, no file). */
+int pss_reader_create(int32_t device, pss_reader **out);
+/* Adopts COPIES of a device-resident chunk (text n bytes, SA n int32). */
+int pss_reader_add_chunk_device(pss_reader *r, const void *d_text, const void *d_sa, uint32_t n);
+/* Chunks resident in this reader. */
+uint64_t pss_reader_num_chunks(const pss_reader *r);
+
+/* Per-batch statistics of the last pss_reader_search_batch call. */
+typedef struct pss_search_stats {
+    uint64_t queries;
+    uint64_t hits;          /* suffix-array hits before per-chunk dedupe */
+    uint64_t entries;       /* entries returned */
+    uint64_t result_bytes;
+    double ms_device;       /* HIP-event time of the kernels of the batch */
+    double ms_interval;     /* ... of the interval-search kernel alone */
+} pss_search_stats;
+
+/*
+ * Reader::search (src/lib.rs:201-287) for a whole batch in one call, i.e.
+ * Reader.search_multiple (pysubstringsearch/__init__.py:61-73): query q is
+ * qbytes[qoffsets[q] .. qoffsets[q+1]).  For every query and every resident
+ * chunk: the maximal suffix-array interval whose suffixes start with the
+ * query (src/lib.rs:209-252), the entry around each hit (newline scan,
+ * src/lib.rs:266-273), deduplicated per (query, chunk) on the entry's start
+ * offset (src/lib.rs:262,274).  Entries come back query-major (all entries of
+ * query 0, then query 1, ...), inside a query chunk-major.
+ */
+int pss_reader_search_batch(pss_reader *r, const uint8_t *qbytes, const uint64_t *qoffsets,
+                            uint32_t nq, pss_result **out);
+int pss_reader_last_stats(const pss_reader *r, pss_search_stats *stats);
+/* Drops the chunks and closes the reader. */
+int pss_reader_close(pss_reader *r);
+
+/* Result accessors; memory stays owned by the result until pss_result_free. */
+uint64_t pss_result_num_queries(const pss_result *res);
+uint64_t pss_result_num_entries(const pss_result *res);
+const uint64_t *pss_result_query_counts(const pss_result *res);  /* [num_queries] entries per query */
+const uint64_t *pss_result_offsets(const pss_result *res);       /* [num_entries + 1] into bytes */
+const uint8_t *pss_result_bytes(const pss_result *res);
+void pss_result_free(pss_result *res);
+
+/* ---- synthetic corpora (used by bench.py and the tests) -- */
+
+#define PSS_CORPUS_LINES 0     /* 38-symbol alphabet, '\n' with p = 1/40 */
+#define PSS_CORPUS_WORDS 1     /* 65536-word vocabulary, skewed, realistic LCP */
+#define PSS_CORPUS_RUNS 2      /* lines of one repeated symbol from {a,b}, run <= 8192 */
+#define PSS_CORPUS_PERIODIC 3  /* "a"*4095 + "\n" repeated */
+/* Fills out[0..n) on the host; deterministic in (kind, n, chunk_index). */
+int pss_gen_corpus(int kind, uint8_t *out, uint64_t n, uint64_t chunk_index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSS_H */

@@ -1,0 +1,202 @@
+"""pysubstringsearch_amd -- MI355X-native drop-in for ``pysubstringsearch``.
+
+Same classes, method names, argument names and error behaviour as the
+reference Python layer (pysubstringsearch/__init__.py:6-73 over
+src/lib.rs:42-288); the work is done by hand-written HIP kernels for gfx950
+behind the C ABI of ``libpss.so`` (include/pss.h):
+
+* ``Writer`` builds each chunk's 32-bit suffix array on the GPU and writes the
+  reference's ``.idx`` chunk records byte for byte.
+* ``Reader`` keeps text and suffix arrays resident in HBM;
+  ``search_multiple`` is ONE batched device call (one wavefront per query)
+  instead of a Python loop.
+
+Extras that do not change the reference signatures: ``device=`` keyword,
+``close()`` / context-manager support, ``Reader(..., shard=(i, n))``.
+"""
+import ctypes
+import os
+import typing
+
+from . import _ffi
+from ._ffi import lib as _lib
+
+__all__ = ['Writer', 'Reader', 'device_count']
+
+
+def device_count() -> int:
+    return _lib.pss_device_count()
+
+
+def _default_device() -> int:
+    for var in ('PSS_DEVICE', 'LOCAL_RANK'):
+        v = os.environ.get(var)
+        if v is not None and v.isdigit():
+            n = device_count()
+            return int(v) % n if n else int(v)
+    return 0
+
+
+def _utf8(value, name: str) -> bytes:
+    # pyo3 `&str` extraction: only str is accepted (bytes -> TypeError)
+    if not isinstance(value, str):
+        raise TypeError(f"argument '{name}': '{type(value).__name__}' object cannot be converted to 'PyString'")
+    return value.encode('utf-8')
+
+
+def _path(value, name: str) -> bytes:
+    if not isinstance(value, str):
+        raise TypeError(f"argument '{name}': '{type(value).__name__}' object cannot be converted to 'PyString'")
+    return os.fsencode(value)
+
+
+class Writer:
+    """Reference: pysubstringsearch/__init__.py:6-41, src/lib.rs:42-144."""
+
+    def __init__(
+        self,
+        index_file_path: str,
+        max_chunk_len: typing.Optional[int] = None,
+        *,
+        device: typing.Optional[int] = None,
+    ) -> None:
+        if max_chunk_len is not None:
+            if not isinstance(max_chunk_len, int) or isinstance(max_chunk_len, bool):
+                raise TypeError("argument 'max_chunk_len': must be an int or None")
+            if max_chunk_len < 0:
+                raise OverflowError("can't convert negative int to unsigned")   # Option<usize>
+        self._h = ctypes.c_void_p()
+        path = _path(index_file_path, 'index_file_path')
+        rc = _lib.pss_writer_open(
+            path, -1 if max_chunk_len is None else max_chunk_len,
+            _default_device() if device is None else device, ctypes.byref(self._h))
+        _ffi.check(rc, index_file_path)
+        self.writer = self   # the reference wrapper exposes `.writer` (__init__.py:12)
+
+    def _handle(self):
+        if not self._h:
+            raise ValueError('I/O operation on closed Writer')
+        return self._h
+
+    def add_entries_from_file_lines(self, input_file_path: str) -> None:
+        _ffi.check(_lib.pss_writer_add_file_lines(self._handle(), _path(input_file_path, 'input_file_path')),
+                   input_file_path)
+
+    def add_entry(self, text: str) -> None:
+        b = _utf8(text, 'text')
+        _ffi.check(_lib.pss_writer_add_entry(self._handle(), b, len(b)))
+
+    def dump_data(self) -> None:
+        _ffi.check(_lib.pss_writer_dump(self._handle()))
+
+    def finalize(self) -> None:
+        _ffi.check(_lib.pss_writer_finalize(self._handle()))
+
+    def close(self) -> None:
+        """Finalize and release the file (the reference does this on drop, src/lib.rs:138-144)."""
+        if self._h:
+            h, self._h = self._h, ctypes.c_void_p()
+            _ffi.check(_lib.pss_writer_close(h))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Reader:
+    """Reference: pysubstringsearch/__init__.py:44-73, src/lib.rs:146-288."""
+
+    def __init__(
+        self,
+        index_file_path: str,
+        *,
+        device: typing.Optional[int] = None,
+        shard: typing.Tuple[int, int] = (0, 1),
+    ) -> None:
+        self._h = ctypes.c_void_p()
+        path = _path(index_file_path, 'index_file_path')
+        rc = _lib.pss_reader_open(
+            path, _default_device() if device is None else device, shard[0], shard[1], ctypes.byref(self._h))
+        _ffi.check(rc, index_file_path)
+        self.reader = self   # the reference wrapper exposes `.reader` (__init__.py:49)
+
+    @classmethod
+    def _from_handle(cls, handle) -> 'Reader':
+        r = cls.__new__(cls)
+        r._h = handle
+        r.reader = r
+        return r
+
+    def _handle(self):
+        if not self._h:
+            raise ValueError('I/O operation on closed Reader')
+        return self._h
+
+    @property
+    def num_chunks(self) -> int:
+        return _lib.pss_reader_num_chunks(self._handle())
+
+    def search_batch_raw(self, patterns: typing.Sequence[bytes]):
+        """One batched device call.  Returns (entries, per_query_counts): the
+        entry byte strings query-major, and how many belong to each query."""
+        nq = len(patterns)
+        blob = b''.join(patterns)
+        offs = (ctypes.c_uint64 * (nq + 1))()
+        pos = 0
+        for i, p in enumerate(patterns):
+            offs[i] = pos
+            pos += len(p)
+        offs[nq] = pos
+        res = ctypes.c_void_p()
+        rc = _lib.pss_reader_search_batch(self._handle(), blob, offs, nq, ctypes.byref(res))
+        _ffi.check(rc)
+        try:
+            n = _lib.pss_result_num_entries(res)
+            counts = list(_lib.pss_result_query_counts(res)[:nq]) if nq else []
+            entries = []
+            if n:
+                off = _lib.pss_result_offsets(res)
+                data = ctypes.string_at(_lib.pss_result_bytes(res), off[n])
+                o = off[:n + 1]
+                entries = [data[o[i]:o[i + 1]] for i in range(n)]
+            return entries, counts
+        finally:
+            _lib.pss_result_free(res)
+
+    def last_stats(self) -> dict:
+        st = _ffi.SearchStats()
+        _ffi.check(_lib.pss_reader_last_stats(self._handle(), ctypes.byref(st)))
+        return st.as_dict()
+
+    def search(self, substring: str) -> typing.List[str]:
+        entries, _ = self.search_batch_raw([_utf8(substring, 'substring')])
+        return [e.decode('utf-8') for e in entries]
+
+    def search_multiple(self, substrings: typing.List[str]) -> typing.List[str]:
+        entries, _ = self.search_batch_raw([_utf8(s, 'substring') for s in substrings])
+        return [e.decode('utf-8') for e in entries]
+
+    def close(self) -> None:
+        if self._h:
+            h, self._h = self._h, ctypes.c_void_p()
+            _lib.pss_reader_close(h)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,121 @@
+"""ctypes binding of libpss.so (C ABI: include/pss.h).
+
+The engine has no CPU fallback: if the shared library is missing this module
+raises at import, and every compute call raises ``RuntimeError`` when no HIP
+device is usable.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpss.so')
+
+PSS_OK, PSS_EINVAL, PSS_ENOMEM, PSS_EIO, PSS_ETOOBIG, PSS_EDEVICE, PSS_EFORMAT = 0, -1, -2, -3, -4, -5, -6
+
+CORPUS_LINES, CORPUS_WORDS, CORPUS_RUNS, CORPUS_PERIODIC = 0, 1, 2, 3
+
+
+class SaStats(ctypes.Structure):
+    _fields_ = [
+        ('sigma', ctypes.c_uint32),
+        ('code_bits', ctypes.c_uint32),
+        ('key_chars', ctypes.c_uint32),
+        ('initial_passes', ctypes.c_uint32),
+        ('rounds', ctypes.c_uint32),
+        ('round_passes', ctypes.c_uint32),
+        ('sum_active', ctypes.c_uint64),
+        ('sort_elems', ctypes.c_uint64),
+        ('ms_total', ctypes.c_double),
+        ('ms_sort', ctypes.c_double),
+        ('sort_launches', ctypes.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class SearchStats(ctypes.Structure):
+    _fields_ = [
+        ('queries', ctypes.c_uint64),
+        ('hits', ctypes.c_uint64),
+        ('entries', ctypes.c_uint64),
+        ('result_bytes', ctypes.c_uint64),
+        ('ms_device', ctypes.c_double),
+        ('ms_interval', ctypes.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f'{LIB_PATH} is missing: build the HIP engine first '
+            '(python -c "import __graft_entry__ as g; g.build()" or make -C pysubstringsearch_amd/csrc). '
+            'pysubstringsearch_amd has no CPU fallback.')
+    L = ctypes.CDLL(LIB_PATH, use_errno=True)
+    vp, cp, i32, i64, u32, u64 = (ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int32, ctypes.c_int64,
+                                  ctypes.c_uint32, ctypes.c_uint64)
+    pvp = ctypes.POINTER(vp)
+    sig = {
+        'pss_device_count': (ctypes.c_int, []),
+        'pss_last_error': (ctypes.c_size_t, [cp, ctypes.c_size_t]),
+        'pss_sa_build': (i32, [vp, vp, i32, i32]),
+        'pss_sa_build_device': (i32, [vp, vp, i32, i32, u32, ctypes.POINTER(SaStats)]),
+        'pss_writer_open': (ctypes.c_int, [cp, i64, i32, pvp]),
+        'pss_writer_add_entry': (ctypes.c_int, [vp, cp, u64]),
+        'pss_writer_add_file_lines': (ctypes.c_int, [vp, cp]),
+        'pss_writer_dump': (ctypes.c_int, [vp]),
+        'pss_writer_finalize': (ctypes.c_int, [vp]),
+        'pss_writer_close': (ctypes.c_int, [vp]),
+        'pss_writer_chunk_limit': (u64, [vp]),
+        'pss_reader_open': (ctypes.c_int, [cp, i32, i32, i32, pvp]),
+        'pss_reader_create': (ctypes.c_int, [i32, pvp]),
+        'pss_reader_add_chunk_device': (ctypes.c_int, [vp, vp, vp, u32]),
+        'pss_reader_num_chunks': (u64, [vp]),
+        'pss_reader_search_batch': (ctypes.c_int, [vp, vp, vp, u32, pvp]),
+        'pss_reader_last_stats': (ctypes.c_int, [vp, ctypes.POINTER(SearchStats)]),
+        'pss_reader_close': (ctypes.c_int, [vp]),
+        'pss_result_num_queries': (u64, [vp]),
+        'pss_result_num_entries': (u64, [vp]),
+        'pss_result_query_counts': (ctypes.POINTER(u64), [vp]),
+        'pss_result_offsets': (ctypes.POINTER(u64), [vp]),
+        'pss_result_bytes': (ctypes.POINTER(ctypes.c_uint8), [vp]),
+        'pss_result_free': (None, [vp]),
+        'pss_gen_corpus': (ctypes.c_int, [ctypes.c_int, vp, u64, u64]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+lib = _load()
+
+
+def last_error() -> str:
+    buf = ctypes.create_string_buffer(2048)
+    lib.pss_last_error(buf, len(buf))
+    return buf.value.decode('utf-8', 'replace')
+
+
+def check(rc: int, what: str = '') -> None:
+    """Maps a C-ABI status to the exception the reference raises for it
+    (io::Error -> OSError by errno, src/lib.rs:55,71; ValueError, src/lib.rs:93)."""
+    if rc == PSS_OK:
+        return
+    msg = last_error()
+    if rc == PSS_EIO:
+        e = ctypes.get_errno()
+        raise OSError(e, os.strerror(e), what or None)
+    if rc == PSS_ETOOBIG:
+        raise ValueError('entry is too big')
+    if rc == PSS_ENOMEM:
+        raise MemoryError(msg)
+    if rc == PSS_EFORMAT:
+        raise OSError(msg)
+    if rc == PSS_EINVAL:
+        raise ValueError(msg)
+    raise RuntimeError(msg or f'libpss error {rc}')

@@ -1,0 +1,530 @@
+// capi.cpp -- the extern "C" surface declared in include/pss.h: container
+// writer / reader (the .idx chunk-record format of reference src/lib.rs:105-124
+// and 162-199) around the device suffix-array builder and the device search.
+#include <cerrno>
+#include <vector>
+
+#include "common.h"
+#include "sa_build.h"
+#include "search.h"
+
+using namespace pss;
+
+namespace {
+
+constexpr int W_TEXT = 24, W_SA = 25;   // DeviceCtx slots used by the writer / host SA entry point
+
+template <typename F>
+int guarded(F &&f)
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        set_error("host allocation failed");
+        return PSS_ENOMEM;
+    } catch (const std::exception &e) {
+        set_error("internal error: %s", e.what());
+        return PSS_EDEVICE;
+    } catch (...) {
+        set_error("internal error");
+        return PSS_EDEVICE;
+    }
+}
+
+int io_error(const char *what)
+{
+    const int e = errno ? errno : EIO;
+    set_error("%s: %s", what, strerror(e));
+    errno = e;
+    return PSS_EIO;
+}
+
+// Host text -> SA on `ctx` (upload, build, download).
+int sa_build_host(DeviceCtx *ctx, const uint8_t *T, int32_t *SA, int32_t n, pss_sa_stats *stats)
+{
+    if (n < 2) {
+        if (n == 1) SA[0] = 0;
+        return PSS_OK;
+    }
+    PSS_TRY(ctx->slot[W_TEXT].reserve((size_t)n + 64));
+    PSS_TRY(ctx->slot[W_SA].reserve((size_t)n * 4));
+    PSS_HIP(hipMemcpyAsync(ctx->slot[W_TEXT].p, T, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    PSS_TRY(sa_build_device(ctx, ctx->slot[W_TEXT].p, ctx->slot[W_SA].p, n, 0, stats));
+    PSS_HIP(hipMemcpyAsync(SA, ctx->slot[W_SA].p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PSS_HIP(hipStreamSynchronize(ctx->stream));
+    return PSS_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ library --
+
+extern "C" int pss_device_count(void)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return c;
+}
+
+extern "C" size_t pss_last_error(char *buf, size_t cap)
+{
+    const std::string &e = last_error();
+    if (buf && cap) {
+        const size_t k = e.size() < cap - 1 ? e.size() : cap - 1;
+        memcpy(buf, e.data(), k);
+        buf[k] = 0;
+    }
+    return e.size();
+}
+
+// --------------------------------------------------------------- SA builder --
+
+extern "C" int32_t pss_sa_build(const uint8_t *T, int32_t *SA, int32_t n, int32_t device)
+{
+    return guarded([&]() -> int {
+        if (T == nullptr || SA == nullptr || n < 0) {   // libsais.c:6599-6602
+            set_error("pss_sa_build: bad arguments");
+            return PSS_EINVAL;
+        }
+        if (n < 2) {                                    // libsais.c:6603-6607
+            if (n == 1) SA[0] = 0;
+            return PSS_OK;
+        }
+        DeviceCtx *ctx;
+        PSS_TRY(get_ctx(device, &ctx));
+        return sa_build_host(ctx, T, SA, n, nullptr);
+    });
+}
+
+extern "C" int32_t pss_sa_build_device(const void *d_T, void *d_SA, int32_t n, int32_t device, uint32_t flags,
+                                       pss_sa_stats *stats)
+{
+    return guarded([&]() -> int {
+        DeviceCtx *ctx;
+        PSS_TRY(get_ctx(device, &ctx));
+        return sa_build_device(ctx, d_T, d_SA, n, flags, stats);
+    });
+}
+
+// ------------------------------------------------------------------- Writer --
+
+struct pss_writer {
+    FILE *fp = nullptr;
+    uint8_t *buf = nullptr;
+    size_t len = 0;
+    size_t limit = 0;    // the reference's Vec capacity (src/lib.rs:62), see reserve()
+    size_t alloc = 0;
+    int device = 0;
+    std::vector<int32_t> sa;
+};
+
+namespace {
+
+// The reference's chunk limit is the capacity of a Rust Vec<u8> (lib.rs:62,75,
+// 92,96).  Appending past it grows the Vec by the standard amortised rule
+// new_cap = max(8, 2*cap, len+additional), which silently raises the limit;
+// mirrored here so chunk boundaries stay byte-identical even in that corner.
+int w_reserve(pss_writer *w, size_t additional)
+{
+    if (w->limit - w->len < additional) {
+        size_t nc = w->limit * 2;
+        if (nc < w->len + additional) nc = w->len + additional;
+        if (nc < 8) nc = 8;
+        w->limit = nc;
+    }
+    const size_t need = w->len + additional;
+    if (need > w->alloc) {
+        size_t na = w->alloc ? w->alloc : 65536;
+        while (na < need) na *= 2;
+        uint8_t *nb = static_cast<uint8_t *>(realloc(w->buf, na));
+        if (!nb) {
+            set_error("host allocation of %zu bytes failed", na);
+            return PSS_ENOMEM;
+        }
+        w->buf = nb;
+        w->alloc = na;
+    }
+    return PSS_OK;
+}
+
+int w_append(pss_writer *w, const uint8_t *p, size_t l)
+{
+    PSS_TRY(w_reserve(w, l));
+    if (l) memcpy(w->buf + w->len, p, l);
+    w->len += l;
+    PSS_TRY(w_reserve(w, 1));
+    w->buf[w->len++] = '\n';
+    return PSS_OK;
+}
+
+void put_u32le(uint8_t *p, uint32_t v)
+{
+    p[0] = (uint8_t)v;
+    p[1] = (uint8_t)(v >> 8);
+    p[2] = (uint8_t)(v >> 16);
+    p[3] = (uint8_t)(v >> 24);
+}
+
+// src/lib.rs:105-124
+int w_dump(pss_writer *w)
+{
+    if (w->len == 0) return PSS_OK;
+    if (w->len >= ((size_t)1 << 31)) {
+        set_error("chunk of %zu bytes exceeds the 32-bit suffix array", w->len);
+        return PSS_EINVAL;
+    }
+    DeviceCtx *ctx;
+    PSS_TRY(get_ctx(w->device, &ctx));
+    w->sa.resize(w->len);
+    PSS_TRY(sa_build_host(ctx, w->buf, w->sa.data(), (int32_t)w->len, nullptr));
+    uint8_t hdr[4];
+    errno = 0;
+    put_u32le(hdr, (uint32_t)w->len);
+    if (fwrite(hdr, 1, 4, w->fp) != 4) return io_error("write");
+    if (fwrite(w->buf, 1, w->len, w->fp) != w->len) return io_error("write");
+    put_u32le(hdr, (uint32_t)(w->len * 4));   // wraps like `as u32` at n >= 2^30 (lib.rs:116)
+    if (fwrite(hdr, 1, 4, w->fp) != 4) return io_error("write");
+    // x86-64 / little-endian host: int32 in memory == i32le on disk (lib.rs:117-119)
+    if (fwrite(w->sa.data(), 4, w->len, w->fp) != w->len) return io_error("write");
+    w->len = 0;
+    return PSS_OK;
+}
+
+}  // namespace
+
+extern "C" int pss_writer_open(const char *path, int64_t max_chunk_len, int32_t device, pss_writer **out)
+{
+    return guarded([&]() -> int {
+        if (!path || !out) {
+            set_error("pss_writer_open: bad arguments");
+            return PSS_EINVAL;
+        }
+        errno = 0;
+        FILE *fp = fopen(path, "wb");   // File::create truncates, lib.rs:55
+        if (!fp) return io_error(path);
+        pss_writer *w = new pss_writer();
+        w->fp = fp;
+        w->limit = max_chunk_len < 0 ? (size_t)512 * 1024 * 1024 : (size_t)max_chunk_len;   // lib.rs:57
+        w->device = device;
+        *out = w;
+        return PSS_OK;
+    });
+}
+
+extern "C" int pss_writer_add_entry(pss_writer *w, const uint8_t *text, uint64_t len)
+{
+    return guarded([&]() -> int {
+        if (!w || (!text && len)) return PSS_EINVAL;
+        if (len > w->limit) {   // lib.rs:92-94
+            set_error("entry is too big");
+            return PSS_ETOOBIG;
+        }
+        if (w->len + len + 1 > w->limit) PSS_TRY(w_dump(w));   // lib.rs:96-98
+        return w_append(w, text, (size_t)len);                 // lib.rs:99-100
+    });
+}
+
+// src/lib.rs:67-86.  Line rule of bstr 0.2 `for_byte_line` (Cargo.toml pins
+// bstr = "0.2"; not vendored): a line ends after each '\n'; that '\n' and then
+// one preceding '\r' are stripped; a final unterminated line is delivered
+// as is; an empty file has no lines.  No size check, no UTF-8 validation.
+extern "C" int pss_writer_add_file_lines(pss_writer *w, const char *path)
+{
+    return guarded([&]() -> int {
+        if (!w || !path) return PSS_EINVAL;
+        errno = 0;
+        FILE *in = fopen(path, "rb");
+        if (!in) return io_error(path);
+        std::vector<uint8_t> line;
+        std::vector<uint8_t> block((size_t)1 << 20);
+        int rc = PSS_OK;
+        auto deliver = [&](bool terminated) -> int {
+            size_t l = line.size();
+            if (terminated && l && line[l - 1] == '\r') --l;
+            if (w->len + l + 1 > w->limit) PSS_TRY(w_dump(w));   // lib.rs:75-77
+            return w_append(w, line.data(), l);
+        };
+        for (;;) {
+            const size_t got = fread(block.data(), 1, block.size(), in);
+            if (got == 0) break;
+            size_t p = 0;
+            while (p < got && rc == PSS_OK) {
+                const uint8_t *nl = static_cast<const uint8_t *>(memchr(block.data() + p, '\n', got - p));
+                const size_t e = nl ? (size_t)(nl - block.data()) : got;
+                line.insert(line.end(), block.begin() + p, block.begin() + e);
+                if (nl) {
+                    rc = deliver(true);
+                    line.clear();
+                    p = e + 1;
+                } else {
+                    p = got;
+                }
+            }
+            if (rc != PSS_OK) break;
+        }
+        if (rc == PSS_OK && ferror(in)) rc = io_error(path);
+        if (rc == PSS_OK && !line.empty()) rc = deliver(false);
+        fclose(in);
+        return rc;
+    });
+}
+
+extern "C" int pss_writer_dump(pss_writer *w)
+{
+    return guarded([&]() -> int { return w ? w_dump(w) : PSS_EINVAL; });
+}
+
+extern "C" int pss_writer_finalize(pss_writer *w)
+{
+    return guarded([&]() -> int {
+        if (!w) return PSS_EINVAL;
+        if (w->len) PSS_TRY(w_dump(w));   // lib.rs:129-131
+        errno = 0;
+        if (fflush(w->fp) != 0) return io_error("flush");   // lib.rs:132
+        return PSS_OK;
+    });
+}
+
+extern "C" int pss_writer_close(pss_writer *w)
+{
+    return guarded([&]() -> int {
+        if (!w) return PSS_OK;
+        int rc = PSS_OK;
+        if (w->len) rc = w_dump(w);   // Drop -> finalize, lib.rs:138-144
+        errno = 0;
+        if (fclose(w->fp) != 0 && rc == PSS_OK) rc = io_error("close");
+        free(w->buf);
+        delete w;
+        return rc;
+    });
+}
+
+extern "C" uint64_t pss_writer_chunk_limit(const pss_writer *w) { return w ? w->limit : 0; }
+
+// ------------------------------------------------------------------- Reader --
+
+struct pss_reader {
+    int device = 0;
+    DeviceCtx *ctx = nullptr;
+    std::vector<ChunkDesc> chunks;      // device pointers of resident chunks
+    ChunkDesc *d_descs = nullptr;
+    size_t d_descs_cap = 0;
+    bool dirty = true;
+    pss_search_stats last{};
+};
+
+struct pss_result {
+    HostResult r;
+};
+
+namespace {
+
+int reader_alloc_chunk(pss_reader *r, uint32_t n, void **d_text, void **d_sa)
+{
+    PSS_HIP(hipSetDevice(r->device));
+    *d_text = nullptr;
+    *d_sa = nullptr;
+    hipError_t e = hipMalloc(d_text, (size_t)n + 32);
+    if (e == hipSuccess) e = hipMalloc(d_sa, (size_t)n * 4 + 16);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (*d_text) (void)hipFree(*d_text);
+        set_error("hipMalloc of a %u-byte chunk failed: %s", n, hipGetErrorString(e));
+        return PSS_ENOMEM;
+    }
+    PSS_HIP(hipMemsetAsync(static_cast<uint8_t *>(*d_text) + n, 0, 32, r->ctx->stream));
+    return PSS_OK;
+}
+
+void reader_free(pss_reader *r)
+{
+    if (!r) return;
+    if (r->ctx) (void)hipSetDevice(r->device);
+    for (auto &c : r->chunks) {
+        (void)hipFree(const_cast<uint8_t *>(c.text));
+        (void)hipFree(const_cast<uint32_t *>(c.sa));
+    }
+    if (r->d_descs) (void)hipFree(r->d_descs);
+    delete r;
+}
+
+// Reads `bytes` from fp into device memory through a bounce buffer.
+int upload_from_file(pss_reader *r, FILE *fp, void *dst, size_t bytes, std::vector<uint8_t> &bounce)
+{
+    size_t done = 0;
+    while (done < bytes) {
+        const size_t k = std::min(bounce.size(), bytes - done);
+        if (fread(bounce.data(), 1, k, fp) != k) {
+            set_error("failed to fill whole buffer (truncated index file)");   // UnexpectedEof
+            return PSS_EFORMAT;
+        }
+        PSS_HIP(hipMemcpyAsync(static_cast<uint8_t *>(dst) + done, bounce.data(), k, hipMemcpyHostToDevice,
+                               r->ctx->stream));
+        PSS_HIP(hipStreamSynchronize(r->ctx->stream));
+        done += k;
+    }
+    return PSS_OK;
+}
+
+}  // namespace
+
+extern "C" int pss_reader_create(int32_t device, pss_reader **out)
+{
+    return guarded([&]() -> int {
+        if (!out) return PSS_EINVAL;
+        DeviceCtx *ctx;
+        PSS_TRY(get_ctx(device, &ctx));
+        pss_reader *r = new pss_reader();
+        r->device = device;
+        r->ctx = ctx;
+        *out = r;
+        return PSS_OK;
+    });
+}
+
+extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_index, int32_t shard_count,
+                               pss_reader **out)
+{
+    return guarded([&]() -> int {
+        if (!path || !out || shard_count < 1 || shard_index < 0 || shard_index >= shard_count) {
+            set_error("pss_reader_open: bad arguments");
+            return PSS_EINVAL;
+        }
+        errno = 0;
+        FILE *fp = fopen(path, "rb");   // File::open, lib.rs:165 (NotFound -> FileNotFoundError)
+        if (!fp) return io_error(path);
+        struct Closer {
+            FILE *f;
+            ~Closer() { fclose(f); }
+        } closer{fp};
+        if (fseeko(fp, 0, SEEK_END) != 0) return io_error(path);
+        const uint64_t flen = (uint64_t)ftello(fp);   // fs::metadata().len(), lib.rs:168-169
+        fseeko(fp, 0, SEEK_SET);
+        DeviceCtx *ctx;
+        PSS_TRY(get_ctx(device, &ctx));
+        pss_reader *r = new pss_reader();
+        r->device = device;
+        r->ctx = ctx;
+        std::vector<uint8_t> bounce((size_t)64 << 20);
+        uint64_t bytes_read = 0;
+        int64_t index = 0;
+        int rc = PSS_OK;
+        while (bytes_read < flen) {   // lib.rs:174
+            uint8_t hdr[4];
+            if (fread(hdr, 1, 4, fp) != 4) { set_error("failed to fill whole buffer (truncated index file)"); rc = PSS_EFORMAT; break; }
+            const uint32_t dlen = (uint32_t)hdr[0] | (uint32_t)hdr[1] << 8 | (uint32_t)hdr[2] << 16 | (uint32_t)hdr[3] << 24;
+            const bool mine = (index % shard_count) == shard_index;
+            void *d_text = nullptr, *d_sa = nullptr;
+            if (mine && dlen) {
+                rc = reader_alloc_chunk(r, dlen, &d_text, &d_sa);
+                if (rc) break;
+                r->chunks.push_back(ChunkDesc{static_cast<uint8_t *>(d_text), static_cast<uint32_t *>(d_sa), dlen, 0});
+                rc = upload_from_file(r, fp, d_text, dlen, bounce);
+                if (rc) break;
+            } else if (fseeko(fp, dlen, SEEK_CUR) != 0) { rc = io_error(path); break; }
+            if (fread(hdr, 1, 4, fp) != 4) { set_error("failed to fill whole buffer (truncated index file)"); rc = PSS_EFORMAT; break; }
+            const uint32_t slen = (uint32_t)hdr[0] | (uint32_t)hdr[1] << 8 | (uint32_t)hdr[2] << 16 | (uint32_t)hdr[3] << 24;
+            if ((uint64_t)slen != (uint64_t)dlen * 4 && dlen < (1u << 30)) {
+                set_error("chunk %lld: suffix array of %u bytes does not match %u bytes of text", (long long)index, slen, dlen);
+                rc = PSS_EFORMAT;
+                break;
+            }
+            if (mine && dlen) {
+                rc = upload_from_file(r, fp, d_sa, (size_t)dlen * 4, bounce);
+                if (rc) break;
+            } else {
+                if (bytes_read + 8 + dlen + (uint64_t)slen > flen) { set_error("failed to fill whole buffer (truncated index file)"); rc = PSS_EFORMAT; break; }
+                if (fseeko(fp, slen, SEEK_CUR) != 0) { rc = io_error(path); break; }
+            }
+            bytes_read += 8 + (uint64_t)dlen + slen;   // lib.rs:184
+            ++index;
+        }
+        if (rc != PSS_OK) {
+            reader_free(r);
+            return rc;
+        }
+        *out = r;
+        return PSS_OK;
+    });
+}
+
+extern "C" int pss_reader_add_chunk_device(pss_reader *r, const void *d_text, const void *d_sa, uint32_t n)
+{
+    return guarded([&]() -> int {
+        if (!r || (n && (!d_text || !d_sa))) return PSS_EINVAL;
+        if (n == 0) return PSS_OK;
+        void *t = nullptr, *s = nullptr;
+        PSS_TRY(reader_alloc_chunk(r, n, &t, &s));
+        r->chunks.push_back(ChunkDesc{static_cast<uint8_t *>(t), static_cast<uint32_t *>(s), n, 0});
+        PSS_HIP(hipMemcpyAsync(t, d_text, n, hipMemcpyDeviceToDevice, r->ctx->stream));
+        PSS_HIP(hipMemcpyAsync(s, d_sa, (size_t)n * 4, hipMemcpyDeviceToDevice, r->ctx->stream));
+        PSS_HIP(hipStreamSynchronize(r->ctx->stream));
+        r->dirty = true;
+        return PSS_OK;
+    });
+}
+
+extern "C" uint64_t pss_reader_num_chunks(const pss_reader *r) { return r ? r->chunks.size() : 0; }
+
+extern "C" int pss_reader_search_batch(pss_reader *r, const uint8_t *qbytes, const uint64_t *qoffsets, uint32_t nq,
+                                       pss_result **out)
+{
+    return guarded([&]() -> int {
+        if (!r || !out || (nq && !qoffsets)) {
+            set_error("pss_reader_search_batch: bad arguments");
+            return PSS_EINVAL;
+        }
+        PSS_HIP(hipSetDevice(r->device));
+        const uint32_t nc = (uint32_t)r->chunks.size();
+        if (r->dirty && nc) {
+            if (r->d_descs_cap < nc) {
+                if (r->d_descs) (void)hipFree(r->d_descs);
+                r->d_descs = nullptr;
+                PSS_HIP(hipMalloc(reinterpret_cast<void **>(&r->d_descs), sizeof(ChunkDesc) * nc));
+                r->d_descs_cap = nc;
+            }
+            PSS_HIP(hipMemcpy(r->d_descs, r->chunks.data(), sizeof(ChunkDesc) * nc, hipMemcpyHostToDevice));
+            r->dirty = false;
+        }
+        pss_result *res = new pss_result();
+        const int rc = search_batch_device(r->ctx, r->d_descs, nc, qbytes, qoffsets, nq, &res->r, &r->last);
+        if (rc != PSS_OK) {
+            pss_result_free(res);
+            return rc;
+        }
+        *out = res;
+        return PSS_OK;
+    });
+}
+
+extern "C" int pss_reader_last_stats(const pss_reader *r, pss_search_stats *stats)
+{
+    if (!r || !stats) return PSS_EINVAL;
+    *stats = r->last;
+    return PSS_OK;
+}
+
+extern "C" int pss_reader_close(pss_reader *r)
+{
+    return guarded([&]() -> int {
+        reader_free(r);
+        return PSS_OK;
+    });
+}
+
+extern "C" uint64_t pss_result_num_queries(const pss_result *res) { return res ? res->r.nq : 0; }
+extern "C" uint64_t pss_result_num_entries(const pss_result *res) { return res ? res->r.n_entries : 0; }
+extern "C" const uint64_t *pss_result_query_counts(const pss_result *res) { return res ? res->r.qcount : nullptr; }
+extern "C" const uint64_t *pss_result_offsets(const pss_result *res) { return res ? res->r.offsets : nullptr; }
+extern "C" const uint8_t *pss_result_bytes(const pss_result *res) { return res ? res->r.bytes : nullptr; }
+extern "C" void pss_result_free(pss_result *res)
+{
+    if (!res) return;
+    free(res->r.qcount);
+    free(res->r.offsets);
+    free(res->r.bytes);
+    delete res;
+}

@@ -1,0 +1,62 @@
+// common.h -- host-side plumbing shared by the engine: error reporting across
+// the C ABI, per-device context (stream + grow-only HBM workspace slots).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../include/pss.h"
+
+namespace pss {
+
+void set_error(const char *fmt, ...);
+const std::string &last_error();
+
+#define PSS_HIP(expr)                                                                   \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            pss::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return (_e == hipErrorOutOfMemory) ? PSS_ENOMEM : PSS_EDEVICE;              \
+        }                                                                               \
+    } while (0)
+
+#define PSS_TRY(expr)               \
+    do {                            \
+        int _rc = (expr);           \
+        if (_rc != PSS_OK) return _rc; \
+    } while (0)
+
+// A grow-only device allocation, reused across calls.
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+// One per (process, device): a stream and named workspace slots.
+struct DeviceCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    static constexpr int kSlots = 32;
+    DevBuf slot[kSlots];
+    void *pinned = nullptr;   // small pinned host scratch for D2H of counters
+    size_t pinned_cap = 0;
+};
+
+// Validates `device`, makes it current, returns its context (created lazily).
+int get_ctx(int device, DeviceCtx **out);
+// Frees every workspace slot of every context (memory pressure relief).
+void trim_all();
+
+static inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace pss

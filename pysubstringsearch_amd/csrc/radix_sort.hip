@@ -1,0 +1,395 @@
+// radix_sort.hip -- LSD radix sort of (u64 key, u32 value) pairs for gfx950.
+//
+// One pass = three launches over R contiguous "ranges" of the input
+// (R <= 1024 workgroups, a multiple of 8, one range per workgroup):
+//
+//   rs_hist     every workgroup counts the 256 digit values of its range in LDS
+//               -> table[digit][range], totals[digit]          (reads 8 B/elem)
+//   rs_scan     256 workgroups turn table[][] into exclusive global offsets
+//   rs_scatter  every workgroup walks its range tile by tile (4096 pairs):
+//                 * coalesced wave-striped loads (8 B keys, 4 B values)
+//                 * per-wave digit ranking with 64-bit ballots: four 4-way
+//                   (2-bit) bucket refinements give the lanes sharing a digit,
+//                   v_mbcnt gives the lane's rank among them, a per-wave LDS
+//                   counter row gives the running count  -> stable rank
+//                 * workgroup prefix sum over the 4x256 wave counters
+//                 * keys, then values, are staged through LDS in digit order
+//                   so each wave writes contiguous runs per digit bucket
+//               (reads 12 B/elem, writes 12 B/elem)
+//
+// No inter-workgroup communication happens inside a launch, so nothing depends
+// on dispatch order or XCD placement; the range->workgroup map is XCD-aware
+// only for L2 write-combining (prims.h: xcd_range_of_block).
+//
+// The first pass of the suffix sort never materialises keys: it packs them on
+// the fly from the recoded text (TextKeys), 1 B/elem read instead of 12.
+//
+// HBM-bound integer work: no MFMA anywhere by design.
+#include "prims.h"
+#include "radix_sort.h"
+
+namespace pss {
+
+constexpr int RS_BLOCK = 256;
+constexpr int RS_WAVES = RS_BLOCK / kWave;
+constexpr int RS_IPT = 16;
+constexpr int RS_TILE = RS_BLOCK * RS_IPT;   // 4096 pairs per tile
+constexpr u32 RS_MAX_RANGES = 1024;
+
+struct PassArgs {
+    const u64 *kin;
+    const u32 *vin;
+    u64 *kout;
+    u32 *vout;
+    const u8 *codes;
+    int code_bits;
+    int key_chars;
+    int plus_one;
+    u32 n;
+    u32 num_tiles;
+    u32 tiles_per_range;
+    u32 num_ranges;
+    int shift;
+    u32 *table;    // [256][num_ranges]
+    u32 *totals;   // [256]
+};
+
+// Packs the keys of 16 consecutive suffixes i0 .. i0+15 (i0 % 16 == 0) from the
+// recoded text.  Sliding window: key(i+1) = ((key(i) << b) | code[i+k]) & mask.
+__device__ __forceinline__ void text_keys16(const u8 *codes, u32 i0, int b, int k, int plus_one, u32 n,
+                                            u64 (&key)[RS_IPT])
+{
+    const uint4 *p = reinterpret_cast<const uint4 *>(codes + i0);
+    const uint4 lo = p[0], hi = p[1];
+    const u64 q0 = (u64)lo.x | ((u64)lo.y << 32), q1 = (u64)lo.z | ((u64)lo.w << 32);
+    const u64 q2 = (u64)hi.x | ((u64)hi.y << 32), q3 = (u64)hi.z | ((u64)hi.w << 32);
+    const u64 mask = (k * b >= 64) ? ~0ull : ((1ull << (k * b)) - 1ull);
+    // first window: bytes 0 .. k-1
+    u64 win = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const u64 src = (j < 8) ? q0 : q1;
+        u32 c = (u32)(src >> ((j & 7) * 8)) & 0xffu;
+        if (plus_one) c = (i0 + j < n) ? c + 1u : 0u;
+        if (j < k) win = (win << b) | c;
+    }
+    key[0] = win;
+    // byte stream starting at byte k (k is wave-uniform): s0 = bytes k..k+7, s1 = k+8..k+15
+    u64 a0, a1, a2;
+    if (k >= 16) { a0 = q2; a1 = q3; a2 = 0; }
+    else if (k >= 8) { a0 = q1; a1 = q2; a2 = q3; }
+    else { a0 = q0; a1 = q1; a2 = q2; }
+    const int sh = (k & 7) * 8;
+    u64 s0 = a0, s1 = a1;
+    if (sh) {
+        s0 = (a0 >> sh) | (a1 << (64 - sh));
+        s1 = (a1 >> sh) | (a2 << (64 - sh));
+    }
+#pragma unroll
+    for (int r = 1; r < RS_IPT; ++r) {
+        const int j = r - 1;
+        const u64 src = (j < 8) ? s0 : s1;
+        u32 c = (u32)(src >> ((j & 7) * 8)) & 0xffu;
+        if (plus_one) c = ((u64)i0 + j + k < n) ? c + 1u : 0u;
+        win = ((win << b) | c) & mask;
+        key[r] = win;
+    }
+}
+
+__device__ __forceinline__ void hist_add(u32 *h, u32 d, bool valid)
+{
+    // wave-uniform digit (sorted or low-entropy input): one LDS add per wave
+    const u32 d0 = __builtin_amdgcn_readfirstlane(d);
+    const u64 vm = __ballot(valid);
+    const u64 same = __ballot(valid && d == d0);
+    if (vm != 0 && same == vm) {
+        if (mbcnt(vm) == 0 && valid) atomicAdd(&h[d0], (u32)__popcll(vm));
+    } else if (valid) {
+        atomicAdd(&h[d], 1u);
+    }
+}
+
+template <bool FROM_TEXT>
+__global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(PassArgs a)
+{
+    __shared__ u32 h[256];
+    const u32 tid = threadIdx.x;
+    const u32 g = blockIdx.x;
+    h[tid] = 0;
+    __syncthreads();
+    const u32 tile0 = g * a.tiles_per_range;
+    const u32 tile1 = min(tile0 + a.tiles_per_range, a.num_tiles);
+    for (u32 tile = tile0; tile < tile1; ++tile) {
+        const u32 base = tile * RS_TILE;
+        if (FROM_TEXT) {
+            const u32 i0 = base + tid * RS_IPT;
+            u64 key[RS_IPT] = {};
+            if (i0 < a.n) text_keys16(a.codes, i0, a.code_bits, a.key_chars, a.plus_one, a.n, key);
+#pragma unroll
+            for (int r = 0; r < RS_IPT; ++r) {
+                const bool valid = (i0 + r) < a.n;
+                hist_add(h, valid ? (u32)(key[r] >> a.shift) & 0xffu : 0u, valid);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RS_IPT / 2; ++r) {
+                const u32 i = base + r * (2 * RS_BLOCK) + tid * 2;
+                u64 k0 = 0, k1 = 0;
+                if (i + 1 < a.n) {
+                    const ulonglong2 kk = *reinterpret_cast<const ulonglong2 *>(a.kin + i);
+                    k0 = kk.x;
+                    k1 = kk.y;
+                } else if (i < a.n) {
+                    k0 = a.kin[i];
+                }
+                hist_add(h, (u32)(k0 >> a.shift) & 0xffu, i < a.n);
+                hist_add(h, (u32)(k1 >> a.shift) & 0xffu, i + 1 < a.n);
+            }
+        }
+    }
+    __syncthreads();
+    const u32 c = h[tid];
+    a.table[tid * a.num_ranges + g] = c;
+    if (c) atomicAdd(&a.totals[tid], c);
+}
+
+// table[d][g] -> exclusive offset of (digit d, range g) in (d-major, g-minor) order.
+__global__ __launch_bounds__(256) void rs_scan_kernel(u32 *table, const u32 *totals, u32 num_ranges)
+{
+    __shared__ u32 scr[RS_WAVES + 1];
+    const u32 tid = threadIdx.x, d = blockIdx.x;
+    u32 base = 0;
+    (void)block_excl_sum<RS_WAVES>(tid < d ? totals[tid] : 0u, scr, &base);
+    const u32 per = (num_ranges + 255) / 256;
+    u32 *row = table + (size_t)d * num_ranges;
+    const u32 i0 = tid * per, i1 = min(i0 + per, num_ranges);
+    u32 local = 0;
+    for (u32 i = i0; i < i1; ++i) local += row[i];
+    u32 run = base + block_excl_sum<RS_WAVES>(local, scr, nullptr);
+    for (u32 i = i0; i < i1; ++i) {
+        const u32 v = row[i];
+        row[i] = run;
+        run += v;
+    }
+}
+
+template <bool FROM_TEXT>
+__global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(PassArgs a)
+{
+    __shared__ __attribute__((aligned(16))) u64 exch[RS_TILE];   // 32 KiB, reused for values
+    __shared__ u32 wave_hist[RS_WAVES][256];
+    __shared__ u32 s_off[256];     // running global offset of each digit for this range
+    __shared__ u32 s_delta[256];   // s_off - (start of the digit inside the tile)
+    __shared__ u32 s_scr[RS_WAVES + 1];
+
+    const u32 tid = threadIdx.x;
+    const u32 lane = tid & 63u, wave = tid >> 6;
+    const u32 g = xcd_range_of_block(blockIdx.x, gridDim.x);
+    s_off[tid] = a.table[tid * a.num_ranges + g];
+
+    const u32 tile0 = g * a.tiles_per_range;
+    const u32 tile1 = min(tile0 + a.tiles_per_range, a.num_tiles);
+    for (u32 tile = tile0; tile < tile1; ++tile) {
+        const u32 base = tile * RS_TILE;
+        const u32 valid_count = min((u32)RS_TILE, a.n - base);
+
+        u64 key[RS_IPT] = {};
+        u32 val[RS_IPT];
+        u32 rank[RS_IPT];
+        // position of item r inside the tile
+        auto pos_of = [&](int r) -> u32 {
+            return FROM_TEXT ? tid * RS_IPT + r : wave * (kWave * RS_IPT) + r * kWave + lane;
+        };
+        if (FROM_TEXT) {
+            const u32 i0 = base + tid * RS_IPT;
+            if (i0 < a.n) text_keys16(a.codes, i0, a.code_bits, a.key_chars, a.plus_one, a.n, key);
+#pragma unroll
+            for (int r = 0; r < RS_IPT; ++r) val[r] = i0 + r;
+        } else {
+#pragma unroll
+            for (int r = 0; r < RS_IPT; ++r) {
+                const u32 p = pos_of(r);
+                key[r] = (p < valid_count) ? a.kin[base + p] : 0;
+            }
+#pragma unroll
+            for (int r = 0; r < RS_IPT; ++r) {
+                const u32 p = pos_of(r);
+                val[r] = (p < valid_count) ? a.vin[base + p] : 0;
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) wave_hist[w][tid] = 0;
+        __syncthreads();
+
+        // ---- per-wave stable ranking ----
+#pragma unroll
+        for (int r = 0; r < RS_IPT; ++r) {
+            const bool valid = pos_of(r) < valid_count;
+            const u32 d = (u32)(key[r] >> a.shift) & 0xffu;
+            const u64 peers = match_digit8(d, __ballot(valid));
+            const u32 below = mbcnt(peers);
+            u32 prev = 0;
+            if (valid && below == 0) {
+                prev = wave_hist[wave][d];
+                wave_hist[wave][d] = prev + (u32)__popcll(peers);
+            }
+            const int leader = valid ? (int)__builtin_ctzll(peers) : (int)lane;
+            prev = __shfl(prev, leader);
+            rank[r] = prev + below;
+        }
+        __syncthreads();
+
+        // ---- workgroup prefix over digits (thread tid owns digit tid) ----
+        {
+            u32 c[RS_WAVES];
+            u32 total = 0;
+#pragma unroll
+            for (int w = 0; w < RS_WAVES; ++w) {
+                c[w] = wave_hist[w][tid];
+                total += c[w];
+            }
+            const u32 dstart = block_excl_sum<RS_WAVES>(total, s_scr, nullptr);
+            u32 run = dstart;
+#pragma unroll
+            for (int w = 0; w < RS_WAVES; ++w) {
+                wave_hist[w][tid] = run;
+                run += c[w];
+            }
+            const u32 off = s_off[tid];
+            s_delta[tid] = off - dstart;
+            s_off[tid] = off + total;
+        }
+        __syncthreads();
+
+        // ---- keys through LDS in digit order, then out in contiguous runs ----
+#pragma unroll
+        for (int r = 0; r < RS_IPT; ++r) {
+            const bool valid = pos_of(r) < valid_count;
+            const u32 d = (u32)(key[r] >> a.shift) & 0xffu;
+            const u32 lp = wave_hist[wave][d] + rank[r];
+            rank[r] = lp;
+            if (valid) exch[lp] = key[r];
+        }
+        __syncthreads();
+        u32 gpos[RS_IPT];
+#pragma unroll
+        for (int i = 0; i < RS_IPT; ++i) {
+            const u32 p = i * RS_BLOCK + tid;
+            gpos[i] = 0;
+            if (p < valid_count) {
+                const u64 k = exch[p];
+                const u32 d = (u32)(k >> a.shift) & 0xffu;
+                gpos[i] = s_delta[d] + p;
+                a.kout[gpos[i]] = k;
+            }
+        }
+        __syncthreads();
+        u32 *exv = reinterpret_cast<u32 *>(exch);
+#pragma unroll
+        for (int r = 0; r < RS_IPT; ++r) {
+            if (pos_of(r) < valid_count) exv[rank[r]] = val[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RS_IPT; ++i) {
+            const u32 p = i * RS_BLOCK + tid;
+            if (p < valid_count) a.vout[gpos[i]] = exv[p];
+        }
+        __syncthreads();
+    }
+}
+
+size_t radix_sort_workspace_bytes() { return (size_t)256 * RS_MAX_RANGES * 4 + 256 * 4 * 16; }
+
+int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint32_t n, int key_bits,
+                     uint32_t pass_mask, const TextKeys *text, int src, void *work, int *dst,
+                     bool profile, SortStats *stats)
+{
+    const int passes = (key_bits + 7) / 8;
+    int cur = src;
+    bool from_text = text != nullptr;
+    if (n == 0) {
+        *dst = from_text ? 0 : src;
+        return PSS_OK;
+    }
+    const u32 num_tiles = (u32)(((u64)n + RS_TILE - 1) / RS_TILE);
+    const u32 tpr = (num_tiles + RS_MAX_RANGES - 1) / RS_MAX_RANGES;
+    u32 num_ranges = (num_tiles + tpr - 1) / tpr;
+    num_ranges = (num_ranges + 7u) & ~7u;
+
+    u32 *table = static_cast<u32 *>(work);
+    u32 *totals_base = table + (size_t)256 * RS_MAX_RANGES;
+    PSS_HIP(hipMemsetAsync(totals_base, 0, 256 * 4 * 16, ctx->stream));
+
+    hipEvent_t ev[2 * 16];
+    int nev = 0;
+    int executed = 0;
+    for (int p = 0; p < passes; ++p) {
+        if (!((pass_mask >> p) & 1u)) continue;
+        PassArgs a;
+        a.n = n;
+        a.num_tiles = num_tiles;
+        a.tiles_per_range = tpr;
+        a.num_ranges = num_ranges;
+        a.shift = p * 8;
+        a.table = table;
+        a.totals = totals_base + (size_t)256 * (executed & 15);
+        if (executed >= 16) PSS_HIP(hipMemsetAsync(a.totals, 0, 256 * 4, ctx->stream));
+        int out;
+        if (from_text) {
+            a.codes = text->codes;
+            a.code_bits = text->code_bits;
+            a.key_chars = text->key_chars;
+            a.plus_one = text->plus_one;
+            a.kin = nullptr;
+            a.vin = nullptr;
+            out = 0;
+        } else {
+            a.codes = nullptr;
+            a.code_bits = a.key_chars = a.plus_one = 0;
+            a.kin = keys[cur];
+            a.vin = vals[cur];
+            out = cur ^ 1;
+        }
+        a.kout = keys[out];
+        a.vout = vals[out];
+        if (from_text) hipLaunchKernelGGL(rs_hist_kernel<true>, dim3(num_ranges), dim3(RS_BLOCK), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(rs_hist_kernel<false>, dim3(num_ranges), dim3(RS_BLOCK), 0, ctx->stream, a);
+        hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(256), 0, ctx->stream, a.table, a.totals, num_ranges);
+        if (profile && nev < 32) {
+            PSS_HIP(hipEventCreate(&ev[nev]));
+            PSS_HIP(hipEventRecord(ev[nev++], ctx->stream));
+        }
+        if (from_text) hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(num_ranges), dim3(RS_BLOCK), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(num_ranges), dim3(RS_BLOCK), 0, ctx->stream, a);
+        if (profile && nev < 32) {
+            PSS_HIP(hipEventCreate(&ev[nev]));
+            PSS_HIP(hipEventRecord(ev[nev++], ctx->stream));
+        }
+        PSS_HIP(hipGetLastError());
+        cur = out;
+        from_text = false;
+        ++executed;
+        if (stats) {
+            stats->launches += 1;
+            stats->elems += n;
+        }
+    }
+    if (nev) {
+        PSS_HIP(hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i + 1 < nev; i += 2) {
+            float ms = 0.f;
+            PSS_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            if (stats) stats->ms += ms;
+        }
+        for (int i = 0; i < nev; ++i) (void)hipEventDestroy(ev[i]);
+    }
+    if (executed == 0 && text != nullptr) {
+        set_error("radix_sort_pairs: text source needs at least one pass");
+        return PSS_EINVAL;
+    }
+    *dst = cur;
+    return PSS_OK;
+}
+
+}  // namespace pss

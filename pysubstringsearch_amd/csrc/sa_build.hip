@@ -1,0 +1,500 @@
+// sa_build.hip -- suffix-array construction on gfx950 by prefix doubling over
+// the device radix sort (radix_sort.hip).  Replaces libsais() as called from
+// construct_suffix_array (reference src/lib.rs:24-40, contract
+// src/libsais/libsais.h:57-65): same output, different algorithm -- libsais'
+// induced sorting is a serial dependency chain (libsais.c:2105-2136,
+// 4565-4585), this is a data-parallel sort whose SA is identical because the
+// suffix array of a text is unique.
+//
+// Pipeline (all arrays resident in HBM, u32 indices, n < 2^31):
+//
+//   0. sa_symbols      which byte values occur          (reads n)
+//      sa_recode       text -> dense codes 1..sigma, 0 = "past the end"
+//                      (b = bits(sigma) per symbol)     (reads n, writes n)
+//   1. initial sort    radix sort of all n suffixes by the key made of their
+//                      first h0 = min(16, 64/b) symbols, packed on the fly
+//                      from the codes (the end-of-text code 0 sorts first, so
+//                      a suffix that is a proper prefix of another sorts
+//                      before it and keys are never ambiguous)
+//   2. rerank          equal keys = one group; rank = 1 + position of the
+//                      group head; ISA[suffix] = rank; suffixes in groups of
+//                      size 1 are final.  The rest is compacted into the
+//                      ACTIVE list (position, suffix, group rank).
+//   3. doubling round h: for every active suffix i build the key
+//                      (group rank, ISA[i+h] or 0 past the end), radix-sort
+//                      the active list by it, put the suffixes back into their
+//                      group's slots of SA, split groups where keys differ,
+//                      update ISA, drop the now-unique suffixes, h *= 2.
+//      Only unresolved suffixes are ever touched again (Larsson-Sadakane
+//      style filtering), so sum(active) stays near n on natural text.
+//
+// Wave-level work uses 64-bit ballots throughout: group heads and active
+// flags are ballot masks, head positions come from msb(mask), compaction
+// offsets from v_mbcnt.
+#include "prims.h"
+#include "radix_sort.h"
+#include "sa_build.h"
+
+namespace pss {
+
+// ---------------------------------------------------------------- alphabet --
+
+__global__ __launch_bounds__(256) void sa_symbols_kernel(const u8 *T, u32 n, u32 *present)
+{
+    __shared__ u32 seen[256];
+    const u32 tid = threadIdx.x;
+    seen[tid] = 0;
+    __syncthreads();
+    const u32 nvec = n / 16;
+    const uint4 *Tv = reinterpret_cast<const uint4 *>(T);
+    const bool aligned = ((uintptr_t)T & 15) == 0;
+    if (aligned) {
+        for (u32 i = blockIdx.x * blockDim.x + tid; i < nvec; i += gridDim.x * blockDim.x) {
+            const uint4 v = Tv[i];
+            const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int s = 0; s < 32; s += 8) {
+                    const u32 c = (w[k] >> s) & 0xffu;
+                    if (!seen[c]) seen[c] = 1;
+                }
+        }
+    }
+    const u32 tail0 = aligned ? nvec * 16 : 0;
+    for (u32 i = tail0 + blockIdx.x * blockDim.x + tid; i < n; i += gridDim.x * blockDim.x) {
+        const u32 c = T[i];
+        if (!seen[c]) seen[c] = 1;
+    }
+    __syncthreads();
+    if (seen[tid]) present[tid] = 1;
+}
+
+// codes[i] = lut[T[i]] for i < n, 0 for n <= i < n_pad (n_pad % 16 == 0).
+__global__ __launch_bounds__(256) void sa_recode_kernel(const u8 *T, u32 n, u32 n_pad, const u8 *lut, u8 *codes)
+{
+    __shared__ u8 s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const u32 nvec = n_pad / 16;
+    const bool aligned = ((uintptr_t)T & 15) == 0;
+    for (u32 v = blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += gridDim.x * blockDim.x) {
+        const u32 i0 = v * 16;
+        u32 w[4] = {0, 0, 0, 0};
+        if (aligned && i0 + 16 <= n) {
+            const uint4 x = reinterpret_cast<const uint4 *>(T)[v];
+            w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                u32 o = 0;
+#pragma unroll
+                for (int s = 0; s < 32; s += 8) o |= (u32)s_lut[(w[k] >> s) & 0xffu] << s;
+                w[k] = o;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                u32 o = 0;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const u32 i = i0 + k * 4 + s;
+                    const u32 c = (i < n) ? (u32)s_lut[T[i]] : 0u;
+                    o |= c << (s * 8);
+                }
+                w[k] = o;
+            }
+        }
+        reinterpret_cast<uint4 *>(codes)[v] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// ------------------------------------------------------------------ rerank --
+
+constexpr int RR_BLOCK = 256;
+constexpr int RR_WAVES = RR_BLOCK / kWave;
+constexpr int RR_ROWS = 8;                         // rows of 64 elements per wave
+constexpr int RR_WSEG = RR_ROWS * kWave;           // 512 elements per wave
+constexpr int RR_TILE = RR_WSEG * RR_WAVES;        // 2048 elements per tile
+constexpr u32 RR_MAX_RANGES = 1024;
+
+struct RerankArgs {
+    const u64 *keys;     // sorted keys of the m elements
+    const u32 *idx;      // their suffix indices
+    const u32 *pos;      // their SA positions (nullptr: element t sits at SA position t)
+    u32 m;
+    u32 num_tiles, tiles_per_range, num_ranges;
+    u32 *agg_head;       // [ranges] 1 + last group-head index of the range (0 = none)
+    u32 *agg_cnt;        // [ranges] active elements of the range
+    u32 *SA;
+    u32 *ISA;
+    u32 *pos_out, *idx_out, *grp_out;
+    u32 *counters;       // [0] total active
+};
+
+struct WaveFlags {
+    u64 head[RR_ROWS];   // ballot: element starts a group
+    u64 act[RR_ROWS];    // ballot: element's group has more than one member
+    u64 valid[RR_ROWS];
+};
+
+// Loads the wave's 512-element segment (element (r, lane) = wbase + 64 r + lane)
+// and derives group-head / active ballots from neighbouring keys.
+__device__ __forceinline__ void wave_flags(const u64 *keys, u32 m, u32 wbase, WaveFlags &f)
+{
+    const u32 lane = lane_id();
+    u64 key[RR_ROWS];
+#pragma unroll
+    for (int r = 0; r < RR_ROWS; ++r) {
+        const u32 j = wbase + r * kWave + lane;
+        key[r] = (j < m) ? keys[j] : 0;
+    }
+    // key just before the segment (lane 0) and just after it (lane 63)
+    u64 edge = 0;
+    if (lane == 0 && wbase > 0 && wbase < m) edge = keys[wbase - 1];
+    const u32 jn = wbase + RR_WSEG;
+    if (lane == 63 && jn < m) edge = keys[jn];
+    u64 last = 0;   // key of lane 63 of the previous row
+#pragma unroll
+    for (int r = 0; r < RR_ROWS; ++r) {
+        const u32 j = wbase + r * kWave + lane;
+        u64 pk = __shfl_up(key[r], 1);
+        if (lane == 0) pk = (r == 0) ? edge : last;
+        last = __shfl(key[r], 63);
+        const bool valid = j < m;
+        const bool head = valid && (j == 0 || key[r] != pk);
+        f.head[r] = __ballot(head);
+        f.valid[r] = __ballot(valid);
+    }
+    // is the element right after the segment a head (or the end of the array)?
+    const bool next_seg_head = (jn >= m) || (key[RR_ROWS - 1] != edge);
+    const u64 nsh = (__ballot(next_seg_head) >> 63) & 1ull;   // lane 63's verdict
+#pragma unroll
+    for (int r = 0; r < RR_ROWS; ++r) {
+        // "head or nothing" mask: invalid slots count as heads for the element before them
+        const u64 hv = f.head[r] | ~f.valid[r];
+        const u64 first_next = (r + 1 < RR_ROWS) ? ((f.head[r + 1] | ~f.valid[r + 1]) & 1ull) : nsh;
+        const u64 next = (hv >> 1) | (first_next << 63);
+        f.act[r] = f.valid[r] & ~(f.head[r] & next);
+    }
+}
+
+__global__ __launch_bounds__(RR_BLOCK) void rr_reduce_kernel(RerankArgs a)
+{
+    __shared__ u32 s_head, s_cnt;
+    const u32 g = blockIdx.x;
+    if (threadIdx.x == 0) { s_head = 0; s_cnt = 0; }
+    __syncthreads();
+    const u32 tile0 = g * a.tiles_per_range, tile1 = min(tile0 + a.tiles_per_range, a.num_tiles);
+    u32 whead = 0, wcnt = 0;
+    for (u32 tile = tile0; tile < tile1; ++tile) {
+        const u32 wbase = tile * RR_TILE + wave_id() * RR_WSEG;
+        if (wbase >= a.m) break;
+        WaveFlags f;
+        wave_flags(a.keys, a.m, wbase, f);
+#pragma unroll
+        for (int r = 0; r < RR_ROWS; ++r) {
+            if (f.head[r]) whead = wbase + r * kWave + (63 - __builtin_clzll(f.head[r])) + 1;
+            wcnt += (u32)__popcll(f.act[r]);
+        }
+    }
+    if (lane_id() == 0) {
+        atomicMax(&s_head, whead);
+        atomicAdd(&s_cnt, wcnt);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { a.agg_head[g] = s_head; a.agg_cnt[g] = s_cnt; }
+}
+
+// Exclusive max-scan of agg_head and sum-scan of agg_cnt over <= 1024 ranges.
+__global__ __launch_bounds__(1024) void rr_scan_kernel(u32 *agg_head, u32 *agg_cnt, u32 num_ranges, u32 *counters)
+{
+    __shared__ u32 s_h[16], s_c[16];
+    const u32 t = threadIdx.x, lane = lane_id(), w = wave_id();
+    const u32 h = (t < num_ranges) ? agg_head[t] : 0, c = (t < num_ranges) ? agg_cnt[t] : 0;
+    const u32 ih = wave_incl_max(h), ic = wave_incl_sum(c);
+    if (lane == 63) { s_h[w] = ih; s_c[w] = ic; }
+    __syncthreads();
+    u32 bh = 0, bc = 0, tot = 0;
+    for (u32 k = 0; k < 16; ++k) {
+        if (k < w) { bh = max(bh, s_h[k]); bc += s_c[k]; }
+        tot += s_c[k];
+    }
+    u32 eh = __shfl_up(ih, 1), ec = ic - c;
+    if (lane == 0) eh = 0;
+    if (t < num_ranges) { agg_head[t] = max(bh, eh); agg_cnt[t] = bc + ec; }
+    if (t == 0) counters[0] = tot;
+}
+
+__global__ __launch_bounds__(RR_BLOCK) void rr_apply_kernel(RerankArgs a)
+{
+    __shared__ u32 s_wh[RR_WAVES], s_wc[RR_WAVES];
+    __shared__ u32 s_carry_h, s_carry_c;
+    const u32 g = blockIdx.x, lane = lane_id(), w = wave_id();
+    if (threadIdx.x == 0) { s_carry_h = a.agg_head[g]; s_carry_c = a.agg_cnt[g]; }
+    const u32 tile0 = g * a.tiles_per_range, tile1 = min(tile0 + a.tiles_per_range, a.num_tiles);
+    for (u32 tile = tile0; tile < tile1; ++tile) {
+        const u32 wbase = tile * RR_TILE + w * RR_WSEG;
+        WaveFlags f;
+        wave_flags(a.keys, a.m, min(wbase, a.m), f);
+        u32 whead = 0, wcnt = 0;
+#pragma unroll
+        for (int r = 0; r < RR_ROWS; ++r) {
+            if (f.head[r]) whead = wbase + r * kWave + (63 - __builtin_clzll(f.head[r])) + 1;
+            wcnt += (u32)__popcll(f.act[r]);
+        }
+        if (lane == 0) { s_wh[w] = whead; s_wc[w] = wcnt; }
+        __syncthreads();
+        u32 carry_h = s_carry_h, carry_c = s_carry_c;
+        u32 tile_h = carry_h, tile_c = carry_c;
+#pragma unroll
+        for (int k = 0; k < RR_WAVES; ++k) {
+            if (k < (int)w) { carry_h = max(carry_h, s_wh[k]); carry_c += s_wc[k]; }
+            tile_h = max(tile_h, s_wh[k]);
+            tile_c += s_wc[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { s_carry_h = tile_h; s_carry_c = tile_c; }
+        // outputs
+#pragma unroll
+        for (int r = 0; r < RR_ROWS; ++r) {
+            const u32 rowbase = wbase + r * kWave;
+            const u32 j = rowbase + lane;
+            const u64 le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+            const u64 hm = f.head[r] & le;
+            const u32 hd1 = hm ? rowbase + (63 - __builtin_clzll(hm)) + 1 : carry_h;   // 1 + head index
+            if (j < a.m) {
+                const u32 hd = hd1 - 1;
+                const u32 newrank = (a.pos ? a.pos[hd] : hd) + 1;
+                const u32 pj = a.pos ? a.pos[j] : j;
+                const u32 ij = a.idx[j];
+                a.SA[pj] = ij;
+                a.ISA[ij] = newrank;
+                if ((f.act[r] >> lane) & 1ull) {
+                    const u32 u = carry_c + mbcnt(f.act[r]);
+                    a.pos_out[u] = pj;
+                    a.idx_out[u] = ij;
+                    a.grp_out[u] = newrank;
+                }
+            }
+            if (f.head[r]) carry_h = rowbase + (63 - __builtin_clzll(f.head[r])) + 1;
+            carry_c += (u32)__popcll(f.act[r]);
+        }
+    }
+}
+
+// key(t) = (group rank << rank_bits) | rank of suffix idx[t]+h (0 past the end).
+// Also reduces OR / AND of all keys so the host can skip constant digits.
+__global__ __launch_bounds__(256) void build_keys_kernel(const u32 *idx, const u32 *grp, const u32 *ISA, u32 m,
+                                                           u32 n, u32 h, int rank_bits, u64 *keys, u64 *red)
+{
+    u64 vor = 0, vand = ~0ull;
+    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < m; t += gridDim.x * blockDim.x) {
+        const u64 i2 = (u64)idx[t] + h;
+        const u32 r2 = (i2 < n) ? ISA[i2] : 0u;
+        const u64 key = ((u64)grp[t] << rank_bits) | r2;
+        keys[t] = key;
+        vor |= key;
+        vand &= key;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        vor |= __shfl_xor(vor, o);
+        vand &= __shfl_xor(vand, o);
+    }
+    if (lane_id() == 0) {
+        atomicOr(reinterpret_cast<unsigned long long *>(&red[0]), (unsigned long long)vor);
+        atomicAnd(reinterpret_cast<unsigned long long *>(&red[1]), (unsigned long long)vand);
+    }
+}
+
+// -------------------------------------------------------------------- host --
+
+static void rerank_geometry(u32 m, RerankArgs &a)
+{
+    a.m = m;
+    a.num_tiles = (u32)(((u64)m + RR_TILE - 1) / RR_TILE);
+    a.tiles_per_range = (a.num_tiles + RR_MAX_RANGES - 1) / RR_MAX_RANGES;
+    if (a.tiles_per_range == 0) a.tiles_per_range = 1;
+    a.num_ranges = (a.num_tiles + a.tiles_per_range - 1) / a.tiles_per_range;
+}
+
+enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK };
+
+int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, uint32_t flags, pss_sa_stats *stats)
+{
+    pss_sa_stats st;
+    memset(&st, 0, sizeof st);
+    if (n_in < 0 || (n_in > 0 && (d_T == nullptr || d_SA == nullptr))) {
+        set_error("pss_sa_build: bad arguments");
+        return PSS_EINVAL;
+    }
+    const u32 n = (u32)n_in;
+    const bool profile = flags & 1u;
+    hipStream_t s = ctx->stream;
+    if (n < 2) {
+        if (n == 1) PSS_HIP(hipMemsetAsync(d_SA, 0, 4, s));
+        PSS_HIP(hipStreamSynchronize(s));
+        if (stats) *stats = st;
+        return PSS_OK;
+    }
+    const u8 *T = static_cast<const u8 *>(d_T);
+    u32 *SA = static_cast<u32 *>(d_SA);
+
+    const size_t n_pad = round_up((size_t)n, 16) + 64;
+    PSS_TRY(ctx->slot[S_CODES].reserve(n_pad));
+    PSS_TRY(ctx->slot[S_K0].reserve((size_t)n * 8));
+    PSS_TRY(ctx->slot[S_K1].reserve((size_t)n * 8));
+    PSS_TRY(ctx->slot[S_V0].reserve((size_t)n * 4));
+    PSS_TRY(ctx->slot[S_V1].reserve((size_t)n * 4));
+    PSS_TRY(ctx->slot[S_ISA].reserve((size_t)n * 4));
+    PSS_TRY(ctx->slot[S_P0].reserve((size_t)n * 4));
+    PSS_TRY(ctx->slot[S_P1].reserve((size_t)n * 4));
+    PSS_TRY(ctx->slot[S_GRP].reserve((size_t)n * 4));
+    const size_t sort_ws = radix_sort_workspace_bytes();
+    PSS_TRY(ctx->slot[S_WORK].reserve(sort_ws + 65536));
+    u8 *work = ctx->slot[S_WORK].as<u8>();
+    u8 *small = work + sort_ws;                       // 64 KiB of small device state
+    u32 *d_present = reinterpret_cast<u32 *>(small);              // [256]
+    u8 *d_lut = small + 1024;                                     // [256]
+    u32 *d_agg_head = reinterpret_cast<u32 *>(small + 2048);      // [1024]
+    u32 *d_agg_cnt = reinterpret_cast<u32 *>(small + 2048 + 4096);
+    u64 *d_red = reinterpret_cast<u64 *>(small + 2048 + 8192);    // [2]
+    u32 *d_counters = reinterpret_cast<u32 *>(small + 2048 + 8192 + 64);
+
+    u8 *codes = ctx->slot[S_CODES].as<u8>();
+    u64 *K[2] = {ctx->slot[S_K0].as<u64>(), ctx->slot[S_K1].as<u64>()};
+    u32 *V[2] = {ctx->slot[S_V0].as<u32>(), ctx->slot[S_V1].as<u32>()};
+    u32 *ISA = ctx->slot[S_ISA].as<u32>();
+    u32 *P[2] = {ctx->slot[S_P0].as<u32>(), ctx->slot[S_P1].as<u32>()};
+    u32 *GRP = ctx->slot[S_GRP].as<u32>();
+    u32 *h_small = static_cast<u32 *>(ctx->pinned);
+
+    hipEvent_t ev0, ev1;
+    PSS_HIP(hipEventCreate(&ev0));
+    PSS_HIP(hipEventCreate(&ev1));
+    PSS_HIP(hipEventRecord(ev0, s));
+
+    // ---- 0. alphabet ----
+    const int grid_stream = ctx->num_cus * 8;
+    PSS_HIP(hipMemsetAsync(d_present, 0, 1024, s));
+    hipLaunchKernelGGL(sa_symbols_kernel, dim3(grid_stream), dim3(256), 0, s, T, n, d_present);
+    PSS_HIP(hipMemcpyAsync(h_small, d_present, 1024, hipMemcpyDeviceToHost, s));
+    PSS_HIP(hipStreamSynchronize(s));
+    u8 lut[256];
+    u32 sigma = 0;
+    for (int c = 0; c < 256; ++c) lut[c] = h_small[c] ? (u8)(++sigma) : 0;   // codes 1..sigma (sigma==256: see below)
+    int b = 1;
+    while ((1u << b) <= sigma) ++b;               // codes 0..sigma need b bits
+    int plus_one = 0;
+    if (sigma == 256) {
+        // 257 code points do not fit a byte: keep the raw bytes and let the key
+        // packer add 1 to every in-text symbol (9-bit codes, 0 = past the end).
+        b = 9;
+        plus_one = 1;
+    }
+    int key_chars = 64 / b;
+    if (key_chars > 16) key_chars = 16;
+    if (const char *e = getenv("PSS_KEY_CHARS")) {
+        int v = atoi(e);
+        if (v >= 1 && v <= key_chars) key_chars = v;
+    }
+    st.sigma = sigma;
+    st.code_bits = (u32)b;
+    st.key_chars = (u32)key_chars;
+    if (sigma == 256) {
+        for (int c = 0; c < 256; ++c) lut[c] = (u8)c;
+    }
+    memcpy(h_small + 512, lut, 256);
+    PSS_HIP(hipMemcpyAsync(d_lut, h_small + 512, 256, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(sa_recode_kernel, dim3(grid_stream), dim3(256), 0, s, T, n, (u32)n_pad, d_lut, codes);
+
+    // ---- 1. initial sort on the first key_chars symbols ----
+    SortStats ss;
+    TextKeys tk{codes, b, key_chars, plus_one};
+    const int key_bits0 = key_chars * b;
+    int cur = 0;
+    PSS_TRY(radix_sort_pairs(ctx, K, V, n, key_bits0, 0xffffffffu, &tk, 0, work, &cur, profile, &ss));
+    st.initial_passes = (u32)ss.launches;
+
+    // ---- 2. rerank + compaction ----
+    int rank_bits = 1;
+    while ((1ull << rank_bits) <= (u64)n) ++rank_bits;      // ranks 0..n
+    RerankArgs ra;
+    ra.agg_head = d_agg_head;
+    ra.agg_cnt = d_agg_cnt;
+    ra.SA = SA;
+    ra.ISA = ISA;
+    ra.counters = d_counters;
+    u32 m = n;
+    int pcur = 0;                // P[pcur] holds the positions of the active list (after round 0)
+    bool identity_pos = true;
+    u64 h = (u64)key_chars;
+    for (int round = 0;; ++round) {
+        if (round > 64) {
+            set_error("sa_build: no convergence after 64 rounds (internal error)");
+            return PSS_EDEVICE;
+        }
+        rerank_geometry(m, ra);
+        ra.keys = K[cur];
+        ra.idx = V[cur];
+        ra.pos = identity_pos ? nullptr : P[pcur];
+        ra.pos_out = P[pcur ^ 1];
+        ra.idx_out = V[cur ^ 1];
+        ra.grp_out = GRP;
+        hipLaunchKernelGGL(rr_reduce_kernel, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
+        hipLaunchKernelGGL(rr_scan_kernel, dim3(1), dim3(1024), 0, s, d_agg_head, d_agg_cnt, ra.num_ranges, d_counters);
+        hipLaunchKernelGGL(rr_apply_kernel, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
+        PSS_HIP(hipMemcpyAsync(h_small, d_counters, 4, hipMemcpyDeviceToHost, s));
+        PSS_HIP(hipStreamSynchronize(s));
+        PSS_HIP(hipGetLastError());
+        const u32 m_next = h_small[0];
+        if (m_next == 0) break;
+        if (h >= (u64)n) {
+            set_error("sa_build: %u suffixes unresolved at h=%llu >= n (internal error)", m_next,
+                      (unsigned long long)h);
+            return PSS_EDEVICE;
+        }
+        // ---- 3. doubling round ----
+        m = m_next;
+        pcur ^= 1;
+        identity_pos = false;
+        const int src = cur ^ 1;             // V[src] = compacted suffix indices
+        h_small[0] = 0; h_small[1] = 0; h_small[2] = 0xffffffffu; h_small[3] = 0xffffffffu;
+        PSS_HIP(hipMemcpyAsync(d_red, h_small, 16, hipMemcpyHostToDevice, s));
+        const u32 grid = (u32)std::min<u64>((u64)grid_stream, ((u64)m + 255) / 256);
+        hipLaunchKernelGGL(build_keys_kernel, dim3(grid), dim3(256), 0, s, V[src], GRP, ISA, m, n,
+                           (u32)std::min<u64>(h, 0xffffffffull), rank_bits, K[src], d_red);
+        PSS_HIP(hipMemcpyAsync(h_small, d_red, 16, hipMemcpyDeviceToHost, s));
+        PSS_HIP(hipStreamSynchronize(s));
+        const u64 vor = (u64)h_small[0] | ((u64)h_small[1] << 32);
+        const u64 vand = (u64)h_small[2] | ((u64)h_small[3] << 32);
+        const u64 varying = vor & ~vand;
+        const int key_bits = 2 * rank_bits;
+        u32 mask = 0;
+        for (int p = 0; p < (key_bits + 7) / 8; ++p)
+            if ((varying >> (8 * p)) & 0xffull) mask |= 1u << p;
+        SortStats rs;
+        PSS_TRY(radix_sort_pairs(ctx, K, V, m, key_bits, mask, nullptr, src, work, &cur, profile, &rs));
+        st.rounds += 1;
+        st.round_passes += (u32)rs.launches;
+        st.sum_active += m;
+        ss.launches += rs.launches;
+        ss.elems += rs.elems;
+        ss.ms += rs.ms;
+        h *= 2;
+    }
+    PSS_HIP(hipEventRecord(ev1, s));
+    PSS_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    PSS_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    st.ms_total = ms;
+    st.ms_sort = ss.ms;
+    st.sort_launches = ss.launches;
+    st.sort_elems = ss.elems;
+    if (stats) *stats = st;
+    return PSS_OK;
+}
+
+}  // namespace pss

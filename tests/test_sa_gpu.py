@@ -1,0 +1,64 @@
+"""GPU parity: pss_sa_build (HIP, through the C ABI) == the oracle's suffix
+array, bit for bit (libsais from oracle/_ref when built, else the restatement)."""
+import random
+
+import numpy as np
+import pytest
+
+from tests.util import gen_corpus, sa_gpu
+
+pytestmark = pytest.mark.gpu
+
+ALPHABETS = [b'a', b'ab', b'ab\n', b'\x00', b'\x00\n', b'\x00\xff\n', bytes(range(256)), bytes(range(1, 256)),
+             b'abcdefghijklmnopqrstuvwxyz0123456789 .\n']
+
+
+def test_tiny_contract(oracle):
+    assert sa_gpu(b'').size == 0
+    assert sa_gpu(b'x').tolist() == [0]
+    assert sa_gpu(b'\x00\x00').tolist() == [1, 0]
+    assert sa_gpu(b'ba').tolist() == [1, 0]
+    assert sa_gpu(b'ab\n').tolist() == oracle.sa(b'ab\n').tolist()
+
+
+def test_random_small(oracle):
+    rng = random.Random(7)
+    for it in range(300):
+        a = rng.choice(ALPHABETS)
+        n = rng.randint(2, 300)
+        s = bytes(rng.choice(a) for _ in range(n))
+        got = sa_gpu(s)
+        exp = oracle.sa(s)
+        assert (got == exp).all(), (s, got.tolist(), exp.tolist())
+
+
+@pytest.mark.parametrize('n', [4095, 4096, 4097, 8191, 65536, 100003, 1 << 20])
+@pytest.mark.parametrize('alpha', [2, 4, 39, 256])
+def test_random_sizes(oracle, n, alpha):
+    rng = np.random.default_rng(n * 1000 + alpha)
+    t = rng.integers(0, alpha, size=n, dtype=np.uint8)
+    if alpha == 39:
+        t = np.frombuffer(b'abcdefghijklmnopqrstuvwxyz0123456789 .\n', dtype=np.uint8)[t]
+    got = sa_gpu(t)
+    exp = oracle.sa(t)
+    assert (got == exp).all()
+
+
+@pytest.mark.parametrize('kind,n', [(0, 1 << 20), (1, 1 << 20), (2, 1 << 18), (3, 1 << 16), (3, 1 << 18)])
+def test_corpora(oracle, kind, n):
+    t = gen_corpus(kind, n)
+    got = sa_gpu(t)
+    exp = oracle.sa(t)
+    assert (got == exp).all()
+
+
+def test_structured(oracle):
+    fib = [b'a', b'ab']
+    while len(fib[-1]) < 987:
+        fib.append(fib[-1] + fib[-2])
+    cases = [b'a' * 1000 + b'\n', fib[-1], (b'a' * 63 + b'\n') * 64, b'\x00' * 5000, b'ab' * 5000,
+             bytes(range(256)) * 40, b'\xff' * 4097 + b'\x00' * 17]
+    for s in cases:
+        got = sa_gpu(s)
+        exp = oracle.sa(s)
+        assert (got == exp).all(), s[:32]
