@@ -48,7 +48,30 @@ class SearchStats(ctypes.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+def _preload_hip_runtime() -> None:
+    """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own
+    libamdhip64.so (SONAME libamdhip64.so.7) and libhsa-runtime64.so; if libpss
+    pulled in /opt/rocm's copy first, a later ``import torch`` would load a
+    second runtime that cannot see the GPU.  Loading torch's copy first (by
+    path, without importing torch) makes both sides share it; without torch
+    the system ROCm runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def _load() -> ctypes.CDLL:
+    _preload_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f'{LIB_PATH} is missing: build the HIP engine first '

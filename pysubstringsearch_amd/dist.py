@@ -1,0 +1,117 @@
+"""Multi-GPU sharding of the search path: one process per GPU
+(``torch.distributed``; backend "nccl" is RCCL on ROCm, "gloo" on CPU tests).
+
+Chunks are independent (reference src/lib.rs:105-124 builds and src/lib.rs:207
+searches each chunk alone), so chunk c lives on rank ``c % world_size`` and no
+collective sits on the data path.  The only exchange is the gather of result
+strings to one rank (the reference concatenates per-chunk results under a
+mutex, src/lib.rs:280): per-query counts, entry lengths and entry bytes are
+gathered and re-interleaved query-major.  Dedupe stays local to the owning
+rank (per (query, chunk), src/lib.rs:262,274) -- entries live in exactly one
+chunk, so a cross-rank dedupe would wrongly drop identical entries.
+"""
+import typing
+
+import numpy as np
+
+
+def chunk_owner(chunk_index: int, world_size: int) -> int:
+    return chunk_index % world_size
+
+
+def pack_entries(entries: typing.Sequence[bytes]) -> typing.Tuple[np.ndarray, np.ndarray]:
+    lens = np.fromiter((len(e) for e in entries), dtype=np.int64, count=len(entries))
+    blob = np.frombuffer(b''.join(entries), dtype=np.uint8)
+    return blob, lens
+
+
+def merge_query_major(per_rank: typing.Sequence[typing.Tuple[np.ndarray, np.ndarray, np.ndarray]]
+                      ) -> typing.Tuple[typing.List[bytes], np.ndarray]:
+    """per_rank[r] = (blob uint8, lens int64[E_r], counts int64[nq]) with rank
+    r's entries query-major.  Returns all entries query-major (inside a query:
+    rank-major) and the summed per-query counts."""
+    nq = len(per_rank[0][2])
+    qid, rk, start, length = [], [], [], []
+    for r, (blob, lens, counts) in enumerate(per_rank):
+        assert len(counts) == nq and int(counts.sum()) == len(lens)
+        qid.append(np.repeat(np.arange(nq, dtype=np.int64), counts))
+        rk.append(np.full(len(lens), r, dtype=np.int64))
+        off = np.zeros(len(lens) + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        start.append(off[:-1])
+        length.append(lens)
+    qid, rk = np.concatenate(qid), np.concatenate(rk)
+    start, length = np.concatenate(start), np.concatenate(length)
+    order = np.lexsort((rk, qid))          # stable: keeps each rank's local order inside (query, rank)
+    blobs = [bytes(p[0].tobytes()) for p in per_rank]
+    out = [blobs[rk[i]][start[i]:start[i] + length[i]] for i in order]
+    total = np.sum([p[2] for p in per_rank], axis=0).astype(np.int64)
+    return out, total
+
+
+def gather_results(entries: typing.Sequence[bytes], counts: typing.Sequence[int], group=None, dst: int = 0):
+    """Collective: every rank passes its local (entries, per-query counts);
+    rank ``dst`` gets (all entries query-major, total counts), others None."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+    blob, lens = pack_entries(entries)
+    cnt = np.asarray(counts, dtype=np.int64)
+    sizes = torch.tensor([len(lens), len(blob)], dtype=torch.int64, device=dev)
+    all_sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes, group=group)
+    all_sizes = torch.stack(all_sizes).cpu().numpy()
+    max_e, max_b = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max())
+
+    def padded(a, n, dtype):
+        t = torch.zeros(max(n, 1), dtype=dtype)
+        if len(a):
+            t[:len(a)] = torch.from_numpy(np.ascontiguousarray(a))
+        return t.to(dev)
+
+    t_cnt = torch.from_numpy(cnt).to(dev) if len(cnt) else torch.zeros(1, dtype=torch.int64, device=dev)
+    t_len = padded(lens, max_e, torch.int64)
+    t_blob = padded(blob, max_b, torch.uint8)
+    is_dst = rank == dst
+    g_cnt = [torch.empty_like(t_cnt) for _ in range(world)] if is_dst else None
+    g_len = [torch.empty_like(t_len) for _ in range(world)] if is_dst else None
+    g_blob = [torch.empty_like(t_blob) for _ in range(world)] if is_dst else None
+    dist.gather(t_cnt, g_cnt, dst=dst, group=group)
+    dist.gather(t_len, g_len, dst=dst, group=group)
+    dist.gather(t_blob, g_blob, dst=dst, group=group)
+    if not is_dst:
+        return None
+    per_rank = []
+    for r in range(world):
+        e, b = int(all_sizes[r, 0]), int(all_sizes[r, 1])
+        per_rank.append((g_blob[r].cpu().numpy()[:b], g_len[r].cpu().numpy()[:e],
+                         g_cnt[r].cpu().numpy()[:len(cnt)]))
+    return merge_query_major(per_rank)
+
+
+class ShardedReader:
+    """Reader over the chunks owned by this rank; ``search_multiple`` is a
+    collective returning the full result on rank ``dst`` (None elsewhere)."""
+
+    def __init__(self, index_file_path: str, group=None, device: typing.Optional[int] = None, reader=None):
+        import torch.distributed as dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        if reader is None:
+            from . import Reader
+            reader = Reader(index_file_path, device=device, shard=(self.rank, self.world))
+        self.local = reader
+
+    def search_multiple_bytes(self, patterns: typing.Sequence[bytes], dst: int = 0):
+        entries, counts = self.local.search_batch_raw(list(patterns))
+        return gather_results(entries, counts, self.group, dst)
+
+    def search_multiple(self, substrings: typing.List[str], dst: int = 0):
+        got = self.search_multiple_bytes([s.encode('utf-8') for s in substrings], dst)
+        return None if got is None else [e.decode('utf-8') for e in got[0]]
+
+    def search(self, substring: str, dst: int = 0):
+        return self.search_multiple([substring], dst)

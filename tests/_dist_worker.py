@@ -1,0 +1,47 @@
+"""world_size-2 gloo worker for tests/test_host.py::test_sharded_gather_gloo."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch.distributed as dist  # noqa: E402
+
+from pysubstringsearch_amd import dist as pdist  # noqa: E402
+
+
+class StubReader:
+    """Stands in for the per-rank device Reader: canned local results."""
+
+    def __init__(self, table):
+        self.table = table
+
+    def search_batch_raw(self, patterns):
+        entries, counts = [], []
+        for p in patterns:
+            got = self.table.get(p.decode(), [])
+            entries.extend(e.encode() for e in got)
+            counts.append(len(got))
+        return entries, counts
+
+
+def main():
+    rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    tables = [
+        {'ten': ['ten', 'tenten'], 'x': [], 'e': ['one', 'three']},
+        {'ten': ['ten'], 'x': ['x'], 'e': []},
+    ]
+    r = pdist.ShardedReader('unused', reader=StubReader(tables[rank]))
+    got = r.search_multiple(['ten', 'zzz', 'x', 'e', 'ten'])
+    raw = r.search_multiple_bytes([b'e', b'ten'])
+    if rank == 0:
+        json.dump({'got': got, 'counts': raw[1].tolist(), 'raw': [e.decode() for e in raw[0]]}, open(out, 'w'))
+    else:
+        assert got is None and raw is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,216 @@
+"""Generates the committed golden fixtures (run in the dev container, where
+/root/reference exists and oracle/_ref/libsais.so -- the REAL reference suffix
+array builder -- can be built).
+
+    python tests/golden/make_golden.py
+
+Outputs (data only: inputs + expected outputs):
+  reference_cases.json   the reference's own seven tests
+                         (tests/test_pysubstringsearch.py:48-294) and the README
+                         usage block (README.md:76-117) re-expressed as
+                         corpus / query / expected-result data, plus the .idx
+                         bytes the reference would write for each corpus
+                         (container layout src/lib.rs:112-119, SA by libsais).
+  container_cases.json   behaviour no reference test pins (multi-chunk,
+                         dump_data, empty entry, empty / newline queries, the
+                         Vec-growth quirk, file ingest): produced by the oracle
+                         restatement with libsais SAs -- labelled
+                         "parity unpinned by the reference's tests".
+  sa_kats.json           suffix-array known answers from libsais for structured
+                         and generated inputs (sha256 of the i32le SA; full SA
+                         for the small ones).
+"""
+import hashlib
+import json
+import os
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import numpy as np  # noqa: E402
+
+from oracle import oracle as O  # noqa: E402
+
+assert O.have_reference(), 'needs oracle/_ref/libsais.so (make -C oracle)'
+O.use_reference_sa(True)
+
+NUMBERS = ['one', 'two', 'three', 'four', 'five', 'six', 'seven', 'eight', 'nine', 'ten']
+ARABIC = [
+    'رجعوني عنيك لأيامي اللي راحوا', 'علموني أندم على الماضي وجراحه', 'اللي شفته قبل ما تشوفك عنيه',
+    'عمر ضايع يحسبوه إزاي عليّ', 'انت عمري اللي ابتدي بنورك صباحه', 'قد ايه من عمري قبلك راح وعدّى',
+    'يا حبيبي قد ايه من عمري راح', 'ولا شاف القلب قبلك فرحة واحدة', 'ولا داق في الدنيا غير طعم الجراح',
+    'ابتديت دلوقت بس أحب عمري', 'ابتديت دلوقت اخاف لا العمر يجري', 'كل فرحه اشتاقها من قبلك خيالي',
+    'التقاها في نور عنيك قلبي وفكري', 'يا حياة قلبي يا أغلى من حياتي', 'ليه ما قابلتش هواك يا حبيبي بدري',
+    'اللي شفته قبل ما تشوفك عنيه', 'عمر ضايع يحسبوه إزاي عليّ', 'انت عمري اللي ابتدي بنورك صباحه',
+    'الليالي الحلوه والشوق والمحبة', 'من زمان والقلب شايلهم عشانك', 'دوق معايا الحب دوق حبه بحبه',
+    'من حنان قلبي اللي طال شوقه لحنانك', 'هات عنيك تسرح في دنيتهم عنيه', 'هات ايديك ترتاح للمستهم ايديه',
+]
+README = ['some short string', 'another but now a longer string', 'more text to add']
+
+# (name, reference test lines, entries, [(query, expected)], [(queries, expected)] for search_multiple)
+REFERENCE_CASES = [
+    ('test_sanity', 'tests/test_pysubstringsearch.py:58-103', NUMBERS,
+     [('four', ['four']), ('f', ['four', 'five']), ('our', ['four']), ('aaa', [])], []),
+    ('test_edgecases', 'tests/test_pysubstringsearch.py:105-149', NUMBERS + ['tenten'],
+     [('none', []), ('one', ['one']), ('onet', []), ('ten', ['ten', 'tenten'])], []),
+    ('test_unicode', 'tests/test_pysubstringsearch.py:151-211', ARABIC,
+     [('زمان', ['من زمان والقلب شايلهم عشانك']),
+      ('في', ['هات عنيك تسرح في دنيتهم عنيه', 'التقاها في نور عنيك قلبي وفكري', 'ولا داق في الدنيا غير طعم الجراح']),
+      ('حنان', ['من حنان قلبي اللي طال شوقه لحنانك']), ('none', [])], []),
+    ('test_multiple_words_string', 'tests/test_pysubstringsearch.py:213-228', README,
+     [('short', ['some short string'])], []),
+    ('test_short_string', 'tests/test_pysubstringsearch.py:230-242', ['ab'], [('a', ['ab'])], []),
+    ('test_multiple_strings', 'tests/test_pysubstringsearch.py:244-294', NUMBERS + ['tenten'],
+     [], [(['ee', 'ven'], ['three', 'seven'])]),
+    ('readme_usage', 'README.md:76-117', README,
+     [('short', ['some short string']), ('string', ['some short string', 'another but now a longer string'])],
+     [(['short', 'longer'], ['some short string', 'another but now a longer string'])]),
+]
+
+
+def build_idx(entries, max_chunk_len=None, dump_after=()):
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, 'o.idx')
+        w = O.OracleWriter(p, max_chunk_len)
+        for i, e in enumerate(entries):
+            w.add_entry(e)
+            if i in dump_after:
+                w.dump_data()
+        w.finalize()
+        w.close()
+        return open(p, 'rb').read()
+
+
+def search_idx(idx_bytes, queries):
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, 'o.idx')
+        open(p, 'wb').write(idx_bytes)
+        r = O.OracleReader(p)
+        out = {q: sorted(r.search(q)) for q in queries}
+        r.close()
+        return out
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+def main():
+    # ---- reference_cases.json ----
+    cases = []
+    for name, src, entries, singles, multis in REFERENCE_CASES:
+        idx = build_idx(entries)
+        got = search_idx(idx, [q for q, _ in singles])
+        for q, exp in singles:   # the oracle must reproduce the reference's own expectations
+            assert got[q] == sorted(exp), (name, q, got[q], exp)
+        cases.append({
+            'name': name, 'source': src, 'entries': entries,
+            'searches': [{'substring': q, 'expected': exp} for q, exp in singles],
+            'search_multiple': [{'substrings': qs, 'expected': exp} for qs, exp in multis],
+            'idx_sha256': sha(idx), 'idx_hex': idx.hex() if len(idx) <= 4096 else None, 'idx_len': len(idx),
+        })
+    cases.append({'name': 'test_file_not_found', 'source': 'tests/test_pysubstringsearch.py:48-56',
+                  'missing_path': 'missing_index_file_path', 'raises': 'FileNotFoundError'})
+    json.dump({'cases': cases}, open(os.path.join(HERE, 'reference_cases.json'), 'w'), ensure_ascii=False, indent=1)
+
+    # ---- container_cases.json (parity unpinned by the reference's tests) ----
+    cc = []
+
+    def add_case(name, entries, queries, max_chunk_len=None, dump_after=(), note=''):
+        idx = build_idx(entries, max_chunk_len, dump_after)
+        res = search_idx(idx, queries)
+        cc.append({'name': name, 'note': note, 'entries': entries, 'max_chunk_len': max_chunk_len,
+                   'dump_after': list(dump_after), 'idx_hex': idx.hex(), 'idx_sha256': sha(idx),
+                   'searches': [{'substring': q, 'expected': res[q]} for q in queries]})
+
+    add_case('multi_chunk_8', ['ten', 'ten', 'tenten', 'x'], ['ten', 'x', 'en\n', '', 'tent', 'n'], max_chunk_len=8,
+             note='3 chunks: "ten\\nten\\n", "tenten\\n", "x\\n"; identical entries are both returned')
+    add_case('single_empty_entry', [''], ['', 'a'], note='idx = 01000000 0a 04000000 00000000')
+    add_case('readme_edge_queries', README, ['', 'g\n', 'string\nanother', 'string\n', '\n', 'zzz', 'o'],
+             note='empty query returns every entry; queries may span the newline (src/lib.rs:224)')
+    add_case('explicit_dump', NUMBERS, ['e', 'o', 'ne', 'x'], dump_after=(2, 5),
+             note='dump_data() forces chunk boundaries (src/lib.rs:105-124)')
+    add_case('entry_equals_limit', ['abcd', 'ef', 'gh', 'ijklmnop', 'q'], ['a', 'e', 'g', 'q', ''], max_chunk_len=4,
+             note='len == limit passes the size check and grows the Vec: limit doubles (Rust Vec growth)')
+    add_case('zero_limit', ['', 'ab', ''], ['', 'a'], max_chunk_len=0,
+             note='Vec::with_capacity(0): first push grows the limit to 8')
+    add_case('nul_and_high_bytes', ['a\x00b', '\x00', 'é\x00é', 'zz'], ['\x00', 'a\x00', 'é', 'z', ''],
+             note='0x00 is a legal entry byte; order is unsigned')
+    # file ingest (bstr for_byte_line rule, src/lib.rs:67-86) -- unpinned
+    ingest = []
+    for name, raw in [('lf', b'one\ntwo\nthree\n'), ('crlf', b'one\r\ntwo\r\n'), ('no_trailing_newline', b'one\ntwo'),
+                      ('empty_lines', b'\n\nx\n\n'), ('lone_cr', b'a\rb\r\nc\r'), ('empty_file', b''),
+                      ('only_newline', b'\n'), ('non_utf8', b'\xff\xfe\n\x80abc\n')]:
+        with tempfile.TemporaryDirectory() as d:
+            src = os.path.join(d, 'in.txt')
+            open(src, 'wb').write(raw)
+            p = os.path.join(d, 'o.idx')
+            w = O.OracleWriter(p)
+            w.add_entries_from_file_lines(src)
+            w.close()
+            idx = open(p, 'rb').read()
+        ingest.append({'name': name, 'input_hex': raw.hex(), 'idx_hex': idx.hex()})
+    with tempfile.TemporaryDirectory() as d:   # chunk overflow during ingest
+        raw = b''.join(b'line%03d\n' % i for i in range(40))
+        src = os.path.join(d, 'in.txt')
+        open(src, 'wb').write(raw)
+        p = os.path.join(d, 'o.idx')
+        w = O.OracleWriter(p, 50)
+        w.add_entries_from_file_lines(src)
+        w.close()
+        ingest.append({'name': 'overflow_50', 'input_hex': raw.hex(), 'max_chunk_len': 50,
+                       'idx_hex': open(p, 'rb').read().hex()})
+    json.dump({'note': 'parity unpinned by the reference tests: produced by oracle/pss_oracle.c with libsais SAs',
+               'cases': cc, 'file_ingest': ingest},
+              open(os.path.join(HERE, 'container_cases.json'), 'w'), ensure_ascii=False, indent=1)
+
+    # ---- sa_kats.json ----
+    kats = []
+
+    def kat(name, spec, data):
+        sa = O.sa_reference(data)
+        k = {'name': name, 'spec': spec, 'n': len(data), 'text_sha256': sha(bytes(data)), 'sa_sha256': sha(sa.tobytes())}
+        if len(data) <= 128:
+            k['text_hex'] = bytes(data).hex()
+            k['sa'] = sa.tolist()
+        kats.append(k)
+
+    fib = [b'a', b'ab']
+    while len(fib[-1]) < 987:
+        fib.append(fib[-1] + fib[-2])
+    rng = np.random.default_rng(12345)
+    kat('readme_chunk', 'README entries joined with \\n', ('\n'.join(README) + '\n').encode())
+    kat('a1000_nl', '"a"*1000 + "\\n"', b'a' * 1000 + b'\n')
+    kat('fibonacci_987', 'Fibonacci word of length 987 over {a,b}', fib[-1])
+    kat('perm256', 'numpy default_rng(12345).permutation(256) as bytes', rng.permutation(256).astype(np.uint8).tobytes())
+    kat('zero_ff_nl_4k', 'default_rng(12345) choice of {0x00,0xff,0x0a}, 4096 bytes (after perm256 draw)',
+        np.array([0, 255, 10], dtype=np.uint8)[rng.integers(0, 3, 4096)].tobytes())
+    kat('periodic_64x64', '("a"*63 + "\\n") * 64', (b'a' * 63 + b'\n') * 64)
+    kat('all_zero_5000', '0x00 * 5000', b'\x00' * 5000)
+    kat('zeros_tail', '0xff*4097 + 0x00*17', b'\xff' * 4097 + b'\x00' * 17)
+    kat('lines_1MiB', 'pss_gen_corpus(LINES, 2^20, 0)', O.gen_lines(1 << 20, 0).tobytes())
+    from pysubstringsearch_amd import _ffi
+    for kind, kname in [(1, 'words'), (2, 'runs'), (3, 'periodic')]:
+        buf = np.empty(1 << 20, dtype=np.uint8)
+        _ffi.lib.pss_gen_corpus(kind, buf.ctypes.data, buf.size, 0)
+        kat(f'{kname}_1MiB', f'pss_gen_corpus({kname.upper()}, 2^20, 0)', buf.tobytes())
+    big = {'lines_64MiB': {'text_sha256': '506433993a4ca5a96cc4d4bd9b2b7a780ffded17909ff68af3e6482dd1177830',
+                           'sa_sha256': '9b0307590ee2664c579984cd03a41ff9ca4bd02f6b2e4d9ddaa5e9e71597a807'},
+           'words_64MiB': {'text_sha256': '1e47a9424ae0b545386c3177dcba7099c462522cd4cd728845185dfc1f1c95e0',
+                           'sa_sha256': '7ea71d3d90aa8e1fd8e1870b4ff48c0e95dfde941e5f621ec506ab55507d590f'}}
+    if os.environ.get('PSS_GOLDEN_BIG'):   # re-derive the 64 MiB hashes (minutes)
+        for kind, kname in [(0, 'lines_64MiB'), (1, 'words_64MiB')]:
+            buf = np.empty(1 << 26, dtype=np.uint8)
+            _ffi.lib.pss_gen_corpus(kind, buf.ctypes.data, buf.size, 0)
+            sa = O.sa_reference(buf)
+            assert sha(buf.tobytes()) == big[kname]['text_sha256'], kname
+            assert sha(sa.tobytes()) == big[kname]['sa_sha256'], kname
+    json.dump({'kats': kats, 'generated_big': big}, open(os.path.join(HERE, 'sa_kats.json'), 'w'), indent=1)
+    print('wrote', len(cases), 'reference cases,', len(cc), 'container cases,', len(ingest), 'ingest cases,',
+          len(kats), 'SA KATs')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,212 @@
+"""CPU tests of the host side: the C ABI surface, the Python mirror of the
+reference API, the corpus generators and the multi-process result gather.
+No compute call needs a GPU here (the engine has no CPU fallback)."""
+import ctypes
+import hashlib
+import inspect
+import json
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'pss.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    names = sorted(set(re.findall(r'\b(pss_[a-z0-9_]+)\s*\(', hdr)))
+    assert len(names) >= 25
+    lib = ctypes.CDLL(os.path.join(ROOT, 'pysubstringsearch_amd', 'libpss.so'))
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in include/pss.h but not exported'
+
+
+def test_api_signatures_match_reference(pss):
+    import pysubstringsearch
+    assert pysubstringsearch.Writer is pss.Writer and pysubstringsearch.Reader is pss.Reader
+    # names/order from pysubstringsearch/__init__.py:7-73 of the reference
+    assert list(inspect.signature(pss.Writer.__init__).parameters)[:3] == ['self', 'index_file_path', 'max_chunk_len']
+    assert inspect.signature(pss.Writer.__init__).parameters['max_chunk_len'].default is None
+    assert list(inspect.signature(pss.Writer.add_entry).parameters) == ['self', 'text']
+    assert list(inspect.signature(pss.Writer.add_entries_from_file_lines).parameters) == ['self', 'input_file_path']
+    assert list(inspect.signature(pss.Writer.dump_data).parameters) == ['self']
+    assert list(inspect.signature(pss.Writer.finalize).parameters) == ['self']
+    assert list(inspect.signature(pss.Reader.__init__).parameters)[:2] == ['self', 'index_file_path']
+    assert list(inspect.signature(pss.Reader.search).parameters) == ['self', 'substring']
+    assert list(inspect.signature(pss.Reader.search_multiple).parameters) == ['self', 'substrings']
+
+
+def test_file_not_found(pss):
+    # reference tests/test_pysubstringsearch.py:48-56
+    with pytest.raises(FileNotFoundError):
+        pss.Reader(index_file_path='missing_index_file_path')
+    with pytest.raises(FileNotFoundError):
+        pss.Writer(index_file_path='/nonexistent_dir_xyz/out.idx')
+
+
+def test_writer_argument_errors(pss, tmp_path):
+    p = str(tmp_path / 'w.idx')
+    w = pss.Writer(p, 4)
+    assert os.path.getsize(p) == 0                      # File::create truncates immediately
+    with pytest.raises(ValueError, match='entry is too big'):   # src/lib.rs:92-94
+        w.add_entry('abcdef')
+    with pytest.raises(TypeError):
+        w.add_entry(b'bytes')                            # pyo3 &str accepts only str
+    with pytest.raises(UnicodeEncodeError):
+        w.add_entry('\ud800')                            # lone surrogate
+    with pytest.raises(FileNotFoundError):
+        w.add_entries_from_file_lines(str(tmp_path / 'nope.txt'))
+    with pytest.raises(OverflowError):
+        pss.Writer(p, -1)
+    with pytest.raises(TypeError):
+        pss.Writer(123)
+    w.finalize()                                         # nothing buffered: no device needed
+    w.close()
+    w.close()
+    with pytest.raises(ValueError):
+        w.add_entry('x')
+    assert w.writer is w
+    with pss.Writer(p) as w2:
+        assert w2._h
+    assert os.path.getsize(p) == 0
+
+
+def test_chunk_limit_growth_rule(pss, tmp_path):
+    from pysubstringsearch_amd import _ffi
+    w = pss.Writer(str(tmp_path / 'g.idx'), 4)
+    assert _ffi.lib.pss_writer_chunk_limit(w._h) == 4
+    w.add_entry('abcd')      # len == limit passes the check, the appended '\n' grows the "Vec": 4 -> 8
+    assert _ffi.lib.pss_writer_chunk_limit(w._h) == 8
+    w2 = pss.Writer(str(tmp_path / 'z.idx'), 0)
+    w2.add_entry('')         # Vec::with_capacity(0) -> first push -> 8
+    assert _ffi.lib.pss_writer_chunk_limit(w2._h) == 8
+    for x in (w, w2):        # drop without a GPU: dump fails loudly, file handle is still released
+        with pytest.raises(RuntimeError, match='no usable HIP device') if not pss.device_count() else _noraise():
+            x.close()
+
+
+class _noraise:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def test_compute_fails_loudly_without_gpu(pss, tmp_path):
+    if pss.device_count() > 0:
+        pytest.skip('a GPU is present')
+    from tests.util import sa_gpu
+    with pytest.raises(RuntimeError, match='no usable HIP device'):
+        sa_gpu(b'banana')
+    idx = tmp_path / 'x.idx'
+    idx.write_bytes(bytes.fromhex('010000000a0400000000000000'))
+    with pytest.raises(RuntimeError, match='no usable HIP device'):
+        pss.Reader(str(idx))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'pysubstringsearch_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.cpp', '.hip', '.h')):
+                src = open(os.path.join(dirpath, f), encoding='utf-8').read()
+                assert 'oracle' not in src.replace('oracle restatement', ''), f'{f} mentions the oracle'
+
+
+# ---- corpus generators: C++ (libpss) vs an independent Python restatement of SURVEY 8(d) ----
+
+M64 = (1 << 64) - 1
+
+
+class Xs:
+    def __init__(self, s):
+        self.s = s
+
+    def nx(self):
+        s = self.s
+        s ^= (s << 13) & M64
+        s ^= s >> 7
+        s ^= (s << 17) & M64
+        self.s = s
+        return s >> 32
+
+
+def py_lines(n, chunk=0):
+    alpha = b'abcdefghijklmnopqrstuvwxyz0123456789 .'
+    g = Xs(88172645463325252 + chunk)
+    out = bytearray(n)
+    for i in range(n):
+        r = g.nx()
+        out[i] = 10 if r % 40 == 0 else alpha[(r >> 8) % 38]
+    out[-1] = 10
+    return bytes(out)
+
+
+def py_words(n, chunk=0):
+    v = Xs(0x2545F4914F6CDD1D)
+    vocab = []
+    for _ in range(65536):
+        ln = 3 + v.nx() % 8
+        vocab.append(bytes(97 + v.nx() % 26 for _ in range(ln)))
+    g = Xs(88172645463325252 + chunk)
+    out = bytearray()
+    while len(out) < n:
+        k = 1 + g.nx() % 12
+        ws = []
+        for _ in range(k):
+            a = g.nx() % 65536
+            sh = g.nx() % 16
+            ws.append(vocab[a >> sh])
+        out += b' '.join(ws) + b'\n'
+    out = out[:n]
+    out[-1] = 10
+    return bytes(out)
+
+
+def test_generators_match_python_spec():
+    from tests.util import gen_corpus
+    n = 20000
+    assert gen_corpus(0, n, 3).tobytes() == py_lines(n, 3)
+    assert gen_corpus(1, n, 2).tobytes() == py_words(n, 2)
+    per = gen_corpus(3, 10000).tobytes()
+    assert per[:4096] == b'a' * 4095 + b'\n' and per[-1:] == b'\n' and set(per) == {97, 10}
+    runs = gen_corpus(2, 50000).tobytes()
+    assert set(runs) <= {97, 98, 10} and runs[-1:] == b'\n'
+    assert all(len(set(line)) <= 1 and len(line) <= 8192 for line in runs.split(b'\n'))
+    kats = {k['name']: k for k in json.load(open(os.path.join(ROOT, 'tests', 'golden', 'sa_kats.json')))['kats']}
+    for kind, name in [(0, 'lines_1MiB'), (1, 'words_1MiB'), (2, 'runs_1MiB'), (3, 'periodic_1MiB')]:
+        assert hashlib.sha256(gen_corpus(kind, 1 << 20).tobytes()).hexdigest() == kats[name]['text_sha256']
+
+
+# ---- multi-process gather (N > 1 path), gloo, world_size 2 ----
+
+def test_merge_query_major_unit():
+    from pysubstringsearch_amd import dist as pdist
+    a = pdist.pack_entries([b'ten', b'tenten', b'one']) + (np.array([2, 0, 1]),)
+    b = pdist.pack_entries([b'ten', b'x']) + (np.array([1, 1, 0]),)
+    out, total = pdist.merge_query_major([a, b])
+    assert out == [b'ten', b'tenten', b'ten', b'x', b'one'] and total.tolist() == [3, 1, 1]
+    assert pdist.chunk_owner(9, 8) == 1
+
+
+def test_sharded_gather_gloo(tmp_path):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / 'r0.json')
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', '_dist_worker.py'), str(r), '2', str(port), out],
+                              env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=180) == 0
+    got = json.load(open(out))
+    # query-major; inside a query rank 0's entries then rank 1's; duplicates across queries kept
+    assert got['got'] == ['ten', 'tenten', 'ten', 'x', 'one', 'three', 'ten', 'tenten', 'ten']
+    assert got['counts'] == [2, 3] and got['raw'] == ['one', 'three', 'ten', 'tenten', 'ten']

@@ -1,0 +1,138 @@
+"""CPU tests: the oracle restatement against the committed golden vectors
+(reference tests re-expressed as data, libsais-generated SAs and .idx bytes)."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, 'golden')
+
+
+def load(name):
+    return json.load(open(os.path.join(GOLD, name), encoding='utf-8'))
+
+
+def build_idx(W, path, entries, max_chunk_len=None, dump_after=()):
+    w = W(path, max_chunk_len)
+    for i, e in enumerate(entries):
+        w.add_entry(e)
+        if i in dump_after:
+            w.dump_data()
+    w.finalize()
+    w.close()
+    return open(path, 'rb').read()
+
+
+def test_little_endian_host():
+    assert sys.byteorder == 'little'   # raw int32 writes == i32le (src/lib.rs:117-119)
+
+
+def test_reference_cases(oracle, tmp_path):
+    oracle.use_reference_sa(False)     # the restatement's own SA, not libsais
+    for case in load('reference_cases.json')['cases']:
+        if 'missing_path' in case:
+            with pytest.raises(FileNotFoundError):
+                oracle.OracleReader(str(tmp_path / case['missing_path']))
+            continue
+        p = str(tmp_path / (case['name'] + '.idx'))
+        idx = build_idx(oracle.OracleWriter, p, case['entries'])
+        assert hashlib.sha256(idx).hexdigest() == case['idx_sha256'], case['name']
+        if case['idx_hex']:
+            assert idx.hex() == case['idx_hex']
+        r = oracle.OracleReader(p)
+        for s in case['searches']:
+            assert sorted(r.search(s['substring'])) == sorted(s['expected']), (case['name'], s['substring'])
+        for s in case['search_multiple']:
+            assert sorted(r.search_multiple(s['substrings'])) == sorted(s['expected'])
+        r.close()
+
+
+def test_container_cases(oracle, tmp_path):
+    oracle.use_reference_sa(False)
+    gold = load('container_cases.json')
+    for case in gold['cases']:
+        p = str(tmp_path / (case['name'] + '.idx'))
+        idx = build_idx(oracle.OracleWriter, p, case['entries'], case['max_chunk_len'], case['dump_after'])
+        assert idx.hex() == case['idx_hex'], case['name']
+        r = oracle.OracleReader(p)
+        for s in case['searches']:
+            assert sorted(r.search(s['substring'])) == s['expected'], (case['name'], s['substring'])
+        r.close()
+    for case in gold['file_ingest']:
+        src = tmp_path / (case['name'] + '.txt')
+        src.write_bytes(bytes.fromhex(case['input_hex']))
+        p = str(tmp_path / (case['name'] + '.idx'))
+        w = oracle.OracleWriter(p, case.get('max_chunk_len'))
+        w.add_entries_from_file_lines(str(src))
+        w.close()
+        assert open(p, 'rb').read().hex() == case['idx_hex'], case['name']
+
+
+def test_known_multi_chunk_layout(oracle, tmp_path):
+    # three chunks with these exact suffix arrays
+    p = str(tmp_path / 'm.idx')
+    build_idx(oracle.OracleWriter, p, ['ten', 'ten', 'tenten', 'x'], 8)
+    r = oracle.OracleReader(p)
+    assert r.num_chunks == 3
+    exp = [(b'ten\nten\n', [7, 3, 5, 1, 6, 2, 4, 0]), (b'tenten\n', [6, 4, 1, 5, 2, 3, 0]), (b'x\n', [1, 0])]
+    for c, (data, sa) in enumerate(exp):
+        d, s = r.chunk(c)
+        assert d == data and s.tolist() == sa
+    assert sorted(r.search('ten')) == ['ten', 'ten', 'tenten']
+    assert r.search_multiple(['te', 'en']).count('ten') == 4   # duplicates across queries are kept
+
+
+def _kat_input(k, oracle):
+    from tests.util import gen_corpus
+    fib = [b'a', b'ab']
+    while len(fib[-1]) < 987:
+        fib.append(fib[-1] + fib[-2])
+    rng = np.random.default_rng(12345)
+    perm = rng.permutation(256).astype(np.uint8).tobytes()
+    zfn = np.array([0, 255, 10], dtype=np.uint8)[rng.integers(0, 3, 4096)].tobytes()
+    table = {
+        'a1000_nl': b'a' * 1000 + b'\n', 'fibonacci_987': fib[-1], 'perm256': perm, 'zero_ff_nl_4k': zfn,
+        'periodic_64x64': (b'a' * 63 + b'\n') * 64, 'all_zero_5000': b'\x00' * 5000,
+        'zeros_tail': b'\xff' * 4097 + b'\x00' * 17,
+        'readme_chunk': b'some short string\nanother but now a longer string\nmore text to add\n',
+    }
+    if k['name'] in table:
+        return table[k['name']]
+    kinds = {'lines_1MiB': 0, 'words_1MiB': 1, 'runs_1MiB': 2, 'periodic_1MiB': 3}
+    return gen_corpus(kinds[k['name']], 1 << 20).tobytes()
+
+
+def test_sa_kats_restatement(oracle):
+    for k in load('sa_kats.json')['kats']:
+        data = _kat_input(k, oracle)
+        assert hashlib.sha256(data).hexdigest() == k['text_sha256'], k['name']
+        if k['name'] in ('runs_1MiB', 'periodic_1MiB'):
+            continue   # O(n log n) rounds x 1 MiB on CPU: covered by the GPU test
+        sa = oracle.sa_restatement(data)
+        assert hashlib.sha256(sa.tobytes()).hexdigest() == k['sa_sha256'], k['name']
+        if 'sa' in k:
+            assert sa.tolist() == k['sa']
+
+
+def test_restatement_matches_reference_when_built(oracle):
+    if not oracle.have_reference():
+        pytest.skip('oracle/_ref/libsais.so not present')
+    rng = np.random.default_rng(5)
+    for alpha in (1, 2, 3, 39, 256):
+        for n in (0, 1, 2, 3, 17, 255, 1000, 5000):
+            t = rng.integers(0, alpha, size=n, dtype=np.uint8)
+            assert (oracle.sa_restatement(t) == oracle.sa_reference(t)).all()
+    t = oracle.gen_lines(1 << 18)
+    assert (oracle.sa_restatement(t) == oracle.sa_reference(t)).all()
+
+
+def test_generator_golden(oracle):
+    from tests.util import gen_corpus
+    t = gen_corpus(0, 1 << 20)
+    assert hashlib.sha256(t.tobytes()).hexdigest() == \
+        '33246a0e40f61c2a592fd16dc644ade2e25eae811ca2d7457ce4154000485e99'
+    assert (t == oracle.gen_lines(1 << 20)).all()   # independent C restatement of the generator

@@ -1,0 +1,238 @@
+"""GPU parity (through the C ABI / the Python mirror of the reference API):
+the reference's own tests re-expressed as data, the container goldens, and
+fuzzing against the CPU oracle.  Result lists are compared as multisets
+(assertCountEqual in the reference, tests/test_pysubstringsearch.py:32-37);
+.idx files byte for byte."""
+import hashlib
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import pysubstringsearch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, 'golden')
+
+
+def load(name):
+    return json.load(open(os.path.join(GOLD, name), encoding='utf-8'))
+
+
+def build(path, entries, max_chunk_len=None, dump_after=(), W=None):
+    w = (W or pysubstringsearch.Writer)(path, max_chunk_len)
+    for i, e in enumerate(entries):
+        w.add_entry(e)
+        if i in dump_after:
+            w.dump_data()
+    w.finalize()
+    w.close()
+    return open(path, 'rb').read()
+
+
+def test_reference_tests_as_data(tmp_path):
+    for case in load('reference_cases.json')['cases']:
+        if 'missing_path' in case:
+            with pytest.raises(FileNotFoundError):
+                pysubstringsearch.Reader(index_file_path=case['missing_path'])
+            continue
+        p = str(tmp_path / (case['name'] + '.idx'))
+        writer = pysubstringsearch.Writer(index_file_path=p)
+        for s in case['entries']:
+            writer.add_entry(text=s)
+        writer.finalize()
+        idx = open(p, 'rb').read()
+        assert hashlib.sha256(idx).hexdigest() == case['idx_sha256'], case['name']
+        reader = pysubstringsearch.Reader(index_file_path=p)
+        for s in case['searches']:
+            assert sorted(reader.search(substring=s['substring'])) == sorted(s['expected']), (case['name'], s)
+        for s in case['search_multiple']:
+            assert sorted(reader.search_multiple(substrings=s['substrings'])) == sorted(s['expected'])
+        reader.close()
+        writer.close()
+
+
+def test_container_goldens(tmp_path):
+    gold = load('container_cases.json')
+    for case in gold['cases']:
+        p = str(tmp_path / (case['name'] + '.idx'))
+        idx = build(p, case['entries'], case['max_chunk_len'], case['dump_after'])
+        assert idx.hex() == case['idx_hex'], case['name']
+        with pysubstringsearch.Reader(p) as r:
+            for s in case['searches']:
+                assert sorted(r.search(s['substring'])) == s['expected'], (case['name'], s['substring'])
+    for case in gold['file_ingest']:
+        src = tmp_path / (case['name'] + '.txt')
+        src.write_bytes(bytes.fromhex(case['input_hex']))
+        p = str(tmp_path / (case['name'] + '.idx'))
+        w = pysubstringsearch.Writer(p, case.get('max_chunk_len'))
+        w.add_entries_from_file_lines(str(src))
+        w.close()
+        assert open(p, 'rb').read().hex() == case['idx_hex'], case['name']
+
+
+def test_writer_reuse_after_finalize_and_truncation(tmp_path, oracle):
+    p = str(tmp_path / 'r.idx')
+    w = pysubstringsearch.Writer(p)
+    w.add_entry('alpha')
+    w.finalize()
+    w.finalize()                      # idempotent (src/lib.rs:126-135)
+    w.add_entry('beta')               # a Writer stays usable: appends one more chunk
+    w.close()
+    with pysubstringsearch.Reader(p) as r:
+        assert r.num_chunks == 2 and sorted(r.search('a')) == ['alpha', 'beta']
+    o = oracle.OracleReader(p)
+    assert sorted(o.search('a')) == ['alpha', 'beta']
+    data = open(p, 'rb').read()
+    t = tmp_path / 't.idx'
+    t.write_bytes(data[:-3])          # truncated SA -> UnexpectedEof -> OSError
+    with pytest.raises(OSError):
+        pysubstringsearch.Reader(str(t))
+    e = tmp_path / 'e.idx'
+    e.write_bytes(b'')                # empty file: zero chunks, every search is empty
+    with pysubstringsearch.Reader(str(e)) as r:
+        assert r.search('a') == [] and r.search_multiple(['a', '']) == []
+
+
+def _fuzz_corpus(rng, alphabet, n_entries, max_len):
+    return [''.join(rng.choice(alphabet) for _ in range(rng.randint(0, max_len))) for _ in range(n_entries)]
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_fuzz_against_oracle(tmp_path, oracle, seed):
+    rng = random.Random(seed)
+    alphabet = rng.choice(['ab', 'abc', 'ab \n'.replace('\n', ''), 'abcdefgh', 'aé☃', '\x00a'])
+    entries = _fuzz_corpus(rng, alphabet, rng.randint(1, 400), rng.choice([3, 12, 60]))
+    limit = rng.choice([None, 64, 257, 5000])
+    if limit is not None:
+        limit = max(limit, max(len(e.encode()) for e in entries) + 1)
+    p = str(tmp_path / 'f.idx')
+    q = str(tmp_path / 'o.idx')
+    idx = build(p, entries, limit)
+    oracle.use_reference_sa(False)
+    ref = build(q, entries, limit, W=oracle.OracleWriter)
+    assert idx == ref                                   # byte-identical container
+    text = '\n'.join(entries) + '\n'
+    queries = ['', 'a', 'b', 'ab', 'ba', 'zz', '\n', 'a\n', '\na']
+    for _ in range(60):
+        s = rng.randrange(len(text))
+        queries.append(text[s:s + rng.randint(1, 9)])
+    for _ in range(20):
+        queries.append(''.join(rng.choice(alphabet) for _ in range(rng.randint(1, 6))))
+    o = oracle.OracleReader(q)
+    with pysubstringsearch.Reader(p) as r:
+        for s in queries:
+            assert sorted(r.search(s)) == sorted(o.search(s)), repr(s)
+        got = r.search_multiple(queries)                # one batched device call
+        exp = o.search_multiple(queries)
+        assert sorted(got) == sorted(exp)
+        ents, counts = r.search_batch_raw([s.encode() for s in queries])
+        oe, oc = o.search_multiple_bytes([s.encode() for s in queries])
+        assert counts == oc.tolist()                    # per-query counts, query-major order
+        pos = 0
+        for c in counts:                                # per-query multisets line up query by query
+            assert sorted(ents[pos:pos + c]) == sorted(oe[pos:pos + c])
+            pos += c
+
+
+def test_long_entries_and_patterns(tmp_path, oracle):
+    rng = random.Random(99)
+    entries = ['a' * 5000, 'a' * 4999 + 'b', ('ab' * 3000), 'x' * 70 + 'needle' + 'y' * 70,
+               ''.join(rng.choice('abc') for _ in range(20000))]
+    p = str(tmp_path / 'l.idx')
+    build(p, entries)
+    o = oracle.OracleReader(p)
+    qs = ['a' * 100, 'a' * 4999 + 'b', 'ab' * 40, 'needle', 'x' * 65, 'a' * 5001, 'ba' * 33 + 'b', entries[4][777:777 + 300]]
+    with pysubstringsearch.Reader(p) as r:
+        for s in qs:
+            assert sorted(r.search(s)) == sorted(o.search(s)), s[:20]
+        assert sorted(r.search_multiple(qs)) == sorted(o.search_multiple(qs))
+
+
+def test_one_mib_chunks_batch(tmp_path, oracle):
+    """3 chunks x 1 MiB of the `lines` corpus via file ingest; 2000 mixed queries in one batch."""
+    from tests.util import gen_corpus
+    src = tmp_path / 'corpus.txt'
+    with open(src, 'wb') as f:
+        for c in range(3):
+            f.write(gen_corpus(0, 1 << 20, c).tobytes())
+    p = str(tmp_path / 'c.idx')
+    w = pysubstringsearch.Writer(p, 1 << 20)
+    w.add_entries_from_file_lines(str(src))
+    w.close()
+    q = str(tmp_path / 'o.idx')
+    oracle.use_reference_sa(oracle.have_reference())
+    ow = oracle.OracleWriter(q, 1 << 20)
+    ow.add_entries_from_file_lines(str(src))
+    ow.close()
+    oracle.use_reference_sa(False)
+    assert hashlib.sha256(open(p, 'rb').read()).hexdigest() == hashlib.sha256(open(q, 'rb').read()).hexdigest()
+    text = open(src, 'rb').read()
+    rng = np.random.default_rng(1)
+    qs = []
+    while len(qs) < 1000:
+        s = int(rng.integers(0, len(text) - 40))
+        ln = int(rng.integers(2, 12))
+        cand = text[s:s + ln]
+        if b'\n' not in cand:
+            qs.append(cand)
+    alpha = b'abcdefghijklmnopqrstuvwxyz0123456789 .'
+    for _ in range(1000):
+        qs.append(bytes(alpha[int(i)] for i in rng.integers(0, 38, int(rng.integers(4, 9)))))
+    o = oracle.OracleReader(q)
+    with pysubstringsearch.Reader(p) as r:
+        assert r.num_chunks == 3
+        ents, counts = r.search_batch_raw(qs)
+        oe, oc = o.search_multiple_bytes(qs)
+        assert counts == oc.tolist()
+        assert sorted(ents) == sorted(oe)
+        st = r.last_stats()
+        assert st['queries'] == len(qs) and st['entries'] == len(ents)
+    # sharded readers: each owns chunk c % 2, union == whole
+    with pysubstringsearch.Reader(p, shard=(0, 2)) as r0, pysubstringsearch.Reader(p, shard=(1, 2)) as r1:
+        assert (r0.num_chunks, r1.num_chunks) == (2, 1)
+        e0, c0 = r0.search_batch_raw(qs[:200])
+        e1, c1 = r1.search_batch_raw(qs[:200])
+        from pysubstringsearch_amd import dist as pdist
+        merged, total = pdist.merge_query_major([pdist.pack_entries(e0) + (np.array(c0),),
+                                                 pdist.pack_entries(e1) + (np.array(c1),)])
+        oe2, oc2 = o.search_multiple_bytes(qs[:200])
+        assert total.tolist() == oc2.tolist() and sorted(merged) == sorted(oe2)
+
+
+def test_sa_kats_gpu():
+    from tests.test_oracle import _kat_input
+    from tests.util import sa_gpu
+    for k in load('sa_kats.json')['kats']:
+        data = _kat_input(k, None)
+        sa = sa_gpu(data)
+        assert hashlib.sha256(sa.tobytes()).hexdigest() == k['sa_sha256'], k['name']
+        if 'sa' in k:
+            assert sa.tolist() == k['sa']
+
+
+def test_sa_properties_at_scale():
+    """64 MiB (size-independent properties + the pinned libsais hash of SURVEY 8(c)(6))."""
+    import torch
+    from pysubstringsearch_amd import _ffi
+    from tests.util import gen_corpus
+    gold = load('sa_kats.json')['generated_big']
+    for kind, name in [(0, 'lines_64MiB'), (1, 'words_64MiB')]:
+        n = 1 << 26
+        host = gen_corpus(kind, n)
+        assert hashlib.sha256(host.tobytes()).hexdigest() == gold[name]['text_sha256']
+        dT = torch.from_numpy(host).cuda()
+        dSA = torch.empty(n, dtype=torch.int32, device='cuda')
+        _ffi.check(_ffi.lib.pss_sa_build_device(dT.data_ptr(), dSA.data_ptr(), n, 0, 0, None))
+        sa = dSA.cpu().numpy()
+        assert hashlib.sha256(sa.tobytes()).hexdigest() == gold[name]['sa_sha256']
+        # permutation + sortedness on a strided sample of adjacent pairs
+        assert np.array_equal(np.sort(sa[:: 1]), np.arange(n, dtype=np.int32)) if n <= (1 << 26) else True
+        text = host.tobytes()
+        for j in range(1, n, n // 20000):
+            a, b = int(sa[j - 1]), int(sa[j])
+            assert text[a:a + 64] <= text[b:b + 64]
