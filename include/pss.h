@@ -59,7 +59,14 @@ typedef struct pss_sa_stats {
     uint64_t sort_elems;       /* sum over every radix pass of elements moved */
     double ms_total;           /* device time of the whole build (HIP events) */
     double ms_sort;            /* device time inside radix passes (profile mode only) */
-    uint64_t sort_launches;    /* radix-pass kernel launches */
+    uint64_t sort_launches;    /* radix-pass (scatter kernel) launches */
+    /* profile mode: the dominant kernel, rs_scatter_kernel<false> (reads 8 B key
+     * + 4 B value, writes the same: 24 algorithmic bytes per element) */
+    double ms_pairs;           /* summed duration of its launches */
+    uint64_t pairs_launches;
+    uint64_t pairs_elems;      /* elements summed over those launches */
+    double ms_text;            /* first pass, rs_scatter_kernel<true> (1 B in, 12 B out) */
+    uint64_t text_launches;
 } pss_sa_stats;
 
 /*

@@ -28,6 +28,11 @@ class SaStats(ctypes.Structure):
         ('ms_total', ctypes.c_double),
         ('ms_sort', ctypes.c_double),
         ('sort_launches', ctypes.c_uint64),
+        ('ms_pairs', ctypes.c_double),
+        ('pairs_launches', ctypes.c_uint64),
+        ('pairs_elems', ctypes.c_uint64),
+        ('ms_text', ctypes.c_double),
+        ('text_launches', ctypes.c_uint64),
     ]
 
     def as_dict(self):

@@ -19,7 +19,14 @@ struct TextKeys {
 struct SortStats {
     uint64_t launches = 0;   // scatter-kernel launches
     uint64_t elems = 0;      // elements moved, summed over passes
-    double ms = 0.0;         // device time of all passes (profile mode)
+    double ms = 0.0;         // device time of all scatter launches (profile mode)
+    // profile mode, split by scatter-kernel instantiation:
+    double ms_text = 0.0;    //   rs_scatter_kernel<true>  (first pass, keys packed from text)
+    uint64_t text_launches = 0;
+    double ms_pairs = 0.0;   //   rs_scatter_kernel<false> (12 B in + 12 B out per element)
+    uint64_t pairs_launches = 0;
+    uint64_t pairs_elems = 0;
+    uint64_t small_launches = 0;   // single-workgroup LDS sorts (n <= 4096)
 };
 
 // Workspace the sort needs besides the ping-pong buffers.

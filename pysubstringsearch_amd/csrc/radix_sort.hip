@@ -299,6 +299,46 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(PassArgs a)
     }
 }
 
+// Tiny inputs (<= one tile): one workgroup, bitonic network in LDS over the
+// whole 64-bit key.  Not stable -- callers only use it where ties stay tied
+// (doubling rounds: equal keys remain one group and are re-sorted later).
+__global__ __launch_bounds__(RS_BLOCK) void rs_small_sort_kernel(u64 *keys, u32 *vals, u32 n)
+{
+    __shared__ u64 sk[RS_TILE];
+    __shared__ u32 sv[RS_TILE];
+    const u32 tid = threadIdx.x;
+    u32 np2 = 2;
+    while (np2 < n) np2 <<= 1;
+    for (u32 i = tid; i < np2; i += RS_BLOCK) {
+        sk[i] = i < n ? keys[i] : ~0ull;
+        sv[i] = i < n ? vals[i] : 0xffffffffu;
+    }
+    __syncthreads();
+    for (u32 k = 2; k <= np2; k <<= 1) {
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            for (u32 i = tid; i < np2; i += RS_BLOCK) {
+                const u32 x = i ^ j;
+                if (x > i) {
+                    const bool up = (i & k) == 0;
+                    const u64 a = sk[i], b = sk[x];
+                    if ((a > b) == up) {
+                        sk[i] = b;
+                        sk[x] = a;
+                        const u32 t = sv[i];
+                        sv[i] = sv[x];
+                        sv[x] = t;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (u32 i = tid; i < n; i += RS_BLOCK) {
+        keys[i] = sk[i];
+        vals[i] = sv[i];
+    }
+}
+
 size_t radix_sort_workspace_bytes() { return (size_t)256 * RS_MAX_RANGES * 4 + 256 * 4 * 16; }
 
 int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint32_t n, int key_bits,
@@ -312,6 +352,13 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
         *dst = from_text ? 0 : src;
         return PSS_OK;
     }
+    if (!from_text && n <= (u32)RS_TILE) {
+        hipLaunchKernelGGL(rs_small_sort_kernel, dim3(1), dim3(RS_BLOCK), 0, ctx->stream, keys[src], vals[src], n);
+        PSS_HIP(hipGetLastError());
+        if (stats) stats->small_launches += 1;
+        *dst = src;
+        return PSS_OK;
+    }
     const u32 num_tiles = (u32)(((u64)n + RS_TILE - 1) / RS_TILE);
     const u32 tpr = (num_tiles + RS_MAX_RANGES - 1) / RS_MAX_RANGES;
     u32 num_ranges = (num_tiles + tpr - 1) / tpr;
@@ -322,6 +369,7 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
     PSS_HIP(hipMemsetAsync(totals_base, 0, 256 * 4 * 16, ctx->stream));
 
     hipEvent_t ev[2 * 16];
+    bool ev_text[16];
     int nev = 0;
     int executed = 0;
     for (int p = 0; p < passes; ++p) {
@@ -357,6 +405,7 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
         else hipLaunchKernelGGL(rs_hist_kernel<false>, dim3(num_ranges), dim3(RS_BLOCK), 0, ctx->stream, a);
         hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(256), 0, ctx->stream, a.table, a.totals, num_ranges);
         if (profile && nev < 32) {
+            ev_text[nev / 2] = from_text;
             PSS_HIP(hipEventCreate(&ev[nev]));
             PSS_HIP(hipEventRecord(ev[nev++], ctx->stream));
         }
@@ -380,7 +429,11 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
         for (int i = 0; i + 1 < nev; i += 2) {
             float ms = 0.f;
             PSS_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
-            if (stats) stats->ms += ms;
+            if (stats) {
+                stats->ms += ms;
+                if (ev_text[i / 2]) { stats->ms_text += ms; stats->text_launches += 1; }
+                else { stats->ms_pairs += ms; stats->pairs_launches += 1; stats->pairs_elems += n; }
+            }
         }
         for (int i = 0; i < nev; ++i) (void)hipEventDestroy(ev[i]);
     }

@@ -481,6 +481,9 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         ss.launches += rs.launches;
         ss.elems += rs.elems;
         ss.ms += rs.ms;
+        ss.ms_pairs += rs.ms_pairs;
+        ss.pairs_launches += rs.pairs_launches;
+        ss.pairs_elems += rs.pairs_elems;
         h *= 2;
     }
     PSS_HIP(hipEventRecord(ev1, s));
@@ -493,6 +496,11 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     st.ms_sort = ss.ms;
     st.sort_launches = ss.launches;
     st.sort_elems = ss.elems;
+    st.ms_pairs = ss.ms_pairs;
+    st.pairs_launches = ss.pairs_launches;
+    st.pairs_elems = ss.pairs_elems;
+    st.ms_text = ss.ms_text;
+    st.text_launches = ss.text_launches;
     if (stats) *stats = st;
     return PSS_OK;
 }
