@@ -67,6 +67,7 @@ typedef struct pss_sa_stats {
     uint64_t pairs_elems;      /* elements summed over those launches */
     double ms_text;            /* first pass, rs_scatter_kernel<true> (1 B in, 12 B out) */
     uint64_t text_launches;
+    uint64_t sparse;           /* 1: rounds ran without an inverse suffix array (hash + key search) */
 } pss_sa_stats;
 
 /*

@@ -33,6 +33,7 @@ class SaStats(ctypes.Structure):
         ('pairs_elems', ctypes.c_uint64),
         ('ms_text', ctypes.c_double),
         ('text_launches', ctypes.c_uint64),
+        ('sparse', ctypes.c_uint64),
     ]
 
     def as_dict(self):

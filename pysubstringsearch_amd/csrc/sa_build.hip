@@ -35,15 +35,23 @@
 #include "radix_sort.h"
 #include "sa_build.h"
 
+#include <algorithm>
+#include <cmath>
+
 namespace pss {
 
 // ---------------------------------------------------------------- alphabet --
 
-__global__ __launch_bounds__(256) void sa_symbols_kernel(const u8 *T, u32 n, u32 *present)
+// present[c] = 1 for every byte value that occurs (exact); counts[c] += its
+// occurrences inside a 1/16 sample of the 16-byte vectors (for the entropy
+// estimate that sizes the initial key).
+__global__ __launch_bounds__(256) void sa_symbols_kernel(const u8 *T, u32 n, u32 *present, u32 *counts)
 {
     __shared__ u32 seen[256];
+    __shared__ u32 cnt[256];
     const u32 tid = threadIdx.x;
     seen[tid] = 0;
+    cnt[tid] = 0;
     __syncthreads();
     const u32 nvec = n / 16;
     const uint4 *Tv = reinterpret_cast<const uint4 *>(T);
@@ -52,12 +60,14 @@ __global__ __launch_bounds__(256) void sa_symbols_kernel(const u8 *T, u32 n, u32
         for (u32 i = blockIdx.x * blockDim.x + tid; i < nvec; i += gridDim.x * blockDim.x) {
             const uint4 v = Tv[i];
             const u32 w[4] = {v.x, v.y, v.z, v.w};
+            const bool sample = (i & 15u) == 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int s = 0; s < 32; s += 8) {
                     const u32 c = (w[k] >> s) & 0xffu;
                     if (!seen[c]) seen[c] = 1;
+                    if (sample) atomicAdd(&cnt[c], 1u);
                 }
         }
     }
@@ -65,9 +75,11 @@ __global__ __launch_bounds__(256) void sa_symbols_kernel(const u8 *T, u32 n, u32
     for (u32 i = tail0 + blockIdx.x * blockDim.x + tid; i < n; i += gridDim.x * blockDim.x) {
         const u32 c = T[i];
         if (!seen[c]) seen[c] = 1;
+        atomicAdd(&cnt[c], 1u);
     }
     __syncthreads();
     if (seen[tid]) present[tid] = 1;
+    if (cnt[tid]) atomicAdd(&counts[tid], cnt[tid]);
 }
 
 // codes[i] = lut[T[i]] for i < n, 0 for n <= i < n_pad (n_pad % 16 == 0).
@@ -129,6 +141,8 @@ struct RerankArgs {
     u32 *ISA;
     u32 *pos_out, *idx_out, *grp_out;
     u32 *counters;       // [0] total active
+    u64 *ht;             // sparse mode: suffix -> rank hash table (see ht_*)
+    u32 ht_mask;
 };
 
 struct WaveFlags {
@@ -225,6 +239,67 @@ __global__ __launch_bounds__(1024) void rr_scan_kernel(u32 *agg_head, u32 *agg_c
     if (t == 0) counters[0] = tot;
 }
 
+// ---- sparse mode: ranks without an inverse suffix array ----------------------
+// When the initial sort leaves only a sliver of the suffixes unresolved
+// (m0 <= n / 1024), scattering a full n-entry ISA (4 B random writes, ~16x HBM
+// sector amplification) would cost more than the rest of the build.  Instead:
+//   * every initially-active suffix lives in an open-addressing hash table
+//     (entry = (suffix+1) << 32 | rank), refreshed each round;
+//   * any other suffix j was unique after the initial sort, so its rank is
+//     1 + lower_bound(sorted initial keys, key(j)) -- a binary search over the
+//     still-intact sorted key array, no text comparison, depth independent of h.
+
+__device__ __forceinline__ u32 ht_slot(u32 idx, u32 mask) { return (idx * 0x9E3779B1u) & mask; }
+
+__device__ __forceinline__ void ht_insert(u64 *ht, u32 mask, u32 idx, u32 rank)
+{
+    const u64 entry = ((u64)(idx + 1u) << 32) | rank;
+    u32 h = ht_slot(idx, mask);
+    for (;;) {
+        const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&ht[h]), 0ull,
+                                                 (unsigned long long)entry);
+        if (old == 0ull) return;
+        h = (h + 1u) & mask;
+    }
+}
+
+__device__ __forceinline__ void ht_update(u64 *ht, u32 mask, u32 idx, u32 rank)
+{
+    u32 h = ht_slot(idx, mask);
+    for (;;) {
+        const u64 e = ht[h];
+        if ((u32)(e >> 32) == idx + 1u) {
+            ht[h] = ((u64)(idx + 1u) << 32) | rank;
+            return;
+        }
+        if (e == 0) return;   // not an initially-active suffix: cannot happen
+        h = (h + 1u) & mask;
+    }
+}
+
+// rank of suffix j, or 0 if j is not in the table
+__device__ __forceinline__ u32 ht_lookup(const u64 *ht, u32 mask, u32 idx)
+{
+    u32 h = ht_slot(idx, mask);
+    for (;;) {
+        const u64 e = ht[h];
+        if ((u32)(e >> 32) == idx + 1u) return (u32)e;
+        if (e == 0) return 0;
+        h = (h + 1u) & mask;
+    }
+}
+
+__global__ __launch_bounds__(256) void ht_insert_kernel(u64 *ht, u32 mask, const u32 *idx, const u32 *grp, u32 m)
+{
+    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < m; t += gridDim.x * blockDim.x)
+        ht_insert(ht, mask, idx[t], grp[t]);
+}
+
+constexpr int MODE_ISA = 0;    // dense: ISA[suffix] = rank
+constexpr int MODE_NONE = 1;   // initial rerank when the sparse path was chosen
+constexpr int MODE_HT = 2;     // sparse rounds: refresh the hash table
+
+template <int MODE>
 __global__ __launch_bounds__(RR_BLOCK) void rr_apply_kernel(RerankArgs a)
 {
     __shared__ u32 s_wh[RR_WAVES], s_wc[RR_WAVES];
@@ -268,7 +343,8 @@ __global__ __launch_bounds__(RR_BLOCK) void rr_apply_kernel(RerankArgs a)
                 const u32 pj = a.pos ? a.pos[j] : j;
                 const u32 ij = a.idx[j];
                 a.SA[pj] = ij;
-                a.ISA[ij] = newrank;
+                if (MODE == MODE_ISA) a.ISA[ij] = newrank;
+                if (MODE == MODE_HT) ht_update(a.ht, a.ht_mask, ij, newrank);
                 if ((f.act[r] >> lane) & 1ull) {
                     const u32 u = carry_c + mbcnt(f.act[r]);
                     a.pos_out[u] = pj;
@@ -284,15 +360,57 @@ __global__ __launch_bounds__(RR_BLOCK) void rr_apply_kernel(RerankArgs a)
 
 // key(t) = (group rank << rank_bits) | rank of suffix idx[t]+h (0 past the end).
 // Also reduces OR / AND of all keys so the host can skip constant digits.
-__global__ __launch_bounds__(256) void build_keys_kernel(const u32 *idx, const u32 *grp, const u32 *ISA, u32 m,
-                                                           u32 n, u32 h, int rank_bits, u64 *keys, u64 *red)
+struct KeyArgs {
+    const u32 *idx;
+    const u32 *grp;
+    const u32 *ISA;       // dense mode
+    const u64 *ht;        // sparse mode
+    u32 ht_mask;
+    const u64 *k0;        // sparse mode: sorted initial keys (n of them)
+    const u8 *codes;
+    int code_bits, key_chars, plus_one;
+    u32 m, n, h;
+    int rank_bits;
+    u64 *keys;
+    u64 *red;
+};
+
+__device__ __forceinline__ u64 text_key_at(const u8 *codes, u32 j, int b, int k, int plus_one, u32 n)
+{
+    u64 key = 0;
+    for (int c = 0; c < k; ++c) {
+        u32 v = codes[j + c];          // zero padded past n
+        if (plus_one) v = ((u64)j + c < n) ? v + 1u : 0u;
+        key = (key << b) | v;
+    }
+    return key;
+}
+
+template <bool SPARSE>
+__global__ __launch_bounds__(256) void build_keys_kernel(KeyArgs a)
 {
     u64 vor = 0, vand = ~0ull;
-    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < m; t += gridDim.x * blockDim.x) {
-        const u64 i2 = (u64)idx[t] + h;
-        const u32 r2 = (i2 < n) ? ISA[i2] : 0u;
-        const u64 key = ((u64)grp[t] << rank_bits) | r2;
-        keys[t] = key;
+    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < a.m; t += gridDim.x * blockDim.x) {
+        const u64 i2 = (u64)a.idx[t] + a.h;
+        u32 r2 = 0;
+        if (i2 < a.n) {
+            if (SPARSE) {
+                r2 = ht_lookup(a.ht, a.ht_mask, (u32)i2);
+                if (r2 == 0) {
+                    const u64 key = text_key_at(a.codes, (u32)i2, a.code_bits, a.key_chars, a.plus_one, a.n);
+                    u32 lo = 0, hi = a.n;
+                    while (lo < hi) {
+                        const u32 mid = lo + ((hi - lo) >> 1);
+                        if (a.k0[mid] < key) lo = mid + 1; else hi = mid;
+                    }
+                    r2 = lo + 1;
+                }
+            } else {
+                r2 = a.ISA[i2];
+            }
+        }
+        const u64 key = ((u64)a.grp[t] << a.rank_bits) | r2;
+        a.keys[t] = key;
         vor |= key;
         vand &= key;
     }
@@ -302,8 +420,8 @@ __global__ __launch_bounds__(256) void build_keys_kernel(const u32 *idx, const u
         vand &= __shfl_xor(vand, o);
     }
     if (lane_id() == 0) {
-        atomicOr(reinterpret_cast<unsigned long long *>(&red[0]), (unsigned long long)vor);
-        atomicAnd(reinterpret_cast<unsigned long long *>(&red[1]), (unsigned long long)vand);
+        atomicOr(reinterpret_cast<unsigned long long *>(&a.red[0]), (unsigned long long)vor);
+        atomicAnd(reinterpret_cast<unsigned long long *>(&a.red[1]), (unsigned long long)vand);
     }
 }
 
@@ -319,6 +437,32 @@ static void rerank_geometry(u32 m, RerankArgs &a)
 }
 
 enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK };
+
+// Initial key width.  Model the text as i.i.d. with per-symbol collision
+// probability c = sum p_i^2 (from the sampled counts): two suffixes agree on k
+// symbols with probability c^k, so about n * c^k of the suffixes stay tied.
+// Pick the smallest k that leaves <= 1/4096 of them tied (the sparse path
+// finishes those almost for free), then widen k to fill the last radix pass.
+// A wrong guess costs speed only: whatever stays tied goes to the doubling rounds.
+static int choose_key_chars(const u32 *counts, u32 n, int b, int kmax)
+{
+    double tot = 0, c = 0;
+    for (int i = 0; i < 256; ++i) tot += counts[i];
+    if (tot <= 0) return kmax;
+    for (int i = 0; i < 256; ++i) {
+        const double p = counts[i] / tot;
+        c += p * p;
+    }
+    if (c >= 0.999999) return kmax;
+    const double need = (12.0 + log2((double)n)) / -log2(c);
+    int k = (int)ceil(need);
+    if (k < 1) k = 1;
+    if (k > kmax) k = kmax;
+    const int passes = (k * b + 7) / 8;
+    k = (passes * 8) / b;
+    if (k > kmax) k = kmax;
+    return k;
+}
 
 int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, uint32_t flags, pss_sa_stats *stats)
 {
@@ -346,7 +490,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     PSS_TRY(ctx->slot[S_K1].reserve((size_t)n * 8));
     PSS_TRY(ctx->slot[S_V0].reserve((size_t)n * 4));
     PSS_TRY(ctx->slot[S_V1].reserve((size_t)n * 4));
-    PSS_TRY(ctx->slot[S_ISA].reserve((size_t)n * 4));
+    PSS_TRY(ctx->slot[S_ISA].reserve((size_t)n * 4 + 64));
     PSS_TRY(ctx->slot[S_P0].reserve((size_t)n * 4));
     PSS_TRY(ctx->slot[S_P1].reserve((size_t)n * 4));
     PSS_TRY(ctx->slot[S_GRP].reserve((size_t)n * 4));
@@ -354,12 +498,12 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     PSS_TRY(ctx->slot[S_WORK].reserve(sort_ws + 65536));
     u8 *work = ctx->slot[S_WORK].as<u8>();
     u8 *small = work + sort_ws;                       // 64 KiB of small device state
-    u32 *d_present = reinterpret_cast<u32 *>(small);              // [256]
-    u8 *d_lut = small + 1024;                                     // [256]
-    u32 *d_agg_head = reinterpret_cast<u32 *>(small + 2048);      // [1024]
-    u32 *d_agg_cnt = reinterpret_cast<u32 *>(small + 2048 + 4096);
-    u64 *d_red = reinterpret_cast<u64 *>(small + 2048 + 8192);    // [2]
-    u32 *d_counters = reinterpret_cast<u32 *>(small + 2048 + 8192 + 64);
+    u32 *d_present = reinterpret_cast<u32 *>(small);              // [256] presence, [256] sampled counts
+    u8 *d_lut = small + 2048;                                     // [256]
+    u32 *d_agg_head = reinterpret_cast<u32 *>(small + 4096);      // [1024]
+    u32 *d_agg_cnt = reinterpret_cast<u32 *>(small + 8192);       // [1024]
+    u64 *d_red = reinterpret_cast<u64 *>(small + 12288);          // [2]
+    u32 *d_counters = reinterpret_cast<u32 *>(small + 12288 + 64);
 
     u8 *codes = ctx->slot[S_CODES].as<u8>();
     u64 *K[2] = {ctx->slot[S_K0].as<u64>(), ctx->slot[S_K1].as<u64>()};
@@ -376,13 +520,13 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
 
     // ---- 0. alphabet ----
     const int grid_stream = ctx->num_cus * 8;
-    PSS_HIP(hipMemsetAsync(d_present, 0, 1024, s));
-    hipLaunchKernelGGL(sa_symbols_kernel, dim3(grid_stream), dim3(256), 0, s, T, n, d_present);
-    PSS_HIP(hipMemcpyAsync(h_small, d_present, 1024, hipMemcpyDeviceToHost, s));
+    PSS_HIP(hipMemsetAsync(d_present, 0, 2048, s));
+    hipLaunchKernelGGL(sa_symbols_kernel, dim3(grid_stream), dim3(256), 0, s, T, n, d_present, d_present + 256);
+    PSS_HIP(hipMemcpyAsync(h_small, d_present, 2048, hipMemcpyDeviceToHost, s));
     PSS_HIP(hipStreamSynchronize(s));
     u8 lut[256];
     u32 sigma = 0;
-    for (int c = 0; c < 256; ++c) lut[c] = h_small[c] ? (u8)(++sigma) : 0;   // codes 1..sigma (sigma==256: see below)
+    for (int c = 0; c < 256; ++c) lut[c] = h_small[c] ? (u8)(++sigma) : 0;   // codes 1..sigma
     int b = 1;
     while ((1u << b) <= sigma) ++b;               // codes 0..sigma need b bits
     int plus_one = 0;
@@ -391,21 +535,20 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         // packer add 1 to every in-text symbol (9-bit codes, 0 = past the end).
         b = 9;
         plus_one = 1;
+        for (int c = 0; c < 256; ++c) lut[c] = (u8)c;
     }
-    int key_chars = 64 / b;
-    if (key_chars > 16) key_chars = 16;
+    int kmax = 64 / b;
+    if (kmax > 16) kmax = 16;
+    int key_chars = choose_key_chars(h_small + 256, n, b, kmax);
     if (const char *e = getenv("PSS_KEY_CHARS")) {
-        int v = atoi(e);
-        if (v >= 1 && v <= key_chars) key_chars = v;
+        const int v = atoi(e);
+        if (v >= 1 && v <= kmax) key_chars = v;
     }
     st.sigma = sigma;
     st.code_bits = (u32)b;
     st.key_chars = (u32)key_chars;
-    if (sigma == 256) {
-        for (int c = 0; c < 256; ++c) lut[c] = (u8)c;
-    }
-    memcpy(h_small + 512, lut, 256);
-    PSS_HIP(hipMemcpyAsync(d_lut, h_small + 512, 256, hipMemcpyHostToDevice, s));
+    memcpy(h_small + 1024, lut, 256);
+    PSS_HIP(hipMemcpyAsync(d_lut, h_small + 1024, 256, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(sa_recode_kernel, dim3(grid_stream), dim3(256), 0, s, T, n, (u32)n_pad, d_lut, codes);
 
     // ---- 1. initial sort on the first key_chars symbols ----
@@ -416,18 +559,24 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     PSS_TRY(radix_sort_pairs(ctx, K, V, n, key_bits0, 0xffffffffu, &tk, 0, work, &cur, profile, &ss));
     st.initial_passes = (u32)ss.launches;
 
-    // ---- 2. rerank + compaction ----
+    // ---- 2. rerank + compaction, 3. doubling rounds ----
     int rank_bits = 1;
     while ((1ull << rank_bits) <= (u64)n) ++rank_bits;      // ranks 0..n
     RerankArgs ra;
+    memset(&ra, 0, sizeof ra);
     ra.agg_head = d_agg_head;
     ra.agg_cnt = d_agg_cnt;
     ra.SA = SA;
     ra.ISA = ISA;
     ra.counters = d_counters;
+    ra.ht = reinterpret_cast<u64 *>(ISA);     // the two modes never coexist
     u32 m = n;
-    int pcur = 0;                // P[pcur] holds the positions of the active list (after round 0)
+    int pcur = 0;                // P[pcur] holds the SA positions of the active list (after round 0)
     bool identity_pos = true;
+    bool sparse = false;
+    const int k0buf = cur;       // K[k0buf] = sorted initial keys (kept intact in sparse mode)
+    u64 *SK[2] = {nullptr, nullptr};   // sparse mode: small ping-pong key buffers
+    u64 **Kr = K;
     u64 h = (u64)key_chars;
     for (int round = 0;; ++round) {
         if (round > 64) {
@@ -435,7 +584,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
             return PSS_EDEVICE;
         }
         rerank_geometry(m, ra);
-        ra.keys = K[cur];
+        ra.keys = Kr[cur];
         ra.idx = V[cur];
         ra.pos = identity_pos ? nullptr : P[pcur];
         ra.pos_out = P[pcur ^ 1];
@@ -443,27 +592,64 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         ra.grp_out = GRP;
         hipLaunchKernelGGL(rr_reduce_kernel, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
         hipLaunchKernelGGL(rr_scan_kernel, dim3(1), dim3(1024), 0, s, d_agg_head, d_agg_cnt, ra.num_ranges, d_counters);
-        hipLaunchKernelGGL(rr_apply_kernel, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
         PSS_HIP(hipMemcpyAsync(h_small, d_counters, 4, hipMemcpyDeviceToHost, s));
         PSS_HIP(hipStreamSynchronize(s));
-        PSS_HIP(hipGetLastError());
         const u32 m_next = h_small[0];
+        if (round == 0) {
+            const char *e = getenv("PSS_SPARSE");
+            sparse = e ? atoi(e) != 0 : ((u64)m_next * 1024 <= (u64)n);
+            if ((u64)m_next * 16 > (u64)n) sparse = false;   // the hash table must fit the ISA buffer
+            if (m_next == 0) sparse = true;   // nothing left: skip the ISA altogether
+        }
+        if (!sparse) hipLaunchKernelGGL(rr_apply_kernel<MODE_ISA>, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
+        else if (round == 0) hipLaunchKernelGGL(rr_apply_kernel<MODE_NONE>, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
+        else hipLaunchKernelGGL(rr_apply_kernel<MODE_HT>, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
+        PSS_HIP(hipGetLastError());
         if (m_next == 0) break;
         if (h >= (u64)n) {
             set_error("sa_build: %u suffixes unresolved at h=%llu >= n (internal error)", m_next,
                       (unsigned long long)h);
             return PSS_EDEVICE;
         }
-        // ---- 3. doubling round ----
         m = m_next;
         pcur ^= 1;
         identity_pos = false;
         const int src = cur ^ 1;             // V[src] = compacted suffix indices
+        if (sparse && round == 0) {
+            // hash table over the initially-active suffixes, in the (unused) ISA buffer
+            u32 cap = 1024;
+            while (cap < 4u * m) cap <<= 1;
+            ra.ht_mask = cap - 1;
+            PSS_HIP(hipMemsetAsync(ra.ht, 0, (size_t)cap * 8, s));
+            const u32 g2 = (u32)std::min<u64>((u64)grid_stream, ((u64)m + 255) / 256);
+            hipLaunchKernelGGL(ht_insert_kernel, dim3(g2), dim3(256), 0, s, ra.ht, ra.ht_mask, V[src], GRP, m);
+            // small key buffers carved out of the free big key buffer
+            SK[0] = K[k0buf ^ 1];
+            SK[1] = K[k0buf ^ 1] + (size_t)m;
+            Kr = SK;
+        }
         h_small[0] = 0; h_small[1] = 0; h_small[2] = 0xffffffffu; h_small[3] = 0xffffffffu;
         PSS_HIP(hipMemcpyAsync(d_red, h_small, 16, hipMemcpyHostToDevice, s));
+        KeyArgs ka;
+        ka.idx = V[src];
+        ka.grp = GRP;
+        ka.ISA = ISA;
+        ka.ht = ra.ht;
+        ka.ht_mask = ra.ht_mask;
+        ka.k0 = K[k0buf];
+        ka.codes = codes;
+        ka.code_bits = b;
+        ka.key_chars = key_chars;
+        ka.plus_one = plus_one;
+        ka.m = m;
+        ka.n = n;
+        ka.h = (u32)std::min<u64>(h, 0xffffffffull);
+        ka.rank_bits = rank_bits;
+        ka.keys = Kr[src];
+        ka.red = d_red;
         const u32 grid = (u32)std::min<u64>((u64)grid_stream, ((u64)m + 255) / 256);
-        hipLaunchKernelGGL(build_keys_kernel, dim3(grid), dim3(256), 0, s, V[src], GRP, ISA, m, n,
-                           (u32)std::min<u64>(h, 0xffffffffull), rank_bits, K[src], d_red);
+        if (sparse) hipLaunchKernelGGL(build_keys_kernel<true>, dim3(grid), dim3(256), 0, s, ka);
+        else hipLaunchKernelGGL(build_keys_kernel<false>, dim3(grid), dim3(256), 0, s, ka);
         PSS_HIP(hipMemcpyAsync(h_small, d_red, 16, hipMemcpyDeviceToHost, s));
         PSS_HIP(hipStreamSynchronize(s));
         const u64 vor = (u64)h_small[0] | ((u64)h_small[1] << 32);
@@ -474,7 +660,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         for (int p = 0; p < (key_bits + 7) / 8; ++p)
             if ((varying >> (8 * p)) & 0xffull) mask |= 1u << p;
         SortStats rs;
-        PSS_TRY(radix_sort_pairs(ctx, K, V, m, key_bits, mask, nullptr, src, work, &cur, profile, &rs));
+        PSS_TRY(radix_sort_pairs(ctx, Kr, V, m, key_bits, mask, nullptr, src, work, &cur, profile, &rs));
         st.rounds += 1;
         st.round_passes += (u32)rs.launches;
         st.sum_active += m;
@@ -501,6 +687,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     st.pairs_elems = ss.pairs_elems;
     st.ms_text = ss.ms_text;
     st.text_launches = ss.text_launches;
+    st.sparse = sparse ? 1u : 0u;
     if (stats) *stats = st;
     return PSS_OK;
 }

@@ -62,3 +62,19 @@ def test_structured(oracle):
         got = sa_gpu(s)
         exp = oracle.sa(s)
         assert (got == exp).all(), s[:32]
+
+
+@pytest.mark.parametrize('sparse', ['0', '1'])
+@pytest.mark.parametrize('key_chars', [None, '2', '5'])
+def test_forced_modes(oracle, monkeypatch, sparse, key_chars):
+    """Both rank-lookup modes (inverse SA vs hash table + key search) and short
+    initial keys (many doubling rounds) give the same suffix array."""
+    monkeypatch.setenv('PSS_SPARSE', sparse)
+    if key_chars:
+        monkeypatch.setenv('PSS_KEY_CHARS', key_chars)
+    rng = np.random.default_rng(11)
+    cases = [gen_corpus(0, 300000), gen_corpus(1, 200000), gen_corpus(2, 70000), gen_corpus(3, 50000),
+             rng.integers(0, 256, 100000, dtype=np.uint8), rng.integers(0, 2, 150000, dtype=np.uint8),
+             np.frombuffer((b'abcde' * 2000 + b'\n') * 7 + b'xyz' * 100, dtype=np.uint8)]
+    for t in cases:
+        assert (sa_gpu(t) == oracle.sa(t)).all()
