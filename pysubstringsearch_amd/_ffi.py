@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpss.so')
+LIB_PATH = os.environ.get('PSS_LIBPSS') or os.path.join(_HERE, 'libpss.so')   # override: kernel A/B experiments
 
 PSS_OK, PSS_EINVAL, PSS_ENOMEM, PSS_EIO, PSS_ETOOBIG, PSS_EDEVICE, PSS_EFORMAT = 0, -1, -2, -3, -4, -5, -6
 

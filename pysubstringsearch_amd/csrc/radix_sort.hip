@@ -30,9 +30,18 @@
 
 namespace pss {
 
-constexpr int RS_BLOCK = 256;
+#ifndef PSS_RS_BLOCK
+#define PSS_RS_BLOCK 256
+#endif
+#ifndef PSS_RS_IPT
+#define PSS_RS_IPT 16
+#endif
+#ifndef PSS_RS_MINWAVES
+#define PSS_RS_MINWAVES 1
+#endif
+constexpr int RS_BLOCK = PSS_RS_BLOCK;
 constexpr int RS_WAVES = RS_BLOCK / kWave;
-constexpr int RS_IPT = 16;
+constexpr int RS_IPT = PSS_RS_IPT;
 constexpr int RS_TILE = RS_BLOCK * RS_IPT;   // 4096 pairs per tile
 constexpr u32 RS_MAX_RANGES = 1024;
 
@@ -115,7 +124,7 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(PassArgs a)
     __shared__ u32 h[256];
     const u32 tid = threadIdx.x;
     const u32 g = blockIdx.x;
-    h[tid] = 0;
+    if (tid < 256) h[tid] = 0;
     __syncthreads();
     const u32 tile0 = g * a.tiles_per_range;
     const u32 tile1 = min(tile0 + a.tiles_per_range, a.num_tiles);
@@ -148,24 +157,26 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(PassArgs a)
         }
     }
     __syncthreads();
-    const u32 c = h[tid];
-    a.table[tid * a.num_ranges + g] = c;
-    if (c) atomicAdd(&a.totals[tid], c);
+    if (tid < 256) {
+        const u32 c = h[tid];
+        a.table[tid * a.num_ranges + g] = c;
+        if (c) atomicAdd(&a.totals[tid], c);
+    }
 }
 
 // table[d][g] -> exclusive offset of (digit d, range g) in (d-major, g-minor) order.
 __global__ __launch_bounds__(256) void rs_scan_kernel(u32 *table, const u32 *totals, u32 num_ranges)
 {
-    __shared__ u32 scr[RS_WAVES + 1];
+    __shared__ u32 scr[4 + 1];
     const u32 tid = threadIdx.x, d = blockIdx.x;
     u32 base = 0;
-    (void)block_excl_sum<RS_WAVES>(tid < d ? totals[tid] : 0u, scr, &base);
+    (void)block_excl_sum<4>(tid < d ? totals[tid] : 0u, scr, &base);
     const u32 per = (num_ranges + 255) / 256;
     u32 *row = table + (size_t)d * num_ranges;
     const u32 i0 = tid * per, i1 = min(i0 + per, num_ranges);
     u32 local = 0;
     for (u32 i = i0; i < i1; ++i) local += row[i];
-    u32 run = base + block_excl_sum<RS_WAVES>(local, scr, nullptr);
+    u32 run = base + block_excl_sum<4>(local, scr, nullptr);
     for (u32 i = i0; i < i1; ++i) {
         const u32 v = row[i];
         row[i] = run;
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(256) void rs_scan_kernel(u32 *table, const u32 *tot
 }
 
 template <bool FROM_TEXT>
-__global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(PassArgs a)
+__global__ __launch_bounds__(RS_BLOCK, PSS_RS_MINWAVES) void rs_scatter_kernel(PassArgs a)
 {
     __shared__ __attribute__((aligned(16))) u64 exch[RS_TILE];   // 32 KiB, reused for values
     __shared__ u32 wave_hist[RS_WAVES][256];
@@ -185,7 +196,7 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(PassArgs a)
     const u32 tid = threadIdx.x;
     const u32 lane = tid & 63u, wave = tid >> 6;
     const u32 g = xcd_range_of_block(blockIdx.x, gridDim.x);
-    s_off[tid] = a.table[tid * a.num_ranges + g];
+    if (tid < 256) s_off[tid] = a.table[tid * a.num_ranges + g];
 
     const u32 tile0 = g * a.tiles_per_range;
     const u32 tile1 = min(tile0 + a.tiles_per_range, a.num_tiles);
@@ -217,8 +228,7 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(PassArgs a)
                 val[r] = (p < valid_count) ? a.vin[base + p] : 0;
             }
         }
-#pragma unroll
-        for (int w = 0; w < RS_WAVES; ++w) wave_hist[w][tid] = 0;
+        for (u32 i = tid; i < RS_WAVES * 256; i += RS_BLOCK) (&wave_hist[0][0])[i] = 0;
         __syncthreads();
 
         // ---- per-wave stable ranking ----
@@ -239,25 +249,29 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(PassArgs a)
         }
         __syncthreads();
 
-        // ---- workgroup prefix over digits (thread tid owns digit tid) ----
+        // ---- workgroup prefix over digits (thread d < 256 owns digit d) ----
         {
             u32 c[RS_WAVES];
             u32 total = 0;
+            if (tid < 256) {
 #pragma unroll
-            for (int w = 0; w < RS_WAVES; ++w) {
-                c[w] = wave_hist[w][tid];
-                total += c[w];
+                for (int w = 0; w < RS_WAVES; ++w) {
+                    c[w] = wave_hist[w][tid];
+                    total += c[w];
+                }
             }
             const u32 dstart = block_excl_sum<RS_WAVES>(total, s_scr, nullptr);
-            u32 run = dstart;
+            if (tid < 256) {
+                u32 run = dstart;
 #pragma unroll
-            for (int w = 0; w < RS_WAVES; ++w) {
-                wave_hist[w][tid] = run;
-                run += c[w];
+                for (int w = 0; w < RS_WAVES; ++w) {
+                    wave_hist[w][tid] = run;
+                    run += c[w];
+                }
+                const u32 off = s_off[tid];
+                s_delta[tid] = off - dstart;
+                s_off[tid] = off + total;
             }
-            const u32 off = s_off[tid];
-            s_delta[tid] = off - dstart;
-            s_off[tid] = off + total;
         }
         __syncthreads();
 
