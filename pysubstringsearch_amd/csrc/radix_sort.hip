@@ -61,6 +61,7 @@ struct PassArgs {
     int shift;
     u32 *table;    // [256][num_ranges]
     u32 *totals;   // [256]
+    int debug;     // experiments only: 1 = identity destinations, 2 = no stores
 };
 
 // Packs the keys of 16 consecutive suffixes i0 .. i0+15 (i0 % 16 == 0) from the
@@ -195,7 +196,11 @@ __global__ __launch_bounds__(RS_BLOCK, PSS_RS_MINWAVES) void rs_scatter_kernel(P
 
     const u32 tid = threadIdx.x;
     const u32 lane = tid & 63u, wave = tid >> 6;
+#ifdef PSS_RS_NO_XCD
+    const u32 g = blockIdx.x;
+#else
     const u32 g = xcd_range_of_block(blockIdx.x, gridDim.x);
+#endif
     if (tid < 256) s_off[tid] = a.table[tid * a.num_ranges + g];
 
     const u32 tile0 = g * a.tiles_per_range;
@@ -232,20 +237,26 @@ __global__ __launch_bounds__(RS_BLOCK, PSS_RS_MINWAVES) void rs_scatter_kernel(P
         __syncthreads();
 
         // ---- per-wave stable ranking ----
+        // Round r ranks item r of every lane.  Lanes sharing a digit are found
+        // with ballots (match_digit8); the lowest of them adds the group size
+        // to the wave's LDS counter with a returning atomic (ds_add_rtn), so the
+        // 16 rounds pipeline instead of waiting on a load-modify-store each.
+        u32 prev[RS_IPT];
 #pragma unroll
         for (int r = 0; r < RS_IPT; ++r) {
             const bool valid = pos_of(r) < valid_count;
             const u32 d = (u32)(key[r] >> a.shift) & 0xffu;
             const u64 peers = match_digit8(d, __ballot(valid));
             const u32 below = mbcnt(peers);
-            u32 prev = 0;
-            if (valid && below == 0) {
-                prev = wave_hist[wave][d];
-                wave_hist[wave][d] = prev + (u32)__popcll(peers);
-            }
-            const int leader = valid ? (int)__builtin_ctzll(peers) : (int)lane;
-            prev = __shfl(prev, leader);
-            rank[r] = prev + below;
+            prev[r] = 0;
+            if (valid && below == 0) prev[r] = atomicAdd(&wave_hist[wave][d], (u32)__popcll(peers));
+            const u32 leader = valid ? (u32)__builtin_ctzll(peers) : lane;
+            rank[r] = below | (leader << 16);
+        }
+#pragma unroll
+        for (int r = 0; r < RS_IPT; ++r) {
+            const u32 p = __shfl(prev[r], (int)(rank[r] >> 16));
+            rank[r] = p + (rank[r] & 0xffffu);
         }
         __syncthreads();
 
@@ -294,7 +305,12 @@ __global__ __launch_bounds__(RS_BLOCK, PSS_RS_MINWAVES) void rs_scatter_kernel(P
                 const u64 k = exch[p];
                 const u32 d = (u32)(k >> a.shift) & 0xffu;
                 gpos[i] = s_delta[d] + p;
-                a.kout[gpos[i]] = k;
+                if (a.debug == 1) gpos[i] = base + p;
+#ifdef PSS_RS_NT
+                if (a.debug != 2) __builtin_nontemporal_store(k, &a.kout[gpos[i]]);
+#else
+                if (a.debug != 2) a.kout[gpos[i]] = k;
+#endif
             }
         }
         __syncthreads();
@@ -307,7 +323,11 @@ __global__ __launch_bounds__(RS_BLOCK, PSS_RS_MINWAVES) void rs_scatter_kernel(P
 #pragma unroll
         for (int i = 0; i < RS_IPT; ++i) {
             const u32 p = i * RS_BLOCK + tid;
-            if (p < valid_count) a.vout[gpos[i]] = exv[p];
+#ifdef PSS_RS_NT
+            if (p < valid_count && a.debug != 2) __builtin_nontemporal_store(exv[p], &a.vout[gpos[i]]);
+#else
+            if (p < valid_count && a.debug != 2) a.vout[gpos[i]] = exv[p];
+#endif
         }
         __syncthreads();
     }
@@ -389,6 +409,7 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
     for (int p = 0; p < passes; ++p) {
         if (!((pass_mask >> p) & 1u)) continue;
         PassArgs a;
+        a.debug = getenv("PSS_RS_DEBUG") ? atoi(getenv("PSS_RS_DEBUG")) : 0;
         a.n = n;
         a.num_tiles = num_tiles;
         a.tiles_per_range = tpr;

@@ -1,6 +1,7 @@
 """Exploration: time pss_sa_build_device on synthetic corpora (device-resident)."""
 import ctypes
 import hashlib
+import os
 import sys
 import time
 
@@ -29,7 +30,7 @@ def main():
     st = _ffi.SaStats()
     for r in range(reps):
         t0 = time.time()
-        rc = _ffi.lib.pss_sa_build_device(dT.data_ptr(), dSA.data_ptr(), n, 0, 1 if r == reps - 1 else 0, ctypes.byref(st))
+        rc = _ffi.lib.pss_sa_build_device(dT.data_ptr(), dSA.data_ptr(), n, 0, 1 if (r == reps - 1 or os.environ.get('PSS_PROFILE_ALL')) else 0, ctypes.byref(st))
         _ffi.check(rc)
         wall = time.time() - t0
         d = st.as_dict()
