@@ -61,7 +61,6 @@ struct PassArgs {
     int shift;
     u32 *table;    // [256][num_ranges]
     u32 *totals;   // [256]
-    int debug;     // experiments only: 1 = identity destinations, 2 = no stores
 };
 
 // Packs the keys of 16 consecutive suffixes i0 .. i0+15 (i0 % 16 == 0) from the
@@ -185,151 +184,161 @@ __global__ __launch_bounds__(256) void rs_scan_kernel(u32 *table, const u32 *tot
     }
 }
 
+// One tile of the scatter pass.  FULL = every slot of the tile holds an element
+// (all but the last tile of the input): the per-item bounds predicates fold away.
+template <bool FROM_TEXT, bool FULL, int IPT>
+__device__ __forceinline__ void scatter_tile(const PassArgs &a, u32 base, u32 valid_count, u64 *exch,
+                                             u32 (*wave_hist)[256], u32 *s_off, u32 *s_delta, u32 *s_scr)
+{
+    const u32 tid = threadIdx.x;
+    const u32 lane = tid & 63u, wave = tid >> 6;
+    u64 key[IPT] = {};
+    u32 val[IPT];
+    u32 rank[IPT];
+    // position of item r inside the tile
+    auto pos_of = [&](int r) -> u32 {
+        return FROM_TEXT ? tid * IPT + r : wave * (kWave * IPT) + r * kWave + lane;
+    };
+    auto is_valid = [&](int r) -> bool { return FULL || pos_of(r) < valid_count; };
+    if (FROM_TEXT) {
+        const u32 i0 = base + tid * IPT;
+        if (FULL || i0 < a.n) {
+            static_assert(!FROM_TEXT || IPT == RS_IPT, "text tiles are 16 items per thread");
+            u64 (&k16)[RS_IPT] = reinterpret_cast<u64 (&)[RS_IPT]>(key);
+            text_keys16(a.codes, i0, a.code_bits, a.key_chars, a.plus_one, a.n, k16);
+        }
+#pragma unroll
+        for (int r = 0; r < IPT; ++r) val[r] = i0 + r;
+    } else {
+#pragma unroll
+        for (int r = 0; r < IPT; ++r) key[r] = is_valid(r) ? a.kin[base + pos_of(r)] : 0;
+    }
+    for (u32 i = tid; i < RS_WAVES * 256; i += RS_BLOCK) (&wave_hist[0][0])[i] = 0;
+    __syncthreads();
+
+    // ---- per-wave stable ranking ----
+    // Round r ranks item r of every lane.  Lanes sharing a digit are found
+    // with ballots (match_digit8); the lowest of them adds the group size
+    // to the wave's LDS counter with a returning atomic (ds_add_rtn), so the
+    // 16 rounds pipeline instead of waiting on a load-modify-store each.
+    u32 prev[IPT];
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+        const bool valid = is_valid(r);
+        const u32 d = (u32)(key[r] >> a.shift) & 0xffu;
+        const u64 peers = match_digit8(d, FULL ? ~0ull : __ballot(valid));
+        const u32 below = mbcnt(peers);
+        prev[r] = 0;
+        if (valid && below == 0) prev[r] = atomicAdd(&wave_hist[wave][d], (u32)__popcll(peers));
+        const u32 leader = valid ? (u32)__builtin_ctzll(peers) : lane;
+        rank[r] = below | (leader << 16);
+    }
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+        const u32 p = __shfl(prev[r], (int)(rank[r] >> 16));
+        rank[r] = p + (rank[r] & 0xffffu);
+    }
+    __syncthreads();
+
+    // ---- workgroup prefix over digits (thread d < 256 owns digit d) ----
+    {
+        u32 c[RS_WAVES];
+        u32 total = 0;
+        if (tid < 256) {
+#pragma unroll
+            for (int w = 0; w < RS_WAVES; ++w) {
+                c[w] = wave_hist[w][tid];
+                total += c[w];
+            }
+        }
+        const u32 dstart = block_excl_sum<RS_WAVES>(total, s_scr, nullptr);
+        if (tid < 256) {
+            u32 run = dstart;
+#pragma unroll
+            for (int w = 0; w < RS_WAVES; ++w) {
+                wave_hist[w][tid] = run;
+                run += c[w];
+            }
+            const u32 off = s_off[tid];
+            s_delta[tid] = off - dstart;
+            s_off[tid] = off + total;
+        }
+    }
+    __syncthreads();
+
+    // ---- keys through LDS in digit order, then out in contiguous runs ----
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+        const u32 d = (u32)(key[r] >> a.shift) & 0xffu;
+        const u32 lp = wave_hist[wave][d] + rank[r];
+        rank[r] = lp;
+        if (is_valid(r)) exch[lp] = key[r];
+    }
+    __syncthreads();
+    u32 gpos[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        const u32 p = i * RS_BLOCK + tid;
+        gpos[i] = 0;
+        if (FULL || p < valid_count) {
+            const u64 k = exch[p];
+            const u32 d = (u32)(k >> a.shift) & 0xffu;
+            gpos[i] = s_delta[d] + p;
+            a.kout[gpos[i]] = k;
+        }
+    }
+    __syncthreads();
+    u32 *exv = reinterpret_cast<u32 *>(exch);
+    if (!FROM_TEXT) {
+#pragma unroll
+        for (int r = 0; r < IPT; ++r) val[r] = is_valid(r) ? a.vin[base + pos_of(r)] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+        if (is_valid(r)) exv[rank[r]] = val[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        const u32 p = i * RS_BLOCK + tid;
+        if (FULL || p < valid_count) a.vout[gpos[i]] = exv[p];
+    }
+    __syncthreads();
+}
+
+#ifndef PSS_RS_PAIR_IPT
+#define PSS_RS_PAIR_IPT 16
+#endif
+constexpr int RS_PAIR_IPT = PSS_RS_PAIR_IPT;   // items per thread of the (key, value) scatter; divides RS_IPT
+
 template <bool FROM_TEXT>
 __global__ __launch_bounds__(RS_BLOCK, PSS_RS_MINWAVES) void rs_scatter_kernel(PassArgs a)
 {
-    __shared__ __attribute__((aligned(16))) u64 exch[RS_TILE];   // 32 KiB, reused for values
+    constexpr int IPT = FROM_TEXT ? RS_IPT : RS_PAIR_IPT;
+    constexpr u32 SUB = RS_BLOCK * IPT;                               // elements per sub-tile
+    __shared__ __attribute__((aligned(16))) u64 exch[SUB];            // reused for values
     __shared__ u32 wave_hist[RS_WAVES][256];
     __shared__ u32 s_off[256];     // running global offset of each digit for this range
     __shared__ u32 s_delta[256];   // s_off - (start of the digit inside the tile)
     __shared__ u32 s_scr[RS_WAVES + 1];
 
     const u32 tid = threadIdx.x;
-    const u32 lane = tid & 63u, wave = tid >> 6;
-#ifdef PSS_RS_NO_XCD
-    const u32 g = blockIdx.x;
-#else
     const u32 g = xcd_range_of_block(blockIdx.x, gridDim.x);
-#endif
     if (tid < 256) s_off[tid] = a.table[tid * a.num_ranges + g];
 
     const u32 tile0 = g * a.tiles_per_range;
     const u32 tile1 = min(tile0 + a.tiles_per_range, a.num_tiles);
-    for (u32 tile = tile0; tile < tile1; ++tile) {
-        const u32 base = tile * RS_TILE;
-        const u32 valid_count = min((u32)RS_TILE, a.n - base);
-
-        u64 key[RS_IPT] = {};
-        u32 val[RS_IPT];
-        u32 rank[RS_IPT];
-        // position of item r inside the tile
-        auto pos_of = [&](int r) -> u32 {
-            return FROM_TEXT ? tid * RS_IPT + r : wave * (kWave * RS_IPT) + r * kWave + lane;
-        };
-        if (FROM_TEXT) {
-            const u32 i0 = base + tid * RS_IPT;
-            if (i0 < a.n) text_keys16(a.codes, i0, a.code_bits, a.key_chars, a.plus_one, a.n, key);
-#pragma unroll
-            for (int r = 0; r < RS_IPT; ++r) val[r] = i0 + r;
-        } else {
-#pragma unroll
-            for (int r = 0; r < RS_IPT; ++r) {
-                const u32 p = pos_of(r);
-                key[r] = (p < valid_count) ? a.kin[base + p] : 0;
-            }
-#pragma unroll
-            for (int r = 0; r < RS_IPT; ++r) {
-                const u32 p = pos_of(r);
-                val[r] = (p < valid_count) ? a.vin[base + p] : 0;
-            }
-        }
-        for (u32 i = tid; i < RS_WAVES * 256; i += RS_BLOCK) (&wave_hist[0][0])[i] = 0;
-        __syncthreads();
-
-        // ---- per-wave stable ranking ----
-        // Round r ranks item r of every lane.  Lanes sharing a digit are found
-        // with ballots (match_digit8); the lowest of them adds the group size
-        // to the wave's LDS counter with a returning atomic (ds_add_rtn), so the
-        // 16 rounds pipeline instead of waiting on a load-modify-store each.
-        u32 prev[RS_IPT];
-#pragma unroll
-        for (int r = 0; r < RS_IPT; ++r) {
-            const bool valid = pos_of(r) < valid_count;
-            const u32 d = (u32)(key[r] >> a.shift) & 0xffu;
-            const u64 peers = match_digit8(d, __ballot(valid));
-            const u32 below = mbcnt(peers);
-            prev[r] = 0;
-            if (valid && below == 0) prev[r] = atomicAdd(&wave_hist[wave][d], (u32)__popcll(peers));
-            const u32 leader = valid ? (u32)__builtin_ctzll(peers) : lane;
-            rank[r] = below | (leader << 16);
-        }
-#pragma unroll
-        for (int r = 0; r < RS_IPT; ++r) {
-            const u32 p = __shfl(prev[r], (int)(rank[r] >> 16));
-            rank[r] = p + (rank[r] & 0xffffu);
-        }
-        __syncthreads();
-
-        // ---- workgroup prefix over digits (thread d < 256 owns digit d) ----
-        {
-            u32 c[RS_WAVES];
-            u32 total = 0;
-            if (tid < 256) {
-#pragma unroll
-                for (int w = 0; w < RS_WAVES; ++w) {
-                    c[w] = wave_hist[w][tid];
-                    total += c[w];
-                }
-            }
-            const u32 dstart = block_excl_sum<RS_WAVES>(total, s_scr, nullptr);
-            if (tid < 256) {
-                u32 run = dstart;
-#pragma unroll
-                for (int w = 0; w < RS_WAVES; ++w) {
-                    wave_hist[w][tid] = run;
-                    run += c[w];
-                }
-                const u32 off = s_off[tid];
-                s_delta[tid] = off - dstart;
-                s_off[tid] = off + total;
-            }
-        }
-        __syncthreads();
-
-        // ---- keys through LDS in digit order, then out in contiguous runs ----
-#pragma unroll
-        for (int r = 0; r < RS_IPT; ++r) {
-            const bool valid = pos_of(r) < valid_count;
-            const u32 d = (u32)(key[r] >> a.shift) & 0xffu;
-            const u32 lp = wave_hist[wave][d] + rank[r];
-            rank[r] = lp;
-            if (valid) exch[lp] = key[r];
-        }
-        __syncthreads();
-        u32 gpos[RS_IPT];
-#pragma unroll
-        for (int i = 0; i < RS_IPT; ++i) {
-            const u32 p = i * RS_BLOCK + tid;
-            gpos[i] = 0;
-            if (p < valid_count) {
-                const u64 k = exch[p];
-                const u32 d = (u32)(k >> a.shift) & 0xffu;
-                gpos[i] = s_delta[d] + p;
-                if (a.debug == 1) gpos[i] = base + p;
-#ifdef PSS_RS_NT
-                if (a.debug != 2) __builtin_nontemporal_store(k, &a.kout[gpos[i]]);
-#else
-                if (a.debug != 2) a.kout[gpos[i]] = k;
-#endif
-            }
-        }
-        __syncthreads();
-        u32 *exv = reinterpret_cast<u32 *>(exch);
-#pragma unroll
-        for (int r = 0; r < RS_IPT; ++r) {
-            if (pos_of(r) < valid_count) exv[rank[r]] = val[r];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < RS_IPT; ++i) {
-            const u32 p = i * RS_BLOCK + tid;
-#ifdef PSS_RS_NT
-            if (p < valid_count && a.debug != 2) __builtin_nontemporal_store(exv[p], &a.vout[gpos[i]]);
-#else
-            if (p < valid_count && a.debug != 2) a.vout[gpos[i]] = exv[p];
-#endif
-        }
-        __syncthreads();
+    if (tile0 >= tile1) return;
+    const u32 e0 = tile0 * (u32)RS_TILE;                       // n < 2^31: no overflow
+    const u32 e1_full = tile1 * (u32)RS_TILE;
+    const u32 e1 = e1_full < a.n ? e1_full : a.n;
+    for (u32 base = e0; base < e1; base += SUB) {
+        const u32 left = e1 - base;
+        const u32 valid_count = left < SUB ? left : SUB;
+        if (valid_count == SUB)
+            scatter_tile<FROM_TEXT, true, IPT>(a, base, valid_count, exch, wave_hist, s_off, s_delta, s_scr);
+        else
+            scatter_tile<FROM_TEXT, false, IPT>(a, base, valid_count, exch, wave_hist, s_off, s_delta, s_scr);
     }
 }
 
@@ -404,12 +413,14 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
 
     hipEvent_t ev[2 * 16];
     bool ev_text[16];
-    int nev = 0;
+    int nev = 0, nev_created = 0;
+    if (profile) {   // created up front: a hipEventCreate between launch and record would idle the GPU
+        for (; nev_created < 32; ++nev_created) PSS_HIP(hipEventCreate(&ev[nev_created]));
+    }
     int executed = 0;
     for (int p = 0; p < passes; ++p) {
         if (!((pass_mask >> p) & 1u)) continue;
         PassArgs a;
-        a.debug = getenv("PSS_RS_DEBUG") ? atoi(getenv("PSS_RS_DEBUG")) : 0;
         a.n = n;
         a.num_tiles = num_tiles;
         a.tiles_per_range = tpr;
@@ -441,15 +452,11 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
         hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(256), 0, ctx->stream, a.table, a.totals, num_ranges);
         if (profile && nev < 32) {
             ev_text[nev / 2] = from_text;
-            PSS_HIP(hipEventCreate(&ev[nev]));
             PSS_HIP(hipEventRecord(ev[nev++], ctx->stream));
         }
         if (from_text) hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(num_ranges), dim3(RS_BLOCK), 0, ctx->stream, a);
         else hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(num_ranges), dim3(RS_BLOCK), 0, ctx->stream, a);
-        if (profile && nev < 32) {
-            PSS_HIP(hipEventCreate(&ev[nev]));
-            PSS_HIP(hipEventRecord(ev[nev++], ctx->stream));
-        }
+        if (profile && nev < 32) PSS_HIP(hipEventRecord(ev[nev++], ctx->stream));
         PSS_HIP(hipGetLastError());
         cur = out;
         from_text = false;
@@ -470,8 +477,8 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
                 else { stats->ms_pairs += ms; stats->pairs_launches += 1; stats->pairs_elems += n; }
             }
         }
-        for (int i = 0; i < nev; ++i) (void)hipEventDestroy(ev[i]);
     }
+    for (int i = 0; i < nev_created; ++i) (void)hipEventDestroy(ev[i]);
     if (executed == 0 && text != nullptr) {
         set_error("radix_sort_pairs: text source needs at least one pass");
         return PSS_EINVAL;

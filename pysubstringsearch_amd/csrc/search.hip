@@ -143,7 +143,7 @@ template <typename In>
 __global__ __launch_bounds__(SC_BLOCK) void scan_reduce_kernel(In in, u64 n, u64 per_block, u64 *partial)
 {
     __shared__ u64 scr[SC_BLOCK / kWave];
-    const u64 b0 = (u64)blockIdx.x * per_block, b1 = min(b0 + per_block, n);
+    const u64 b0 = (u64)blockIdx.x * per_block, b1 = (b0 + per_block < n) ? b0 + per_block : n;
     u64 acc = 0;
     for (u64 i = b0 + threadIdx.x; i < b1; i += SC_BLOCK) acc += in(i);
     u64 tot;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(SC_BLOCK) void scan_apply_kernel(In in, u64 n, u64 
                                                                 u64 *out, const u64 *total)
 {
     __shared__ u64 scr[SC_BLOCK / kWave];
-    const u64 b0 = (u64)blockIdx.x * per_block, b1 = min(b0 + per_block, n);
+    const u64 b0 = (u64)blockIdx.x * per_block, b1 = (b0 + per_block < n) ? b0 + per_block : n;
     u64 carry = partial[blockIdx.x];
     for (u64 base = b0; base < b1; base += SC_BLOCK) {
         const u64 i = base + threadIdx.x;
