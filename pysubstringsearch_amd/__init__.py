@@ -21,6 +21,11 @@ import typing
 from . import _ffi
 from ._ffi import lib as _lib
 
+try:   # C loop for result lists (csrc/pyglue.c); plain Python slicing if it was not built
+    from . import _pssglue
+except ImportError:   # pragma: no cover
+    _pssglue = None
+
 __all__ = ['Writer', 'Reader', 'device_count']
 
 
@@ -144,9 +149,7 @@ class Reader:
     def num_chunks(self) -> int:
         return _lib.pss_reader_num_chunks(self._handle())
 
-    def search_batch_raw(self, patterns: typing.Sequence[bytes]):
-        """One batched device call.  Returns (entries, per_query_counts): the
-        entry byte strings query-major, and how many belong to each query."""
+    def _search_batch(self, patterns: typing.Sequence[bytes], as_str: bool):
         nq = len(patterns)
         blob = b''.join(patterns)
         offs = (ctypes.c_uint64 * (nq + 1))()
@@ -164,12 +167,24 @@ class Reader:
             entries = []
             if n:
                 off = _lib.pss_result_offsets(res)
-                data = ctypes.string_at(_lib.pss_result_bytes(res), off[n])
-                o = off[:n + 1]
-                entries = [data[o[i]:o[i + 1]] for i in range(n)]
+                base = _lib.pss_result_bytes(res)
+                if _pssglue is not None:
+                    entries = _pssglue.entries_to_list(ctypes.cast(base, ctypes.c_void_p).value,
+                                                       ctypes.cast(off, ctypes.c_void_p).value, n, as_str)
+                else:
+                    data = ctypes.string_at(base, off[n])
+                    o = off[:n + 1]
+                    entries = [data[o[i]:o[i + 1]] for i in range(n)]
+                    if as_str:
+                        entries = [e.decode('utf-8') for e in entries]
             return entries, counts
         finally:
             _lib.pss_result_free(res)
+
+    def search_batch_raw(self, patterns: typing.Sequence[bytes]):
+        """One batched device call.  Returns (entries, per_query_counts): the
+        entry byte strings query-major, and how many belong to each query."""
+        return self._search_batch(patterns, False)
 
     def last_stats(self) -> dict:
         st = _ffi.SearchStats()
@@ -177,12 +192,10 @@ class Reader:
         return st.as_dict()
 
     def search(self, substring: str) -> typing.List[str]:
-        entries, _ = self.search_batch_raw([_utf8(substring, 'substring')])
-        return [e.decode('utf-8') for e in entries]
+        return self._search_batch([_utf8(substring, 'substring')], True)[0]
 
     def search_multiple(self, substrings: typing.List[str]) -> typing.List[str]:
-        entries, _ = self.search_batch_raw([_utf8(s, 'substring') for s in substrings])
-        return [e.decode('utf-8') for e in entries]
+        return self._search_batch([_utf8(s, 'substring') for s in substrings], True)[0]
 
     def close(self) -> None:
         if self._h:

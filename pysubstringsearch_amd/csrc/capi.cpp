@@ -2,6 +2,7 @@
 // writer / reader (the .idx chunk-record format of reference src/lib.rs:105-124
 // and 162-199) around the device suffix-array builder and the device search.
 #include <cerrno>
+#include <chrono>
 #include <vector>
 
 #include "common.h"
@@ -12,7 +13,21 @@ using namespace pss;
 
 namespace {
 
-constexpr int W_TEXT = 24, W_SA = 25;   // DeviceCtx slots used by the writer / host SA entry point
+constexpr int W_TEXT = 24, W_SA = 25;
+
+// PSS_TIMING=1: phase timings of the host pipeline on stderr
+struct Phase {
+    const char *name;
+    std::chrono::steady_clock::time_point t0;
+    static bool on() { static const bool v = getenv("PSS_TIMING") != nullptr; return v; }
+    explicit Phase(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {}
+    ~Phase()
+    {
+        if (on())
+            fprintf(stderr, "[pss] %-22s %8.2f ms\n", name,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};   // DeviceCtx slots used by the writer / host SA entry point
 
 template <typename F>
 int guarded(F &&f)
@@ -118,7 +133,6 @@ struct pss_writer {
     size_t limit = 0;    // the reference's Vec capacity (src/lib.rs:62), see reserve()
     size_t alloc = 0;
     int device = 0;
-    std::vector<int32_t> sa;
 };
 
 namespace {
@@ -168,6 +182,31 @@ void put_u32le(uint8_t *p, uint32_t v)
     p[3] = (uint8_t)(v >> 24);
 }
 
+// Streams `bytes` of device memory to fp: the D2H copy of piece i+1 (pinned
+// staging, copy stream) runs while piece i is written to the file.
+int download_to_file(DeviceCtx *ctx, const void *src, size_t bytes, FILE *fp)
+{
+    PSS_TRY(ctx->ensure_staging());
+    const size_t piece = DeviceCtx::kStage;
+    const size_t pieces = (bytes + piece - 1) / piece;
+    auto issue = [&](size_t i) -> int {
+        const size_t off = i * piece, k = std::min(piece, bytes - off);
+        PSS_HIP(hipMemcpyAsync(ctx->stage[i & 1], static_cast<const uint8_t *>(src) + off, k, hipMemcpyDeviceToHost,
+                               ctx->copy_stream));
+        PSS_HIP(hipEventRecord(ctx->stage_ev[i & 1], ctx->copy_stream));
+        return PSS_OK;
+    };
+    if (pieces) PSS_TRY(issue(0));
+    for (size_t i = 0; i < pieces; ++i) {
+        PSS_HIP(hipEventSynchronize(ctx->stage_ev[i & 1]));
+        if (i + 1 < pieces) PSS_TRY(issue(i + 1));
+        const size_t off = i * piece, k = std::min(piece, bytes - off);
+        errno = 0;
+        if (fwrite(ctx->stage[i & 1], 1, k, fp) != k) return io_error("write");
+    }
+    return PSS_OK;
+}
+
 // src/lib.rs:105-124
 int w_dump(pss_writer *w)
 {
@@ -178,17 +217,40 @@ int w_dump(pss_writer *w)
     }
     DeviceCtx *ctx;
     PSS_TRY(get_ctx(w->device, &ctx));
-    w->sa.resize(w->len);
-    PSS_TRY(sa_build_host(ctx, w->buf, w->sa.data(), (int32_t)w->len, nullptr));
+    const size_t n = w->len;
     uint8_t hdr[4];
     errno = 0;
-    put_u32le(hdr, (uint32_t)w->len);
-    if (fwrite(hdr, 1, 4, w->fp) != 4) return io_error("write");
-    if (fwrite(w->buf, 1, w->len, w->fp) != w->len) return io_error("write");
-    put_u32le(hdr, (uint32_t)(w->len * 4));   // wraps like `as u32` at n >= 2^30 (lib.rs:116)
+    put_u32le(hdr, (uint32_t)n);
+    if (n < 2) {
+        // libsais.c:6603-6607: n == 1 -> SA[0] = 0
+        if (fwrite(hdr, 1, 4, w->fp) != 4 || fwrite(w->buf, 1, n, w->fp) != n) return io_error("write");
+        put_u32le(hdr, 4);
+        const uint8_t zero[4] = {0, 0, 0, 0};
+        if (fwrite(hdr, 1, 4, w->fp) != 4 || fwrite(zero, 1, 4, w->fp) != 4) return io_error("write");
+        w->len = 0;
+        return PSS_OK;
+    }
+    // upload + build first (the file stays untouched if the device fails), then
+    // text from the host buffer and the suffix array streamed straight from HBM
+    PSS_TRY(ctx->slot[W_TEXT].reserve(n + 64));
+    PSS_TRY(ctx->slot[W_SA].reserve(n * 4));
+    {
+        Phase ph("dump: upload+build");
+        PSS_HIP(hipMemcpyAsync(ctx->slot[W_TEXT].p, w->buf, n, hipMemcpyHostToDevice, ctx->stream));
+        PSS_TRY(sa_build_device(ctx, ctx->slot[W_TEXT].p, ctx->slot[W_SA].p, (int32_t)n, 0, nullptr));
+    }
+    {
+        Phase ph("dump: write text");
+        if (fwrite(hdr, 1, 4, w->fp) != 4) return io_error("write");
+        if (fwrite(w->buf, 1, n, w->fp) != n) return io_error("write");
+    }
+    put_u32le(hdr, (uint32_t)(n * 4));   // wraps like `as u32` at n >= 2^30 (lib.rs:116)
     if (fwrite(hdr, 1, 4, w->fp) != 4) return io_error("write");
     // x86-64 / little-endian host: int32 in memory == i32le on disk (lib.rs:117-119)
-    if (fwrite(w->sa.data(), 4, w->len, w->fp) != w->len) return io_error("write");
+    {
+        Phase ph("dump: SA -> file");
+        PSS_TRY(download_to_file(ctx, ctx->slot[W_SA].p, n * 4, w->fp));
+    }
     w->len = 0;
     return PSS_OK;
 }
@@ -235,38 +297,79 @@ extern "C" int pss_writer_add_file_lines(pss_writer *w, const char *path)
 {
     return guarded([&]() -> int {
         if (!w || !path) return PSS_EINVAL;
+        Phase ph_all("add_file_lines total");
         errno = 0;
         FILE *in = fopen(path, "rb");
         if (!in) return io_error(path);
-        std::vector<uint8_t> line;
-        std::vector<uint8_t> block((size_t)1 << 20);
+        std::vector<uint8_t> line;                       // carry: the unterminated tail of the previous block
+        std::vector<uint8_t> block((size_t)4 << 20);
         int rc = PSS_OK;
-        auto deliver = [&](bool terminated) -> int {
-            size_t l = line.size();
-            if (terminated && l && line[l - 1] == '\r') --l;
+        auto deliver = [&](const uint8_t *p, size_t l, bool terminated) -> int {
+            if (terminated && l && p[l - 1] == '\r') --l;
             if (w->len + l + 1 > w->limit) PSS_TRY(w_dump(w));   // lib.rs:75-77
-            return w_append(w, line.data(), l);
+            return w_append(w, p, l);
+        };
+        // Whole '\n'-terminated lines without any '\r' are appended in bulk: the
+        // per-line rule "flush when the next line does not fit, then append" is the
+        // same as "append the longest run of whole lines that fits, flush, go on".
+        auto bulk = [&](const uint8_t *p, size_t size) -> int {
+            size_t pos = 0;
+            while (pos < size) {
+                const size_t room = w->limit > w->len ? w->limit - w->len : 0;
+                size_t k = 0;
+                if (size - pos <= room) {
+                    k = size - pos;
+                } else if (room) {
+                    const void *q = memrchr(p + pos, '\n', room);
+                    if (q) k = (size_t)(static_cast<const uint8_t *>(q) - (p + pos)) + 1;
+                }
+                if (k) {
+                    PSS_TRY(w_reserve(w, k));
+                    memcpy(w->buf + w->len, p + pos, k);
+                    w->len += k;
+                    pos += k;
+                } else {   // the next line does not fit: per-line rule (flush, then append, growing if it must)
+                    const uint8_t *nl = static_cast<const uint8_t *>(memchr(p + pos, '\n', size - pos));
+                    const size_t l = (size_t)(nl - (p + pos));
+                    PSS_TRY(deliver(p + pos, l, false));
+                    pos += l + 1;
+                }
+            }
+            return PSS_OK;
         };
         for (;;) {
             const size_t got = fread(block.data(), 1, block.size(), in);
             if (got == 0) break;
             size_t p = 0;
-            while (p < got && rc == PSS_OK) {
-                const uint8_t *nl = static_cast<const uint8_t *>(memchr(block.data() + p, '\n', got - p));
+            if (!line.empty()) {   // finish the carried line first
+                const uint8_t *nl = static_cast<const uint8_t *>(memchr(block.data(), '\n', got));
                 const size_t e = nl ? (size_t)(nl - block.data()) : got;
-                line.insert(line.end(), block.begin() + p, block.begin() + e);
-                if (nl) {
-                    rc = deliver(true);
-                    line.clear();
-                    p = e + 1;
-                } else {
-                    p = got;
-                }
+                line.insert(line.end(), block.begin(), block.begin() + e);
+                if (!nl) continue;
+                rc = deliver(line.data(), line.size(), true);
+                line.clear();
+                p = e + 1;
+                if (rc != PSS_OK) break;
             }
-            if (rc != PSS_OK) break;
+            const void *last = p < got ? memrchr(block.data() + p, '\n', got - p) : nullptr;
+            const size_t whole_end = last ? (size_t)(static_cast<const uint8_t *>(last) - block.data()) + 1 : p;
+            if (whole_end > p) {
+                if (memchr(block.data() + p, '\r', whole_end - p) == nullptr) {
+                    rc = bulk(block.data() + p, whole_end - p);
+                } else {
+                    while (p < whole_end && rc == PSS_OK) {
+                        const uint8_t *nl = static_cast<const uint8_t *>(memchr(block.data() + p, '\n', whole_end - p));
+                        const size_t e = (size_t)(nl - block.data());
+                        rc = deliver(block.data() + p, e - p, true);
+                        p = e + 1;
+                    }
+                }
+                if (rc != PSS_OK) break;
+            }
+            line.insert(line.end(), block.begin() + whole_end, block.begin() + got);
         }
         if (rc == PSS_OK && ferror(in)) rc = io_error(path);
-        if (rc == PSS_OK && !line.empty()) rc = deliver(false);
+        if (rc == PSS_OK && !line.empty()) rc = deliver(line.data(), line.size(), false);
         fclose(in);
         return rc;
     });
@@ -351,21 +454,30 @@ void reader_free(pss_reader *r)
     delete r;
 }
 
-// Reads `bytes` from fp into device memory through a bounce buffer.
-int upload_from_file(pss_reader *r, FILE *fp, void *dst, size_t bytes, std::vector<uint8_t> &bounce)
+// Reads `bytes` from fp into device memory: fread of piece i+1 (into the other
+// pinned staging buffer) overlaps the H2D copy of piece i on the copy stream.
+int upload_from_file(pss_reader *r, FILE *fp, void *dst, size_t bytes)
 {
-    size_t done = 0;
+    DeviceCtx *ctx = r->ctx;
+    PSS_TRY(ctx->ensure_staging());
+    const size_t piece = DeviceCtx::kStage;
+    size_t done = 0, i = 0;
     while (done < bytes) {
-        const size_t k = std::min(bounce.size(), bytes - done);
-        if (fread(bounce.data(), 1, k, fp) != k) {
+        const size_t k = std::min(piece, bytes - done);
+        const int b = (int)(i & 1);
+        if (i >= 2) PSS_HIP(hipEventSynchronize(ctx->stage_ev[b]));   // staging buffer b is free again
+        if (fread(ctx->stage[b], 1, k, fp) != k) {
+            (void)hipStreamSynchronize(ctx->copy_stream);
             set_error("failed to fill whole buffer (truncated index file)");   // UnexpectedEof
             return PSS_EFORMAT;
         }
-        PSS_HIP(hipMemcpyAsync(static_cast<uint8_t *>(dst) + done, bounce.data(), k, hipMemcpyHostToDevice,
-                               r->ctx->stream));
-        PSS_HIP(hipStreamSynchronize(r->ctx->stream));
+        PSS_HIP(hipMemcpyAsync(static_cast<uint8_t *>(dst) + done, ctx->stage[b], k, hipMemcpyHostToDevice,
+                               ctx->copy_stream));
+        PSS_HIP(hipEventRecord(ctx->stage_ev[b], ctx->copy_stream));
         done += k;
+        ++i;
     }
+    PSS_HIP(hipStreamSynchronize(ctx->copy_stream));
     return PSS_OK;
 }
 
@@ -408,7 +520,6 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
         pss_reader *r = new pss_reader();
         r->device = device;
         r->ctx = ctx;
-        std::vector<uint8_t> bounce((size_t)64 << 20);
         uint64_t bytes_read = 0;
         int64_t index = 0;
         int rc = PSS_OK;
@@ -422,7 +533,7 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
                 rc = reader_alloc_chunk(r, dlen, &d_text, &d_sa);
                 if (rc) break;
                 r->chunks.push_back(ChunkDesc{static_cast<uint8_t *>(d_text), static_cast<uint32_t *>(d_sa), dlen, 0});
-                rc = upload_from_file(r, fp, d_text, dlen, bounce);
+                rc = upload_from_file(r, fp, d_text, dlen);
                 if (rc) break;
             } else if (fseeko(fp, dlen, SEEK_CUR) != 0) { rc = io_error(path); break; }
             if (fread(hdr, 1, 4, fp) != 4) { set_error("failed to fill whole buffer (truncated index file)"); rc = PSS_EFORMAT; break; }
@@ -433,7 +544,7 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
                 break;
             }
             if (mine && dlen) {
-                rc = upload_from_file(r, fp, d_sa, (size_t)dlen * 4, bounce);
+                rc = upload_from_file(r, fp, d_sa, (size_t)dlen * 4);
                 if (rc) break;
             } else {
                 if (bytes_read + 8 + dlen + (uint64_t)slen > flen) { set_error("failed to fill whole buffer (truncated index file)"); rc = PSS_EFORMAT; break; }

@@ -46,6 +46,17 @@ void DevBuf::release()
     cap = 0;
 }
 
+int DeviceCtx::ensure_staging()
+{
+    if (stage[0]) return PSS_OK;
+    PSS_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        PSS_HIP(hipHostMalloc(&stage[i], kStage, hipHostMallocDefault));
+        PSS_HIP(hipEventCreateWithFlags(&stage_ev[i], hipEventDisableTiming));
+    }
+    return PSS_OK;
+}
+
 static constexpr int kMaxDevices = 64;
 static DeviceCtx g_ctx[kMaxDevices];
 static std::mutex g_ctx_mu;

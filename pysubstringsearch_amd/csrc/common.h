@@ -50,6 +50,13 @@ struct DeviceCtx {
     DevBuf slot[kSlots];
     void *pinned = nullptr;   // small pinned host scratch for D2H of counters
     size_t pinned_cap = 0;
+    // Two pinned staging buffers + a copy stream: file <-> HBM transfers are
+    // double-buffered so the PCIe copy of piece i overlaps the file I/O of piece i+1.
+    static constexpr size_t kStage = (size_t)64 << 20;
+    void *stage[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    int ensure_staging();
 };
 
 // Validates `device`, makes it current, returns its context (created lazily).

@@ -143,6 +143,7 @@ struct RerankArgs {
     u32 *counters;       // [0] total active
     u64 *ht;             // sparse mode: suffix -> rank hash table (see ht_*)
     u32 ht_mask;
+    int rank_bits;       // doubling rounds: key = (old group rank << rank_bits) | rank2
 };
 
 struct WaveFlags {
@@ -153,10 +154,9 @@ struct WaveFlags {
 
 // Loads the wave's 512-element segment (element (r, lane) = wbase + 64 r + lane)
 // and derives group-head / active ballots from neighbouring keys.
-__device__ __forceinline__ void wave_flags(const u64 *keys, u32 m, u32 wbase, WaveFlags &f)
+__device__ __forceinline__ void wave_flags(const u64 *keys, u32 m, u32 wbase, WaveFlags &f, u64 (&key)[RR_ROWS])
 {
     const u32 lane = lane_id();
-    u64 key[RR_ROWS];
 #pragma unroll
     for (int r = 0; r < RR_ROWS; ++r) {
         const u32 j = wbase + r * kWave + lane;
@@ -204,7 +204,8 @@ __global__ __launch_bounds__(RR_BLOCK) void rr_reduce_kernel(RerankArgs a)
         const u32 wbase = tile * RR_TILE + wave_id() * RR_WSEG;
         if (wbase >= a.m) break;
         WaveFlags f;
-        wave_flags(a.keys, a.m, wbase, f);
+        u64 key[RR_ROWS];
+        wave_flags(a.keys, a.m, wbase, f, key);
 #pragma unroll
         for (int r = 0; r < RR_ROWS; ++r) {
             if (f.head[r]) whead = wbase + r * kWave + (63 - __builtin_clzll(f.head[r])) + 1;
@@ -310,7 +311,8 @@ __global__ __launch_bounds__(RR_BLOCK) void rr_apply_kernel(RerankArgs a)
     for (u32 tile = tile0; tile < tile1; ++tile) {
         const u32 wbase = tile * RR_TILE + w * RR_WSEG;
         WaveFlags f;
-        wave_flags(a.keys, a.m, min(wbase, a.m), f);
+        u64 key[RR_ROWS];
+        wave_flags(a.keys, a.m, min(wbase, a.m), f, key);
         u32 whead = 0, wcnt = 0;
 #pragma unroll
         for (int r = 0; r < RR_ROWS; ++r) {
@@ -343,7 +345,10 @@ __global__ __launch_bounds__(RR_BLOCK) void rr_apply_kernel(RerankArgs a)
                 const u32 pj = a.pos ? a.pos[j] : j;
                 const u32 ij = a.idx[j];
                 a.SA[pj] = ij;
-                if (MODE == MODE_ISA) a.ISA[ij] = newrank;
+                // in a doubling round the key's high half is the old group rank: a suffix
+                // whose rank did not change (e.g. every old group's head) needs no ISA write
+                if (MODE == MODE_ISA && (a.pos == nullptr || newrank != (u32)(key[r] >> a.rank_bits)))
+                    a.ISA[ij] = newrank;
                 if (MODE == MODE_HT) ht_update(a.ht, a.ht_mask, ij, newrank);
                 if ((f.act[r] >> lane) & 1ull) {
                     const u32 u = carry_c + mbcnt(f.act[r]);
@@ -570,6 +575,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     ra.ISA = ISA;
     ra.counters = d_counters;
     ra.ht = reinterpret_cast<u64 *>(ISA);     // the two modes never coexist
+    ra.rank_bits = rank_bits;
     u32 m = n;
     int pcur = 0;                // P[pcur] holds the SA positions of the active list (after round 0)
     bool identity_pos = true;

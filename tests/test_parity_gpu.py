@@ -236,3 +236,35 @@ def test_sa_properties_at_scale():
         for j in range(1, n, n // 20000):
             a, b = int(sa[j - 1]), int(sa[j])
             assert text[a:a + 64] <= text[b:b + 64]
+
+
+@pytest.mark.parametrize('seed', range(5))
+def test_file_ingest_fuzz(tmp_path, oracle, seed):
+    """add_entries_from_file_lines (bulk fast path + per-line path) vs the oracle's
+    line-by-line restatement: byte-identical .idx for random files and chunk limits."""
+    rng = random.Random(100 + seed)
+    parts = []
+    for _ in range(rng.randint(1, 3000)):
+        ln = rng.choice([0, 1, 2, 5, 17, 40, 80, 300])
+        body = bytes(rng.choice(b'abcxyz \t') for _ in range(rng.randint(0, ln)))
+        term = rng.choices([b'\n', b'\r\n', b'\r'], weights=[90, 7 if seed % 2 else 0, 3 if seed % 2 else 0])[0]
+        parts.append(body + term)
+    raw = b''.join(parts)
+    if rng.random() < 0.5:
+        raw = raw.rstrip(b'\n') + b'tail-without-newline'
+    src = tmp_path / 'in.txt'
+    src.write_bytes(raw)
+    for limit in (None, rng.choice([64, 100, 257]), rng.choice([1000, 4096, 30000]), 7):
+        p, q = str(tmp_path / 'g.idx'), str(tmp_path / 'o.idx')
+        w = pysubstringsearch.Writer(p, limit)
+        w.add_entry('a')
+        w.add_entries_from_file_lines(str(src))
+        w.add_entry('z')
+        w.close()
+        oracle.use_reference_sa(False)
+        ow = oracle.OracleWriter(q, limit)
+        ow.add_entry('a')
+        ow.add_entries_from_file_lines(str(src))
+        ow.add_entry('z')
+        ow.close()
+        assert open(p, 'rb').read() == open(q, 'rb').read(), (seed, limit)
