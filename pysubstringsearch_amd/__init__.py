@@ -26,7 +26,7 @@ try:   # C loop for result lists (csrc/pyglue.c); plain Python slicing if it was
 except ImportError:   # pragma: no cover
     _pssglue = None
 
-__all__ = ['Writer', 'Reader', 'device_count']
+__all__ = ['Writer', 'Reader', 'PackedResult', 'device_count']
 
 
 def device_count() -> int:
@@ -116,6 +116,12 @@ class Writer:
             pass
 
 
+class PackedResult(typing.NamedTuple):
+    data: typing.Any      # numpy uint8: all entries back to back
+    offsets: typing.Any   # numpy uint64 [num_entries + 1]
+    counts: typing.Any    # numpy uint64 [num_queries]
+
+
 class Reader:
     """Reference: pysubstringsearch/__init__.py:44-73, src/lib.rs:146-288."""
 
@@ -153,11 +159,16 @@ class Reader:
         nq = len(patterns)
         blob = b''.join(patterns)
         offs = (ctypes.c_uint64 * (nq + 1))()
-        pos = 0
-        for i, p in enumerate(patterns):
-            offs[i] = pos
-            pos += len(p)
-        offs[nq] = pos
+        if nq > 64:
+            import numpy as np
+            view = np.ctypeslib.as_array(offs)
+            np.cumsum(np.fromiter(map(len, patterns), dtype=np.uint64, count=nq), out=view[1:])
+        else:
+            pos = 0
+            for i, p in enumerate(patterns):
+                offs[i] = pos
+                pos += len(p)
+            offs[nq] = pos
         res = ctypes.c_void_p()
         rc = _lib.pss_reader_search_batch(self._handle(), blob, offs, nq, ctypes.byref(res))
         _ffi.check(rc)
@@ -178,6 +189,32 @@ class Reader:
                     if as_str:
                         entries = [e.decode('utf-8') for e in entries]
             return entries, counts
+        finally:
+            _lib.pss_result_free(res)
+
+    def search_batch_packed(self, patterns: typing.Sequence[bytes]) -> 'PackedResult':
+        """One batched device call, zero per-entry Python objects: numpy copies of
+        the packed result (entry i of the batch = data[offsets[i]:offsets[i+1]],
+        entries are query-major, counts[q] of them belong to query q).  For
+        hit-heavy batches the Python list of ``search_multiple`` costs more than
+        the search itself (~50 ns per entry); this is the bulk alternative."""
+        import numpy as np
+        nq = len(patterns)
+        blob = b''.join(patterns)
+        offs = np.zeros(nq + 1, dtype=np.uint64)
+        if nq:
+            np.cumsum(np.fromiter(map(len, patterns), dtype=np.uint64, count=nq), out=offs[1:])
+        res = ctypes.c_void_p()
+        _ffi.check(_lib.pss_reader_search_batch(self._handle(), blob, offs.ctypes.data, nq, ctypes.byref(res)))
+        try:
+            n = _lib.pss_result_num_entries(res)
+            counts = np.ctypeslib.as_array(_lib.pss_result_query_counts(res), shape=(nq,)).copy() if nq else \
+                np.zeros(0, np.uint64)
+            offsets = np.ctypeslib.as_array(_lib.pss_result_offsets(res), shape=(n + 1,)).copy()
+            total = int(offsets[n])
+            data = np.ctypeslib.as_array(_lib.pss_result_bytes(res), shape=(total,)).copy() if total else \
+                np.zeros(0, np.uint8)
+            return PackedResult(data, offsets, counts)
         finally:
             _lib.pss_result_free(res)
 

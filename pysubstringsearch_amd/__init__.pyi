@@ -1,0 +1,69 @@
+import typing
+
+
+class Writer:
+    writer: 'Writer'
+
+    def __init__(
+        self,
+        index_file_path: str,
+        max_chunk_len: typing.Optional[int] = None,
+        *,
+        device: typing.Optional[int] = None,
+    ) -> None: ...
+
+    def add_entries_from_file_lines(self, input_file_path: str) -> None: ...
+
+    def add_entry(self, text: str) -> None: ...
+
+    def dump_data(self) -> None: ...
+
+    def finalize(self) -> None: ...
+
+    def close(self) -> None: ...
+
+    def __enter__(self) -> 'Writer': ...
+
+    def __exit__(self, *exc: typing.Any) -> None: ...
+
+
+class PackedResult(typing.NamedTuple):
+    data: typing.Any      # numpy uint8 array: all entries back to back
+    offsets: typing.Any   # numpy uint64 array [num_entries + 1]
+    counts: typing.Any    # numpy uint64 array [num_queries]
+
+
+class Reader:
+    reader: 'Reader'
+
+    def __init__(
+        self,
+        index_file_path: str,
+        *,
+        device: typing.Optional[int] = None,
+        shard: typing.Tuple[int, int] = (0, 1),
+    ) -> None: ...
+
+    @property
+    def num_chunks(self) -> int: ...
+
+    def search(self, substring: str) -> typing.List[str]: ...
+
+    def search_multiple(self, substrings: typing.List[str]) -> typing.List[str]: ...
+
+    def search_batch_raw(
+        self, patterns: typing.Sequence[bytes],
+    ) -> typing.Tuple[typing.List[bytes], typing.List[int]]: ...
+
+    def search_batch_packed(self, patterns: typing.Sequence[bytes]) -> PackedResult: ...
+
+    def last_stats(self) -> typing.Dict[str, float]: ...
+
+    def close(self) -> None: ...
+
+    def __enter__(self) -> 'Reader': ...
+
+    def __exit__(self, *exc: typing.Any) -> None: ...
+
+
+def device_count() -> int: ...

@@ -203,10 +203,18 @@ static int device_excl_scan(DeviceCtx *ctx, In in, u64 n, u64 *partial, u64 *d_t
 
 // ------------------------------------------------------------- hit -> entry --
 
+// High bit of every byte of x that is zero (exact, no cross-byte carries).
+__device__ __forceinline__ u64 zero_bytes(u64 x)
+{
+    const u64 m = 0x7f7f7f7f7f7f7f7full;
+    return ~(((x & m) + m) | x | m);
+}
+
 __global__ __launch_bounds__(256) void hit_lines_kernel(const ChunkDesc *chunks, u32 nc, const u8 *qbytes,
                                                           const u64 *qoff, u64 nvq, const u32 *lo, const u64 *hit_off,
                                                           u64 H, u32 *start_out, u32 *len_out)
 {
+    const u64 NL = 0x0a0a0a0a0a0a0a0aull;
     for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < H; t += (u64)gridDim.x * blockDim.x) {
         // owning (query, chunk): last vq with hit_off[vq] <= t
         u64 a = 0, b = nvq;
@@ -220,18 +228,38 @@ __global__ __launch_bounds__(256) void hit_lines_kernel(const ChunkDesc *chunks,
         const u8 *pat = qbytes + qoff[q];
         const u32 plen = (u32)(qoff[q + 1] - qoff[q]);
         const u32 di = ch.sa[lo[vq] + (u32)(t - hit_off[vq])];
-        // backwards to the entry start; any earlier occurrence inside the entry makes this hit a duplicate
-        const u8 first = plen ? pat[0] : 0;
-        u32 p = di;
-        bool dup = false;
-        while (p > 0) {
-            const u8 ch_b = ch.text[p - 1];
-            if (ch_b == '\n') break;
-            --p;
-            if (plen == 0 || (ch_b == first && cmp_suffix(ch.text, ch.n, p, pat, plen) == 0)) {
-                dup = true;
-                break;
+        // Backwards, 8 bytes at a time, to the entry start (lib.rs:270-273).  Any
+        // earlier occurrence of the query inside the entry makes this hit a duplicate
+        // (lib.rs:262,274): candidates are the bytes equal to the query's first byte.
+        const u64 first = plen ? 0x0101010101010101ull * pat[0] : 0;
+        u32 p = di;            // scan frontier: bytes [p, di) hold no newline
+        bool dup = false, at_start = false;
+        while (p >= 8 && !dup && !at_start) {
+            const u64 w = load_u64_unaligned(ch.text + p - 8);      // byte k of w = text[p-8+k]
+            const u64 nlm = zero_bytes(w ^ NL);
+            u32 keep_from = 0;                                       // first byte index of w inside the entry
+            if (nlm) {
+                keep_from = (u32)((63 - __builtin_clzll(nlm)) >> 3) + 1;
+                at_start = true;
             }
+            if (plen == 0) {
+                dup = keep_from < 8;                                 // an earlier position exists in the entry
+            } else {
+                u64 cand = zero_bytes(w ^ first);
+                if (keep_from) cand &= keep_from < 8 ? ~0ull << (8 * keep_from) : 0ull;
+                while (cand && !dup) {
+                    const u32 k = (u32)(__builtin_ctzll(cand) >> 3);
+                    cand &= cand - 1;
+                    dup = cmp_suffix(ch.text, ch.n, p - 8 + k, pat, plen) == 0;
+                }
+            }
+            p = at_start ? p - 8 + keep_from : p - 8;
+        }
+        while (p > 0 && !dup && !at_start) {                         // the first < 8 bytes of the chunk
+            const u8 cb = ch.text[p - 1];
+            if (cb == '\n') break;
+            --p;
+            dup = plen == 0 || (cb == pat[0] && cmp_suffix(ch.text, ch.n, p, pat, plen) == 0);
         }
         if (dup) {
             len_out[t] = kSkip;
@@ -239,10 +267,18 @@ __global__ __launch_bounds__(256) void hit_lines_kernel(const ChunkDesc *chunks,
             continue;
         }
         const u32 line_start = p;
-        // forwards to the entry end (lib.rs:266-269; no newline: len - 1)
+        // forwards to the entry end (lib.rs:266-269; no newline: len - 1); text is zero padded past n
         u32 e = di;
-        while (e < ch.n && ch.text[e] != '\n') ++e;
-        if (e == ch.n) e = ch.n - 1;
+        for (;;) {
+            const u64 nlm = zero_bytes(load_u64_unaligned(ch.text + e) ^ NL);
+            if (nlm) {
+                e += (u32)(__builtin_ctzll(nlm) >> 3);
+                break;
+            }
+            e += 8;
+            if (e >= ch.n) break;
+        }
+        if (e >= ch.n) e = ch.n - 1;
         start_out[t] = line_start;
         len_out[t] = e >= line_start ? e - line_start : 0;
     }
@@ -264,7 +300,12 @@ __global__ __launch_bounds__(256) void emit_kernel(const ChunkDesc *chunks, u32 
         const u64 o = boff[t];
         ent_off[eidx[t]] = o;
         const u8 *src = ch.text + start[t];
-        for (u32 i = 0; i < l; ++i) out[o + i] = src[i];
+        u32 i = 0;
+        for (; i + 8 <= l; i += 8) {                       // 8 bytes per step, unaligned on both sides
+            const u64 v = load_u64_unaligned(src + i);
+            __builtin_memcpy(out + o + i, &v, 8);
+        }
+        for (; i < l; ++i) out[o + i] = src[i];
     }
 }
 

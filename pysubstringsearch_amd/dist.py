@@ -74,14 +74,15 @@ def gather_results(entries: typing.Sequence[bytes], counts: typing.Sequence[int]
     t_cnt = torch.from_numpy(cnt).to(dev) if len(cnt) else torch.zeros(1, dtype=torch.int64, device=dev)
     t_len = padded(lens, max_e, torch.int64)
     t_blob = padded(blob, max_b, torch.uint8)
-    is_dst = rank == dst
-    g_cnt = [torch.empty_like(t_cnt) for _ in range(world)] if is_dst else None
-    g_len = [torch.empty_like(t_len) for _ in range(world)] if is_dst else None
-    g_blob = [torch.empty_like(t_blob) for _ in range(world)] if is_dst else None
-    dist.gather(t_cnt, g_cnt, dst=dst, group=group)
-    dist.gather(t_len, g_len, dst=dst, group=group)
-    dist.gather(t_blob, g_blob, dst=dst, group=group)
-    if not is_dst:
+    # all_gather (not gather): supported by every backend/version; the payload is
+    # small (result strings), so the extra copies to non-destination ranks are noise
+    g_cnt = [torch.empty_like(t_cnt) for _ in range(world)]
+    g_len = [torch.empty_like(t_len) for _ in range(world)]
+    g_blob = [torch.empty_like(t_blob) for _ in range(world)]
+    dist.all_gather(g_cnt, t_cnt, group=group)
+    dist.all_gather(g_len, t_len, group=group)
+    dist.all_gather(g_blob, t_blob, group=group)
+    if rank != dst:
         return None
     per_rank = []
     for r in range(world):

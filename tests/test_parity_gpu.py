@@ -268,3 +268,22 @@ def test_file_ingest_fuzz(tmp_path, oracle, seed):
         ow.add_entry('z')
         ow.close()
         assert open(p, 'rb').read() == open(q, 'rb').read(), (seed, limit)
+
+
+def test_packed_result_api(tmp_path, oracle):
+    entries = ['alpha beta', 'beta gamma', 'gamma', 'alphabet', '']
+    p = str(tmp_path / 'p.idx')
+    build(p, entries)
+    o = oracle.OracleReader(p)
+    qs = [b'alpha', b'gamma', b'zzz', b'', b'a']
+    with pysubstringsearch.Reader(p) as r:
+        pk = r.search_batch_packed(qs)
+        ents, counts = r.search_batch_raw(qs)
+        assert pk.counts.tolist() == counts
+        blob = pk.data.tobytes()
+        got = [blob[int(pk.offsets[i]):int(pk.offsets[i + 1])] for i in range(len(pk.offsets) - 1)]
+        assert got == ents
+        oe, oc = o.search_multiple_bytes(qs)
+        assert counts == oc.tolist() and sorted(got) == sorted(oe)
+        empty = r.search_batch_packed([])
+        assert empty.counts.size == 0 and empty.offsets.tolist() == [0]
