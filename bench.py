@@ -111,10 +111,18 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     dist = None
+    # Test hook for 1-GPU boxes: PSS_BENCH_BACKEND=gloo lets every rank share GPU 0
+    # so the N > 1 code path (sharding, gather, max-over-ranks timing) can be exercised.
+    backend = os.environ.get('PSS_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from pysubstringsearch_amd import Reader, _ffi
@@ -175,7 +183,7 @@ def main():
     sync_all()
     total_s = time.perf_counter() - t_begin
     sa_stats = st.as_dict()
-    t = torch.tensor([build_s, search_s, total_s], dtype=torch.float64, device='cuda')
+    t = torch.tensor([build_s, search_s, total_s], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     build_s, search_s, total_s = t.tolist()

@@ -67,7 +67,10 @@ typedef struct pss_sa_stats {
     uint64_t pairs_elems;      /* elements summed over those launches */
     double ms_text;            /* first pass, rs_scatter_kernel<true> (1 B in, 12 B out) */
     uint64_t text_launches;
-    uint64_t sparse;           /* 1: rounds ran without an inverse suffix array (hash + key search) */
+    uint64_t mode;             /* how ties were resolved: 0 doubling over an inverse SA (dense), 1 sparse
+                                  (hash + key search, no ISA), 2 text rounds only, 3 text rounds then dense */
+    uint64_t text_rounds;      /* rounds that extended ties with symbols packed from the text */
+    uint64_t big_elems;        /* members of groups > 256 handled by the chained radix sorts, summed */
 } pss_sa_stats;
 
 /*

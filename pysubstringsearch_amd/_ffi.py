@@ -33,7 +33,9 @@ class SaStats(ctypes.Structure):
         ('pairs_elems', ctypes.c_uint64),
         ('ms_text', ctypes.c_double),
         ('text_launches', ctypes.c_uint64),
-        ('sparse', ctypes.c_uint64),
+        ('mode', ctypes.c_uint64),
+        ('text_rounds', ctypes.c_uint64),
+        ('big_elems', ctypes.c_uint64),
     ]
 
     def as_dict(self):

@@ -34,6 +34,7 @@
 #include "prims.h"
 #include "radix_sort.h"
 #include "sa_build.h"
+#include "scan.h"
 
 #include <algorithm>
 #include <cmath>
@@ -133,6 +134,8 @@ struct RerankArgs {
     const u64 *keys;     // sorted keys of the m elements
     const u32 *idx;      // their suffix indices
     const u32 *pos;      // their SA positions (nullptr: element t sits at SA position t)
+    const u32 *grp;      // text rounds: current group rank of every element (keys alone do not
+                         // identify the group); nullptr when the key carries the group
     u32 m;
     u32 num_tiles, tiles_per_range, num_ranges;
     u32 *agg_head;       // [ranges] 1 + last group-head index of the range (0 = none)
@@ -154,33 +157,49 @@ struct WaveFlags {
 
 // Loads the wave's 512-element segment (element (r, lane) = wbase + 64 r + lane)
 // and derives group-head / active ballots from neighbouring keys.
-__device__ __forceinline__ void wave_flags(const u64 *keys, u32 m, u32 wbase, WaveFlags &f, u64 (&key)[RR_ROWS])
+__device__ __forceinline__ void wave_flags(const u64 *keys, const u32 *grp, u32 m, u32 wbase, WaveFlags &f,
+                                           u64 (&key)[RR_ROWS])
 {
     const u32 lane = lane_id();
+    u32 g[RR_ROWS];
 #pragma unroll
     for (int r = 0; r < RR_ROWS; ++r) {
         const u32 j = wbase + r * kWave + lane;
         key[r] = (j < m) ? keys[j] : 0;
+        g[r] = (grp && j < m) ? grp[j] : 0;
     }
-    // key just before the segment (lane 0) and just after it (lane 63)
+    // element just before the segment (lane 0) and just after it (lane 63)
     u64 edge = 0;
-    if (lane == 0 && wbase > 0 && wbase < m) edge = keys[wbase - 1];
+    u32 gedge = 0;
     const u32 jn = wbase + RR_WSEG;
-    if (lane == 63 && jn < m) edge = keys[jn];
-    u64 last = 0;   // key of lane 63 of the previous row
+    if (lane == 0 && wbase > 0 && wbase < m) {
+        edge = keys[wbase - 1];
+        if (grp) gedge = grp[wbase - 1];
+    }
+    if (lane == 63 && jn < m) {
+        edge = keys[jn];
+        if (grp) gedge = grp[jn];
+    }
+    u64 last = 0;   // key / group of lane 63 of the previous row
+    u32 glast = 0;
 #pragma unroll
     for (int r = 0; r < RR_ROWS; ++r) {
         const u32 j = wbase + r * kWave + lane;
         u64 pk = __shfl_up(key[r], 1);
-        if (lane == 0) pk = (r == 0) ? edge : last;
+        u32 pg = __shfl_up(g[r], 1);
+        if (lane == 0) {
+            pk = (r == 0) ? edge : last;
+            pg = (r == 0) ? gedge : glast;
+        }
         last = __shfl(key[r], 63);
+        glast = __shfl(g[r], 63);
         const bool valid = j < m;
-        const bool head = valid && (j == 0 || key[r] != pk);
+        const bool head = valid && (j == 0 || key[r] != pk || g[r] != pg);
         f.head[r] = __ballot(head);
         f.valid[r] = __ballot(valid);
     }
     // is the element right after the segment a head (or the end of the array)?
-    const bool next_seg_head = (jn >= m) || (key[RR_ROWS - 1] != edge);
+    const bool next_seg_head = (jn >= m) || (key[RR_ROWS - 1] != edge) || (g[RR_ROWS - 1] != gedge);
     const u64 nsh = (__ballot(next_seg_head) >> 63) & 1ull;   // lane 63's verdict
 #pragma unroll
     for (int r = 0; r < RR_ROWS; ++r) {
@@ -205,7 +224,7 @@ __global__ __launch_bounds__(RR_BLOCK) void rr_reduce_kernel(RerankArgs a)
         if (wbase >= a.m) break;
         WaveFlags f;
         u64 key[RR_ROWS];
-        wave_flags(a.keys, a.m, wbase, f, key);
+        wave_flags(a.keys, a.grp, a.m, wbase, f, key);
 #pragma unroll
         for (int r = 0; r < RR_ROWS; ++r) {
             if (f.head[r]) whead = wbase + r * kWave + (63 - __builtin_clzll(f.head[r])) + 1;
@@ -312,7 +331,7 @@ __global__ __launch_bounds__(RR_BLOCK) void rr_apply_kernel(RerankArgs a)
         const u32 wbase = tile * RR_TILE + w * RR_WSEG;
         WaveFlags f;
         u64 key[RR_ROWS];
-        wave_flags(a.keys, a.m, min(wbase, a.m), f, key);
+        wave_flags(a.keys, a.grp, a.m, min(wbase, a.m), f, key);
         u32 whead = 0, wcnt = 0;
 #pragma unroll
         for (int r = 0; r < RR_ROWS; ++r) {
@@ -347,7 +366,7 @@ __global__ __launch_bounds__(RR_BLOCK) void rr_apply_kernel(RerankArgs a)
                 a.SA[pj] = ij;
                 // in a doubling round the key's high half is the old group rank: a suffix
                 // whose rank did not change (e.g. every old group's head) needs no ISA write
-                if (MODE == MODE_ISA && (a.pos == nullptr || newrank != (u32)(key[r] >> a.rank_bits)))
+                if (MODE == MODE_ISA && (a.pos == nullptr || a.grp != nullptr || newrank != (u32)(key[r] >> a.rank_bits)))
                     a.ISA[ij] = newrank;
                 if (MODE == MODE_HT) ht_update(a.ht, a.ht_mask, ij, newrank);
                 if ((f.act[r] >> lane) & 1ull) {
@@ -382,11 +401,17 @@ struct KeyArgs {
 
 __device__ __forceinline__ u64 text_key_at(const u8 *codes, u32 j, int b, int k, int plus_one, u32 n)
 {
+    // k <= 16 symbols starting at j: two unaligned 8-byte loads (codes are zero padded past n)
+    const u64 w0 = load_u64_unaligned(codes + j);
+    const u64 w1 = k > 8 ? load_u64_unaligned(codes + j + 8) : 0ull;
     u64 key = 0;
-    for (int c = 0; c < k; ++c) {
-        u32 v = codes[j + c];          // zero padded past n
-        if (plus_one) v = ((u64)j + c < n) ? v + 1u : 0u;
-        key = (key << b) | v;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        if (c < k) {
+            u32 v = (u32)((c < 8 ? w0 : w1) >> ((c & 7) * 8)) & 0xffu;
+            if (plus_one) v = ((u64)j + c < n) ? v + 1u : 0u;
+            key = (key << b) | v;
+        }
     }
     return key;
 }
@@ -430,6 +455,208 @@ __global__ __launch_bounds__(256) void build_keys_kernel(KeyArgs a)
     }
 }
 
+// ---- text rounds: extend every tied group by the NEXT symbols of the text ----
+// Natural text leaves most suffixes tied after the initial sort, but in small
+// groups and only for a few dozen more symbols.  Instead of ranks (which need
+// an n-entry inverse suffix array: n random 4-byte writes plus m random reads
+// per round) a round then sorts each group by a 64-bit key packed from the text
+// at offset h: small groups (<= GS_CAP members) are ranked inside LDS by direct
+// counting, the few large groups go through two chained radix sorts
+// (text key, then group).  No ISA exists in this mode; if ties survive
+// TEXT_ROUNDS_MAX rounds (repetitive data) the ISA is built once and the
+// doubling rounds take over.
+
+__global__ __launch_bounds__(256) void text_keys_kernel(const u32 *idx, u32 m, u32 n, u32 h, const u8 *codes, int b,
+                                                          int k, int plus_one, u64 *keys)
+{
+    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < m; t += gridDim.x * blockDim.x) {
+        const u64 j = (u64)idx[t] + h;
+        keys[t] = (j < n) ? text_key_at(codes, (u32)j, b, k, plus_one, n) : 0ull;
+    }
+}
+
+constexpr int GS_T = 2048;      // elements per workgroup window
+#ifndef PSS_GS_CAP
+#define PSS_GS_CAP 512
+#endif
+constexpr int GS_CAP = PSS_GS_CAP;     // largest group ranked in LDS (= halo on both sides)
+constexpr int GS_LDS = GS_T + 2 * GS_CAP;
+
+// Sorts every group of <= GS_CAP members by key (ties keep their order) into
+// okey/oidx; members of larger groups are copied through and flagged in big[].
+// blk_big[b] / blk_heads[b] = flagged elements / flagged group heads of window b.
+// Group extents come from two workgroup scans over the head flags of the LDS
+// range (last head at or before i, first head after i), so every element knows
+// its group in O(1); only members of small groups run the O(size) counting loop.
+constexpr int GS_PER = GS_LDS / 256;   // LDS elements owned by one thread in the extent scans
+static_assert(GS_LDS % 256 == 0, "extent scans assume an even split");
+
+__global__ __launch_bounds__(256) void group_sort_kernel(const u64 *key, const u32 *idx, const u32 *grp, u32 m,
+                                                           u64 *okey, u32 *oidx, u8 *big, u32 *blk_big, u32 *blk_heads)
+{
+    __shared__ u64 s_key[GS_LDS];
+    __shared__ u32 s_grp[GS_LDS];
+    __shared__ u16 s_start[GS_LDS];   // LDS index of the head of i's group
+    __shared__ u16 s_end[GS_LDS];     // LDS index one past the last member of i's group
+    __shared__ u32 s_wave[2][4];
+    __shared__ u32 s_cnt[2];
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const u32 base = blockIdx.x * GS_T;
+    const u32 lo = base >= (u32)GS_CAP ? base - GS_CAP : 0;
+    const u32 hi_want = base + GS_T + GS_CAP;
+    const u32 hi = hi_want < m ? hi_want : m;
+    const u32 cnt = hi - lo;                       // valid LDS elements
+    for (u32 i = tid; i < (u32)GS_LDS; i += 256) {
+        s_key[i] = (i < cnt) ? key[lo + i] : 0;
+        s_grp[i] = (i < cnt) ? grp[lo + i] : 0xffffffffu;
+    }
+    if (tid < 2) s_cnt[tid] = 0;
+    __syncthreads();
+    // head flags of my GS_PER consecutive elements; index 0 and everything past the data count as heads
+    const u32 i0 = tid * GS_PER;
+    u32 hm = 0;
+#pragma unroll
+    for (int q = 0; q < GS_PER; ++q) {
+        const u32 i = i0 + q;
+        const bool head = i == 0 || i >= cnt || s_grp[i] != s_grp[i - 1];
+        hm |= (head ? 1u : 0u) << q;
+    }
+    // last head at or before i: exclusive max-scan over threads of (1 + index of my last head)
+    const u32 my_last = hm ? i0 + (31 - __builtin_clz(hm)) + 1 : 0;
+    u32 incl = wave_incl_max(my_last);
+    if (lane == 63) s_wave[0][wave] = incl;
+    // first head after i: exclusive min-scan from the right of my first head -> max-scan of (GS_LDS - index)
+    const u32 my_first_rev = hm ? GS_LDS - (i0 + (u32)__builtin_ctz(hm)) : 0;
+    // reverse lane order inside the wave so that a forward max-scan runs right-to-left
+    u32 rincl = wave_incl_max(__shfl(my_first_rev, 63 - (int)lane));
+    if (lane == 63) s_wave[1][3 - wave] = rincl;
+    __syncthreads();
+    u32 carry = 0;
+    for (u32 w = 0; w < wave; ++w) carry = max(carry, s_wave[0][w]);
+    u32 excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = 0;
+    u32 last_head1 = max(carry, excl);             // 1 + LDS index of the last head before my block of elements
+    u32 rcarry = 0;
+    for (u32 w = 0; w < 3 - wave; ++w) rcarry = max(rcarry, s_wave[1][w]);
+    u32 rexcl = __shfl_up(rincl, 1);
+    if (lane == 0) rexcl = 0;
+    // rexcl belongs to reversed lane (63 - lane); bring it back
+    const u32 rmine = __shfl(rexcl, 63 - (int)lane);
+    const u32 next_rev = max(rcarry, rmine);       // GS_LDS - (LDS index of the first head after my elements), 0 = none
+    u32 next_head = next_rev ? GS_LDS - next_rev : GS_LDS;
+#pragma unroll
+    for (int q = 0; q < GS_PER; ++q) {
+        if ((hm >> q) & 1u) last_head1 = i0 + q + 1;
+        s_start[i0 + q] = (u16)(last_head1 - 1);
+    }
+#pragma unroll
+    for (int q = GS_PER - 1; q >= 0; --q) {
+        s_end[i0 + q] = (u16)next_head;
+        if ((hm >> q) & 1u) next_head = i0 + q;
+    }
+    __syncthreads();
+    const u32 wend = (base + GS_T < m) ? base + GS_T : m;
+    u32 nb = 0, nh = 0;
+    for (u32 j = base + tid; j < wend; j += 256) {
+        const u32 i = j - lo;
+        const u64 k = s_key[i];
+        const u32 gs = s_start[i], ge = s_end[i];          // LDS indices, [gs, ge)
+        // a group touching the edge of the LDS range continues outside (unless that edge is the data's edge)
+        const bool open = (gs == 0 && lo > 0) || (ge >= cnt && hi < m);
+        if (open || ge - gs > (u32)GS_CAP) {
+            okey[j] = k;
+            oidx[j] = idx[j];
+            big[j] = 1;
+            ++nb;
+            if (gs == i) ++nh;
+        } else {
+            u32 rank = 0;
+            for (u32 q = gs; q < ge; ++q) {
+                const u64 kq = s_key[q];
+                rank += (kq < k || (kq == k && q < i)) ? 1u : 0u;
+            }
+            okey[lo + gs + rank] = k;
+            oidx[lo + gs + rank] = idx[j];
+            big[j] = 0;
+        }
+    }
+    if (nb) atomicAdd(&s_cnt[0], nb);
+    if (nh) atomicAdd(&s_cnt[1], nh);
+    __syncthreads();
+    if (tid == 0) {
+        blk_big[blockIdx.x] = s_cnt[0];
+        blk_heads[blockIdx.x] = s_cnt[1];
+    }
+}
+
+// Ordered compaction of the flagged elements of window b: their list index
+// bt[], text key and dense group number (0-based ordinal of the big group).
+__global__ __launch_bounds__(256) void big_compact_kernel(const u8 *big, const u32 *grp, const u64 *key, u32 m,
+                                                            const u64 *blk_big_off, const u64 *blk_head_off, u32 *bt,
+                                                            u64 *bkey, u32 *bgid)
+{
+    __shared__ u32 scr[4 + 1];
+    const u32 tid = threadIdx.x;
+    const u32 base = blockIdx.x * GS_T;
+    u32 run_b = (u32)blk_big_off[blockIdx.x];
+    u32 run_h = (u32)blk_head_off[blockIdx.x];
+    for (u32 c = 0; c < (u32)GS_T; c += 256) {
+        const u32 j = base + c + tid;
+        const bool isb = j < m && big[j];
+        const bool ish = isb && (j == 0 || grp[j] != grp[j - 1]);
+        u32 tot_b, tot_h;
+        const u32 eb = block_excl_sum<4>(isb ? 1u : 0u, scr, &tot_b);
+        const u32 eh = block_excl_sum<4>(ish ? 1u : 0u, scr, &tot_h);
+        if (isb) {
+            const u32 u = run_b + eb;
+            bt[u] = j;
+            bkey[u] = key[j];
+            bgid[u] = run_h + eh + (ish ? 1u : 0u) - 1u;   // heads seen so far, this one included
+        }
+        run_b += tot_b;
+        run_h += tot_h;
+    }
+}
+
+// Second key of the chained sort: the dense group number of the v-th element in
+// text-key order.  `unique` appends v so that an unstable sorter (the one-workgroup
+// bitonic path for tiny lists) still keeps the text-key order inside a group.
+__global__ __launch_bounds__(256) void gather_gid_kernel(const u32 *order, const u32 *bgid, u32 nbig, bool unique,
+                                                           u64 *key2)
+{
+    for (u32 v = blockIdx.x * blockDim.x + threadIdx.x; v < nbig; v += gridDim.x * blockDim.x) {
+        const u64 g = bgid[order[v]];
+        key2[v] = unique ? ((g << 32) | v) : g;
+    }
+}
+
+// v-th element of the (group, key)-sorted big list goes to the v-th big slot.
+__global__ __launch_bounds__(256) void big_writeback_kernel(const u32 *order, const u32 *bt, const u64 *tkey,
+                                                              const u32 *idx, u32 nbig, u64 *okey, u32 *oidx)
+{
+    for (u32 v = blockIdx.x * blockDim.x + threadIdx.x; v < nbig; v += gridDim.x * blockDim.x) {
+        const u32 src = bt[order[v]], dst = bt[v];
+        okey[dst] = tkey[src];
+        oidx[dst] = idx[src];
+    }
+}
+
+__global__ __launch_bounds__(256) void iota_kernel(u32 *v, u32 n)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+
+// Switching from text rounds to doubling rounds: rank of every suffix.
+__global__ __launch_bounds__(256) void isa_from_sa_kernel(const u32 *SA, u32 n, u32 *ISA)
+{
+    for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) ISA[SA[j]] = j + 1;
+}
+__global__ __launch_bounds__(256) void isa_active_kernel(const u32 *idx, const u32 *grp, u32 m, u32 *ISA)
+{
+    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < m; t += gridDim.x * blockDim.x) ISA[idx[t]] = grp[t];
+}
+
 // -------------------------------------------------------------------- host --
 
 static void rerank_geometry(u32 m, RerankArgs &a)
@@ -441,7 +668,7 @@ static void rerank_geometry(u32 m, RerankArgs &a)
     a.num_ranges = (a.num_tiles + a.tiles_per_range - 1) / a.tiles_per_range;
 }
 
-enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK };
+enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK, S_GRP2 = 26, S_BIG = 27 };
 
 // Initial key width.  Model the text as i.i.d. with per-symbol collision
 // probability c = sum p_i^2 (from the sampled counts): two suffixes agree on k
@@ -578,38 +805,60 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     ra.rank_bits = rank_bits;
     u32 m = n;
     int pcur = 0;                // P[pcur] holds the SA positions of the active list (after round 0)
+    int gcur = 0;                // G[gcur] holds its group ranks
+    u32 *G[2] = {GRP, nullptr};
     bool identity_pos = true;
-    bool sparse = false;
+    enum Mode { M_DENSE = 0, M_SPARSE = 1, M_TEXT = 2 };
+    Mode mode = M_DENSE;
+    bool was_text = false;
+    int text_rounds = 0;
+    int text_rounds_max = 5;
+    if (const char *e = getenv("PSS_TEXT_ROUNDS")) text_rounds_max = atoi(e);
+    int kt = 64 / b;             // symbols per text-round key
+    if (kt > 16) kt = 16;
     const int k0buf = cur;       // K[k0buf] = sorted initial keys (kept intact in sparse mode)
     u64 *SK[2] = {nullptr, nullptr};   // sparse mode: small ping-pong key buffers
     u64 **Kr = K;
     u64 h = (u64)key_chars;
+    const u32 grid_all = (u32)grid_stream;
     for (int round = 0;; ++round) {
-        if (round > 64) {
-            set_error("sa_build: no convergence after 64 rounds (internal error)");
+        if (round > 96) {
+            set_error("sa_build: no convergence after 96 rounds (internal error)");
             return PSS_EDEVICE;
         }
         rerank_geometry(m, ra);
         ra.keys = Kr[cur];
         ra.idx = V[cur];
         ra.pos = identity_pos ? nullptr : P[pcur];
+        ra.grp = (mode == M_TEXT && round > 0) ? G[gcur] : nullptr;
         ra.pos_out = P[pcur ^ 1];
         ra.idx_out = V[cur ^ 1];
-        ra.grp_out = GRP;
+        if (round == 0) {
+            PSS_TRY(ctx->slot[S_GRP2].reserve((size_t)n * 4));
+            G[1] = ctx->slot[S_GRP2].as<u32>();
+        }
+        ra.grp_out = G[gcur ^ 1];
         hipLaunchKernelGGL(rr_reduce_kernel, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
         hipLaunchKernelGGL(rr_scan_kernel, dim3(1), dim3(1024), 0, s, d_agg_head, d_agg_cnt, ra.num_ranges, d_counters);
         PSS_HIP(hipMemcpyAsync(h_small, d_counters, 4, hipMemcpyDeviceToHost, s));
         PSS_HIP(hipStreamSynchronize(s));
         const u32 m_next = h_small[0];
         if (round == 0) {
-            const char *e = getenv("PSS_SPARSE");
-            sparse = e ? atoi(e) != 0 : ((u64)m_next * 1024 <= (u64)n);
-            if ((u64)m_next * 16 > (u64)n) sparse = false;   // the hash table must fit the ISA buffer
-            if (m_next == 0) sparse = true;   // nothing left: skip the ISA altogether
+            // few ties: sparse (hash + key search); otherwise extend the ties from the text first
+            mode = ((u64)m_next * 1024 <= (u64)n) ? M_SPARSE : M_TEXT;
+            if (const char *e = getenv("PSS_MODE")) {
+                if (!strcmp(e, "dense")) mode = M_DENSE;
+                else if (!strcmp(e, "sparse")) mode = M_SPARSE;
+                else if (!strcmp(e, "text")) mode = M_TEXT;
+            }
+            if (mode == M_SPARSE && (u64)m_next * 16 > (u64)n) mode = M_TEXT;   // hash table must fit the ISA buffer
+            if (m_next == 0) mode = M_SPARSE;                                   // nothing left: no ISA at all
+            if (mode == M_TEXT && text_rounds_max <= 0) mode = M_DENSE;
+            was_text = mode == M_TEXT;
         }
-        if (!sparse) hipLaunchKernelGGL(rr_apply_kernel<MODE_ISA>, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
-        else if (round == 0) hipLaunchKernelGGL(rr_apply_kernel<MODE_NONE>, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
-        else hipLaunchKernelGGL(rr_apply_kernel<MODE_HT>, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
+        if (mode == M_DENSE) hipLaunchKernelGGL(rr_apply_kernel<MODE_ISA>, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
+        else if (mode == M_SPARSE && round > 0) hipLaunchKernelGGL(rr_apply_kernel<MODE_HT>, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
+        else hipLaunchKernelGGL(rr_apply_kernel<MODE_NONE>, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
         PSS_HIP(hipGetLastError());
         if (m_next == 0) break;
         if (h >= (u64)n) {
@@ -619,16 +868,105 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         }
         m = m_next;
         pcur ^= 1;
+        gcur ^= 1;
         identity_pos = false;
-        const int src = cur ^ 1;             // V[src] = compacted suffix indices
-        if (sparse && round == 0) {
+        const int src = cur ^ 1;             // V[src] = compacted suffix indices, G[gcur] their groups, P[pcur] their slots
+        const u32 grid = (u32)std::min<u64>((u64)grid_stream, ((u64)m + 255) / 256);
+
+        // ---------------------------------------------------------- text round --
+        if (mode == M_TEXT && text_rounds < text_rounds_max) {
+            const u32 nblk = (m + GS_T - 1) / GS_T;
+            // scratch inside the (unused) ISA buffer
+            u8 *scr = reinterpret_cast<u8 *>(ISA);
+            size_t o = 0;
+            auto carve = [&](size_t bytes) { u8 *p = scr + o; o = round_up(o + bytes, 64); return p; };
+            u8 *d_big = carve(m);
+            u32 *d_blk_big = reinterpret_cast<u32 *>(carve((size_t)nblk * 4));
+            u32 *d_blk_heads = reinterpret_cast<u32 *>(carve((size_t)nblk * 4));
+            u64 *d_off_big = reinterpret_cast<u64 *>(carve(((size_t)nblk + 1) * 8));
+            u64 *d_off_heads = reinterpret_cast<u64 *>(carve(((size_t)nblk + 1) * 8));
+            u64 *d_partial = reinterpret_cast<u64 *>(carve((SC_MAX_BLOCKS + 2) * 8));
+            u64 *d_total = d_partial + SC_MAX_BLOCKS;
+            hipLaunchKernelGGL(text_keys_kernel, dim3(grid), dim3(256), 0, s, V[src], m, n,
+                               (u32)std::min<u64>(h, 0xffffffffull), codes, b, kt, plus_one, K[src]);
+            hipLaunchKernelGGL(group_sort_kernel, dim3(nblk), dim3(256), 0, s, K[src], V[src], G[gcur], m, K[src ^ 1],
+                               V[src ^ 1], d_big, d_blk_big, d_blk_heads);
+            PSS_TRY(device_excl_scan(ctx, InU32{d_blk_big}, nblk, d_partial, d_total, d_off_big));
+            PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
+            PSS_HIP(hipStreamSynchronize(s));
+            const u32 nbig = h_small[0];
+            bool text_ok = true;
+            if (getenv("PSS_TIMING")) fprintf(stderr, "[pss] text round %d: h=%llu m=%u nbig=%u (%.1f%%)\n", text_rounds, (unsigned long long)h, m, nbig, 100.0 * nbig / m);
+            if (nbig) {
+                // members of large groups go through two chained radix sorts; when they are the
+                // majority the data is repetitive and doubling (logarithmic in the LCP) is the better tool
+                if ((u64)nbig * 2 > (u64)m && (text_rounds > 0 || (u64)nbig * 4 > (u64)m * 3)) {
+                    text_ok = false;
+                } else {
+                    PSS_TRY(ctx->slot[S_BIG].reserve((size_t)nbig * (4 + 4 + 16 + 8) + 1024));
+                    u8 *bscr = ctx->slot[S_BIG].as<u8>();
+                    size_t bo = 0;
+                    auto bcarve = [&](size_t bytes) { u8 *p = bscr + bo; bo = round_up(bo + bytes, 64); return p; };
+                    u32 *d_bt = reinterpret_cast<u32 *>(bcarve((size_t)nbig * 4));
+                    u32 *d_bgid = reinterpret_cast<u32 *>(bcarve((size_t)nbig * 4));
+                    u64 *BK[2] = {reinterpret_cast<u64 *>(bcarve((size_t)nbig * 8)), reinterpret_cast<u64 *>(bcarve((size_t)nbig * 8))};
+                    u32 *BV[2] = {reinterpret_cast<u32 *>(bcarve((size_t)nbig * 4)), reinterpret_cast<u32 *>(bcarve((size_t)nbig * 4))};
+                    PSS_TRY(device_excl_scan(ctx, InU32{d_blk_heads}, nblk, d_partial, d_total, d_off_heads));
+                    PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
+                    hipLaunchKernelGGL(big_compact_kernel, dim3(nblk), dim3(256), 0, s, d_big, G[gcur], K[src], m, d_off_big,
+                                       d_off_heads, d_bt, BK[0], d_bgid);
+                    PSS_HIP(hipStreamSynchronize(s));
+                    const u32 nbig_groups = h_small[0];
+                    // BV[0][u] = u
+                    hipLaunchKernelGGL(iota_kernel, dim3((nbig + 255) / 256), dim3(256), 0, s, BV[0], nbig);
+                    SortStats s1, s2;
+                    int d1 = 0, d2 = 0;
+                    PSS_TRY(radix_sort_pairs(ctx, BK, BV, nbig, kt * b, 0xffffffffu, nullptr, 0, work, &d1, profile, &s1));
+                    int gid_bits = 1;
+                    while ((1ull << gid_bits) < (u64)nbig_groups) ++gid_bits;
+                    hipLaunchKernelGGL(gather_gid_kernel, dim3((nbig + 255) / 256), dim3(256), 0, s, BV[d1], d_bgid, nbig,
+                                       nbig <= 4096u, BK[d1]);
+                    if (nbig_groups > 1)
+                        PSS_TRY(radix_sort_pairs(ctx, BK, BV, nbig, gid_bits, 0xffffffffu, nullptr, d1, work, &d2, profile, &s2));
+                    else d2 = d1;
+                    hipLaunchKernelGGL(big_writeback_kernel, dim3((nbig + 255) / 256), dim3(256), 0, s, BV[d2], d_bt, K[src],
+                                       V[src], nbig, K[src ^ 1], V[src ^ 1]);
+                    st.round_passes += (u32)(s1.launches + s2.launches);
+                    ss.launches += s1.launches + s2.launches;
+                    ss.elems += s1.elems + s2.elems;
+                    ss.ms += s1.ms + s2.ms;
+                    ss.ms_pairs += s1.ms_pairs + s2.ms_pairs;
+                    ss.pairs_launches += s1.pairs_launches + s2.pairs_launches;
+                    ss.pairs_elems += s1.pairs_elems + s2.pairs_elems;
+                    st.big_elems += nbig;
+                }
+            }
+            if (text_ok) {
+                cur = src ^ 1;
+                st.rounds += 1;
+                st.text_rounds += 1;
+                st.sum_active += m;
+                text_rounds += 1;
+                h += (u64)kt;
+                PSS_HIP(hipGetLastError());
+                continue;
+            }
+        }
+        if (mode == M_TEXT) {
+            // ties outlived the text rounds: build the inverse suffix array once, continue by doubling
+            hipLaunchKernelGGL(isa_from_sa_kernel, dim3(grid_all), dim3(256), 0, s, SA, n, ISA);
+            hipLaunchKernelGGL(isa_active_kernel, dim3(grid), dim3(256), 0, s, V[src], G[gcur], m, ISA);
+            mode = M_DENSE;
+        }
+
+        // ------------------------------------------------- doubling round (ranks) --
+        if (mode == M_SPARSE && round == 0) {
             // hash table over the initially-active suffixes, in the (unused) ISA buffer
             u32 cap = 1024;
             while (cap < 4u * m) cap <<= 1;
             ra.ht_mask = cap - 1;
             PSS_HIP(hipMemsetAsync(ra.ht, 0, (size_t)cap * 8, s));
-            const u32 g2 = (u32)std::min<u64>((u64)grid_stream, ((u64)m + 255) / 256);
-            hipLaunchKernelGGL(ht_insert_kernel, dim3(g2), dim3(256), 0, s, ra.ht, ra.ht_mask, V[src], GRP, m);
+            hipLaunchKernelGGL(ht_insert_kernel, dim3(grid), dim3(256), 0, s, ra.ht, ra.ht_mask, V[src], G[gcur], m);
             // small key buffers carved out of the free big key buffer
             SK[0] = K[k0buf ^ 1];
             SK[1] = K[k0buf ^ 1] + (size_t)m;
@@ -638,7 +976,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         PSS_HIP(hipMemcpyAsync(d_red, h_small, 16, hipMemcpyHostToDevice, s));
         KeyArgs ka;
         ka.idx = V[src];
-        ka.grp = GRP;
+        ka.grp = G[gcur];
         ka.ISA = ISA;
         ka.ht = ra.ht;
         ka.ht_mask = ra.ht_mask;
@@ -653,8 +991,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         ka.rank_bits = rank_bits;
         ka.keys = Kr[src];
         ka.red = d_red;
-        const u32 grid = (u32)std::min<u64>((u64)grid_stream, ((u64)m + 255) / 256);
-        if (sparse) hipLaunchKernelGGL(build_keys_kernel<true>, dim3(grid), dim3(256), 0, s, ka);
+        if (mode == M_SPARSE) hipLaunchKernelGGL(build_keys_kernel<true>, dim3(grid), dim3(256), 0, s, ka);
         else hipLaunchKernelGGL(build_keys_kernel<false>, dim3(grid), dim3(256), 0, s, ka);
         PSS_HIP(hipMemcpyAsync(h_small, d_red, 16, hipMemcpyDeviceToHost, s));
         PSS_HIP(hipStreamSynchronize(s));
@@ -693,7 +1030,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     st.pairs_elems = ss.pairs_elems;
     st.ms_text = ss.ms_text;
     st.text_launches = ss.text_launches;
-    st.sparse = sparse ? 1u : 0u;
+    st.mode = was_text ? (mode == M_TEXT ? 2u : 3u) : (u64)mode;
     if (stats) *stats = st;
     return PSS_OK;
 }

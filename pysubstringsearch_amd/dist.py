@@ -21,7 +21,7 @@ def chunk_owner(chunk_index: int, world_size: int) -> int:
 
 def pack_entries(entries: typing.Sequence[bytes]) -> typing.Tuple[np.ndarray, np.ndarray]:
     lens = np.fromiter((len(e) for e in entries), dtype=np.int64, count=len(entries))
-    blob = np.frombuffer(b''.join(entries), dtype=np.uint8)
+    blob = np.frombuffer(b''.join(entries), dtype=np.uint8).copy()   # writable: torch.from_numpy needs it
     return blob, lens
 
 

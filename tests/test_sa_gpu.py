@@ -64,12 +64,15 @@ def test_structured(oracle):
         assert (got == exp).all(), s[:32]
 
 
-@pytest.mark.parametrize('sparse', ['0', '1'])
+@pytest.mark.parametrize('mode', ['dense', 'sparse', 'text', 'text1'])
 @pytest.mark.parametrize('key_chars', [None, '2', '5'])
-def test_forced_modes(oracle, monkeypatch, sparse, key_chars):
-    """Both rank-lookup modes (inverse SA vs hash table + key search) and short
-    initial keys (many doubling rounds) give the same suffix array."""
-    monkeypatch.setenv('PSS_SPARSE', sparse)
+def test_forced_modes(oracle, monkeypatch, mode, key_chars):
+    """Every tie-resolution mode (inverse SA doubling, hash table + key search,
+    text rounds, text rounds falling back to doubling after one round) and short
+    initial keys (many rounds) give the same suffix array."""
+    monkeypatch.setenv('PSS_MODE', mode.rstrip('1'))
+    if mode == 'text1':
+        monkeypatch.setenv('PSS_TEXT_ROUNDS', '1')
     if key_chars:
         monkeypatch.setenv('PSS_KEY_CHARS', key_chars)
     rng = np.random.default_rng(11)
