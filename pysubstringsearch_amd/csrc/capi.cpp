@@ -483,6 +483,25 @@ int upload_from_file(pss_reader *r, FILE *fp, void *dst, size_t bytes)
 
 }  // namespace
 
+namespace {
+// Device copy of the chunk descriptor array (re-uploaded whenever chunks change).
+int reader_sync_descs(pss_reader *r)
+{
+    const uint32_t nc = (uint32_t)r->chunks.size();
+    if (!r->dirty || nc == 0) return PSS_OK;
+    if (r->d_descs_cap < nc) {
+        if (r->d_descs) (void)hipFree(r->d_descs);
+        r->d_descs = nullptr;
+        const size_t cap = nc < 16 ? 16 : (size_t)nc * 2;
+        PSS_HIP(hipMalloc(reinterpret_cast<void **>(&r->d_descs), sizeof(ChunkDesc) * cap));
+        r->d_descs_cap = cap;
+    }
+    PSS_HIP(hipMemcpy(r->d_descs, r->chunks.data(), sizeof(ChunkDesc) * nc, hipMemcpyHostToDevice));
+    r->dirty = false;
+    return PSS_OK;
+}
+}  // namespace
+
 extern "C" int pss_reader_create(int32_t device, pss_reader **out)
 {
     return guarded([&]() -> int {
@@ -553,6 +572,7 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
             bytes_read += 8 + (uint64_t)dlen + slen;   // lib.rs:184
             ++index;
         }
+        if (rc == PSS_OK) rc = reader_sync_descs(r);
         if (rc != PSS_OK) {
             reader_free(r);
             return rc;
@@ -574,7 +594,7 @@ extern "C" int pss_reader_add_chunk_device(pss_reader *r, const void *d_text, co
         PSS_HIP(hipMemcpyAsync(s, d_sa, (size_t)n * 4, hipMemcpyDeviceToDevice, r->ctx->stream));
         PSS_HIP(hipStreamSynchronize(r->ctx->stream));
         r->dirty = true;
-        return PSS_OK;
+        return reader_sync_descs(r);
     });
 }
 
@@ -590,16 +610,7 @@ extern "C" int pss_reader_search_batch(pss_reader *r, const uint8_t *qbytes, con
         }
         PSS_HIP(hipSetDevice(r->device));
         const uint32_t nc = (uint32_t)r->chunks.size();
-        if (r->dirty && nc) {
-            if (r->d_descs_cap < nc) {
-                if (r->d_descs) (void)hipFree(r->d_descs);
-                r->d_descs = nullptr;
-                PSS_HIP(hipMalloc(reinterpret_cast<void **>(&r->d_descs), sizeof(ChunkDesc) * nc));
-                r->d_descs_cap = nc;
-            }
-            PSS_HIP(hipMemcpy(r->d_descs, r->chunks.data(), sizeof(ChunkDesc) * nc, hipMemcpyHostToDevice));
-            r->dirty = false;
-        }
+        PSS_TRY(reader_sync_descs(r));
         pss_result *res = new pss_result();
         const int rc = search_batch_device(r->ctx, r->d_descs, nc, qbytes, qoffsets, nq, &res->r, &r->last);
         if (rc != PSS_OK) {
