@@ -145,15 +145,16 @@ def main():
 
     st = _ffi.SaStats()
     last = {}
+    h = ctypes.c_void_p()
+    _ffi.check(lib.pss_reader_create(dev, ctypes.byref(h)))
+    reader = Reader._from_handle(h)   # device-resident index of this rank, refreshed every step
 
     def step(flags=0):
         t0 = time.perf_counter()
         _ffi.check(lib.pss_sa_build_device(dT.data_ptr(), dSA.data_ptr(), n, dev, flags, ctypes.byref(st)))
         t1 = time.perf_counter()
-        h = ctypes.c_void_p()
-        _ffi.check(lib.pss_reader_create(dev, ctypes.byref(h)))
-        reader = Reader._from_handle(h)
-        _ffi.check(lib.pss_reader_add_chunk_device(h, dT.data_ptr(), dSA.data_ptr(), n))
+        # Writer -> Reader hand-off through HBM (no file): the fresh text + SA replace the resident chunk
+        _ffi.check(lib.pss_reader_set_chunk_device(h, 0, dT.data_ptr(), dSA.data_ptr(), n))
         t2 = time.perf_counter()
         entries, counts = reader.search_batch_raw(queries)
         if world > 1:
@@ -163,7 +164,6 @@ def main():
         t3 = time.perf_counter()
         last['entries'] = len(entries)
         last['search_stats'] = reader.last_stats()
-        reader.close()
         return t1 - t0, t3 - t2
 
     def sync_all():
@@ -257,6 +257,7 @@ def main():
             'secondary': secondary,
         }
         print(json.dumps(out))
+    reader.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

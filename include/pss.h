@@ -122,6 +122,10 @@ int pss_reader_open(const char *path, int32_t device, int32_t shard_index, int32
 int pss_reader_create(int32_t device, pss_reader **out);
 /* Adopts COPIES of a device-resident chunk (text n bytes, SA n int32). */
 int pss_reader_add_chunk_device(pss_reader *r, const void *d_text, const void *d_sa, uint32_t n);
+/* Replaces resident chunk `index` (index == num_chunks appends) by a copy of
+ * the device-resident chunk; reuses the HBM allocation when the size matches
+ * (re-indexing the same shard repeatedly without allocator traffic). */
+int pss_reader_set_chunk_device(pss_reader *r, uint64_t index, const void *d_text, const void *d_sa, uint32_t n);
 /* Chunks resident in this reader. */
 uint64_t pss_reader_num_chunks(const pss_reader *r);
 

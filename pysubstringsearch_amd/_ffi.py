@@ -104,6 +104,7 @@ def _load() -> ctypes.CDLL:
         'pss_reader_open': (ctypes.c_int, [cp, i32, i32, i32, pvp]),
         'pss_reader_create': (ctypes.c_int, [i32, pvp]),
         'pss_reader_add_chunk_device': (ctypes.c_int, [vp, vp, vp, u32]),
+        'pss_reader_set_chunk_device': (ctypes.c_int, [vp, u64, vp, vp, u32]),
         'pss_reader_num_chunks': (u64, [vp]),
         'pss_reader_search_batch': (ctypes.c_int, [vp, vp, vp, u32, pvp]),
         'pss_reader_last_stats': (ctypes.c_int, [vp, ctypes.POINTER(SearchStats)]),

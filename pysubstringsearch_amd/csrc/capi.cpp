@@ -598,6 +598,31 @@ extern "C" int pss_reader_add_chunk_device(pss_reader *r, const void *d_text, co
     });
 }
 
+extern "C" int pss_reader_set_chunk_device(pss_reader *r, uint64_t index, const void *d_text, const void *d_sa,
+                                           uint32_t n)
+{
+    return guarded([&]() -> int {
+        if (!r || !d_text || !d_sa || n == 0 || index > r->chunks.size()) {
+            set_error("pss_reader_set_chunk_device: bad arguments");
+            return PSS_EINVAL;
+        }
+        if (index == r->chunks.size()) return pss_reader_add_chunk_device(r, d_text, d_sa, n);
+        ChunkDesc &c = r->chunks[index];
+        if (c.n != n) {   // different size: fresh allocation
+            void *t = nullptr, *sa = nullptr;
+            PSS_TRY(reader_alloc_chunk(r, n, &t, &sa));
+            (void)hipFree(const_cast<uint8_t *>(c.text));
+            (void)hipFree(const_cast<uint32_t *>(c.sa));
+            c = ChunkDesc{static_cast<uint8_t *>(t), static_cast<uint32_t *>(sa), n, 0};
+            r->dirty = true;
+        }
+        PSS_HIP(hipMemcpyAsync(const_cast<uint8_t *>(c.text), d_text, n, hipMemcpyDeviceToDevice, r->ctx->stream));
+        PSS_HIP(hipMemcpyAsync(const_cast<uint32_t *>(c.sa), d_sa, (size_t)n * 4, hipMemcpyDeviceToDevice, r->ctx->stream));
+        PSS_HIP(hipStreamSynchronize(r->ctx->stream));
+        return reader_sync_descs(r);
+    });
+}
+
 extern "C" uint64_t pss_reader_num_chunks(const pss_reader *r) { return r ? r->chunks.size() : 0; }
 
 extern "C" int pss_reader_search_batch(pss_reader *r, const uint8_t *qbytes, const uint64_t *qoffsets, uint32_t nq,
