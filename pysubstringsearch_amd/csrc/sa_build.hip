@@ -812,6 +812,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     Mode mode = M_DENSE;
     bool was_text = false;
     int text_rounds = 0;
+    u32 m_text_prev = 0;
     int text_rounds_max = 5;
     if (const char *e = getenv("PSS_TEXT_ROUNDS")) text_rounds_max = atoi(e);
     int kt = 64 / b;             // symbols per text-round key
@@ -874,7 +875,12 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         const u32 grid = (u32)std::min<u64>((u64)grid_stream, ((u64)m + 255) / 256);
 
         // ---------------------------------------------------------- text round --
-        if (mode == M_TEXT && text_rounds < text_rounds_max) {
+        // Text rounds advance h linearly; they pay off while each round resolves most
+        // ties (natural-language LCPs).  When a round leaves more than 60 % of its list
+        // tied the data is repetitive (long LCPs): doubling, logarithmic in the LCP, takes over.
+        const bool text_progress = text_rounds == 0 || (u64)m * 10 <= (u64)m_text_prev * 6;
+        if (mode == M_TEXT && text_rounds < text_rounds_max && text_progress) {
+            m_text_prev = m;
             const u32 nblk = (m + GS_T - 1) / GS_T;
             // scratch inside the (unused) ISA buffer
             u8 *scr = reinterpret_cast<u8 *>(ISA);
