@@ -364,9 +364,8 @@ __global__ __launch_bounds__(RR_BLOCK) void rr_apply_kernel(RerankArgs a)
                 const u32 pj = a.pos ? a.pos[j] : j;
                 const u32 ij = a.idx[j];
                 a.SA[pj] = ij;
-                // in a doubling round the key's high half is the old group rank: a suffix
-                // whose rank did not change (e.g. every old group's head) needs no ISA write
-                if (MODE == MODE_ISA && (a.pos == nullptr || a.grp != nullptr || newrank != (u32)(key[r] >> a.rank_bits)))
+                // a suffix whose rank did not change (e.g. every old group's head) needs no ISA write
+                if (MODE == MODE_ISA && (a.pos == nullptr || a.grp == nullptr || newrank != a.grp[j]))
                     a.ISA[ij] = newrank;
                 if (MODE == MODE_HT) ht_update(a.ht, a.ht_mask, ij, newrank);
                 if ((f.act[r] >> lane) & 1ull) {
@@ -472,6 +471,15 @@ __global__ __launch_bounds__(256) void text_keys_kernel(const u32 *idx, u32 m, u
     for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < m; t += gridDim.x * blockDim.x) {
         const u64 j = (u64)idx[t] + h;
         keys[t] = (j < n) ? text_key_at(codes, (u32)j, b, k, plus_one, n) : 0ull;
+    }
+}
+
+// Doubling-round key of the group-local rounds: rank of suffix idx[t]+h (0 past the end).
+__global__ __launch_bounds__(256) void rank_keys_kernel(const u32 *idx, u32 m, u32 n, u32 h, const u32 *ISA, u64 *keys)
+{
+    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < m; t += gridDim.x * blockDim.x) {
+        const u64 j = (u64)idx[t] + h;
+        keys[t] = (j < n) ? (u64)ISA[j] : 0ull;
     }
 }
 
@@ -668,7 +676,7 @@ static void rerank_geometry(u32 m, RerankArgs &a)
     a.num_ranges = (a.num_tiles + a.tiles_per_range - 1) / a.tiles_per_range;
 }
 
-enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK, S_GRP2 = 26, S_BIG = 27 };
+enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK, S_GRP2 = 26, S_BIG = 27, S_SCR = 29 };
 
 // Initial key width.  Model the text as i.i.d. with per-symbol collision
 // probability c = sum p_i^2 (from the sampled counts): two suffixes agree on k
@@ -813,6 +821,9 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     bool was_text = false;
     int text_rounds = 0;
     u32 m_text_prev = 0;
+    bool keyed_grp = true;       // the sorted keys of the previous round carry the group rank in their high half
+    u32 global_above = 0;        // rank rounds use ONE global (group, rank) sort while m stays above this
+    double last_big_frac = 0.0;
     int text_rounds_max = 5;
     if (const char *e = getenv("PSS_TEXT_ROUNDS")) text_rounds_max = atoi(e);
     int kt = 64 / b;             // symbols per text-round key
@@ -831,7 +842,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         ra.keys = Kr[cur];
         ra.idx = V[cur];
         ra.pos = identity_pos ? nullptr : P[pcur];
-        ra.grp = (mode == M_TEXT && round > 0) ? G[gcur] : nullptr;
+        ra.grp = (round > 0 && !keyed_grp) ? G[gcur] : nullptr;   // group-local rounds: keys do not carry the group
         ra.pos_out = P[pcur ^ 1];
         ra.idx_out = V[cur ^ 1];
         if (round == 0) {
@@ -874,16 +885,20 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         const int src = cur ^ 1;             // V[src] = compacted suffix indices, G[gcur] their groups, P[pcur] their slots
         const u32 grid = (u32)std::min<u64>((u64)grid_stream, ((u64)m + 255) / 256);
 
-        // ---------------------------------------------------------- text round --
-        // Text rounds advance h linearly; they pay off while each round resolves most
-        // ties (natural-language LCPs).  When a round leaves more than 60 % of its list
-        // tied the data is repetitive (long LCPs): doubling, logarithmic in the LCP, takes over.
-        const bool text_progress = text_rounds == 0 || (u64)m * 10 <= (u64)m_text_prev * 6;
-        if (mode == M_TEXT && text_rounds < text_rounds_max && text_progress) {
-            m_text_prev = m;
+        // ------------------------------------------------------ group-local round --
+        // One round over the active list: a 64-bit key per suffix, every group sorted by it.
+        //   text round : key = next symbols packed from the text at offset h      (h += kt)
+        //   rank round : key = rank of suffix i+h from the inverse suffix array    (h *= 2)
+        // Groups of <= GS_CAP members are ranked in LDS (group_sort); members of larger groups
+        // go through two chained stable radix sorts (key, then dense group number).
+        // Text rounds advance h linearly; they pay off while each round resolves most ties
+        // (natural-language LCPs).  When a round leaves more than 60 % of its list tied, or large
+        // groups dominate, the data is repetitive: rank rounds, logarithmic in the LCP, take over.
+        auto local_round = [&](bool use_text, bool *bail) -> int {
+            *bail = false;
             const u32 nblk = (m + GS_T - 1) / GS_T;
-            // scratch inside the (unused) ISA buffer
-            u8 *scr = reinterpret_cast<u8 *>(ISA);
+            PSS_TRY(ctx->slot[S_SCR].reserve((size_t)m + (size_t)nblk * 24 + (SC_MAX_BLOCKS + 8) * 8 + 4096));
+            u8 *scr = ctx->slot[S_SCR].as<u8>();
             size_t o = 0;
             auto carve = [&](size_t bytes) { u8 *p = scr + o; o = round_up(o + bytes, 64); return p; };
             u8 *d_big = carve(m);
@@ -893,61 +908,73 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
             u64 *d_off_heads = reinterpret_cast<u64 *>(carve(((size_t)nblk + 1) * 8));
             u64 *d_partial = reinterpret_cast<u64 *>(carve((SC_MAX_BLOCKS + 2) * 8));
             u64 *d_total = d_partial + SC_MAX_BLOCKS;
-            hipLaunchKernelGGL(text_keys_kernel, dim3(grid), dim3(256), 0, s, V[src], m, n,
-                               (u32)std::min<u64>(h, 0xffffffffull), codes, b, kt, plus_one, K[src]);
+            const u32 h32 = (u32)std::min<u64>(h, 0xffffffffull);
+            if (use_text)
+                hipLaunchKernelGGL(text_keys_kernel, dim3(grid), dim3(256), 0, s, V[src], m, n, h32, codes, b, kt, plus_one, K[src]);
+            else
+                hipLaunchKernelGGL(rank_keys_kernel, dim3(grid), dim3(256), 0, s, V[src], m, n, h32, ISA, K[src]);
             hipLaunchKernelGGL(group_sort_kernel, dim3(nblk), dim3(256), 0, s, K[src], V[src], G[gcur], m, K[src ^ 1],
                                V[src ^ 1], d_big, d_blk_big, d_blk_heads);
             PSS_TRY(device_excl_scan(ctx, InU32{d_blk_big}, nblk, d_partial, d_total, d_off_big));
             PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
             PSS_HIP(hipStreamSynchronize(s));
             const u32 nbig = h_small[0];
-            bool text_ok = true;
-            if (getenv("PSS_TIMING")) fprintf(stderr, "[pss] text round %d: h=%llu m=%u nbig=%u (%.1f%%)\n", text_rounds, (unsigned long long)h, m, nbig, 100.0 * nbig / m);
-            if (nbig) {
-                // members of large groups go through two chained radix sorts; when they are the
-                // majority the data is repetitive and doubling (logarithmic in the LCP) is the better tool
-                if ((u64)nbig * 2 > (u64)m && (text_rounds > 0 || (u64)nbig * 4 > (u64)m * 3)) {
-                    text_ok = false;
-                } else {
-                    PSS_TRY(ctx->slot[S_BIG].reserve((size_t)nbig * (4 + 4 + 16 + 8) + 1024));
-                    u8 *bscr = ctx->slot[S_BIG].as<u8>();
-                    size_t bo = 0;
-                    auto bcarve = [&](size_t bytes) { u8 *p = bscr + bo; bo = round_up(bo + bytes, 64); return p; };
-                    u32 *d_bt = reinterpret_cast<u32 *>(bcarve((size_t)nbig * 4));
-                    u32 *d_bgid = reinterpret_cast<u32 *>(bcarve((size_t)nbig * 4));
-                    u64 *BK[2] = {reinterpret_cast<u64 *>(bcarve((size_t)nbig * 8)), reinterpret_cast<u64 *>(bcarve((size_t)nbig * 8))};
-                    u32 *BV[2] = {reinterpret_cast<u32 *>(bcarve((size_t)nbig * 4)), reinterpret_cast<u32 *>(bcarve((size_t)nbig * 4))};
-                    PSS_TRY(device_excl_scan(ctx, InU32{d_blk_heads}, nblk, d_partial, d_total, d_off_heads));
-                    PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
-                    hipLaunchKernelGGL(big_compact_kernel, dim3(nblk), dim3(256), 0, s, d_big, G[gcur], K[src], m, d_off_big,
-                                       d_off_heads, d_bt, BK[0], d_bgid);
-                    PSS_HIP(hipStreamSynchronize(s));
-                    const u32 nbig_groups = h_small[0];
-                    // BV[0][u] = u
-                    hipLaunchKernelGGL(iota_kernel, dim3((nbig + 255) / 256), dim3(256), 0, s, BV[0], nbig);
-                    SortStats s1, s2;
-                    int d1 = 0, d2 = 0;
-                    PSS_TRY(radix_sort_pairs(ctx, BK, BV, nbig, kt * b, 0xffffffffu, nullptr, 0, work, &d1, profile, &s1));
-                    int gid_bits = 1;
-                    while ((1ull << gid_bits) < (u64)nbig_groups) ++gid_bits;
-                    hipLaunchKernelGGL(gather_gid_kernel, dim3((nbig + 255) / 256), dim3(256), 0, s, BV[d1], d_bgid, nbig,
-                                       nbig <= 4096u, BK[d1]);
-                    if (nbig_groups > 1)
-                        PSS_TRY(radix_sort_pairs(ctx, BK, BV, nbig, gid_bits, 0xffffffffu, nullptr, d1, work, &d2, profile, &s2));
-                    else d2 = d1;
-                    hipLaunchKernelGGL(big_writeback_kernel, dim3((nbig + 255) / 256), dim3(256), 0, s, BV[d2], d_bt, K[src],
-                                       V[src], nbig, K[src ^ 1], V[src ^ 1]);
-                    st.round_passes += (u32)(s1.launches + s2.launches);
-                    ss.launches += s1.launches + s2.launches;
-                    ss.elems += s1.elems + s2.elems;
-                    ss.ms += s1.ms + s2.ms;
-                    ss.ms_pairs += s1.ms_pairs + s2.ms_pairs;
-                    ss.pairs_launches += s1.pairs_launches + s2.pairs_launches;
-                    ss.pairs_elems += s1.pairs_elems + s2.pairs_elems;
-                    st.big_elems += nbig;
-                }
+            if (getenv("PSS_TIMING"))
+                fprintf(stderr, "[pss] %s round: h=%llu m=%u large-group members=%u (%.1f%%)\n", use_text ? "text" : "rank",
+                        (unsigned long long)h, m, nbig, 100.0 * nbig / m);
+            last_big_frac = (double)nbig / (double)m;
+            if (nbig == 0) return PSS_OK;
+            if (use_text && (u64)nbig * 2 > (u64)m && (text_rounds > 0 || (u64)nbig * 4 > (u64)m * 3)) {
+                *bail = true;
+                return PSS_OK;
             }
-            if (text_ok) {
+            PSS_TRY(ctx->slot[S_BIG].reserve((size_t)nbig * (4 + 4 + 16 + 8) + 1024));
+            u8 *bscr = ctx->slot[S_BIG].as<u8>();
+            size_t bo = 0;
+            auto bcarve = [&](size_t bytes) { u8 *p = bscr + bo; bo = round_up(bo + bytes, 64); return p; };
+            u32 *d_bt = reinterpret_cast<u32 *>(bcarve((size_t)nbig * 4));
+            u32 *d_bgid = reinterpret_cast<u32 *>(bcarve((size_t)nbig * 4));
+            u64 *BK[2] = {reinterpret_cast<u64 *>(bcarve((size_t)nbig * 8)), reinterpret_cast<u64 *>(bcarve((size_t)nbig * 8))};
+            u32 *BV[2] = {reinterpret_cast<u32 *>(bcarve((size_t)nbig * 4)), reinterpret_cast<u32 *>(bcarve((size_t)nbig * 4))};
+            PSS_TRY(device_excl_scan(ctx, InU32{d_blk_heads}, nblk, d_partial, d_total, d_off_heads));
+            PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
+            hipLaunchKernelGGL(big_compact_kernel, dim3(nblk), dim3(256), 0, s, d_big, G[gcur], K[src], m, d_off_big,
+                               d_off_heads, d_bt, BK[0], d_bgid);
+            PSS_HIP(hipStreamSynchronize(s));
+            const u32 nbig_groups = h_small[0];
+            hipLaunchKernelGGL(iota_kernel, dim3((nbig + 255) / 256), dim3(256), 0, s, BV[0], nbig);
+            SortStats s1, s2;
+            int d1 = 0, d2 = 0;
+            PSS_TRY(radix_sort_pairs(ctx, BK, BV, nbig, use_text ? kt * b : rank_bits, 0xffffffffu, nullptr, 0, work, &d1,
+                                     profile, &s1));
+            int gid_bits = 1;
+            while ((1ull << gid_bits) < (u64)nbig_groups) ++gid_bits;
+            hipLaunchKernelGGL(gather_gid_kernel, dim3((nbig + 255) / 256), dim3(256), 0, s, BV[d1], d_bgid, nbig,
+                               nbig <= 4096u, BK[d1]);
+            if (nbig_groups > 1)
+                PSS_TRY(radix_sort_pairs(ctx, BK, BV, nbig, gid_bits, 0xffffffffu, nullptr, d1, work, &d2, profile, &s2));
+            else d2 = d1;
+            hipLaunchKernelGGL(big_writeback_kernel, dim3((nbig + 255) / 256), dim3(256), 0, s, BV[d2], d_bt, K[src],
+                               V[src], nbig, K[src ^ 1], V[src ^ 1]);
+            st.round_passes += (u32)(s1.launches + s2.launches);
+            ss.launches += s1.launches + s2.launches;
+            ss.elems += s1.elems + s2.elems;
+            ss.ms += s1.ms + s2.ms;
+            ss.ms_pairs += s1.ms_pairs + s2.ms_pairs;
+            ss.pairs_launches += s1.pairs_launches + s2.pairs_launches;
+            ss.pairs_elems += s1.pairs_elems + s2.pairs_elems;
+            st.big_elems += nbig;
+            return PSS_OK;
+        };
+        if (mode == M_TEXT) {
+            const bool text_progress = text_rounds == 0 || (u64)m * 10 <= (u64)m_text_prev * 6;
+            bool bail = true;
+            if (text_rounds < text_rounds_max && text_progress) {
+                m_text_prev = m;
+                PSS_TRY(local_round(true, &bail));
+            }
+            if (!bail) {
+                keyed_grp = false;
                 cur = src ^ 1;
                 st.rounds += 1;
                 st.text_rounds += 1;
@@ -957,15 +984,30 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
                 PSS_HIP(hipGetLastError());
                 continue;
             }
-        }
-        if (mode == M_TEXT) {
-            // ties outlived the text rounds: build the inverse suffix array once, continue by doubling
+            // ties outlived the text rounds: build the inverse suffix array once, continue with rank rounds
             hipLaunchKernelGGL(isa_from_sa_kernel, dim3(grid_all), dim3(256), 0, s, SA, n, ISA);
             hipLaunchKernelGGL(isa_active_kernel, dim3(grid), dim3(256), 0, s, V[src], G[gcur], m, ISA);
             mode = M_DENSE;
         }
+        // Rank rounds: group-local unless large groups dominate (repetitive data) -- then one
+        // global radix sort on (group rank, rank) with constant digits skipped is cheaper than
+        // ranking in LDS + compaction + two chained sorts over nearly everything.
+        if (mode == M_DENSE && m <= global_above) global_above = 0;
+        if (mode == M_DENSE && global_above == 0) {
+            bool bail = false;
+            PSS_TRY(local_round(false, &bail));
+            if (last_big_frac > 0.5) global_above = m / 2;
+            keyed_grp = false;
+            cur = src ^ 1;
+            st.rounds += 1;
+            st.sum_active += m;
+            h *= 2;
+            PSS_HIP(hipGetLastError());
+            continue;
+        }
 
-        // ------------------------------------------------- doubling round (ranks) --
+        // ------------- global doubling round: sparse (hash table + key search) or dense (ISA) --
+        keyed_grp = true;
         if (mode == M_SPARSE && round == 0) {
             // hash table over the initially-active suffixes, in the (unused) ISA buffer
             u32 cap = 1024;
