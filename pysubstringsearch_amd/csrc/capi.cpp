@@ -3,6 +3,9 @@
 // and 162-199) around the device suffix-array builder and the device search.
 #include <cerrno>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -126,6 +129,28 @@ extern "C" int32_t pss_sa_build_device(const void *d_T, void *d_SA, int32_t n, i
 
 // ------------------------------------------------------------------- Writer --
 
+// Chunk records are written by a background thread: while chunk k streams from
+// HBM to the file, the caller already fills (and the GPU builds) chunk k+1.
+// One job in flight; the file is only ever touched by that thread or, when it is
+// idle, by the caller -- so records stay in order.
+struct WriterIo {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool have_job = false, busy = false, stop = false;
+    uint8_t *text = nullptr;      // job: host text (owned by the job until done)
+    size_t text_alloc = 0;
+    size_t n = 0;
+    const void *d_sa = nullptr;   // job: suffix array in HBM
+    int rc = PSS_OK;              // first failure of any job
+    int err_no = 0;
+    std::string err;
+    // staging owned by the thread (pinned double buffer + copy stream)
+    void *stage[2] = {nullptr, nullptr};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
 struct pss_writer {
     FILE *fp = nullptr;
     uint8_t *buf = nullptr;
@@ -133,6 +158,11 @@ struct pss_writer {
     size_t limit = 0;    // the reference's Vec capacity (src/lib.rs:62), see reserve()
     size_t alloc = 0;
     int device = 0;
+    uint8_t *spare = nullptr;     // second host text buffer (swapped with buf at every dump)
+    size_t spare_alloc = 0;
+    DevBuf d_sa[2];               // suffix arrays in HBM: one being written out, one being built
+    int sa_next = 0;
+    WriterIo *io = nullptr;
 };
 
 namespace {
@@ -184,27 +214,122 @@ void put_u32le(uint8_t *p, uint32_t v)
 
 // Streams `bytes` of device memory to fp: the D2H copy of piece i+1 (pinned
 // staging, copy stream) runs while piece i is written to the file.
-int download_to_file(DeviceCtx *ctx, const void *src, size_t bytes, FILE *fp)
+int download_to_file(WriterIo *io, const void *src, size_t bytes, FILE *fp)
 {
-    PSS_TRY(ctx->ensure_staging());
     const size_t piece = DeviceCtx::kStage;
     const size_t pieces = (bytes + piece - 1) / piece;
     auto issue = [&](size_t i) -> int {
         const size_t off = i * piece, k = std::min(piece, bytes - off);
-        PSS_HIP(hipMemcpyAsync(ctx->stage[i & 1], static_cast<const uint8_t *>(src) + off, k, hipMemcpyDeviceToHost,
-                               ctx->copy_stream));
-        PSS_HIP(hipEventRecord(ctx->stage_ev[i & 1], ctx->copy_stream));
+        PSS_HIP(hipMemcpyAsync(io->stage[i & 1], static_cast<const uint8_t *>(src) + off, k, hipMemcpyDeviceToHost,
+                               io->stream));
+        PSS_HIP(hipEventRecord(io->ev[i & 1], io->stream));
         return PSS_OK;
     };
     if (pieces) PSS_TRY(issue(0));
     for (size_t i = 0; i < pieces; ++i) {
-        PSS_HIP(hipEventSynchronize(ctx->stage_ev[i & 1]));
+        PSS_HIP(hipEventSynchronize(io->ev[i & 1]));
         if (i + 1 < pieces) PSS_TRY(issue(i + 1));
         const size_t off = i * piece, k = std::min(piece, bytes - off);
         errno = 0;
-        if (fwrite(ctx->stage[i & 1], 1, k, fp) != k) return io_error("write");
+        if (fwrite(io->stage[i & 1], 1, k, fp) != k) return io_error("write");
     }
     return PSS_OK;
+}
+
+// One chunk record: u32le len | data | u32le 4n | n x i32le  (src/lib.rs:112-119)
+int write_record(pss_writer *w, const uint8_t *text, size_t n, const void *d_sa)
+{
+    uint8_t hdr[4];
+    errno = 0;
+    put_u32le(hdr, (uint32_t)n);
+    {
+        Phase ph("record: write text");
+        if (fwrite(hdr, 1, 4, w->fp) != 4) return io_error("write");
+        if (fwrite(text, 1, n, w->fp) != n) return io_error("write");
+    }
+    put_u32le(hdr, (uint32_t)(n * 4));   // wraps like `as u32` at n >= 2^30 (lib.rs:116)
+    if (fwrite(hdr, 1, 4, w->fp) != 4) return io_error("write");
+    // x86-64 / little-endian host: int32 in memory == i32le on disk (lib.rs:117-119)
+    Phase ph("record: SA -> file");
+    return download_to_file(w->io, d_sa, n * 4, w->fp);
+}
+
+void io_thread_main(pss_writer *w)
+{
+    WriterIo *io = w->io;
+    (void)hipSetDevice(w->device);
+    std::unique_lock<std::mutex> lk(io->mu);
+    for (;;) {
+        io->cv.wait(lk, [&] { return io->have_job || io->stop; });
+        if (!io->have_job && io->stop) return;
+        io->have_job = false;
+        lk.unlock();
+        const int rc = write_record(w, io->text, io->n, io->d_sa);
+        const int e = errno;
+        const std::string msg = rc != PSS_OK ? last_error() : std::string();
+        lk.lock();
+        if (rc != PSS_OK && io->rc == PSS_OK) {
+            io->rc = rc;
+            io->err_no = e;
+            io->err = msg;
+        }
+        io->busy = false;
+        io->cv.notify_all();
+    }
+}
+
+// Blocks until the record in flight (if any) is on its way to the file; reports the
+// first background failure (once).
+int io_wait(pss_writer *w)
+{
+    WriterIo *io = w->io;
+    if (!io) return PSS_OK;
+    std::unique_lock<std::mutex> lk(io->mu);
+    io->cv.wait(lk, [&] { return !io->busy; });
+    if (io->rc != PSS_OK) {
+        const int rc = io->rc;
+        set_error("%s", io->err.c_str());
+        errno = io->err_no;
+        io->rc = PSS_OK;
+        return rc;
+    }
+    return PSS_OK;
+}
+
+int io_start(pss_writer *w)
+{
+    if (w->io) return PSS_OK;
+    PSS_HIP(hipSetDevice(w->device));
+    WriterIo *io = new WriterIo();
+    PSS_HIP(hipStreamCreateWithFlags(&io->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        PSS_HIP(hipHostMalloc(&io->stage[i], DeviceCtx::kStage, hipHostMallocDefault));
+        PSS_HIP(hipEventCreateWithFlags(&io->ev[i], hipEventDisableTiming));
+    }
+    w->io = io;
+    io->th = std::thread(io_thread_main, w);
+    return PSS_OK;
+}
+
+void io_stop(pss_writer *w)
+{
+    WriterIo *io = w->io;
+    if (!io) return;
+    {
+        std::unique_lock<std::mutex> lk(io->mu);
+        io->cv.wait(lk, [&] { return !io->busy; });
+        io->stop = true;
+        io->cv.notify_all();
+    }
+    if (io->th.joinable()) io->th.join();
+    (void)hipSetDevice(w->device);
+    for (int i = 0; i < 2; ++i) {
+        if (io->stage[i]) (void)hipHostFree(io->stage[i]);
+        if (io->ev[i]) (void)hipEventDestroy(io->ev[i]);
+    }
+    if (io->stream) (void)hipStreamDestroy(io->stream);
+    delete io;
+    w->io = nullptr;
 }
 
 // src/lib.rs:105-124
@@ -218,11 +343,12 @@ int w_dump(pss_writer *w)
     DeviceCtx *ctx;
     PSS_TRY(get_ctx(w->device, &ctx));
     const size_t n = w->len;
-    uint8_t hdr[4];
-    errno = 0;
-    put_u32le(hdr, (uint32_t)n);
     if (n < 2) {
-        // libsais.c:6603-6607: n == 1 -> SA[0] = 0
+        // libsais.c:6603-6607: n == 1 -> SA[0] = 0; written by the caller once the thread is idle
+        PSS_TRY(io_wait(w));
+        uint8_t hdr[4];
+        errno = 0;
+        put_u32le(hdr, (uint32_t)n);
         if (fwrite(hdr, 1, 4, w->fp) != 4 || fwrite(w->buf, 1, n, w->fp) != n) return io_error("write");
         put_u32le(hdr, 4);
         const uint8_t zero[4] = {0, 0, 0, 0};
@@ -230,27 +356,37 @@ int w_dump(pss_writer *w)
         w->len = 0;
         return PSS_OK;
     }
-    // upload + build first (the file stays untouched if the device fails), then
-    // text from the host buffer and the suffix array streamed straight from HBM
+    // upload + build into the SA buffer the background writer is NOT reading from
+    DevBuf &sa = w->d_sa[w->sa_next];
+    PSS_HIP(hipSetDevice(w->device));
     PSS_TRY(ctx->slot[W_TEXT].reserve(n + 64));
-    PSS_TRY(ctx->slot[W_SA].reserve(n * 4));
+    PSS_TRY(sa.reserve(n * 4));
     {
         Phase ph("dump: upload+build");
         PSS_HIP(hipMemcpyAsync(ctx->slot[W_TEXT].p, w->buf, n, hipMemcpyHostToDevice, ctx->stream));
-        PSS_TRY(sa_build_device(ctx, ctx->slot[W_TEXT].p, ctx->slot[W_SA].p, (int32_t)n, 0, nullptr));
+        PSS_TRY(sa_build_device(ctx, ctx->slot[W_TEXT].p, sa.p, (int32_t)n, 0, nullptr));
     }
+    PSS_TRY(io_start(w));
+    PSS_TRY(io_wait(w));                      // previous record done: its text buffer is free again
+    WriterIo *io = w->io;
     {
-        Phase ph("dump: write text");
-        if (fwrite(hdr, 1, 4, w->fp) != 4) return io_error("write");
-        if (fwrite(w->buf, 1, n, w->fp) != n) return io_error("write");
+        std::lock_guard<std::mutex> lk(io->mu);
+        // hand the filled text buffer to the job, continue filling the other one
+        uint8_t *done_text = io->text;
+        const size_t done_alloc = io->text_alloc;
+        io->text = w->buf;
+        io->text_alloc = w->alloc;
+        io->n = n;
+        io->d_sa = sa.p;
+        io->have_job = true;
+        io->busy = true;
+        w->buf = done_text ? done_text : w->spare;
+        w->alloc = done_text ? done_alloc : w->spare_alloc;
+        w->spare = nullptr;
+        w->spare_alloc = 0;
+        io->cv.notify_all();
     }
-    put_u32le(hdr, (uint32_t)(n * 4));   // wraps like `as u32` at n >= 2^30 (lib.rs:116)
-    if (fwrite(hdr, 1, 4, w->fp) != 4) return io_error("write");
-    // x86-64 / little-endian host: int32 in memory == i32le on disk (lib.rs:117-119)
-    {
-        Phase ph("dump: SA -> file");
-        PSS_TRY(download_to_file(ctx, ctx->slot[W_SA].p, n * 4, w->fp));
-    }
+    w->sa_next ^= 1;
     w->len = 0;
     return PSS_OK;
 }
@@ -385,6 +521,7 @@ extern "C" int pss_writer_finalize(pss_writer *w)
     return guarded([&]() -> int {
         if (!w) return PSS_EINVAL;
         if (w->len) PSS_TRY(w_dump(w));   // lib.rs:129-131
+        PSS_TRY(io_wait(w));              // the record in flight reaches the file before the flush
         errno = 0;
         if (fflush(w->fp) != 0) return io_error("flush");   // lib.rs:132
         return PSS_OK;
@@ -397,9 +534,18 @@ extern "C" int pss_writer_close(pss_writer *w)
         if (!w) return PSS_OK;
         int rc = PSS_OK;
         if (w->len) rc = w_dump(w);   // Drop -> finalize, lib.rs:138-144
+        const int rc2 = io_wait(w);
+        if (rc == PSS_OK) rc = rc2;
+        if (w->io) {
+            if (w->io->text != w->buf) free(w->io->text);
+            io_stop(w);
+        }
         errno = 0;
         if (fclose(w->fp) != 0 && rc == PSS_OK) rc = io_error("close");
         free(w->buf);
+        free(w->spare);
+        (void)hipSetDevice(w->device);
+        for (auto &b : w->d_sa) b.release();
         delete w;
         return rc;
     });

@@ -81,3 +81,19 @@ def test_forced_modes(oracle, monkeypatch, mode, key_chars):
              np.frombuffer((b'abcde' * 2000 + b'\n') * 7 + b'xyz' * 100, dtype=np.uint8)]
     for t in cases:
         assert (sa_gpu(t) == oracle.sa(t)).all()
+
+
+def test_long_repeats(oracle):
+    """Duplicated blocks with small edits: LCPs in the tens of thousands (text rounds must
+    hand over to rank rounds; large and small groups mixed)."""
+    rng = np.random.default_rng(3)
+    base = gen_corpus(1, 200000).copy()
+    parts = [base]
+    for k in range(5):
+        c = base.copy()
+        for p in rng.integers(0, c.size, 40):
+            c[p] = rng.integers(97, 123)
+        parts.append(c[: int(rng.integers(50000, 200000))])
+    parts.append(np.frombuffer(b'the quick brown fox\n' * 9000, dtype=np.uint8))
+    t = np.concatenate(parts)
+    assert (sa_gpu(t) == oracle.sa(t)).all()
