@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # a fresh checkout has no built artefacts (they are git-ignored): build them once
+    lib = os.path.join(ROOT, 'pysubstringsearch_amd', 'libpss.so')
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.run(['make', '-C', os.path.join(ROOT, 'pysubstringsearch_amd', 'csrc'), '-j4'], check=True,
+                       capture_output=True)
 
 
 @pytest.fixture(scope='session')
