@@ -91,6 +91,13 @@ int32_t pss_sa_build(const uint8_t *T, int32_t *SA, int32_t n, int32_t device);
 int32_t pss_sa_build_device(const void *d_T, void *d_SA, int32_t n, int32_t device,
                             uint32_t flags, pss_sa_stats *stats);
 
+/* The builder's device radix sort on its own (test / measurement utility, no
+ * reference counterpart): stable LSD sort of n (u64 key, u32 value) pairs by the
+ * key bits [0, key_bits), in place, all pointers resident on `device`.
+ * *ms_scatter (optional) receives the summed HIP-event time of the scatter kernel. */
+int32_t pss_sort_pairs_device(void *d_keys, void *d_vals, uint32_t n, int32_t key_bits, int32_t device,
+                              double *ms_scatter);
+
 /* ---- Writer (src/lib.rs:42-144; pysubstringsearch/__init__.py:6-41) ----- */
 
 /* Writer::new, src/lib.rs:50-65.  Creates/truncates `path`.  max_chunk_len < 0

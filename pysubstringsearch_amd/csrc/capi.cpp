@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "common.h"
+#include "radix_sort.h"
 #include "sa_build.h"
 #include "search.h"
 
@@ -124,6 +125,36 @@ extern "C" int32_t pss_sa_build_device(const void *d_T, void *d_SA, int32_t n, i
         DeviceCtx *ctx;
         PSS_TRY(get_ctx(device, &ctx));
         return sa_build_device(ctx, d_T, d_SA, n, flags, stats);
+    });
+}
+
+extern "C" int32_t pss_sort_pairs_device(void *d_keys, void *d_vals, uint32_t n, int32_t key_bits, int32_t device,
+                                         double *ms_scatter)
+{
+    return guarded([&]() -> int {
+        if ((n && (!d_keys || !d_vals)) || key_bits < 1 || key_bits > 64) {
+            set_error("pss_sort_pairs_device: bad arguments");
+            return PSS_EINVAL;
+        }
+        DeviceCtx *ctx;
+        PSS_TRY(get_ctx(device, &ctx));
+        if (n == 0) return PSS_OK;
+        // slots of the SA builder double as the ping-pong partner and workspace
+        PSS_TRY(ctx->slot[1].reserve((size_t)n * 8));
+        PSS_TRY(ctx->slot[3].reserve((size_t)n * 4));
+        PSS_TRY(ctx->slot[9].reserve(radix_sort_workspace_bytes() + 65536));
+        uint64_t *K[2] = {static_cast<uint64_t *>(d_keys), ctx->slot[1].as<uint64_t>()};
+        uint32_t *V[2] = {static_cast<uint32_t *>(d_vals), ctx->slot[3].as<uint32_t>()};
+        SortStats st;
+        int dst = 0;
+        PSS_TRY(radix_sort_pairs(ctx, K, V, n, key_bits, 0xffffffffu, nullptr, 0, ctx->slot[9].p, &dst, ms_scatter != nullptr, &st));
+        if (dst != 0) {
+            PSS_HIP(hipMemcpyAsync(d_keys, K[1], (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            PSS_HIP(hipMemcpyAsync(d_vals, V[1], (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        PSS_HIP(hipStreamSynchronize(ctx->stream));
+        if (ms_scatter) *ms_scatter = st.ms;
+        return PSS_OK;
     });
 }
 

@@ -97,3 +97,23 @@ def test_long_repeats(oracle):
     parts.append(np.frombuffer(b'the quick brown fox\n' * 9000, dtype=np.uint8))
     t = np.concatenate(parts)
     assert (sa_gpu(t) == oracle.sa(t)).all()
+
+
+@pytest.mark.parametrize('n,bits', [(1, 8), (100, 64), (4096, 17), (4097, 40), (70001, 64), (1 << 20, 33)])
+def test_radix_sort_pairs_stable(n, bits):
+    """The device radix sort alone: stable sort of (u64 key, u32 value) pairs == numpy's stable argsort."""
+    import ctypes
+    import torch
+    from pysubstringsearch_amd import _ffi
+    rng = np.random.default_rng(n)
+    mask = (1 << bits) - 1 if bits < 64 else (1 << 64) - 1
+    keys = (rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64)) & np.uint64(mask)
+    if n > 1000:
+        keys[rng.integers(0, n, n // 3)] = keys[0]          # plenty of ties
+    vals = np.arange(n, dtype=np.uint32)
+    dk, dv = torch.from_numpy(keys.view(np.int64)).cuda(), torch.from_numpy(vals.view(np.int32)).cuda()
+    _ffi.check(_ffi.lib.pss_sort_pairs_device(dk.data_ptr(), dv.data_ptr(), n, bits, 0, None))
+    order = np.argsort(keys, kind='stable')
+    assert (dk.cpu().numpy().view(np.uint64) == keys[order]).all()
+    if n > 8192:                                             # the one-tile bitonic path is not stable by design
+        assert (dv.cpu().numpy().view(np.uint32) == vals[order]).all()
