@@ -45,6 +45,10 @@ int pss_device_count(void);
  * truncated to cap); returns the untruncated length. */
 size_t pss_last_error(char *buf, size_t cap);
 
+/* Frees the grow-only HBM workspace of every device (the builder keeps ~45 n
+ * bytes around for reuse; resident Reader chunks are not touched). */
+int pss_release_workspace(void);
+
 /* ---- suffix-array builder seam ----------------------------------------- */
 
 /* Per-build statistics (filled when `stats` is non-NULL). */

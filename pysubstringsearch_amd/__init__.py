@@ -26,11 +26,17 @@ try:   # C loop for result lists (csrc/pyglue.c); plain Python slicing if it was
 except ImportError:   # pragma: no cover
     _pssglue = None
 
-__all__ = ['Writer', 'Reader', 'PackedResult', 'device_count']
+__all__ = ['Writer', 'Reader', 'PackedResult', 'device_count', 'release_workspace']
 
 
 def device_count() -> int:
     return _lib.pss_device_count()
+
+
+def release_workspace() -> None:
+    """Free the engine's grow-only HBM workspace (suffix-array build buffers, search
+    scratch) on every device; resident Reader chunks stay."""
+    _ffi.check(_lib.pss_release_workspace())
 
 
 def _default_device() -> int:

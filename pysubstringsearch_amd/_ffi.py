@@ -91,6 +91,7 @@ def _load() -> ctypes.CDLL:
     pvp = ctypes.POINTER(vp)
     sig = {
         'pss_device_count': (ctypes.c_int, []),
+        'pss_release_workspace': (ctypes.c_int, []),
         'pss_last_error': (ctypes.c_size_t, [cp, ctypes.c_size_t]),
         'pss_sa_build': (i32, [vp, vp, i32, i32]),
         'pss_sa_build_device': (i32, [vp, vp, i32, i32, u32, ctypes.POINTER(SaStats)]),

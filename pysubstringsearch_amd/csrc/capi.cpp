@@ -99,6 +99,14 @@ extern "C" size_t pss_last_error(char *buf, size_t cap)
     return e.size();
 }
 
+extern "C" int pss_release_workspace(void)
+{
+    return guarded([&]() -> int {
+        trim_all();
+        return PSS_OK;
+    });
+}
+
 // --------------------------------------------------------------- SA builder --
 
 extern "C" int32_t pss_sa_build(const uint8_t *T, int32_t *SA, int32_t n, int32_t device)
@@ -114,6 +122,7 @@ extern "C" int32_t pss_sa_build(const uint8_t *T, int32_t *SA, int32_t n, int32_
         }
         DeviceCtx *ctx;
         PSS_TRY(get_ctx(device, &ctx));
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
         return sa_build_host(ctx, T, SA, n, nullptr);
     });
 }
@@ -124,6 +133,7 @@ extern "C" int32_t pss_sa_build_device(const void *d_T, void *d_SA, int32_t n, i
     return guarded([&]() -> int {
         DeviceCtx *ctx;
         PSS_TRY(get_ctx(device, &ctx));
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
         return sa_build_device(ctx, d_T, d_SA, n, flags, stats);
     });
 }
@@ -138,6 +148,7 @@ extern "C" int32_t pss_sort_pairs_device(void *d_keys, void *d_vals, uint32_t n,
         }
         DeviceCtx *ctx;
         PSS_TRY(get_ctx(device, &ctx));
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
         if (n == 0) return PSS_OK;
         // slots of the SA builder double as the ping-pong partner and workspace
         PSS_TRY(ctx->slot[1].reserve((size_t)n * 8));
@@ -373,6 +384,7 @@ int w_dump(pss_writer *w)
     }
     DeviceCtx *ctx;
     PSS_TRY(get_ctx(w->device, &ctx));
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     const size_t n = w->len;
     if (n < 2) {
         // libsais.c:6603-6607: n == 1 -> SA[0] = 0; written by the caller once the thread is idle
@@ -713,6 +725,7 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
         fseeko(fp, 0, SEEK_SET);
         DeviceCtx *ctx;
         PSS_TRY(get_ctx(device, &ctx));
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
         pss_reader *r = new pss_reader();
         r->device = device;
         r->ctx = ctx;
@@ -764,6 +777,7 @@ extern "C" int pss_reader_add_chunk_device(pss_reader *r, const void *d_text, co
     return guarded([&]() -> int {
         if (!r || (n && (!d_text || !d_sa))) return PSS_EINVAL;
         if (n == 0) return PSS_OK;
+        std::lock_guard<std::recursive_mutex> lk(r->ctx->mu);
         void *t = nullptr, *s = nullptr;
         PSS_TRY(reader_alloc_chunk(r, n, &t, &s));
         r->chunks.push_back(ChunkDesc{static_cast<uint8_t *>(t), static_cast<uint32_t *>(s), n, 0});
@@ -783,6 +797,7 @@ extern "C" int pss_reader_set_chunk_device(pss_reader *r, uint64_t index, const 
             set_error("pss_reader_set_chunk_device: bad arguments");
             return PSS_EINVAL;
         }
+        std::lock_guard<std::recursive_mutex> lk(r->ctx->mu);
         if (index == r->chunks.size()) return pss_reader_add_chunk_device(r, d_text, d_sa, n);
         ChunkDesc &c = r->chunks[index];
         if (c.n != n) {   // different size: fresh allocation
@@ -810,6 +825,7 @@ extern "C" int pss_reader_search_batch(pss_reader *r, const uint8_t *qbytes, con
             set_error("pss_reader_search_batch: bad arguments");
             return PSS_EINVAL;
         }
+        std::lock_guard<std::recursive_mutex> lk(r->ctx->mu);
         PSS_HIP(hipSetDevice(r->device));
         const uint32_t nc = (uint32_t)r->chunks.size();
         PSS_TRY(reader_sync_descs(r));

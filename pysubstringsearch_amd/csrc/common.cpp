@@ -96,6 +96,7 @@ void trim_all()
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     for (auto &c : g_ctx) {
         if (c.device < 0) continue;
+        std::lock_guard<std::recursive_mutex> lk2(c.mu);
         (void)hipSetDevice(c.device);
         for (auto &s : c.slot) s.release();
     }

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "../../include/pss.h"
@@ -43,6 +44,10 @@ struct DevBuf {
 
 // One per (process, device): a stream and named workspace slots.
 struct DeviceCtx {
+    // Workspace slots, staging buffers and the stream are shared by every handle on the
+    // device; ctypes releases the GIL, so two Python threads can be inside the library at
+    // once.  Every entry point that touches the context holds this lock for its duration.
+    std::recursive_mutex mu;
     int device = -1;
     hipStream_t stream = nullptr;
     int num_cus = 256;

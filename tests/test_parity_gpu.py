@@ -291,3 +291,47 @@ def test_packed_result_api(tmp_path, oracle):
         assert counts == oc.tolist() and sorted(got) == sorted(oe)
         empty = r.search_batch_packed([])
         assert empty.counts.size == 0 and empty.offsets.tolist() == [0]
+
+
+def test_concurrent_handles_from_threads(tmp_path, oracle):
+    """ctypes drops the GIL: several Python threads inside the engine at once (shared
+    per-device workspace) must still give oracle results."""
+    import threading
+    import pysubstringsearch_amd
+    rng = random.Random(5)
+    corpora = []
+    for k in range(3):
+        entries = [''.join(rng.choice('abcd ') for _ in range(rng.randint(1, 30))) for _ in range(400)]
+        p = str(tmp_path / f't{k}.idx')
+        build(p, entries, 2000)
+        corpora.append((p, entries))
+    errors = []
+
+    def worker(k):
+        try:
+            p, entries = corpora[k]
+            o = oracle.OracleReader(p)
+            qs = ['a', 'ab', 'abc', 'd d', ' ', 'zz'] + [e[:3] for e in entries[:40]]
+            with pysubstringsearch.Reader(p) as r:
+                for _ in range(15):
+                    for s in qs[:12]:
+                        if sorted(r.search(s)) != sorted(o.search(s)):
+                            errors.append((k, s))
+                    if sorted(r.search_multiple(qs)) != sorted(o.search_multiple(qs)):
+                        errors.append((k, 'batch'))
+            q = str(tmp_path / f'w{k}.idx')      # and a Writer in the same thread
+            build(q, entries, 1500)
+            oracle.use_reference_sa(False)
+            assert open(q, 'rb').read() == build(str(tmp_path / f'ow{k}.idx'), entries, 1500, W=oracle.OracleWriter)
+        except Exception as e:   # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+    pysubstringsearch_amd.release_workspace()
+    with pysubstringsearch.Reader(corpora[0][0]) as r:      # still works after the workspace was dropped
+        assert sorted(r.search('a')) == sorted(oracle.OracleReader(corpora[0][0]).search('a'))
