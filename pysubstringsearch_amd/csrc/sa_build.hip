@@ -362,13 +362,16 @@ __global__ __launch_bounds__(RR_BLOCK) void rr_apply_kernel(RerankArgs a)
                 const u32 hd = hd1 - 1;
                 const u32 newrank = (a.pos ? a.pos[hd] : hd) + 1;
                 const u32 pj = a.pos ? a.pos[j] : j;
-                const u32 ij = a.idx[j];
-                a.SA[pj] = ij;
+                const bool is_act = (f.act[r] >> lane) & 1ull;
+                // the suffix index is only needed where something is written with it
+                const bool need_idx = is_act || a.SA != nullptr || MODE == MODE_ISA || MODE == MODE_HT;
+                const u32 ij = need_idx ? a.idx[j] : 0u;
+                if (a.SA) a.SA[pj] = ij;
                 // a suffix whose rank did not change (e.g. every old group's head) needs no ISA write
                 if (MODE == MODE_ISA && (a.pos == nullptr || a.grp == nullptr || newrank != a.grp[j]))
                     a.ISA[ij] = newrank;
                 if (MODE == MODE_HT) ht_update(a.ht, a.ht_mask, ij, newrank);
-                if ((f.act[r] >> lane) & 1ull) {
+                if (is_act) {
                     const u32 u = carry_c + mbcnt(f.act[r]);
                     a.pos_out[u] = pj;
                     a.idx_out[u] = ij;
@@ -795,9 +798,18 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     SortStats ss;
     TextKeys tk{codes, b, key_chars, plus_one};
     const int key_bits0 = key_chars * b;
+    // The sorted suffix indices of the initial sort ARE the suffix array (ties are reordered
+    // later, inside their slots): let the pass that finishes the sort write straight into the
+    // caller's SA buffer.  The text pass writes buffer 0 and the passes alternate, so the
+    // buffer that receives the last pass is known up front.
+    const int passes0 = (key_bits0 + 7) / 8;
+    const int final_buf = (passes0 - 1) & 1;
+    u32 *const v_scratch = V[final_buf];
+    V[final_buf] = SA;
     int cur = 0;
     PSS_TRY(radix_sort_pairs(ctx, K, V, n, key_bits0, 0xffffffffu, &tk, 0, work, &cur, profile, &ss));
     st.initial_passes = (u32)ss.launches;
+    const bool sa_in_place = (cur == final_buf);
 
     // ---- 2. rerank + compaction, 3. doubling rounds ----
     int rank_bits = 1;
@@ -841,6 +853,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         rerank_geometry(m, ra);
         ra.keys = Kr[cur];
         ra.idx = V[cur];
+        ra.SA = (round == 0 && sa_in_place) ? nullptr : SA;      // round 0: the sort already wrote SA
         ra.pos = identity_pos ? nullptr : P[pcur];
         ra.grp = (round > 0 && !keyed_grp) ? G[gcur] : nullptr;   // group-local rounds: keys do not carry the group
         ra.pos_out = P[pcur ^ 1];
@@ -872,6 +885,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         else if (mode == M_SPARSE && round > 0) hipLaunchKernelGGL(rr_apply_kernel<MODE_HT>, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
         else hipLaunchKernelGGL(rr_apply_kernel<MODE_NONE>, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
         PSS_HIP(hipGetLastError());
+        if (round == 0) V[final_buf] = v_scratch;                 // later rounds must not scribble over SA
         if (m_next == 0) break;
         if (h >= (u64)n) {
             set_error("sa_build: %u suffixes unresolved at h=%llu >= n (internal error)", m_next,
