@@ -1,0 +1,90 @@
+"""Property tests (hypothesis): the oracle against brute force on CPU; the HIP engine
+against the oracle on the GPU, over arbitrary byte strings and entry lists."""
+import os
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+small_alphabet_bytes = st.lists(st.sampled_from([0, 1, 10, 97, 98, 255]), min_size=0, max_size=200).map(bytes)
+any_bytes = st.binary(min_size=0, max_size=300)
+
+
+def brute_sa(t: bytes):
+    return sorted(range(len(t)), key=lambda i: t[i:])
+
+
+@settings(max_examples=150, deadline=None)
+@given(st.one_of(small_alphabet_bytes, any_bytes))
+def test_oracle_sa_is_the_sorted_suffix_order(oracle, t):
+    assert oracle.sa_restatement(t).tolist() == brute_sa(t)
+
+
+def brute_search(entries, pattern: str):
+    # reference semantics: entries joined with '\n'; a hit may start inside an entry and run
+    # across newlines; the entry containing the START of the hit is returned, once per entry
+    text = ('\n'.join(entries) + '\n').encode()
+    pat = pattern.encode()
+    starts = []
+    pos = 0
+    for e in entries:
+        starts.append(pos)
+        pos += len(e.encode()) + 1
+    out = []
+    for k, e in enumerate(entries):
+        lo, hi = starts[k], starts[k] + len(e.encode())      # hit start may be anywhere in [lo, hi] (hi = the '\n')
+        if any(text.startswith(pat, p) for p in range(lo, hi + 1)):
+            out.append(e)
+    return out
+
+
+entry = st.text(alphabet=st.sampled_from('ab é'), min_size=0, max_size=12)
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(st.lists(entry, min_size=1, max_size=30), st.text(alphabet=st.sampled_from('ab é\n'), min_size=0, max_size=4))
+def test_oracle_search_matches_brute_force(oracle, tmp_path_factory, entries, pattern):
+    p = str(tmp_path_factory.mktemp('h') / 'o.idx')
+    w = oracle.OracleWriter(p, 64)
+    for e in entries:
+        w.add_entry(e)
+    w.close()
+    r = oracle.OracleReader(p)
+    # chunking (limit 64) must not matter as long as the pattern does not span a chunk boundary
+    if '\n' not in pattern:
+        assert sorted(r.search(pattern)) == sorted(brute_search(entries, pattern))
+    r.close()
+
+
+@pytest.mark.gpu
+@settings(max_examples=120, deadline=None)
+@given(st.one_of(small_alphabet_bytes, any_bytes, st.binary(min_size=4000, max_size=9000)))
+def test_gpu_sa_matches_oracle(oracle, t):
+    from tests.util import sa_gpu
+    assert (sa_gpu(t) == oracle.sa_restatement(t)).all()
+
+
+@pytest.mark.gpu
+@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(st.lists(entry, min_size=1, max_size=60), st.lists(st.text(alphabet=st.sampled_from('ab é\n'), min_size=0, max_size=5),
+                                                           min_size=1, max_size=8), st.sampled_from([None, 16, 40]))
+def test_gpu_container_and_search_match_oracle(oracle, tmp_path_factory, entries, patterns, limit):
+    import pysubstringsearch
+    d = tmp_path_factory.mktemp('g')
+    p, q = str(d / 'g.idx'), str(d / 'o.idx')
+    if limit is not None:
+        limit = max(limit, max(len(e.encode()) for e in entries) + 1)
+    w, ow = pysubstringsearch.Writer(p, limit), oracle.OracleWriter(q, limit)
+    for e in entries:
+        w.add_entry(e)
+        ow.add_entry(e)
+    w.close()
+    ow.close()
+    assert open(p, 'rb').read() == open(q, 'rb').read()
+    o = oracle.OracleReader(q)
+    with pysubstringsearch.Reader(p) as r:
+        assert sorted(r.search_multiple(patterns)) == sorted(o.search_multiple(patterns))
+        for s in patterns:
+            assert sorted(r.search(s)) == sorted(o.search(s))
+    o.close()
