@@ -99,6 +99,37 @@ __device__ __forceinline__ u32 wave_bound(const u8 *text, u32 n, const u32 *sa, 
     return lo;
 }
 
+// Large batches: one LANE per (query, chunk) and plain binary searches.  The 64-ary wave
+// search above minimises latency (5+5 dependent steps) but touches 64 random SA + text
+// sectors per step, ~80 KB per pair -- at 1.5 M pairs (100 k queries x 15 chunks) that is
+// HBM-bound.  A binary search reads ~2 sectors per step (29+29 steps, the top levels shared in
+// L2), 20x less traffic; with tens of thousands of pairs in flight the longer dependent chain
+// is hidden by parallelism instead.
+__global__ __launch_bounds__(256) void search_interval_lane_kernel(const ChunkDesc *chunks, u32 nc, const u8 *qbytes,
+                                                                     const u64 *qoff, u64 nvq, u32 *lo_out,
+                                                                     u32 *cnt_out)
+{
+    const u64 vq = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vq >= nvq) return;
+    const u32 q = (u32)(vq / nc), c = (u32)(vq % nc);
+    const ChunkDesc ch = chunks[c];
+    const u8 *pat = qbytes + qoff[q];
+    const u32 plen = (u32)(qoff[q + 1] - qoff[q]);
+    u32 lo = 0, hi = ch.n;                       // lower bound: first suffix not < pattern
+    while (lo < hi) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if (cmp_suffix(ch.text, ch.n, ch.sa[mid], pat, plen) < 0) lo = mid + 1; else hi = mid;
+    }
+    const u32 L = lo;
+    hi = ch.n;                                   // upper bound: first suffix > pattern and not prefixed by it
+    while (lo < hi) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if (cmp_suffix(ch.text, ch.n, ch.sa[mid], pat, plen) <= 0) lo = mid + 1; else hi = mid;
+    }
+    lo_out[vq] = L;
+    cnt_out[vq] = lo - L;
+}
+
 __global__ __launch_bounds__(256) void search_interval_kernel(const ChunkDesc *chunks, u32 nc, const u8 *qbytes,
                                                                 const u64 *qoff, u64 nvq, u32 *lo_out, u32 *cnt_out)
 {
@@ -464,8 +495,12 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
         // overflow: fall through to the general path (qcount is still all zero)
         for (u32 i = 0; i < nq; ++i) res->qcount[i] = 0;
     }
-    hipLaunchKernelGGL(search_interval_kernel, dim3((u32)((nvq + waves_per_block - 1) / waves_per_block)), dim3(256), 0,
-                       s, d_chunks, nc, d_q, d_qoff, nvq, d_lo, d_cnt);
+    if (nvq >= 32768 && !getenv("PSS_WAVE_SEARCH"))
+        hipLaunchKernelGGL(search_interval_lane_kernel, dim3((u32)((nvq + 255) / 256)), dim3(256), 0, s, d_chunks, nc,
+                           d_q, d_qoff, nvq, d_lo, d_cnt);
+    else
+        hipLaunchKernelGGL(search_interval_kernel, dim3((u32)((nvq + waves_per_block - 1) / waves_per_block)), dim3(256),
+                           0, s, d_chunks, nc, d_q, d_qoff, nvq, d_lo, d_cnt);
     PSS_HIP(hipEventRecord(e1, s));
     PSS_TRY(device_excl_scan(ctx, InU32{d_cnt}, nvq, d_partial, d_total, d_hitoff));
     PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));

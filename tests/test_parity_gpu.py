@@ -335,3 +335,27 @@ def test_concurrent_handles_from_threads(tmp_path, oracle):
     pysubstringsearch_amd.release_workspace()
     with pysubstringsearch.Reader(corpora[0][0]) as r:      # still works after the workspace was dropped
         assert sorted(r.search('a')) == sorted(oracle.OracleReader(corpora[0][0]).search('a'))
+
+
+def test_large_batch_lane_search(tmp_path, oracle):
+    """>= 32768 (query, chunk) pairs switch the interval search to one lane per pair."""
+    from tests.util import gen_corpus
+    src = tmp_path / 'c.txt'
+    src.write_bytes(gen_corpus(1, 1 << 19).tobytes())
+    p = str(tmp_path / 'c.idx')
+    w = pysubstringsearch.Writer(p, 1 << 17)
+    w.add_entries_from_file_lines(str(src))
+    w.close()
+    text = src.read_bytes()
+    rng = np.random.default_rng(9)
+    qs = [b'', b'a', b'\n', b'zzzzzz']
+    while len(qs) < 9000:
+        s = int(rng.integers(0, len(text) - 20))
+        qs.append(text[s:s + int(rng.integers(1, 14))])
+    o = oracle.OracleReader(p)
+    with pysubstringsearch.Reader(p) as r:
+        assert r.num_chunks * len(qs) >= 32768
+        ents, counts = r.search_batch_raw(qs)
+        oe, oc = o.search_multiple_bytes(qs)
+        assert counts == oc.tolist()
+        assert sorted(ents) == sorted(oe)

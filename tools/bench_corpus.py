@@ -89,6 +89,11 @@ def main():
     out.update({'batch_s': round(best, 5), 'batched_queries_per_sec': round(len(queries) / best, 1),
                 'entries': len(entries), 'hits_per_query': round(stats['hits'] / len(queries), 3),
                 'ms_device': round(stats['ms_device'], 3), 'ms_interval': round(stats['ms_interval'], 3)})
+    t0 = time.perf_counter()
+    pk = reader.search_batch_packed(queries)
+    dt = time.perf_counter() - t0
+    out.update({'packed_batch_s': round(dt, 5), 'packed_queries_per_sec': round(len(queries) / dt, 1),
+                'packed_bytes': int(pk.data.size)})
     # single-query latency
     lat = []
     for q in queries[:args.single_reps]:
