@@ -8,25 +8,29 @@
 //
 // Pipeline (all arrays resident in HBM, u32 indices, n < 2^31):
 //
-//   0. sa_symbols      which byte values occur          (reads n)
+//   0. sa_symbols      which byte values occur (+ sampled counts)   (reads n)
 //      sa_recode       text -> dense codes 1..sigma, 0 = "past the end"
-//                      (b = bits(sigma) per symbol)     (reads n, writes n)
-//   1. initial sort    radix sort of all n suffixes by the key made of their
-//                      first h0 = min(16, 64/b) symbols, packed on the fly
-//                      from the codes (the end-of-text code 0 sorts first, so
-//                      a suffix that is a proper prefix of another sorts
-//                      before it and keys are never ambiguous)
-//   2. rerank          equal keys = one group; rank = 1 + position of the
-//                      group head; ISA[suffix] = rank; suffixes in groups of
-//                      size 1 are final.  The rest is compacted into the
-//                      ACTIVE list (position, suffix, group rank).
-//   3. doubling round h: for every active suffix i build the key
-//                      (group rank, ISA[i+h] or 0 past the end), radix-sort
-//                      the active list by it, put the suffixes back into their
-//                      group's slots of SA, split groups where keys differ,
-//                      update ISA, drop the now-unique suffixes, h *= 2.
-//      Only unresolved suffixes are ever touched again (Larsson-Sadakane
-//      style filtering), so sum(active) stays near n on natural text.
+//                      (b = bits(sigma) per symbol)                 (reads n, writes n)
+//   1. initial sort    radix sort of all n suffixes by a 64-bit key made of their
+//                      first h0 symbols, packed on the fly from the codes (the
+//                      end-of-text code 0 sorts first, so a suffix that is a proper
+//                      prefix of another sorts before it and keys are never
+//                      ambiguous); h0 from the symbol statistics (choose_key_chars);
+//                      the pass that finishes the sort writes SA in place
+//   2. rerank          equal keys = one group; rank = 1 + SA position of the group
+//                      head; suffixes in groups of size 1 are final, the rest is
+//                      compacted into the ACTIVE list (SA slot, suffix, group rank)
+//   3. rounds on the active list only, until it is empty (see the host loop):
+//        sparse  few ties (lines): doubling, ranks from a hash table of the tied
+//                suffixes + binary search in the sorted initial keys; no ISA
+//        text    natural text: every group extended by the next 64/b symbols
+//                packed from the text at offset h; no ranks, no ISA
+//        rank    repetitive data / after text rounds stop paying: ISA built once,
+//                key = ISA[i+h], h doubles (Larsson-Sadakane)
+//      text and rank rounds share one machinery: groups of <= 512 members are
+//      ranked in LDS (group_sort_kernel), larger ones go through two chained
+//      stable radix sorts; a rank round falls back to one global (group, rank)
+//      radix sort while large groups dominate.
 //
 // Wave-level work uses 64-bit ballots throughout: group heads and active
 // flags are ballot masks, head positions come from msb(mask), compaction
@@ -315,8 +319,8 @@ __global__ __launch_bounds__(256) void ht_insert_kernel(u64 *ht, u32 mask, const
         ht_insert(ht, mask, idx[t], grp[t]);
 }
 
-constexpr int MODE_ISA = 0;    // dense: ISA[suffix] = rank
-constexpr int MODE_NONE = 1;   // initial rerank when the sparse path was chosen
+constexpr int MODE_ISA = 0;    // rank rounds: ISA[suffix] = rank (only where it changed)
+constexpr int MODE_NONE = 1;   // no rank storage: initial rerank of the sparse / text paths, text rounds
 constexpr int MODE_HT = 2;     // sparse rounds: refresh the hash table
 
 template <int MODE>
