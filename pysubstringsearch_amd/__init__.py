@@ -163,24 +163,28 @@ class Reader:
 
     def _search_batch(self, patterns: typing.Sequence[bytes], as_str: bool):
         nq = len(patterns)
-        blob = b''.join(patterns)
-        offs = (ctypes.c_uint64 * (nq + 1))()
-        if nq > 64:
-            import numpy as np
-            view = np.ctypeslib.as_array(offs)
-            np.cumsum(np.fromiter(map(len, patterns), dtype=np.uint64, count=nq), out=view[1:])
+        if _pssglue is not None:
+            blob, offs = _pssglue.pack_queries(patterns)      # one C loop: blob + u64 offsets
         else:
+            blob = b''.join(patterns)
+            arr = (ctypes.c_uint64 * (nq + 1))()
             pos = 0
             for i, p in enumerate(patterns):
-                offs[i] = pos
+                arr[i] = pos
                 pos += len(p)
-            offs[nq] = pos
+            arr[nq] = pos
+            offs = bytes(arr)
         res = ctypes.c_void_p()
         rc = _lib.pss_reader_search_batch(self._handle(), blob, offs, nq, ctypes.byref(res))
         _ffi.check(rc)
         try:
             n = _lib.pss_result_num_entries(res)
-            counts = list(_lib.pss_result_query_counts(res)[:nq]) if nq else []
+            if not nq:
+                counts = []
+            elif _pssglue is not None:
+                counts = _pssglue.u64_list(ctypes.cast(_lib.pss_result_query_counts(res), ctypes.c_void_p).value, nq)
+            else:
+                counts = list(_lib.pss_result_query_counts(res)[:nq])
             entries = []
             if n:
                 off = _lib.pss_result_offsets(res)

@@ -7,6 +7,7 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <stdint.h>
+#include <string.h>
 
 /* entries_to_list(bytes_addr: int, offsets_addr: int, n: int, as_str: bool) -> list */
 static PyObject *entries_to_list(PyObject *self, PyObject *args)
@@ -33,7 +34,70 @@ static PyObject *entries_to_list(PyObject *self, PyObject *args)
     return list;
 }
 
+/* pack_queries(seq_of_bytes) -> (blob: bytes, offsets: bytes holding (n+1) little-endian u64)
+ * One C loop instead of b''.join + a numpy cumsum; raises TypeError on a non-bytes item. */
+static PyObject *pack_queries(PyObject *self, PyObject *arg)
+{
+    (void)self;
+    PyObject *seq = PySequence_Fast(arg, "expected a sequence of bytes");
+    if (!seq) return NULL;
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
+    PyObject **items = PySequence_Fast_ITEMS(seq);
+    Py_ssize_t total = 0;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        if (!PyBytes_Check(items[i])) {
+            Py_DECREF(seq);
+            PyErr_SetString(PyExc_TypeError, "queries must be bytes");
+            return NULL;
+        }
+        total += PyBytes_GET_SIZE(items[i]);
+    }
+    PyObject *blob = PyBytes_FromStringAndSize(NULL, total);
+    PyObject *offs = PyBytes_FromStringAndSize(NULL, (n + 1) * (Py_ssize_t)sizeof(uint64_t));
+    if (!blob || !offs) {
+        Py_XDECREF(blob);
+        Py_XDECREF(offs);
+        Py_DECREF(seq);
+        return NULL;
+    }
+    char *bp = PyBytes_AS_STRING(blob);
+    uint64_t *op = (uint64_t *)PyBytes_AS_STRING(offs);
+    uint64_t pos = 0;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        const Py_ssize_t l = PyBytes_GET_SIZE(items[i]);
+        op[i] = pos;
+        memcpy(bp + pos, PyBytes_AS_STRING(items[i]), (size_t)l);
+        pos += (uint64_t)l;
+    }
+    op[n] = pos;
+    Py_DECREF(seq);
+    return Py_BuildValue("(NN)", blob, offs);
+}
+
+/* u64_list(addr: int, n: int) -> list[int] */
+static PyObject *u64_list(PyObject *self, PyObject *args)
+{
+    unsigned long long addr;
+    Py_ssize_t n;
+    (void)self;
+    if (!PyArg_ParseTuple(args, "Kn", &addr, &n)) return NULL;
+    const uint64_t *p = (const uint64_t *)(uintptr_t)addr;
+    PyObject *list = PyList_New(n);
+    if (!list) return NULL;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject *o = PyLong_FromUnsignedLongLong(p[i]);
+        if (!o) {
+            Py_DECREF(list);
+            return NULL;
+        }
+        PyList_SET_ITEM(list, i, o);
+    }
+    return list;
+}
+
 static PyMethodDef methods[] = {
+    {"pack_queries", pack_queries, METH_O, "sequence of bytes -> (blob, u64 offsets as bytes)"},
+    {"u64_list", u64_list, METH_VARARGS, "(address, n) -> list of ints"},
     {"entries_to_list", entries_to_list, METH_VARARGS, "packed (bytes, offsets) -> list of str / bytes"},
     {NULL, NULL, 0, NULL},
 };
