@@ -41,6 +41,9 @@ size_t radix_sort_workspace_bytes();
 // Stable.  `work` must hold radix_sort_workspace_bytes().
 int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint32_t n, int key_bits,
                      uint32_t pass_mask, const TextKeys *text, int src, void *work, int *dst,
-                     bool profile, SortStats *stats);
+                     bool profile, SortStats *stats, bool ties_last = false);
+// ties_last: the last executed pass (which must not be the text pass) writes NO keys; bit 31 of
+// every output value is set iff the element's full key equals its predecessor's in the output
+// ("tied": not the head of its group).  Values must be < 2^31.
 
 }  // namespace pss

@@ -61,6 +61,13 @@ struct PassArgs {
     int shift;
     u32 *table;    // [256][num_ranges]
     u32 *totals;   // [256]
+    // final pass of the suffix sort (TIES variant): no keys are written; bit 31 of every value
+    // says "equal key as my predecessor in the output".  First / last key of each (range, digit)
+    // go to these tables so rs_fix_ties can settle the one element per (range, digit) whose
+    // predecessor lives in another range.
+    u64 *first_key;   // [num_ranges][256]
+    u64 *last_key;    // [num_ranges][256]
+    u32 *has;         // [num_ranges][256]
 };
 
 // Packs the keys of 16 consecutive suffixes i0 .. i0+15 (i0 % 16 == 0) from the
@@ -186,9 +193,14 @@ __global__ __launch_bounds__(256) void rs_scan_kernel(u32 *table, const u32 *tot
 
 // One tile of the scatter pass.  FULL = every slot of the tile holds an element
 // (all but the last tile of the input): the per-item bounds predicates fold away.
-template <bool FROM_TEXT, bool FULL, int IPT>
+// TIES (final pass of the suffix sort): equal full keys are neighbours in the digit-ordered
+// exchange buffer, so "same key as my predecessor" is decided right there (s_tk / s_tv carry
+// the last key of every digit from the previous tiles of the range); only values are written,
+// with that bit in bit 31.
+template <bool FROM_TEXT, bool FULL, int IPT, bool TIES>
 __device__ __forceinline__ void scatter_tile(const PassArgs &a, u32 base, u32 valid_count, u64 *exch,
-                                             u32 (*wave_hist)[256], u32 *s_off, u32 *s_delta, u32 *s_scr)
+                                             u32 (*wave_hist)[256], u32 *s_off, u32 *s_delta, u32 *s_scr,
+                                             u32 g, u32 *s_dstart, u32 *s_cnt, u64 *s_tk, u32 *s_tv)
 {
     const u32 tid = threadIdx.x;
     const u32 lane = tid & 63u, wave = tid >> 6;
@@ -262,6 +274,10 @@ __device__ __forceinline__ void scatter_tile(const PassArgs &a, u32 base, u32 va
             const u32 off = s_off[tid];
             s_delta[tid] = off - dstart;
             s_off[tid] = off + total;
+            if (TIES) {
+                s_dstart[tid] = dstart;
+                s_cnt[tid] = total;
+            }
         }
     }
     __syncthreads();
@@ -276,6 +292,7 @@ __device__ __forceinline__ void scatter_tile(const PassArgs &a, u32 base, u32 va
     }
     __syncthreads();
     u32 gpos[IPT];
+    u32 tied = 0;   // TIES: bit i = element i has the same key as its predecessor
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
         const u32 p = i * RS_BLOCK + tid;
@@ -284,10 +301,31 @@ __device__ __forceinline__ void scatter_tile(const PassArgs &a, u32 base, u32 va
             const u64 k = exch[p];
             const u32 d = (u32)(k >> a.shift) & 0xffu;
             gpos[i] = s_delta[d] + p;
-            a.kout[gpos[i]] = k;
+            if (TIES) {
+                const u32 ds = s_dstart[d];
+                bool t;
+                if (p > ds) {
+                    t = exch[p - 1] == k;
+                } else if (s_tv[d]) {
+                    t = s_tk[d] == k;                           // last key of this digit in an earlier tile
+                } else {
+                    t = false;                                  // first of its digit in the whole range:
+                    a.first_key[(size_t)g * 256 + d] = k;       // settled by rs_fix_ties
+                }
+                tied |= (t ? 1u : 0u) << i;
+            } else {
+                a.kout[gpos[i]] = k;
+            }
         }
     }
     __syncthreads();
+    if (TIES) {
+        if (tid < 256 && s_cnt[tid]) {
+            s_tk[tid] = exch[s_dstart[tid] + s_cnt[tid] - 1];
+            s_tv[tid] = 1;
+        }
+        __syncthreads();
+    }
     u32 *exv = reinterpret_cast<u32 *>(exch);
     if (!FROM_TEXT) {
 #pragma unroll
@@ -301,7 +339,7 @@ __device__ __forceinline__ void scatter_tile(const PassArgs &a, u32 base, u32 va
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
         const u32 p = i * RS_BLOCK + tid;
-        if (FULL || p < valid_count) a.vout[gpos[i]] = exv[p];
+        if (FULL || p < valid_count) a.vout[gpos[i]] = TIES ? (exv[p] | (((tied >> i) & 1u) << 31)) : exv[p];
     }
     __syncthreads();
 }
@@ -311,7 +349,7 @@ __device__ __forceinline__ void scatter_tile(const PassArgs &a, u32 base, u32 va
 #endif
 constexpr int RS_PAIR_IPT = PSS_RS_PAIR_IPT;   // items per thread of the (key, value) scatter; divides RS_IPT
 
-template <bool FROM_TEXT>
+template <bool FROM_TEXT, bool TIES = false>
 __global__ __launch_bounds__(RS_BLOCK, PSS_RS_MINWAVES) void rs_scatter_kernel(PassArgs a)
 {
     constexpr int IPT = FROM_TEXT ? RS_IPT : RS_PAIR_IPT;
@@ -321,14 +359,22 @@ __global__ __launch_bounds__(RS_BLOCK, PSS_RS_MINWAVES) void rs_scatter_kernel(P
     __shared__ u32 s_off[256];     // running global offset of each digit for this range
     __shared__ u32 s_delta[256];   // s_off - (start of the digit inside the tile)
     __shared__ u32 s_scr[RS_WAVES + 1];
+    __shared__ u32 s_dstart[TIES ? 256 : 1], s_cnt[TIES ? 256 : 1], s_tv[TIES ? 256 : 1];
+    __shared__ u64 s_tk[TIES ? 256 : 1];
 
     const u32 tid = threadIdx.x;
     const u32 g = xcd_range_of_block(blockIdx.x, gridDim.x);
-    if (tid < 256) s_off[tid] = a.table[tid * a.num_ranges + g];
+    if (tid < 256) {
+        s_off[tid] = a.table[tid * a.num_ranges + g];
+        if (TIES) s_tv[tid] = 0;
+    }
 
     const u32 tile0 = g * a.tiles_per_range;
     const u32 tile1 = min(tile0 + a.tiles_per_range, a.num_tiles);
-    if (tile0 >= tile1) return;
+    if (tile0 >= tile1) {
+        if (TIES && tid < 256) a.has[(size_t)g * 256 + tid] = 0;
+        return;
+    }
     const u32 e0 = tile0 * (u32)RS_TILE;                       // n < 2^31: no overflow
     const u32 e1_full = tile1 * (u32)RS_TILE;
     const u32 e1 = e1_full < a.n ? e1_full : a.n;
@@ -336,9 +382,32 @@ __global__ __launch_bounds__(RS_BLOCK, PSS_RS_MINWAVES) void rs_scatter_kernel(P
         const u32 left = e1 - base;
         const u32 valid_count = left < SUB ? left : SUB;
         if (valid_count == SUB)
-            scatter_tile<FROM_TEXT, true, IPT>(a, base, valid_count, exch, wave_hist, s_off, s_delta, s_scr);
+            scatter_tile<FROM_TEXT, true, IPT, TIES>(a, base, valid_count, exch, wave_hist, s_off, s_delta, s_scr, g,
+                                                     s_dstart, s_cnt, s_tk, s_tv);
         else
-            scatter_tile<FROM_TEXT, false, IPT>(a, base, valid_count, exch, wave_hist, s_off, s_delta, s_scr);
+            scatter_tile<FROM_TEXT, false, IPT, TIES>(a, base, valid_count, exch, wave_hist, s_off, s_delta, s_scr, g,
+                                                      s_dstart, s_cnt, s_tk, s_tv);
+    }
+    if (TIES && tid < 256) {
+        a.has[(size_t)g * 256 + tid] = s_tv[tid];
+        if (s_tv[tid]) a.last_key[(size_t)g * 256 + tid] = s_tk[tid];
+    }
+}
+
+// TIES epilogue: the first element of digit d in range g follows, in the output, the last
+// element of digit d of the nearest earlier range that had one.  One thread per digit walks the
+// ranges in order (256 x <= 1024 table entries).
+__global__ __launch_bounds__(256) void rs_fix_ties_kernel(const u64 *first_key, const u64 *last_key, const u32 *has,
+                                                            const u32 *table, u32 num_ranges, u32 *vout)
+{
+    const u32 d = threadIdx.x;
+    bool have = false;
+    u64 prev = 0;
+    for (u32 g = 0; g < num_ranges; ++g) {
+        if (!has[(size_t)g * 256 + d]) continue;
+        if (have && prev == first_key[(size_t)g * 256 + d]) vout[table[d * num_ranges + g]] |= 0x80000000u;
+        prev = last_key[(size_t)g * 256 + d];
+        have = true;
     }
 }
 
@@ -382,11 +451,15 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_small_sort_kernel(u64 *keys, u32 
     }
 }
 
-size_t radix_sort_workspace_bytes() { return (size_t)256 * RS_MAX_RANGES * 4 + 256 * 4 * 16; }
+size_t radix_sort_workspace_bytes()
+{
+    // digit table + 16 totals rows + (first key, last key, has) tables of the TIES pass
+    return (size_t)256 * RS_MAX_RANGES * 4 + 256 * 4 * 16 + (size_t)256 * RS_MAX_RANGES * (8 + 8 + 4);
+}
 
 int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint32_t n, int key_bits,
                      uint32_t pass_mask, const TextKeys *text, int src, void *work, int *dst,
-                     bool profile, SortStats *stats)
+                     bool profile, SortStats *stats, bool ties_last)
 {
     const int passes = (key_bits + 7) / 8;
     int cur = src;
@@ -409,6 +482,12 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
 
     u32 *table = static_cast<u32 *>(work);
     u32 *totals_base = table + (size_t)256 * RS_MAX_RANGES;
+    u64 *first_key = reinterpret_cast<u64 *>(totals_base + 256 * 16);
+    u64 *last_key = first_key + (size_t)256 * RS_MAX_RANGES;
+    u32 *has = reinterpret_cast<u32 *>(last_key + (size_t)256 * RS_MAX_RANGES);
+    int last_pass = -1;
+    for (int p = 0; p < passes; ++p)
+        if ((pass_mask >> p) & 1u) last_pass = p;
     PSS_HIP(hipMemsetAsync(totals_base, 0, 256 * 4 * 16, ctx->stream));
 
     hipEvent_t ev[2 * 16];
@@ -427,6 +506,10 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
         a.num_ranges = num_ranges;
         a.shift = p * 8;
         a.table = table;
+        a.first_key = first_key;
+        a.last_key = last_key;
+        a.has = has;
+        const bool ties = ties_last && p == last_pass && !from_text;
         a.totals = totals_base + (size_t)256 * (executed & 15);
         if (executed >= 16) PSS_HIP(hipMemsetAsync(a.totals, 0, 256 * 4, ctx->stream));
         int out;
@@ -455,7 +538,11 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
             PSS_HIP(hipEventRecord(ev[nev++], ctx->stream));
         }
         if (from_text) hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(num_ranges), dim3(RS_BLOCK), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(num_ranges), dim3(RS_BLOCK), 0, ctx->stream, a);
+        else if (ties) {
+            hipLaunchKernelGGL((rs_scatter_kernel<false, true>), dim3(num_ranges), dim3(RS_BLOCK), 0, ctx->stream, a);
+            hipLaunchKernelGGL(rs_fix_ties_kernel, dim3(1), dim3(256), 0, ctx->stream, first_key, last_key, has, table,
+                               num_ranges, a.vout);
+        } else hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(num_ranges), dim3(RS_BLOCK), 0, ctx->stream, a);
         if (profile && nev < 32) PSS_HIP(hipEventRecord(ev[nev++], ctx->stream));
         PSS_HIP(hipGetLastError());
         cur = out;

@@ -140,6 +140,8 @@ struct RerankArgs {
     const u32 *pos;      // their SA positions (nullptr: element t sits at SA position t)
     const u32 *grp;      // text rounds: current group rank of every element (keys alone do not
                          // identify the group); nullptr when the key carries the group
+    const u32 *tied_sa;  // initial rerank after a TIES final pass: no keys; element j's suffix is
+                         // tied_sa[j] & 0x7fffffff, bit 31 = same key as element j-1
     u32 m;
     u32 num_tiles, tiles_per_range, num_ranges;
     u32 *agg_head;       // [ranges] 1 + last group-head index of the range (0 = none)
@@ -161,6 +163,37 @@ struct WaveFlags {
 
 // Loads the wave's 512-element segment (element (r, lane) = wbase + 64 r + lane)
 // and derives group-head / active ballots from neighbouring keys.
+// Variant for the initial rerank after a TIES final pass: heads come from bit 31 of the
+// flagged suffix array, no neighbour comparison is needed.  v[r] receives the raw values.
+__device__ __forceinline__ void wave_flags_tied(const u32 *tied_sa, u32 m, u32 wbase, WaveFlags &f, u32 (&v)[RR_ROWS])
+{
+    const u32 lane = lane_id();
+#pragma unroll
+    for (int r = 0; r < RR_ROWS; ++r) {
+        const u32 j = wbase + r * kWave + lane;
+        v[r] = (j < m) ? tied_sa[j] : 0;
+    }
+    const u32 jn = wbase + RR_WSEG;
+    u32 edge = 0;
+    if (lane == 63 && jn < m) edge = tied_sa[jn];
+#pragma unroll
+    for (int r = 0; r < RR_ROWS; ++r) {
+        const u32 j = wbase + r * kWave + lane;
+        const bool valid = j < m;
+        f.head[r] = __ballot(valid && (j == 0 || !(v[r] >> 31)));
+        f.valid[r] = __ballot(valid);
+    }
+    const bool next_seg_head = (jn >= m) || !(edge >> 31);
+    const u64 nsh = (__ballot(next_seg_head) >> 63) & 1ull;
+#pragma unroll
+    for (int r = 0; r < RR_ROWS; ++r) {
+        const u64 hv = f.head[r] | ~f.valid[r];
+        const u64 first_next = (r + 1 < RR_ROWS) ? ((f.head[r + 1] | ~f.valid[r + 1]) & 1ull) : nsh;
+        const u64 next = (hv >> 1) | (first_next << 63);
+        f.act[r] = f.valid[r] & ~(f.head[r] & next);
+    }
+}
+
 __device__ __forceinline__ void wave_flags(const u64 *keys, const u32 *grp, u32 m, u32 wbase, WaveFlags &f,
                                            u64 (&key)[RR_ROWS])
 {
@@ -228,7 +261,9 @@ __global__ __launch_bounds__(RR_BLOCK) void rr_reduce_kernel(RerankArgs a)
         if (wbase >= a.m) break;
         WaveFlags f;
         u64 key[RR_ROWS];
-        wave_flags(a.keys, a.grp, a.m, wbase, f, key);
+        u32 tv[RR_ROWS];
+        if (a.tied_sa) wave_flags_tied(a.tied_sa, a.m, wbase, f, tv);
+        else wave_flags(a.keys, a.grp, a.m, wbase, f, key);
 #pragma unroll
         for (int r = 0; r < RR_ROWS; ++r) {
             if (f.head[r]) whead = wbase + r * kWave + (63 - __builtin_clzll(f.head[r])) + 1;
@@ -335,7 +370,9 @@ __global__ __launch_bounds__(RR_BLOCK) void rr_apply_kernel(RerankArgs a)
         const u32 wbase = tile * RR_TILE + w * RR_WSEG;
         WaveFlags f;
         u64 key[RR_ROWS];
-        wave_flags(a.keys, a.grp, a.m, min(wbase, a.m), f, key);
+        u32 tv[RR_ROWS] = {};
+        if (a.tied_sa) wave_flags_tied(a.tied_sa, a.m, min(wbase, a.m), f, tv);
+        else wave_flags(a.keys, a.grp, a.m, min(wbase, a.m), f, key);
         u32 whead = 0, wcnt = 0;
 #pragma unroll
         for (int r = 0; r < RR_ROWS; ++r) {
@@ -369,7 +406,15 @@ __global__ __launch_bounds__(RR_BLOCK) void rr_apply_kernel(RerankArgs a)
                 const bool is_act = (f.act[r] >> lane) & 1ull;
                 // the suffix index is only needed where something is written with it
                 const bool need_idx = is_act || a.SA != nullptr || MODE == MODE_ISA || MODE == MODE_HT;
-                const u32 ij = need_idx ? a.idx[j] : 0u;
+                u32 ij;
+                if (a.tied_sa) {
+                    // The flag bit is NOT cleared here (a neighbouring workgroup may still be reading
+                    // it).  Every flagged element is tied, hence active, hence rewritten clean by the
+                    // next round's `SA[slot] = suffix`; readers in between mask bit 31.
+                    ij = tv[r] & 0x7fffffffu;
+                } else {
+                    ij = need_idx ? a.idx[j] : 0u;
+                }
                 if (a.SA) a.SA[pj] = ij;
                 // a suffix whose rank did not change (e.g. every old group's head) needs no ISA write
                 if (MODE == MODE_ISA && (a.pos == nullptr || a.grp == nullptr || newrank != a.grp[j]))
@@ -396,7 +441,8 @@ struct KeyArgs {
     const u32 *ISA;       // dense mode
     const u64 *ht;        // sparse mode
     u32 ht_mask;
-    const u64 *k0;        // sparse mode: sorted initial keys (n of them)
+    const u32 *sa;        // sparse mode: suffix array after the initial sort (every initial group
+                          // occupies its final slots, so the key order along it is the initial key order)
     const u8 *codes;
     int code_bits, key_chars, plus_one;
     u32 m, n, h;
@@ -437,7 +483,8 @@ __global__ __launch_bounds__(256) void build_keys_kernel(KeyArgs a)
                     u32 lo = 0, hi = a.n;
                     while (lo < hi) {
                         const u32 mid = lo + ((hi - lo) >> 1);
-                        if (a.k0[mid] < key) lo = mid + 1; else hi = mid;
+                        if (text_key_at(a.codes, a.sa[mid] & 0x7fffffffu, a.code_bits, a.key_chars, a.plus_one, a.n) < key) lo = mid + 1;
+                        else hi = mid;
                     }
                     r2 = lo + 1;
                 }
@@ -665,7 +712,8 @@ __global__ __launch_bounds__(256) void iota_kernel(u32 *v, u32 n)
 // Switching from text rounds to doubling rounds: rank of every suffix.
 __global__ __launch_bounds__(256) void isa_from_sa_kernel(const u32 *SA, u32 n, u32 *ISA)
 {
-    for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) ISA[SA[j]] = j + 1;
+    for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+        ISA[SA[j] & 0x7fffffffu] = j + 1;   // bit 31 may still carry a tie flag of the initial sort
 }
 __global__ __launch_bounds__(256) void isa_active_kernel(const u32 *idx, const u32 *grp, u32 m, u32 *ISA)
 {
@@ -815,7 +863,11 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     u32 *const v_scratch = V[final_buf];
     V[final_buf] = SA;
     int cur = 0;
-    PSS_TRY(radix_sort_pairs(ctx, K, V, n, key_bits0, 0xffffffffu, &tk, 0, work, &cur, profile, &ss));
+    // With >= 2 passes the last one also settles the groups: it writes no keys, only the suffix
+    // indices with bit 31 = "tied with my predecessor" (radix_sort.hip, TIES) -- 8 B/suffix less
+    // to write, and the rerank reads 4-byte flagged values instead of comparing 8-byte keys.
+    const bool ties = passes0 >= 2 && !getenv("PSS_NO_TIES_PASS");
+    PSS_TRY(radix_sort_pairs(ctx, K, V, n, key_bits0, 0xffffffffu, &tk, 0, work, &cur, profile, &ss, ties));
     st.initial_passes = (u32)ss.launches;
     const bool sa_in_place = (cur == final_buf);
 
@@ -862,6 +914,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         ra.keys = Kr[cur];
         ra.idx = V[cur];
         ra.SA = (round == 0 && sa_in_place) ? nullptr : SA;      // round 0: the sort already wrote SA
+        ra.tied_sa = (round == 0 && ties) ? V[cur] : nullptr;
         ra.pos = identity_pos ? nullptr : P[pcur];
         ra.grp = (round > 0 && !keyed_grp) ? G[gcur] : nullptr;   // group-local rounds: keys do not carry the group
         ra.pos_out = P[pcur ^ 1];
@@ -1050,7 +1103,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         ka.ISA = ISA;
         ka.ht = ra.ht;
         ka.ht_mask = ra.ht_mask;
-        ka.k0 = K[k0buf];
+        ka.sa = SA;
         ka.codes = codes;
         ka.code_bits = b;
         ka.key_chars = key_chars;
