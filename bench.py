@@ -10,7 +10,7 @@ queries (5 000 sampled from the text, 5 000 random) through the batched search.
   value            index-build GB/s  = chunk bytes of all ranks / build time
   queries_per_sec  batched queries/s = queries / (H2D queries + kernels + D2H
                    results + Python list construction [+ gather to rank 0])
-  roofline         dominant kernel rs_scatter_kernel<false>: 24 algorithmic
+  roofline         dominant kernel rs_scatter_kernel<false, false>: 24 algorithmic
                    bytes per element (8 B key + 4 B value in, same out) over its
                    HIP-event duration, against the 8 TB/s HBM peak
   cpu_baseline     the reference's libsais (oracle/_ref) on a bounded sample,
@@ -226,7 +226,7 @@ def main():
                     traffic = None
             roof = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                    'kernel': 'rs_scatter_kernel<false>', 'launches_per_build': prof['pairs_launches'],
+                    'kernel': 'rs_scatter_kernel<false, false>', 'launches_per_build': prof['pairs_launches'],
                     'ms_per_launch': round(ms_per_launch, 4), 'algorithmic_bytes_per_launch': int(bytes_per_launch)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

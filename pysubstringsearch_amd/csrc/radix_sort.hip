@@ -491,7 +491,7 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
     PSS_HIP(hipMemsetAsync(totals_base, 0, 256 * 4 * 16, ctx->stream));
 
     hipEvent_t ev[2 * 16];
-    bool ev_text[16];
+    int ev_kind[16];   // 0 = text pass, 1 = (key, value) pass, 2 = final TIES pass
     int nev = 0, nev_created = 0;
     if (profile) {   // created up front: a hipEventCreate between launch and record would idle the GPU
         for (; nev_created < 32; ++nev_created) PSS_HIP(hipEventCreate(&ev[nev_created]));
@@ -534,7 +534,7 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
         else hipLaunchKernelGGL(rs_hist_kernel<false>, dim3(num_ranges), dim3(RS_BLOCK), 0, ctx->stream, a);
         hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(256), 0, ctx->stream, a.table, a.totals, num_ranges);
         if (profile && nev < 32) {
-            ev_text[nev / 2] = from_text;
+            ev_kind[nev / 2] = from_text ? 0 : (ties ? 2 : 1);
             PSS_HIP(hipEventRecord(ev[nev++], ctx->stream));
         }
         if (from_text) hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(num_ranges), dim3(RS_BLOCK), 0, ctx->stream, a);
@@ -560,8 +560,8 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
             PSS_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
             if (stats) {
                 stats->ms += ms;
-                if (ev_text[i / 2]) { stats->ms_text += ms; stats->text_launches += 1; }
-                else { stats->ms_pairs += ms; stats->pairs_launches += 1; stats->pairs_elems += n; }
+                if (ev_kind[i / 2] == 0) { stats->ms_text += ms; stats->text_launches += 1; }
+                else if (ev_kind[i / 2] == 1) { stats->ms_pairs += ms; stats->pairs_launches += 1; stats->pairs_elems += n; }
             }
         }
     }
