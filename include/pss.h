@@ -64,7 +64,7 @@ typedef struct pss_sa_stats {
     double ms_total;           /* device time of the whole build (HIP events) */
     double ms_sort;            /* device time inside radix passes (profile mode only) */
     uint64_t sort_launches;    /* radix-pass (scatter kernel) launches */
-    /* profile mode: the dominant kernel, rs_scatter_kernel<false> (reads 8 B key
+    /* profile mode: the dominant kernel, rs_scatter_kernel<false, false> (reads 8 B key
      * + 4 B value, writes the same: 24 algorithmic bytes per element) */
     double ms_pairs;           /* summed duration of its launches */
     uint64_t pairs_launches;
