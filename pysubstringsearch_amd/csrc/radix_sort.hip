@@ -395,20 +395,22 @@ __global__ __launch_bounds__(RS_BLOCK, PSS_RS_MINWAVES) void rs_scatter_kernel(P
 }
 
 // TIES epilogue: the first element of digit d in range g follows, in the output, the last
-// element of digit d of the nearest earlier range that had one.  One thread per digit walks the
-// ranges in order (256 x <= 1024 table entries).
-__global__ __launch_bounds__(256) void rs_fix_ties_kernel(const u64 *first_key, const u64 *last_key, const u32 *has,
-                                                            const u32 *table, u32 num_ranges, u32 *vout)
+// element of digit d of the nearest earlier range that had one.  One workgroup per digit, one
+// thread per range; the nearest earlier range comes from a workgroup max-scan.
+__global__ __launch_bounds__(1024) void rs_fix_ties_kernel(const u64 *first_key, const u64 *last_key, const u32 *has,
+                                                             const u32 *table, u32 num_ranges, u32 *vout)
 {
-    const u32 d = threadIdx.x;
-    bool have = false;
-    u64 prev = 0;
-    for (u32 g = 0; g < num_ranges; ++g) {
-        if (!has[(size_t)g * 256 + d]) continue;
-        if (have && prev == first_key[(size_t)g * 256 + d]) vout[table[d * num_ranges + g]] |= 0x80000000u;
-        prev = last_key[(size_t)g * 256 + d];
-        have = true;
-    }
+    __shared__ u32 s_wave[16];
+    const u32 d = blockIdx.x, g = threadIdx.x, lane = g & 63u, wave = g >> 6;
+    const bool mine = g < num_ranges && has[(size_t)g * 256 + d] != 0;
+    const u32 incl = wave_incl_max(mine ? g + 1 : 0u);        // 1 + last range with digit d, up to and including g
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    u32 prev1 = __shfl_up(incl, 1);
+    if (lane == 0) prev1 = 0;
+    for (u32 w = 0; w < wave; ++w) prev1 = max(prev1, s_wave[w]);
+    if (mine && prev1 && last_key[(size_t)(prev1 - 1) * 256 + d] == first_key[(size_t)g * 256 + d])
+        vout[table[d * num_ranges + g]] |= 0x80000000u;
 }
 
 // Tiny inputs (<= one tile): one workgroup, bitonic network in LDS over the
@@ -540,7 +542,7 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
         if (from_text) hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(num_ranges), dim3(RS_BLOCK), 0, ctx->stream, a);
         else if (ties) {
             hipLaunchKernelGGL((rs_scatter_kernel<false, true>), dim3(num_ranges), dim3(RS_BLOCK), 0, ctx->stream, a);
-            hipLaunchKernelGGL(rs_fix_ties_kernel, dim3(1), dim3(256), 0, ctx->stream, first_key, last_key, has, table,
+            hipLaunchKernelGGL(rs_fix_ties_kernel, dim3(256), dim3(1024), 0, ctx->stream, first_key, last_key, has, table,
                                num_ranges, a.vout);
         } else hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(num_ranges), dim3(RS_BLOCK), 0, ctx->stream, a);
         if (profile && nev < 32) PSS_HIP(hipEventRecord(ev[nev++], ctx->stream));

@@ -129,7 +129,10 @@ __global__ __launch_bounds__(256) void sa_recode_kernel(const u8 *T, u32 n, u32 
 
 constexpr int RR_BLOCK = 256;
 constexpr int RR_WAVES = RR_BLOCK / kWave;
-constexpr int RR_ROWS = 8;                         // rows of 64 elements per wave
+#ifndef PSS_RR_ROWS
+#define PSS_RR_ROWS 8
+#endif
+constexpr int RR_ROWS = PSS_RR_ROWS;               // rows of 64 elements per wave
 constexpr int RR_WSEG = RR_ROWS * kWave;           // 512 elements per wave
 constexpr int RR_TILE = RR_WSEG * RR_WAVES;        // 2048 elements per tile
 constexpr u32 RR_MAX_RANGES = 1024;
@@ -276,6 +279,51 @@ __global__ __launch_bounds__(RR_BLOCK) void rr_reduce_kernel(RerankArgs a)
     }
     __syncthreads();
     if (threadIdx.x == 0) { a.agg_head[g] = s_head; a.agg_cnt[g] = s_cnt; }
+}
+
+// rr_reduce for the flagged suffix array of a TIES final pass: only bit 31 matters, so every
+// lane takes four consecutive elements with one 16-byte load (element j is active iff it or its
+// successor is flagged; it is a head iff it is not flagged).
+__global__ __launch_bounds__(RR_BLOCK) void rr_reduce_tied_kernel(RerankArgs a)
+{
+    __shared__ u32 s_head, s_cnt;
+    const u32 g = blockIdx.x, tid = threadIdx.x, lane = lane_id();
+    if (tid == 0) { s_head = 0; s_cnt = 0; }
+    __syncthreads();
+    const u64 e0 = (u64)g * a.tiles_per_range * RR_TILE;
+    const u64 e1 = min(e0 + (u64)a.tiles_per_range * RR_TILE, (u64)a.m);
+    u32 cnt = 0, head = 0;
+    for (u64 jb = e0; jb < e1; jb += 4 * RR_BLOCK) {     // uniform trip count: the shuffles need whole waves
+        const u64 j = jb + 4ull * tid;
+        u32 v[4] = {0, 0, 0, 0};
+        if (j + 4 <= (u64)a.m) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(a.tied_sa + j);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+            for (int c = 0; c < 4; ++c)
+                if (j + c < (u64)a.m) v[c] = a.tied_sa[j + c];
+        }
+        if (j == 0) v[0] &= 0x7fffffffu;
+        u32 nxt = __shfl_down(v[0], 1);
+        if (lane == 63) nxt = (j + 4 < (u64)a.m) ? a.tied_sa[j + 4] : 0u;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (j + c < (u64)a.m) {
+                const u32 tn = (c < 3) ? v[c + 1] : nxt;
+                const bool next_tied = (j + c + 1 < (u64)a.m) && (tn >> 31);
+                cnt += ((v[c] >> 31) || next_tied) ? 1u : 0u;
+                if (!(v[c] >> 31)) head = (u32)(j + c) + 1u;
+            }
+        }
+    }
+    cnt = wave_incl_sum(cnt);
+    head = wave_incl_max(head);
+    if (lane == 63) {
+        atomicMax(&s_head, head);
+        atomicAdd(&s_cnt, cnt);
+    }
+    __syncthreads();
+    if (tid == 0) { a.agg_head[g] = s_head; a.agg_cnt[g] = s_cnt; }
 }
 
 // Exclusive max-scan of agg_head and sum-scan of agg_cnt over <= 1024 ranges.
@@ -429,6 +477,103 @@ __global__ __launch_bounds__(RR_BLOCK) void rr_apply_kernel(RerankArgs a)
             }
             if (f.head[r]) carry_h = rowbase + (63 - __builtin_clzll(f.head[r])) + 1;
             carry_c += (u32)__popcll(f.act[r]);
+        }
+    }
+}
+
+// rr_apply for the flagged suffix array of a TIES final pass when nothing but the active list
+// is written (MODE_NONE, SA already in place, element t sits at SA position t).  Same tiling as
+// rr_apply_kernel, but every lane owns 2 x 4 consecutive elements (16-byte loads): heads and
+// compaction offsets come from two wave scans per half instead of ballots.
+__global__ __launch_bounds__(RR_BLOCK) void rr_apply_tied_kernel(RerankArgs a)
+{
+    static_assert(RR_WSEG == 512, "two halves of 64 lanes x 4 elements");
+    __shared__ u32 s_wh[RR_WAVES], s_wc[RR_WAVES];
+    __shared__ u32 s_carry_h, s_carry_c;
+    const u32 g = blockIdx.x, lane = lane_id(), w = wave_id();
+    if (threadIdx.x == 0) { s_carry_h = a.agg_head[g]; s_carry_c = a.agg_cnt[g]; }
+    const u32 tile0 = g * a.tiles_per_range, tile1 = min(tile0 + a.tiles_per_range, a.num_tiles);
+    const u64 m = a.m;
+    for (u32 tile = tile0; tile < tile1; ++tile) {
+        const u64 wbase = (u64)tile * RR_TILE + (u64)w * RR_WSEG;
+        u32 v[2][4];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const u64 j = wbase + 256u * hf + 4u * lane;
+            if (j + 4 <= m) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(a.tied_sa + j);
+                v[hf][0] = q.x; v[hf][1] = q.y; v[hf][2] = q.z; v[hf][3] = q.w;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[hf][c] = (j + c < m) ? a.tied_sa[j + c] : 0u;
+            }
+        }
+        if (wbase == 0 && lane == 0) v[0][0] &= 0x7fffffffu;
+        u32 after = 0;                                     // first element past the wave's segment
+        if (lane == 63 && wbase + RR_WSEG < m) after = a.tied_sa[wbase + RR_WSEG];
+        u32 lane_cnt[2], nxt[2];
+        u32 wcnt = 0, whead = 0;
+        u32 excl_c[2], excl_h[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const u64 j = wbase + 256u * hf + 4u * lane;
+            u32 nx = __shfl_down(v[hf][0], 1);
+            const u32 first_b = __shfl(v[1][0], 0);
+            if (lane == 63) nx = (hf == 0) ? first_b : after;
+            nxt[hf] = nx;
+            u32 c_ = 0, h_ = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (j + c < m) {
+                    const u32 tn = (c < 3) ? v[hf][c + 1] : nx;
+                    const bool next_tied = (j + c + 1 < m) && (tn >> 31);
+                    c_ += ((v[hf][c] >> 31) || next_tied) ? 1u : 0u;
+                    if (!(v[hf][c] >> 31)) h_ = (u32)(j + c) + 1u;
+                }
+            }
+            lane_cnt[hf] = c_;
+            const u32 ic = wave_incl_sum(c_), ih = wave_incl_max(h_);
+            excl_c[hf] = wcnt + ic - c_;
+            u32 eh = __shfl_up(ih, 1);
+            if (lane == 0) eh = 0;
+            excl_h[hf] = max(whead, eh);
+            wcnt += __shfl(ic, 63);
+            whead = max(whead, __shfl(ih, 63));
+        }
+        if (lane == 0) { s_wh[w] = whead; s_wc[w] = wcnt; }
+        __syncthreads();
+        u32 carry_h = s_carry_h, carry_c = s_carry_c;
+        u32 tile_h = carry_h, tile_c = carry_c;
+#pragma unroll
+        for (int k = 0; k < RR_WAVES; ++k) {
+            if (k < (int)w) { carry_h = max(carry_h, s_wh[k]); carry_c += s_wc[k]; }
+            tile_h = max(tile_h, s_wh[k]);
+            tile_c += s_wc[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { s_carry_h = tile_h; s_carry_c = tile_c; }
+        if (wcnt == 0) continue;                           // nothing active in this wave's segment
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            if (lane_cnt[hf] == 0) continue;
+            const u64 j = wbase + 256u * hf + 4u * lane;
+            u32 u = carry_c + excl_c[hf];
+            u32 hd1 = max(carry_h, excl_h[hf]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (j + c < m) {
+                    const u32 x = v[hf][c];
+                    if (!(x >> 31)) hd1 = (u32)(j + c) + 1u;
+                    const u32 tn = (c < 3) ? v[hf][c + 1] : nxt[hf];
+                    const bool next_tied = (j + c + 1 < m) && (tn >> 31);
+                    if ((x >> 31) || next_tied) {
+                        a.pos_out[u] = (u32)(j + c);
+                        a.idx_out[u] = x & 0x7fffffffu;
+                        a.grp_out[u] = hd1;
+                        ++u;
+                    }
+                }
+            }
         }
     }
 }
@@ -924,7 +1069,8 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
             G[1] = ctx->slot[S_GRP2].as<u32>();
         }
         ra.grp_out = G[gcur ^ 1];
-        hipLaunchKernelGGL(rr_reduce_kernel, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
+        if (ra.tied_sa) hipLaunchKernelGGL(rr_reduce_tied_kernel, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
+        else hipLaunchKernelGGL(rr_reduce_kernel, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
         hipLaunchKernelGGL(rr_scan_kernel, dim3(1), dim3(1024), 0, s, d_agg_head, d_agg_cnt, ra.num_ranges, d_counters);
         PSS_HIP(hipMemcpyAsync(h_small, d_counters, 4, hipMemcpyDeviceToHost, s));
         PSS_HIP(hipStreamSynchronize(s));
@@ -944,6 +1090,8 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         }
         if (mode == M_DENSE) hipLaunchKernelGGL(rr_apply_kernel<MODE_ISA>, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
         else if (mode == M_SPARSE && round > 0) hipLaunchKernelGGL(rr_apply_kernel<MODE_HT>, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
+        else if (ra.tied_sa && ra.SA == nullptr && ra.pos == nullptr)
+            hipLaunchKernelGGL(rr_apply_tied_kernel, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
         else hipLaunchKernelGGL(rr_apply_kernel<MODE_NONE>, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
         PSS_HIP(hipGetLastError());
         if (round == 0) V[final_buf] = v_scratch;                 // later rounds must not scribble over SA
