@@ -74,7 +74,9 @@ typedef struct pss_sa_stats {
     uint64_t mode;             /* how ties were resolved: 0 doubling over an inverse SA (dense), 1 sparse
                                   (hash + key search, no ISA), 2 text rounds only, 3 text rounds then dense */
     uint64_t text_rounds;      /* rounds that extended ties with symbols packed from the text */
-    uint64_t big_elems;        /* members of groups > 256 handled by the chained radix sorts, summed */
+    uint64_t big_elems;        /* members of groups > 512 handled by the chained radix sorts, summed */
+    uint64_t key_bits;         /* bits of the initial sort key: key_chars * code_bits minus the low bits of the
+                                  last symbol that were left out to save a pass */
 } pss_sa_stats;
 
 /*

@@ -36,6 +36,7 @@ class SaStats(ctypes.Structure):
         ('mode', ctypes.c_uint64),
         ('text_rounds', ctypes.c_uint64),
         ('big_elems', ctypes.c_uint64),
+        ('key_bits', ctypes.c_uint64),
     ]
 
     def as_dict(self):

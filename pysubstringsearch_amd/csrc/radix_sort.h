@@ -14,6 +14,8 @@ struct TextKeys {
     int code_bits;
     int key_chars;          // <= 16
     int plus_one;           // 1: codes are raw bytes, symbol = byte + 1 inside the text (sigma == 256)
+    int drop = 0;           // low bits of the packed key left out of the sort key (< code_bits): the last
+                            // symbol then only contributes its high bits -- a monotone coarsening
 };
 
 struct SortStats {

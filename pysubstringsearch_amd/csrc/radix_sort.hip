@@ -54,6 +54,7 @@ struct PassArgs {
     int code_bits;
     int key_chars;
     int plus_one;
+    int key_drop;   // text pass: sort key = packed key >> key_drop
     u32 n;
     u32 num_tiles;
     u32 tiles_per_range;
@@ -72,7 +73,7 @@ struct PassArgs {
 
 // Packs the keys of 16 consecutive suffixes i0 .. i0+15 (i0 % 16 == 0) from the
 // recoded text.  Sliding window: key(i+1) = ((key(i) << b) | code[i+k]) & mask.
-__device__ __forceinline__ void text_keys16(const u8 *codes, u32 i0, int b, int k, int plus_one, u32 n,
+__device__ __forceinline__ void text_keys16(const u8 *codes, u32 i0, int b, int k, int plus_one, int drop, u32 n,
                                             u64 (&key)[RS_IPT])
 {
     const uint4 *p = reinterpret_cast<const uint4 *>(codes + i0);
@@ -89,7 +90,7 @@ __device__ __forceinline__ void text_keys16(const u8 *codes, u32 i0, int b, int 
         if (plus_one) c = (i0 + j < n) ? c + 1u : 0u;
         if (j < k) win = (win << b) | c;
     }
-    key[0] = win;
+    key[0] = win >> drop;
     // byte stream starting at byte k (k is wave-uniform): s0 = bytes k..k+7, s1 = k+8..k+15
     u64 a0, a1, a2;
     if (k >= 16) { a0 = q2; a1 = q3; a2 = 0; }
@@ -108,7 +109,7 @@ __device__ __forceinline__ void text_keys16(const u8 *codes, u32 i0, int b, int 
         u32 c = (u32)(src >> ((j & 7) * 8)) & 0xffu;
         if (plus_one) c = ((u64)i0 + j + k < n) ? c + 1u : 0u;
         win = ((win << b) | c) & mask;
-        key[r] = win;
+        key[r] = win >> drop;
     }
 }
 
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(PassArgs a)
         if (FROM_TEXT) {
             const u32 i0 = base + tid * RS_IPT;
             u64 key[RS_IPT] = {};
-            if (i0 < a.n) text_keys16(a.codes, i0, a.code_bits, a.key_chars, a.plus_one, a.n, key);
+            if (i0 < a.n) text_keys16(a.codes, i0, a.code_bits, a.key_chars, a.plus_one, a.key_drop, a.n, key);
 #pragma unroll
             for (int r = 0; r < RS_IPT; ++r) {
                 const bool valid = (i0 + r) < a.n;
@@ -217,7 +218,7 @@ __device__ __forceinline__ void scatter_tile(const PassArgs &a, u32 base, u32 va
         if (FULL || i0 < a.n) {
             static_assert(!FROM_TEXT || IPT == RS_IPT, "text tiles are 16 items per thread");
             u64 (&k16)[RS_IPT] = reinterpret_cast<u64 (&)[RS_IPT]>(key);
-            text_keys16(a.codes, i0, a.code_bits, a.key_chars, a.plus_one, a.n, k16);
+            text_keys16(a.codes, i0, a.code_bits, a.key_chars, a.plus_one, a.key_drop, a.n, k16);
         }
 #pragma unroll
         for (int r = 0; r < IPT; ++r) val[r] = i0 + r;
@@ -520,12 +521,13 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
             a.code_bits = text->code_bits;
             a.key_chars = text->key_chars;
             a.plus_one = text->plus_one;
+            a.key_drop = text->drop;
             a.kin = nullptr;
             a.vin = nullptr;
             out = 0;
         } else {
             a.codes = nullptr;
-            a.code_bits = a.key_chars = a.plus_one = 0;
+            a.code_bits = a.key_chars = a.plus_one = a.key_drop = 0;
             a.kin = keys[cur];
             a.vin = vals[cur];
             out = cur ^ 1;

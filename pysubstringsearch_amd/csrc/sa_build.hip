@@ -865,6 +865,53 @@ __global__ __launch_bounds__(256) void isa_active_kernel(const u32 *idx, const u
     for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < m; t += gridDim.x * blockDim.x) ISA[idx[t]] = grp[t];
 }
 
+// ---- sizing the initial sort from a sample ---------------------------------
+// The initial sort costs one pass per 8 key bits; every suffix it leaves tied
+// costs about ten times a pass's per-element price in the rounds.  How many
+// suffixes W key bits leave tied depends on the data, not only on the symbol
+// frequencies (natural text repeats far more than i.i.d. symbols do), so it is
+// measured: S stratified random suffixes, their full-width keys sorted, and for
+// every W = 8 P the sample members that share their top W bits with a sorted
+// neighbour counted.  A member collides inside the sample with probability
+// (group size - 1) * S / n, hence tied fraction ~= count / S * n / S (an
+// overestimate when groups are large -- the safe direction).
+__global__ __launch_bounds__(256) void sample_keys_kernel(const u8 *codes, u32 n, u32 S, int b, int kmax, int plus_one,
+                                                            u64 *keys, u32 *vals)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S) return;
+    const u32 stride = n / S;
+    u64 x = ((u64)t + 1) * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 29;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 32;
+    const u32 pos = t * stride + (u32)(x % stride);
+    const int bits = kmax * b;
+    keys[t] = text_key_at(codes, pos, b, kmax, plus_one, n) << (64 - bits);
+    vals[t] = t;
+}
+
+__global__ __launch_bounds__(256) void sample_ties_kernel(const u64 *keys, u32 S, u32 *tied /* [8]: W = 8, 16, .. 64 */)
+{
+    __shared__ u32 s_c[8];
+    if (threadIdx.x < 8) s_c[threadIdx.x] = 0;
+    __syncthreads();
+    u32 c[8] = {};
+    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < S; t += gridDim.x * blockDim.x) {
+        const u64 k = keys[t];
+        const u64 dp = t > 0 ? (keys[t - 1] ^ k) : ~0ull, dn = t + 1 < S ? (keys[t + 1] ^ k) : ~0ull;
+        // equal top W bits with a neighbour <=> its xor has at least W leading zeros
+        const int lz = max(dp ? __builtin_clzll(dp) : 64, dn ? __builtin_clzll(dn) : 64);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) c[w] += lz >= 8 * (w + 1) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int w = 0; w < 8; ++w)
+        if (c[w]) atomicAdd(&s_c[w], c[w]);
+    __syncthreads();
+    if (threadIdx.x < 8 && s_c[threadIdx.x]) atomicAdd(&tied[threadIdx.x], s_c[threadIdx.x]);
+}
+
 // -------------------------------------------------------------------- host --
 
 static void rerank_geometry(u32 m, RerankArgs &a)
@@ -997,8 +1044,40 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
 
     // ---- 1. initial sort on the first key_chars symbols ----
     SortStats ss;
-    TextKeys tk{codes, b, key_chars, plus_one};
-    const int key_bits0 = key_chars * b;
+    int key_drop = 0;
+    if (n >= (1u << 24) && !getenv("PSS_KEY_CHARS") && !getenv("PSS_NO_SAMPLE")) {
+        // measured sizing (see sample_keys_kernel): the fewest passes that leave <= 2 % tied
+        const u32 S = 1u << 21;
+        const int bits_max = kmax * b, pmax = (bits_max + 7) / 8;
+        u32 *d_tied = d_counters + 16;
+        PSS_HIP(hipMemsetAsync(d_tied, 0, 32, s));
+        hipLaunchKernelGGL(sample_keys_kernel, dim3(S / 256), dim3(256), 0, s, codes, n, S, b, kmax, plus_one, K[0], V[0]);
+        u32 mask = 0;
+        for (int p = 0; p < 8; ++p)
+            if (8 * (p + 1) > 64 - bits_max) mask |= 1u << p;     // digits below the key are zero
+        int sd = 0;
+        PSS_TRY(radix_sort_pairs(ctx, K, V, S, 64, mask, nullptr, 0, work, &sd, false, nullptr));
+        hipLaunchKernelGGL(sample_ties_kernel, dim3(256), dim3(256), 0, s, K[sd], S, d_tied);
+        PSS_HIP(hipMemcpyAsync(h_small, d_tied, 32, hipMemcpyDeviceToHost, s));
+        PSS_HIP(hipStreamSynchronize(s));
+        key_chars = kmax;
+        for (int p = 2; p < pmax; ++p) {
+            const double est = (double)h_small[p - 1] / S * ((double)n / S);
+            if (est <= 0.02) {
+                key_chars = (8 * p + b - 1) / b;
+                key_drop = key_chars * b - 8 * p;
+                break;
+            }
+        }
+        st.key_chars = (u32)key_chars;
+    }
+    if (const char *e = getenv("PSS_KEY_DROP")) {
+        const int v = atoi(e);
+        if (v >= 0 && v < b && key_chars > 1) key_drop = v;
+    }
+    TextKeys tk{codes, b, key_chars, plus_one, key_drop};
+    const int key_bits0 = key_chars * b - key_drop;
+    st.key_bits = (u64)key_bits0;
     // The sorted suffix indices of the initial sort ARE the suffix array (ties are reordered
     // later, inside their slots): let the pass that finishes the sort write straight into the
     // caller's SA buffer.  The text pass writes buffer 0 and the passes alternate, so the
@@ -1048,7 +1127,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     const int k0buf = cur;       // K[k0buf] = sorted initial keys (kept intact in sparse mode)
     u64 *SK[2] = {nullptr, nullptr};   // sparse mode: small ping-pong key buffers
     u64 **Kr = K;
-    u64 h = (u64)key_chars;
+    u64 h = (u64)(key_drop ? key_chars - 1 : key_chars);   // symbols every group is known to share
     const u32 grid_all = (u32)grid_stream;
     for (int round = 0;; ++round) {
         if (round > 96) {
