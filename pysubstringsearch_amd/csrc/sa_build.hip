@@ -1054,9 +1054,11 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         hipLaunchKernelGGL(sample_keys_kernel, dim3(S / 256), dim3(256), 0, s, codes, n, S, b, kmax, plus_one, K[0], V[0]);
         u32 mask = 0;
         for (int p = 0; p < 8; ++p)
-            if (8 * (p + 1) > 64 - bits_max) mask |= 1u << p;     // digits below the key are zero
+            if (8 * (p + 1) > 64 - 8 * (pmax - 1)) mask |= 1u << p;   // only the top 8 (pmax - 1) bits are ever compared
         int sd = 0;
-        PSS_TRY(radix_sort_pairs(ctx, K, V, S, 64, mask, nullptr, 0, work, &sd, false, nullptr));
+        PSS_TRY(radix_sort_pairs(ctx, K, V, S, 64, mask, nullptr, 0, work, &sd, profile, &ss));
+        ss.launches = 0;   // (the profile figures of these launches stay in: same kernel, same stream)
+        ss.elems = 0;
         hipLaunchKernelGGL(sample_ties_kernel, dim3(256), dim3(256), 0, s, K[sd], S, d_tied);
         PSS_HIP(hipMemcpyAsync(h_small, d_tied, 32, hipMemcpyDeviceToHost, s));
         PSS_HIP(hipStreamSynchronize(s));
