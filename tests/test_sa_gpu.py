@@ -83,6 +83,31 @@ def test_forced_modes(oracle, monkeypatch, mode, key_chars):
         assert (sa_gpu(t) == oracle.sa(t)).all()
 
 
+@pytest.mark.parametrize('mode', ['dense', 'sparse', 'text'])
+@pytest.mark.parametrize('key_chars,drop', [('3', '1'), ('5', '2'), ('4', '3'), ('7', '5'), ('2', '7')])
+def test_coarsened_last_symbol(oracle, monkeypatch, mode, key_chars, drop):
+    """The sort key may leave out low bits of its last symbol (the sampled sizing does that to
+    save a pass at n >= 2^24); groups then share one symbol less than the key packs.  Forced
+    here at small sizes, over every alphabet width (drop >= code_bits is ignored)."""
+    monkeypatch.setenv('PSS_MODE', mode)
+    monkeypatch.setenv('PSS_KEY_CHARS', key_chars)
+    monkeypatch.setenv('PSS_KEY_DROP', drop)
+    rng = np.random.default_rng(5)
+    cases = [gen_corpus(0, 250000), gen_corpus(1, 150000), gen_corpus(2, 60000), gen_corpus(3, 40000),
+             rng.integers(0, 256, 90000, dtype=np.uint8), rng.integers(0, 2, 120000, dtype=np.uint8),
+             rng.integers(0, 100, 120000, dtype=np.uint8)]
+    for t in cases:
+        assert (sa_gpu(t) == oracle.sa(t)).all()
+
+
+def test_sampled_sizing_sizes(oracle):
+    """n >= 2^24: the initial sort is sized from a sorted sample of suffix keys; both outcomes
+    (fewer passes + coarsened key on `lines`, full-width key on `words`) against libsais."""
+    for kind, n in ((0, (1 << 24) + 12345), (1, 1 << 24)):
+        t = gen_corpus(kind, n)
+        assert (sa_gpu(t) == oracle.sa(t)).all()
+
+
 def test_long_repeats(oracle):
     """Duplicated blocks with small edits: LCPs in the tens of thousands (text rounds must
     hand over to rank rounds; large and small groups mixed)."""
