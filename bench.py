@@ -10,9 +10,12 @@ queries (5 000 sampled from the text, 5 000 random) through the batched search.
   value            index-build GB/s  = chunk bytes of all ranks / build time
   queries_per_sec  batched queries/s = queries / (H2D queries + kernels + D2H
                    results + Python list construction [+ gather to rank 0])
-  roofline         dominant kernel rs_scatter_kernel<false, false>: 24 algorithmic
-                   bytes per element (8 B key + 4 B value in, same out) over its
-                   HIP-event duration, against the 8 TB/s HBM peak
+  roofline         dominant kernel (the scatter instantiation with the largest summed
+                   duration; `lines`: fs_scatter_kernel<4, 4>, 4 B key + 4 B value in,
+                   same out = 16 algorithmic bytes per element) over its HIP-event
+                   duration, against the 8 TB/s HBM peak
+  build_roofline   the whole build against the same peak: modelled algorithmic bytes
+                   (A_model) / build time, beside A_min = 5 n and the PMC-measured bytes
   cpu_baseline     the reference's libsais (oracle/_ref) on a bounded sample,
                    rank 0, N = 1 only
 
@@ -212,22 +215,65 @@ def main():
         del w_dT
 
     if rank == 0:
-        roof = None
+        # dominant kernel = the scatter instantiation with the largest summed duration in the profiled
+        # build: the passes of the initial sort are fs_scatter_kernel<KIN, KOUT> (key plane bytes in /
+        # out, 4-byte values), the sorts of the rounds and of the sizing sample rs_scatter_kernel<false>
+        cands = []
+        for idx in range(9):
+            if prof['fs_launches'][idx]:
+                kin, kout = (idx // 3) * 4, (idx % 3) * 4
+                bpe = (kin + 4 if kin else 1) + kout + 4          # the text pass reads 1 B / suffix
+                cands.append((prof['fs_ms'][idx], f'fs_scatter_kernel<{kin}, {kout}>', prof['fs_launches'][idx],
+                              prof['fs_elems'][idx], bpe))
         if prof['pairs_launches']:
-            bytes_per_launch = 24.0 * prof['pairs_elems'] / prof['pairs_launches']
-            ms_per_launch = prof['ms_pairs'] / prof['pairs_launches']
+            cands.append((prof['ms_pairs'], 'rs_scatter_kernel<false>', prof['pairs_launches'], prof['pairs_elems'], 24))
+        roof = None
+        if cands:
+            ms_sum, kname, launches, elems, bpe = max(cands)
+            bytes_per_launch = float(bpe) * elems / launches
+            ms_per_launch = ms_sum / launches
             achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9
             traffic = None
             pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-            if os.path.exists(pmc):
+            if os.path.exists(pmc) and args.corpus == 'lines' and args.logn == 29:
                 try:
-                    traffic = json.load(open(pmc)).get('rs_scatter_pairs_bytes_per_launch')
+                    traffic = json.load(open(pmc)).get('kernels', {}).get(kname, {}).get('bytes_per_launch')
                 except Exception:
                     traffic = None
             roof = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                    'kernel': 'rs_scatter_kernel<false, false>', 'launches_per_build': prof['pairs_launches'],
+                    'kernel': kname, 'launches_per_build': launches, 'algorithmic_bytes_per_element': bpe,
                     'ms_per_launch': round(ms_per_launch, 4), 'algorithmic_bytes_per_launch': int(bytes_per_launch)}
+        # whole-build roofline: A_min = read T once + write SA once; A_model = what this
+        # algorithm must move: alphabet 3 n, the passes of the initial sort (below),
+        # initial rerank 8 n, ~80 B per active suffix and round
+        build_ms = build_s / args.steps * 1e3
+        # initial sort: pass p reads its key plane twice (histogram + scatter) and the values once,
+        # writes the next plane and the values; planes are 8 B while > 32 key bits remain, then 4 B
+        a_sort, kin = 0, 0
+        passes0 = sa_stats['initial_passes']
+        for p in range(passes0):
+            rem = sa_stats['key_bits'] - 8 * (p + 1)
+            kout = 0 if rem <= 0 else (4 if rem <= 32 else 8)
+            a_sort += ((2 * kin + 4) if kin else 2) * n + (kout + 4) * n
+            kin = kout
+        a_sort += 32 * max(0, sa_stats['sort_elems'] - passes0 * n)     # (u64, u32) pair passes of the rounds
+        a_model = 3 * n + 8 * n + a_sort + 80 * sa_stats['sum_active']
+        measured = None
+        pmcb = os.path.join(ROOT, 'profiles', 'pmc_build_traffic.json')
+        if os.path.exists(pmcb) and args.corpus == 'lines' and args.logn == 29:
+            try:
+                measured = json.load(open(pmcb)).get('total_bytes')
+            except Exception:
+                measured = None
+        # SURVEY 8(d)'s yardstick (64-bit keys in every pass, P = 8): 5 n + sum over rounds of n_r (32 P + 44)
+        a_survey = 5 * n + 300 * (n + sa_stats['sum_active'])
+        build_roof = {'a_min_bytes': 5 * n, 'a_model_bytes': int(a_model),
+                      'survey_model_bytes': int(a_survey), 'survey_model_frac': round(a_survey / build_ms / 1e6 / HBM_PEAK_GBS, 4),
+                      'effective_gbs_a_min': round(5 * n / build_ms / 1e6, 1),
+                      'achieved': round(a_model / build_ms / 1e6, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                      'frac': round(a_model / build_ms / 1e6 / HBM_PEAK_GBS, 4), 'traffic': measured,
+                      'passes': sa_stats['initial_passes'], 'rounds': sa_stats['rounds'], 'sum_active': sa_stats['sum_active']}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(host, queries, args.cpu_sample_logn)
@@ -251,8 +297,9 @@ def main():
             'entries_per_batch': last.get('entries'),
             'search_stats': last.get('search_stats'),
             'sa_stats': {k: sa_stats[k] for k in ('sigma', 'code_bits', 'key_chars', 'initial_passes', 'rounds',
-                                                  'round_passes', 'sum_active', 'sort_launches', 'mode', 'ms_total')},
+                                                  'round_passes', 'sum_active', 'sort_launches', 'mode', 'key_bits', 'ms_total')},
             'roofline': roof,
+            'build_roofline': build_roof,
             'cpu_baseline': cpu,
             'secondary': secondary,
         }

@@ -64,8 +64,8 @@ typedef struct pss_sa_stats {
     double ms_total;           /* device time of the whole build (HIP events) */
     double ms_sort;            /* device time inside radix passes (profile mode only) */
     uint64_t sort_launches;    /* radix-pass (scatter kernel) launches */
-    /* profile mode: the dominant kernel, rs_scatter_kernel<false, false> (reads 8 B key
-     * + 4 B value, writes the same: 24 algorithmic bytes per element) */
+    /* profile mode: rs_scatter_kernel<false>, the generic (u64 key, u32 value) pass of the rounds
+     * and of the sizing sample (reads 8 B key + 4 B value, writes the same: 24 B per element) */
     double ms_pairs;           /* summed duration of its launches */
     uint64_t pairs_launches;
     uint64_t pairs_elems;      /* elements summed over those launches */
@@ -77,6 +77,12 @@ typedef struct pss_sa_stats {
     uint64_t big_elems;        /* members of groups > 512 handled by the chained radix sorts, summed */
     uint64_t key_bits;         /* bits of the initial sort key: key_chars * code_bits minus the low bits of the
                                   last symbol that were left out to save a pass */
+    /* profile mode: passes of the initial sort, fs_scatter_kernel<KIN, KOUT> (key plane bytes in / out;
+     * KIN 0 = packed from the text, KOUT 0 = last pass; values are 4 B in and out, 4 B only out of the
+     * text pass).  Index = (KIN / 4) * 3 + KOUT / 4. */
+    double fs_ms[9];
+    uint64_t fs_launches[9];
+    uint64_t fs_elems[9];
 } pss_sa_stats;
 
 /*

@@ -37,10 +37,16 @@ class SaStats(ctypes.Structure):
         ('text_rounds', ctypes.c_uint64),
         ('big_elems', ctypes.c_uint64),
         ('key_bits', ctypes.c_uint64),
+        ('fs_ms', ctypes.c_double * 9),
+        ('fs_launches', ctypes.c_uint64 * 9),
+        ('fs_elems', ctypes.c_uint64 * 9),
     ]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        for k in ('fs_ms', 'fs_launches', 'fs_elems'):
+            d[k] = list(d[k])
+        return d
 
 
 class SearchStats(ctypes.Structure):

@@ -29,6 +29,11 @@ struct SortStats {
     uint64_t pairs_launches = 0;
     uint64_t pairs_elems = 0;
     uint64_t small_launches = 0;   // single-workgroup LDS sorts (n <= 4096)
+    // flag-carrying passes of the initial suffix sort, fs_scatter_kernel<KIN, KOUT>:
+    // index = (KIN / 4) * 3 + KOUT / 4   (KIN 0 = keys packed from the text, KOUT 0 = last pass)
+    double fs_ms[9] = {};
+    uint64_t fs_launches[9] = {};
+    uint64_t fs_elems[9] = {};
 };
 
 // Workspace the sort needs besides the ping-pong buffers.
@@ -43,9 +48,16 @@ size_t radix_sort_workspace_bytes();
 // Stable.  `work` must hold radix_sort_workspace_bytes().
 int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint32_t n, int key_bits,
                      uint32_t pass_mask, const TextKeys *text, int src, void *work, int *dst,
-                     bool profile, SortStats *stats, bool ties_last = false);
-// ties_last: the last executed pass (which must not be the text pass) writes NO keys; bit 31 of
-// every output value is set iff the element's full key equals its predecessor's in the output
-// ("tied": not the head of its group).  Values must be < 2^31.
+                     bool profile, SortStats *stats);
+
+// Initial suffix sort: value(i) = i for all n suffixes, sorted (stably) by the low key_bits of
+// (packed text key >> text->drop).  Every pass stores only the digits it has not consumed yet
+// (8-byte key plane while more than 32 bits remain, then 4 bytes, none in the last pass) and
+// carries in bit 31 of each value whether the element's consumed digits equal its predecessor's;
+// after the last pass that bit says "full key equal to my predecessor's" (tied: not the head of
+// its group).  Needs key_bits > 8 (at least two passes).  Pass p writes buffer p & 1; *dst
+// receives the buffer index of the final values.
+int suffix_sort_flags(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint32_t n, int key_bits,
+                      const TextKeys *text, void *work, int *dst, bool profile, SortStats *stats);
 
 }  // namespace pss

@@ -43,7 +43,10 @@ constexpr int RS_BLOCK = PSS_RS_BLOCK;
 constexpr int RS_WAVES = RS_BLOCK / kWave;
 constexpr int RS_IPT = PSS_RS_IPT;
 constexpr int RS_TILE = RS_BLOCK * RS_IPT;   // 4096 pairs per tile
-constexpr u32 RS_MAX_RANGES = 1024;
+#ifndef PSS_RS_MAX_RANGES
+#define PSS_RS_MAX_RANGES 1024
+#endif
+constexpr u32 RS_MAX_RANGES = PSS_RS_MAX_RANGES;   // <= 1024 (one thread per range in the scan / fix kernels)
 
 struct PassArgs {
     const u64 *kin;
@@ -62,13 +65,15 @@ struct PassArgs {
     int shift;
     u32 *table;    // [256][num_ranges]
     u32 *totals;   // [256]
-    // final pass of the suffix sort (TIES variant): no keys are written; bit 31 of every value
-    // says "equal key as my predecessor in the output".  First / last key of each (range, digit)
-    // go to these tables so rs_fix_ties can settle the one element per (range, digit) whose
-    // predecessor lives in another range.
-    u64 *first_key;   // [num_ranges][256]
-    u64 *last_key;    // [num_ranges][256]
-    u32 *has;         // [num_ranges][256]
+    // flag-carrying passes of the initial suffix sort (fs_*): 4-byte key planes and the tables
+    // from which fs_fix settles the one element per (range, digit) whose predecessor lives in
+    // another range
+    const u32 *kin32;
+    u32 *kout32;
+    u32 *has;         // [num_ranges][256] the range holds the digit
+    u32 *first_z;     // [num_ranges][256] group number of its first / last element of the digit
+    u32 *last_z;
+    u32 *zeros;       // [num_ranges] group heads seen in the range
 };
 
 // Packs the keys of 16 consecutive suffixes i0 .. i0+15 (i0 % 16 == 0) from the
@@ -194,14 +199,9 @@ __global__ __launch_bounds__(256) void rs_scan_kernel(u32 *table, const u32 *tot
 
 // One tile of the scatter pass.  FULL = every slot of the tile holds an element
 // (all but the last tile of the input): the per-item bounds predicates fold away.
-// TIES (final pass of the suffix sort): equal full keys are neighbours in the digit-ordered
-// exchange buffer, so "same key as my predecessor" is decided right there (s_tk / s_tv carry
-// the last key of every digit from the previous tiles of the range); only values are written,
-// with that bit in bit 31.
-template <bool FROM_TEXT, bool FULL, int IPT, bool TIES>
+template <bool FROM_TEXT, bool FULL, int IPT>
 __device__ __forceinline__ void scatter_tile(const PassArgs &a, u32 base, u32 valid_count, u64 *exch,
-                                             u32 (*wave_hist)[256], u32 *s_off, u32 *s_delta, u32 *s_scr,
-                                             u32 g, u32 *s_dstart, u32 *s_cnt, u64 *s_tk, u32 *s_tv)
+                                             u32 (*wave_hist)[256], u32 *s_off, u32 *s_delta, u32 *s_scr)
 {
     const u32 tid = threadIdx.x;
     const u32 lane = tid & 63u, wave = tid >> 6;
@@ -275,10 +275,6 @@ __device__ __forceinline__ void scatter_tile(const PassArgs &a, u32 base, u32 va
             const u32 off = s_off[tid];
             s_delta[tid] = off - dstart;
             s_off[tid] = off + total;
-            if (TIES) {
-                s_dstart[tid] = dstart;
-                s_cnt[tid] = total;
-            }
         }
     }
     __syncthreads();
@@ -293,7 +289,6 @@ __device__ __forceinline__ void scatter_tile(const PassArgs &a, u32 base, u32 va
     }
     __syncthreads();
     u32 gpos[IPT];
-    u32 tied = 0;   // TIES: bit i = element i has the same key as its predecessor
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
         const u32 p = i * RS_BLOCK + tid;
@@ -302,31 +297,13 @@ __device__ __forceinline__ void scatter_tile(const PassArgs &a, u32 base, u32 va
             const u64 k = exch[p];
             const u32 d = (u32)(k >> a.shift) & 0xffu;
             gpos[i] = s_delta[d] + p;
-            if (TIES) {
-                const u32 ds = s_dstart[d];
-                bool t;
-                if (p > ds) {
-                    t = exch[p - 1] == k;
-                } else if (s_tv[d]) {
-                    t = s_tk[d] == k;                           // last key of this digit in an earlier tile
-                } else {
-                    t = false;                                  // first of its digit in the whole range:
-                    a.first_key[(size_t)g * 256 + d] = k;       // settled by rs_fix_ties
-                }
-                tied |= (t ? 1u : 0u) << i;
-            } else {
-                a.kout[gpos[i]] = k;
-            }
+#ifdef PSS_EXPERIMENT_SEQ_STORES
+            gpos[i] = base + p;      // timing experiment only (wrong output): same work, sequential stores
+#endif
+            a.kout[gpos[i]] = k;
         }
     }
     __syncthreads();
-    if (TIES) {
-        if (tid < 256 && s_cnt[tid]) {
-            s_tk[tid] = exch[s_dstart[tid] + s_cnt[tid] - 1];
-            s_tv[tid] = 1;
-        }
-        __syncthreads();
-    }
     u32 *exv = reinterpret_cast<u32 *>(exch);
     if (!FROM_TEXT) {
 #pragma unroll
@@ -340,7 +317,7 @@ __device__ __forceinline__ void scatter_tile(const PassArgs &a, u32 base, u32 va
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
         const u32 p = i * RS_BLOCK + tid;
-        if (FULL || p < valid_count) a.vout[gpos[i]] = TIES ? (exv[p] | (((tied >> i) & 1u) << 31)) : exv[p];
+        if (FULL || p < valid_count) a.vout[gpos[i]] = exv[p];
     }
     __syncthreads();
 }
@@ -350,7 +327,7 @@ __device__ __forceinline__ void scatter_tile(const PassArgs &a, u32 base, u32 va
 #endif
 constexpr int RS_PAIR_IPT = PSS_RS_PAIR_IPT;   // items per thread of the (key, value) scatter; divides RS_IPT
 
-template <bool FROM_TEXT, bool TIES = false>
+template <bool FROM_TEXT>
 __global__ __launch_bounds__(RS_BLOCK, PSS_RS_MINWAVES) void rs_scatter_kernel(PassArgs a)
 {
     constexpr int IPT = FROM_TEXT ? RS_IPT : RS_PAIR_IPT;
@@ -360,22 +337,14 @@ __global__ __launch_bounds__(RS_BLOCK, PSS_RS_MINWAVES) void rs_scatter_kernel(P
     __shared__ u32 s_off[256];     // running global offset of each digit for this range
     __shared__ u32 s_delta[256];   // s_off - (start of the digit inside the tile)
     __shared__ u32 s_scr[RS_WAVES + 1];
-    __shared__ u32 s_dstart[TIES ? 256 : 1], s_cnt[TIES ? 256 : 1], s_tv[TIES ? 256 : 1];
-    __shared__ u64 s_tk[TIES ? 256 : 1];
 
     const u32 tid = threadIdx.x;
     const u32 g = xcd_range_of_block(blockIdx.x, gridDim.x);
-    if (tid < 256) {
-        s_off[tid] = a.table[tid * a.num_ranges + g];
-        if (TIES) s_tv[tid] = 0;
-    }
+    if (tid < 256) s_off[tid] = a.table[tid * a.num_ranges + g];
 
     const u32 tile0 = g * a.tiles_per_range;
     const u32 tile1 = min(tile0 + a.tiles_per_range, a.num_tiles);
-    if (tile0 >= tile1) {
-        if (TIES && tid < 256) a.has[(size_t)g * 256 + tid] = 0;
-        return;
-    }
+    if (tile0 >= tile1) return;
     const u32 e0 = tile0 * (u32)RS_TILE;                       // n < 2^31: no overflow
     const u32 e1_full = tile1 * (u32)RS_TILE;
     const u32 e1 = e1_full < a.n ? e1_full : a.n;
@@ -383,35 +352,315 @@ __global__ __launch_bounds__(RS_BLOCK, PSS_RS_MINWAVES) void rs_scatter_kernel(P
         const u32 left = e1 - base;
         const u32 valid_count = left < SUB ? left : SUB;
         if (valid_count == SUB)
-            scatter_tile<FROM_TEXT, true, IPT, TIES>(a, base, valid_count, exch, wave_hist, s_off, s_delta, s_scr, g,
-                                                     s_dstart, s_cnt, s_tk, s_tv);
+            scatter_tile<FROM_TEXT, true, IPT>(a, base, valid_count, exch, wave_hist, s_off, s_delta, s_scr);
         else
-            scatter_tile<FROM_TEXT, false, IPT, TIES>(a, base, valid_count, exch, wave_hist, s_off, s_delta, s_scr, g,
-                                                      s_dstart, s_cnt, s_tk, s_tv);
-    }
-    if (TIES && tid < 256) {
-        a.has[(size_t)g * 256 + tid] = s_tv[tid];
-        if (s_tv[tid]) a.last_key[(size_t)g * 256 + tid] = s_tk[tid];
+            scatter_tile<FROM_TEXT, false, IPT>(a, base, valid_count, exch, wave_hist, s_off, s_delta, s_scr);
     }
 }
 
-// TIES epilogue: the first element of digit d in range g follows, in the output, the last
-// element of digit d of the nearest earlier range that had one.  One workgroup per digit, one
-// thread per range; the nearest earlier range comes from a workgroup max-scan.
-__global__ __launch_bounds__(1024) void rs_fix_ties_kernel(const u64 *first_key, const u64 *last_key, const u32 *has,
-                                                             const u32 *table, u32 num_ranges, u32 *vout)
+// =====================================================================================
+// Initial suffix sort: flag-carrying passes with shrinking keys (fs_*)
+//
+// An LSD pass never looks at a digit again once it has consumed it, but the suffix sort
+// must end with "is my full key equal to my predecessor's?" for every element.  Instead
+// of carrying the consumed digits along for that one comparison, every pass carries ONE
+// BIT per element (bit 31 of the value): t_p(x) = "the digits consumed so far, L_p(x),
+// equal those of my predecessor in the current order" (the order is sorted by L_p, so
+// equal L_p are neighbours).  With Z(x) = number of elements up to and including x whose
+// bit is clear (the dense rank of L_p(x)), two elements have L_p(x) == L_p(y) iff
+// Z(x) == Z(y).  The next pass moves x behind y = its predecessor inside its digit bucket,
+// and t_{p+1}(x) = [Z(x) == Z(y)].  Z is a prefix count in tile order: ballots inside the
+// tile, a running carry across the tiles of a range; the one element per (range, digit)
+// whose predecessor lives in another range is settled by an epilogue from per-range tables
+// (first / last Z per digit, heads per range).
+//
+// So a pass stores only the digits it has not consumed yet: the key plane is 8 bytes while
+// more than 32 bits remain, 4 bytes afterwards, and absent in the last pass.  `lines`
+// (40-bit key): 1 B -> 4+4 B, three passes of 4+4 -> 4+4 B (the last writes 0+4), instead
+// of 8+4 B in and out everywhere.
+// =====================================================================================
+
+// digit histogram of a 4-byte key plane (low 8 bits), 16 items per thread
+__global__ __launch_bounds__(RS_BLOCK) void fs_hist32_kernel(PassArgs a)
 {
-    __shared__ u32 s_wave[16];
+    __shared__ u32 h[256];
+    const u32 tid = threadIdx.x;
+    const u32 g = blockIdx.x;
+    if (tid < 256) h[tid] = 0;
+    __syncthreads();
+    const u32 tile0 = g * a.tiles_per_range;
+    const u32 tile1 = min(tile0 + a.tiles_per_range, a.num_tiles);
+    for (u32 tile = tile0; tile < tile1; ++tile) {
+        const u32 base = tile * RS_TILE;
+#pragma unroll
+        for (int r = 0; r < RS_IPT / 4; ++r) {
+            const u32 i = base + r * (4 * RS_BLOCK) + tid * 4;
+            u32 k[4] = {0, 0, 0, 0};
+            if (i + 3 < a.n) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(a.kin32 + i);
+                k[0] = q.x; k[1] = q.y; k[2] = q.z; k[3] = q.w;
+            } else {
+                for (int c = 0; c < 4; ++c)
+                    if (i + c < a.n) k[c] = a.kin32[i + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hist_add(h, k[c] & 0xffu, i + c < a.n);
+        }
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const u32 c = h[tid];
+        a.table[tid * a.num_ranges + g] = c;
+        if (c) atomicAdd(&a.totals[tid], c);
+    }
+}
+
+template <int BYTES> struct FsKey { using type = u64; };
+template <> struct FsKey<4> { using type = u32; };
+
+// One tile.  KIN = bytes of the incoming key plane (0: packed from the text), KOUT = bytes of
+// the outgoing one (0: none, last pass).  zcarry = group heads seen in the earlier tiles of
+// the range (uniform over the workgroup).
+template <int KIN, int KOUT, bool FULL>
+__device__ __forceinline__ void fs_tile(const PassArgs &a, u32 base, u32 valid_count,
+                                        typename FsKey<KIN == 4 ? 4 : 8>::type *exk, u32 *exz,
+                                        u32 (*wave_hist)[256], u32 *s_off, u32 *s_delta, u32 *s_scr, u32 g,
+                                        u32 *s_dstart, u32 *s_cnt, u32 *s_tz, u32 *s_tv, u32 *s_zwave, u32 &zcarry)
+{
+    constexpr bool FROM_TEXT = KIN == 0;
+    constexpr int IPT = RS_IPT;
+    using RK = typename FsKey<KIN == 4 ? 4 : 8>::type;
+    const u32 tid = threadIdx.x;
+    const u32 lane = tid & 63u, wave = tid >> 6;
+    RK key[IPT] = {};
+    u32 val[IPT];
+    u32 zin[IPT];      // group number of the element (before the carries are added)
+    u32 rank[IPT];
+    auto pos_of = [&](int r) -> u32 {
+        return FROM_TEXT ? tid * IPT + r : wave * (kWave * IPT) + r * kWave + lane;
+    };
+    auto is_valid = [&](int r) -> bool { return FULL || pos_of(r) < valid_count; };
+    u32 zwave_total = 0;
+    if (FROM_TEXT) {
+        const u32 i0 = base + tid * IPT;
+        if (FULL || i0 < a.n) {
+            u64 (&k16)[RS_IPT] = reinterpret_cast<u64 (&)[RS_IPT]>(key);
+            text_keys16(a.codes, i0, a.code_bits, a.key_chars, a.plus_one, a.key_drop, a.n, k16);
+        }
+#pragma unroll
+        for (int r = 0; r < IPT; ++r) {
+            val[r] = i0 + r;
+            zin[r] = 0;          // nothing consumed yet: every element belongs to group 0
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < IPT; ++r) {
+            const bool valid = is_valid(r);
+            const u32 at = base + pos_of(r);
+            if (KIN == 4) key[r] = valid ? (RK)a.kin32[at] : (RK)0;
+            else key[r] = valid ? (RK)a.kin[at] : (RK)0;
+            val[r] = valid ? a.vin[at] : 0x80000000u;
+        }
+        // Z in tile order (wave-major, then row, then lane)
+#pragma unroll
+        for (int r = 0; r < IPT; ++r) {
+            const bool head = !(val[r] >> 31);
+            const u64 m = __ballot(head);
+            zin[r] = zwave_total + mbcnt(m) + (head ? 1u : 0u);
+            zwave_total += (u32)__popcll(m);
+        }
+        if (lane == 0) s_zwave[wave] = zwave_total;
+    }
+    for (u32 i = tid; i < RS_WAVES * 256; i += RS_BLOCK) (&wave_hist[0][0])[i] = 0;
+    __syncthreads();
+
+    // ---- per-wave stable ranking (as rs scatter_tile) ----
+    u32 prev[IPT];
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+        const bool valid = is_valid(r);
+        const u32 d = (u32)key[r] & 0xffu;
+        const u64 peers = match_digit8(d, FULL ? ~0ull : __ballot(valid));
+        const u32 below = mbcnt(peers);
+        prev[r] = 0;
+        if (valid && below == 0) prev[r] = atomicAdd(&wave_hist[wave][d], (u32)__popcll(peers));
+        const u32 leader = valid ? (u32)__builtin_ctzll(peers) : lane;
+        rank[r] = below | (leader << 16);
+    }
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+        const u32 p = __shfl(prev[r], (int)(rank[r] >> 16));
+        rank[r] = p + (rank[r] & 0xffffu);
+    }
+    u32 zbase = zcarry, ztile = 0;
+    if (!FROM_TEXT) {
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) {
+            const u32 c = s_zwave[w];
+            if (w < (int)wave) zbase += c;
+            ztile += c;
+        }
+    }
+    __syncthreads();
+
+    // ---- workgroup prefix over digits (thread d < 256 owns digit d) ----
+    {
+        u32 c[RS_WAVES];
+        u32 total = 0;
+        if (tid < 256) {
+#pragma unroll
+            for (int w = 0; w < RS_WAVES; ++w) {
+                c[w] = wave_hist[w][tid];
+                total += c[w];
+            }
+        }
+        const u32 dstart = block_excl_sum<RS_WAVES>(total, s_scr, nullptr);
+        if (tid < 256) {
+            u32 run = dstart;
+#pragma unroll
+            for (int w = 0; w < RS_WAVES; ++w) {
+                wave_hist[w][tid] = run;
+                run += c[w];
+            }
+            const u32 off = s_off[tid];
+            s_delta[tid] = off - dstart;
+            s_off[tid] = off + total;
+            s_dstart[tid] = dstart;
+            s_cnt[tid] = total;
+        }
+    }
+    __syncthreads();
+
+    // ---- keys (and group numbers) through LDS in digit order ----
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+        const u32 d = (u32)key[r] & 0xffu;
+        const u32 lp = wave_hist[wave][d] + rank[r];
+        rank[r] = lp;
+        if (is_valid(r)) {
+            exk[lp] = key[r];
+            if (!FROM_TEXT) exz[lp] = zbase + zin[r];
+        }
+    }
+    __syncthreads();
+    u32 gpos[IPT];
+    u32 tied = 0;   // bit i = element i continues the group of its predecessor in the output
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        const u32 p = i * RS_BLOCK + tid;
+        gpos[i] = 0;
+        if (FULL || p < valid_count) {
+            const RK k = exk[p];
+            const u32 d = (u32)k & 0xffu;
+            const u32 z = FROM_TEXT ? 0u : exz[p];
+            gpos[i] = s_delta[d] + p;
+            const u32 ds = s_dstart[d];
+            bool t;
+            if (p > ds) {
+                t = FROM_TEXT ? true : exz[p - 1] == z;
+            } else if (s_tv[d]) {
+                t = s_tz[d] == z;                              // last of this digit in an earlier tile
+            } else {
+                t = false;                                     // first of its digit in the whole range:
+                a.first_z[(size_t)g * 256 + d] = z;            // settled by fs_fix
+            }
+            tied |= (t ? 1u : 0u) << i;
+            if (KOUT == 8) a.kout[gpos[i]] = (u64)(k >> 8);
+            if (KOUT == 4) a.kout32[gpos[i]] = (u32)(k >> 8);
+        }
+    }
+    __syncthreads();
+    if (tid < 256 && s_cnt[tid]) {
+        s_tz[tid] = FROM_TEXT ? 0u : exz[s_dstart[tid] + s_cnt[tid] - 1];
+        s_tv[tid] = 1;
+    }
+    __syncthreads();
+    u32 *exv = reinterpret_cast<u32 *>(exk);
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+        if (is_valid(r)) exv[rank[r]] = val[r] & 0x7fffffffu;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        const u32 p = i * RS_BLOCK + tid;
+        if (FULL || p < valid_count) a.vout[gpos[i]] = exv[p] | (((tied >> i) & 1u) << 31);
+    }
+    zcarry += ztile;
+    __syncthreads();
+}
+
+template <int KIN, int KOUT>
+__global__ __launch_bounds__(RS_BLOCK, PSS_RS_MINWAVES) void fs_scatter_kernel(PassArgs a)
+{
+    using RK = typename FsKey<KIN == 4 ? 4 : 8>::type;
+    __shared__ __attribute__((aligned(16))) RK exk[RS_TILE];           // reused for values
+    __shared__ u32 exz[KIN == 0 ? 1 : RS_TILE];
+    __shared__ u32 wave_hist[RS_WAVES][256];
+    __shared__ u32 s_off[256], s_delta[256], s_dstart[256], s_cnt[256], s_tz[256], s_tv[256];
+    __shared__ u32 s_scr[RS_WAVES + 1], s_zwave[RS_WAVES];
+
+    const u32 tid = threadIdx.x;
+    const u32 g = xcd_range_of_block(blockIdx.x, gridDim.x);
+    if (tid < 256) {
+        s_off[tid] = a.table[tid * a.num_ranges + g];
+        s_tv[tid] = 0;
+    }
+    const u32 tile0 = g * a.tiles_per_range;
+    const u32 tile1 = min(tile0 + a.tiles_per_range, a.num_tiles);
+    if (tile0 >= tile1) {
+        if (tid < 256) a.has[(size_t)g * 256 + tid] = 0;
+        if (tid == 0) a.zeros[g] = 0;
+        return;
+    }
+    const u32 e0 = tile0 * (u32)RS_TILE;
+    const u32 e1_full = tile1 * (u32)RS_TILE;
+    const u32 e1 = e1_full < a.n ? e1_full : a.n;
+    u32 zcarry = 0;
+    for (u32 base = e0; base < e1; base += RS_TILE) {
+        const u32 left = e1 - base;
+        const u32 valid_count = left < (u32)RS_TILE ? left : (u32)RS_TILE;
+        if (valid_count == (u32)RS_TILE)
+            fs_tile<KIN, KOUT, true>(a, base, valid_count, exk, exz, wave_hist, s_off, s_delta, s_scr, g, s_dstart, s_cnt,
+                                     s_tz, s_tv, s_zwave, zcarry);
+        else
+            fs_tile<KIN, KOUT, false>(a, base, valid_count, exk, exz, wave_hist, s_off, s_delta, s_scr, g, s_dstart, s_cnt,
+                                      s_tz, s_tv, s_zwave, zcarry);
+    }
+    if (tid < 256) {
+        a.has[(size_t)g * 256 + tid] = s_tv[tid];
+        if (s_tv[tid]) a.last_z[(size_t)g * 256 + tid] = s_tz[tid];
+    }
+    if (tid == 0) a.zeros[g] = zcarry;
+}
+
+// Epilogue: the first element of digit d in range g follows, in the output, the last element of
+// digit d of the nearest earlier range that had one; their group numbers are range-local, so the
+// heads of the ranges in between are added (exclusive scan of zeros[]).  One workgroup per digit,
+// one thread per range.
+__global__ __launch_bounds__(1024) void fs_fix_kernel(const u32 *first_z, const u32 *last_z, const u32 *has,
+                                                        const u32 *zeros, const u32 *table, u32 num_ranges, u32 *vout)
+{
+    __shared__ u32 s_wave[16], s_zw[16];
+    __shared__ u32 s_base[1024];
     const u32 d = blockIdx.x, g = threadIdx.x, lane = g & 63u, wave = g >> 6;
     const bool mine = g < num_ranges && has[(size_t)g * 256 + d] != 0;
     const u32 incl = wave_incl_max(mine ? g + 1 : 0u);        // 1 + last range with digit d, up to and including g
-    if (lane == 63) s_wave[wave] = incl;
+    const u32 zc = g < num_ranges ? zeros[g] : 0u;
+    const u32 zincl = wave_incl_sum(zc);
+    if (lane == 63) { s_wave[wave] = incl; s_zw[wave] = zincl; }
     __syncthreads();
     u32 prev1 = __shfl_up(incl, 1);
     if (lane == 0) prev1 = 0;
-    for (u32 w = 0; w < wave; ++w) prev1 = max(prev1, s_wave[w]);
-    if (mine && prev1 && last_key[(size_t)(prev1 - 1) * 256 + d] == first_key[(size_t)g * 256 + d])
-        vout[table[d * num_ranges + g]] |= 0x80000000u;
+    u32 zb = zincl - zc;
+    for (u32 w = 0; w < wave; ++w) { prev1 = max(prev1, s_wave[w]); zb += s_zw[w]; }
+    s_base[g] = zb;                                            // heads in the ranges before g
+    __syncthreads();
+    if (mine && prev1) {
+        const u32 gp = prev1 - 1;
+        if (last_z[(size_t)gp * 256 + d] + s_base[gp] == first_z[(size_t)g * 256 + d] + zb)
+            vout[table[d * num_ranges + g]] |= 0x80000000u;
+    }
 }
 
 // Tiny inputs (<= one tile): one workgroup, bitonic network in LDS over the
@@ -456,13 +705,13 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_small_sort_kernel(u64 *keys, u32 
 
 size_t radix_sort_workspace_bytes()
 {
-    // digit table + 16 totals rows + (first key, last key, has) tables of the TIES pass
-    return (size_t)256 * RS_MAX_RANGES * 4 + 256 * 4 * 16 + (size_t)256 * RS_MAX_RANGES * (8 + 8 + 4);
+    // digit table + 16 totals rows + the (has, first_z, last_z) tables and zeros[] of the fs passes
+    return (size_t)256 * RS_MAX_RANGES * 4 + 256 * 4 * 16 + (size_t)256 * RS_MAX_RANGES * 12 + RS_MAX_RANGES * 4;
 }
 
 int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint32_t n, int key_bits,
                      uint32_t pass_mask, const TextKeys *text, int src, void *work, int *dst,
-                     bool profile, SortStats *stats, bool ties_last)
+                     bool profile, SortStats *stats)
 {
     const int passes = (key_bits + 7) / 8;
     int cur = src;
@@ -485,16 +734,10 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
 
     u32 *table = static_cast<u32 *>(work);
     u32 *totals_base = table + (size_t)256 * RS_MAX_RANGES;
-    u64 *first_key = reinterpret_cast<u64 *>(totals_base + 256 * 16);
-    u64 *last_key = first_key + (size_t)256 * RS_MAX_RANGES;
-    u32 *has = reinterpret_cast<u32 *>(last_key + (size_t)256 * RS_MAX_RANGES);
-    int last_pass = -1;
-    for (int p = 0; p < passes; ++p)
-        if ((pass_mask >> p) & 1u) last_pass = p;
     PSS_HIP(hipMemsetAsync(totals_base, 0, 256 * 4 * 16, ctx->stream));
 
     hipEvent_t ev[2 * 16];
-    int ev_kind[16];   // 0 = text pass, 1 = (key, value) pass, 2 = final TIES pass
+    int ev_kind[16];   // 0 = text pass, 1 = (key, value) pass
     int nev = 0, nev_created = 0;
     if (profile) {   // created up front: a hipEventCreate between launch and record would idle the GPU
         for (; nev_created < 32; ++nev_created) PSS_HIP(hipEventCreate(&ev[nev_created]));
@@ -509,10 +752,6 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
         a.num_ranges = num_ranges;
         a.shift = p * 8;
         a.table = table;
-        a.first_key = first_key;
-        a.last_key = last_key;
-        a.has = has;
-        const bool ties = ties_last && p == last_pass && !from_text;
         a.totals = totals_base + (size_t)256 * (executed & 15);
         if (executed >= 16) PSS_HIP(hipMemsetAsync(a.totals, 0, 256 * 4, ctx->stream));
         int out;
@@ -538,15 +777,11 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
         else hipLaunchKernelGGL(rs_hist_kernel<false>, dim3(num_ranges), dim3(RS_BLOCK), 0, ctx->stream, a);
         hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(256), 0, ctx->stream, a.table, a.totals, num_ranges);
         if (profile && nev < 32) {
-            ev_kind[nev / 2] = from_text ? 0 : (ties ? 2 : 1);
+            ev_kind[nev / 2] = from_text ? 0 : 1;
             PSS_HIP(hipEventRecord(ev[nev++], ctx->stream));
         }
         if (from_text) hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(num_ranges), dim3(RS_BLOCK), 0, ctx->stream, a);
-        else if (ties) {
-            hipLaunchKernelGGL((rs_scatter_kernel<false, true>), dim3(num_ranges), dim3(RS_BLOCK), 0, ctx->stream, a);
-            hipLaunchKernelGGL(rs_fix_ties_kernel, dim3(256), dim3(1024), 0, ctx->stream, first_key, last_key, has, table,
-                               num_ranges, a.vout);
-        } else hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(num_ranges), dim3(RS_BLOCK), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(num_ranges), dim3(RS_BLOCK), 0, ctx->stream, a);
         if (profile && nev < 32) PSS_HIP(hipEventRecord(ev[nev++], ctx->stream));
         PSS_HIP(hipGetLastError());
         cur = out;
@@ -574,6 +809,114 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
         set_error("radix_sort_pairs: text source needs at least one pass");
         return PSS_EINVAL;
     }
+    *dst = cur;
+    return PSS_OK;
+}
+
+
+int suffix_sort_flags(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint32_t n, int key_bits,
+                      const TextKeys *text, void *work, int *dst, bool profile, SortStats *stats)
+{
+    const int passes = (key_bits + 7) / 8;
+    if (passes < 2 || text == nullptr || n == 0) {
+        set_error("suffix_sort_flags: needs a text source, n > 0 and more than 8 key bits");
+        return PSS_EINVAL;
+    }
+    const u32 num_tiles = (u32)(((u64)n + RS_TILE - 1) / RS_TILE);
+    const u32 tpr = (num_tiles + RS_MAX_RANGES - 1) / RS_MAX_RANGES;
+    u32 num_ranges = (num_tiles + tpr - 1) / tpr;
+    num_ranges = (num_ranges + 7u) & ~7u;
+
+    u32 *table = static_cast<u32 *>(work);
+    u32 *totals_base = table + (size_t)256 * RS_MAX_RANGES;
+    u32 *first_z = totals_base + 256 * 16;
+    u32 *last_z = first_z + (size_t)256 * RS_MAX_RANGES;
+    u32 *has = last_z + (size_t)256 * RS_MAX_RANGES;
+    u32 *zeros = has + (size_t)256 * RS_MAX_RANGES;
+    PSS_HIP(hipMemsetAsync(totals_base, 0, 256 * 4 * 16, ctx->stream));
+
+    hipEvent_t ev[2 * 16];
+    int ev_idx[16];
+    int nev = 0, nev_created = 0;
+    if (profile) {
+        for (; nev_created < 2 * passes && nev_created < 32; ++nev_created) PSS_HIP(hipEventCreate(&ev[nev_created]));
+    }
+    int cur = 0, kin = 0;
+    for (int p = 0; p < passes; ++p) {
+        const int rem = key_bits - 8 * (p + 1);
+        const int kout = rem <= 0 ? 0 : (rem <= 32 ? 4 : 8);
+        const int out = (p == 0) ? 0 : cur ^ 1;
+        PassArgs a;
+        memset(&a, 0, sizeof a);
+        a.n = n;
+        a.num_tiles = num_tiles;
+        a.tiles_per_range = tpr;
+        a.num_ranges = num_ranges;
+        a.shift = 0;
+        a.table = table;
+        a.totals = totals_base + 256 * p;
+        a.first_z = first_z;
+        a.last_z = last_z;
+        a.has = has;
+        a.zeros = zeros;
+        if (p == 0) {
+            a.codes = text->codes;
+            a.code_bits = text->code_bits;
+            a.key_chars = text->key_chars;
+            a.plus_one = text->plus_one;
+            a.key_drop = text->drop;
+        } else {
+            a.kin = keys[cur];
+            a.kin32 = reinterpret_cast<const u32 *>(keys[cur]);
+            a.vin = vals[cur];
+        }
+        a.kout = keys[out];
+        a.kout32 = reinterpret_cast<u32 *>(keys[out]);
+        a.vout = vals[out];
+        const dim3 grid(num_ranges), block(RS_BLOCK);
+        if (p == 0) hipLaunchKernelGGL(rs_hist_kernel<true>, grid, block, 0, ctx->stream, a);
+        else if (kin == 8) hipLaunchKernelGGL(rs_hist_kernel<false>, grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL(fs_hist32_kernel, grid, block, 0, ctx->stream, a);
+        hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(256), 0, ctx->stream, a.table, a.totals, num_ranges);
+        if (profile && nev + 1 < nev_created) {
+            ev_idx[nev / 2] = (kin / 4) * 3 + kout / 4;
+            PSS_HIP(hipEventRecord(ev[nev++], ctx->stream));
+        }
+        if (kin == 0 && kout == 8) hipLaunchKernelGGL((fs_scatter_kernel<0, 8>), grid, block, 0, ctx->stream, a);
+        else if (kin == 0 && kout == 4) hipLaunchKernelGGL((fs_scatter_kernel<0, 4>), grid, block, 0, ctx->stream, a);
+        else if (kin == 8 && kout == 8) hipLaunchKernelGGL((fs_scatter_kernel<8, 8>), grid, block, 0, ctx->stream, a);
+        else if (kin == 8 && kout == 4) hipLaunchKernelGGL((fs_scatter_kernel<8, 4>), grid, block, 0, ctx->stream, a);
+        else if (kin == 4 && kout == 4) hipLaunchKernelGGL((fs_scatter_kernel<4, 4>), grid, block, 0, ctx->stream, a);
+        else if (kin == 4 && kout == 0) hipLaunchKernelGGL((fs_scatter_kernel<4, 0>), grid, block, 0, ctx->stream, a);
+        else {
+            set_error("suffix_sort_flags: no kernel for key planes %d -> %d", kin, kout);
+            return PSS_EINVAL;
+        }
+        if (profile && (nev & 1)) PSS_HIP(hipEventRecord(ev[nev++], ctx->stream));
+        hipLaunchKernelGGL(fs_fix_kernel, dim3(256), dim3(1024), 0, ctx->stream, first_z, last_z, has, zeros, table,
+                           num_ranges, a.vout);
+        PSS_HIP(hipGetLastError());
+        cur = out;
+        kin = kout;
+        if (stats) {
+            stats->launches += 1;
+            stats->elems += n;
+        }
+    }
+    if (nev) {
+        PSS_HIP(hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i + 1 < nev; i += 2) {
+            float ms = 0.f;
+            PSS_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            if (stats) {
+                stats->ms += ms;
+                stats->fs_ms[ev_idx[i / 2]] += ms;
+                stats->fs_launches[ev_idx[i / 2]] += 1;
+                stats->fs_elems[ev_idx[i / 2]] += n;
+            }
+        }
+    }
+    for (int i = 0; i < nev_created; ++i) (void)hipEventDestroy(ev[i]);
     *dst = cur;
     return PSS_OK;
 }

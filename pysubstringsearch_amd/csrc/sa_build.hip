@@ -1089,11 +1089,12 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     u32 *const v_scratch = V[final_buf];
     V[final_buf] = SA;
     int cur = 0;
-    // With >= 2 passes the last one also settles the groups: it writes no keys, only the suffix
-    // indices with bit 31 = "tied with my predecessor" (radix_sort.hip, TIES) -- 8 B/suffix less
-    // to write, and the rerank reads 4-byte flagged values instead of comparing 8-byte keys.
+    // With >= 2 passes the sort carries tie flags instead of consumed digits (radix_sort.hip, fs_*):
+    // the last pass writes only the suffix indices with bit 31 = "tied with my predecessor", and
+    // the rerank reads 4-byte flagged values instead of comparing 8-byte keys.
     const bool ties = passes0 >= 2 && !getenv("PSS_NO_TIES_PASS");
-    PSS_TRY(radix_sort_pairs(ctx, K, V, n, key_bits0, 0xffffffffu, &tk, 0, work, &cur, profile, &ss, ties));
+    if (ties) PSS_TRY(suffix_sort_flags(ctx, K, V, n, key_bits0, &tk, work, &cur, profile, &ss));
+    else PSS_TRY(radix_sort_pairs(ctx, K, V, n, key_bits0, 0xffffffffu, &tk, 0, work, &cur, profile, &ss));
     st.initial_passes = (u32)ss.launches;
     const bool sa_in_place = (cur == final_buf);
 
@@ -1382,6 +1383,11 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     st.pairs_elems = ss.pairs_elems;
     st.ms_text = ss.ms_text;
     st.text_launches = ss.text_launches;
+    for (int i = 0; i < 9; ++i) {
+        st.fs_ms[i] = ss.fs_ms[i];
+        st.fs_launches[i] = ss.fs_launches[i];
+        st.fs_elems[i] = ss.fs_elems[i];
+    }
     st.mode = was_text ? (mode == M_TEXT ? 2u : 3u) : (u64)mode;
     if (stats) *stats = st;
     return PSS_OK;
