@@ -21,8 +21,14 @@
 // on dispatch order or XCD placement; the range->workgroup map is XCD-aware
 // only for L2 write-combining (prims.h: xcd_range_of_block).
 //
-// The first pass of the suffix sort never materialises keys: it packs them on
-// the fly from the recoded text (TextKeys), 1 B/elem read instead of 12.
+// A sort whose source is the text never materialises its keys: the first pass
+// packs them on the fly from the recoded text (TextKeys), 1 B/elem read instead
+// of 12.
+//
+// The initial sort of ALL suffixes has its own scatter family further down
+// (fs_scatter_kernel<KIN, KOUT>, suffix_sort_flags): same tiling and ranking, but
+// every pass drops the digit it consumed and carries a tie bit instead, so the
+// key plane shrinks from 8 to 4 to 0 bytes per element.
 //
 // HBM-bound integer work: no MFMA anywhere by design.
 #include "prims.h"
