@@ -421,6 +421,50 @@ __global__ __launch_bounds__(RS_BLOCK) void fs_hist32_kernel(PassArgs a)
     }
 }
 
+// digit histogram of the text pass: only the symbols that reach into bits [drop, drop + 8) of the
+// packed key are assembled (a 32-bit sliding window instead of the full 64-bit key of text_keys16)
+__global__ __launch_bounds__(RS_BLOCK) void fs_hist_text_kernel(PassArgs a)
+{
+    __shared__ u32 h[256];
+    const u32 tid = threadIdx.x;
+    const u32 g = blockIdx.x;
+    if (tid < 256) h[tid] = 0;
+    __syncthreads();
+    const int b = a.code_bits, k = a.key_chars;
+    int nch = (a.key_drop + 8 + b - 1) / b;          // symbols covering the digit (<= 26 bits of window)
+    if (nch > k) nch = k;
+    const u32 off = (u32)(k - nch);                  // first of them, relative to the suffix start
+    const u32 wmask = (nch * b >= 32) ? ~0u : ((1u << (nch * b)) - 1u);
+    const u32 tile0 = g * a.tiles_per_range;
+    const u32 tile1 = min(tile0 + a.tiles_per_range, a.num_tiles);
+    for (u32 tile = tile0; tile < tile1; ++tile) {
+        const u32 i0 = tile * RS_TILE + tid * RS_IPT;
+        if (i0 >= a.n) continue;
+        const uint4 *p = reinterpret_cast<const uint4 *>(a.codes + i0);
+        const uint4 lo = p[0], hi = p[1];
+        const u64 q[4] = {(u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
+                          (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32)};
+        auto sym = [&](u32 j) -> u32 {               // symbol at text position i0 + j, j < 32
+            u32 c = (u32)(q[j >> 3] >> ((j & 7u) * 8u)) & 0xffu;
+            if (a.plus_one) c = ((u64)i0 + j < a.n) ? c + 1u : 0u;
+            return c;
+        };
+        u32 win = 0;
+        for (int t = 0; t < nch; ++t) win = (win << b) | sym(off + (u32)t);
+#pragma unroll
+        for (int r = 0; r < RS_IPT; ++r) {
+            if (r > 0) win = ((win << b) | sym(off + (u32)nch - 1u + (u32)r)) & wmask;
+            hist_add(h, (win >> a.key_drop) & 0xffu, i0 + r < a.n);
+        }
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const u32 c = h[tid];
+        a.table[tid * a.num_ranges + g] = c;
+        if (c) atomicAdd(&a.totals[tid], c);
+    }
+}
+
 template <int BYTES> struct FsKey { using type = u64; };
 template <> struct FsKey<4> { using type = u32; };
 
@@ -880,7 +924,7 @@ int suffix_sort_flags(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint
         a.kout32 = reinterpret_cast<u32 *>(keys[out]);
         a.vout = vals[out];
         const dim3 grid(num_ranges), block(RS_BLOCK);
-        if (p == 0) hipLaunchKernelGGL(rs_hist_kernel<true>, grid, block, 0, ctx->stream, a);
+        if (p == 0) hipLaunchKernelGGL(fs_hist_text_kernel, grid, block, 0, ctx->stream, a);
         else if (kin == 8) hipLaunchKernelGGL(rs_hist_kernel<false>, grid, block, 0, ctx->stream, a);
         else hipLaunchKernelGGL(fs_hist32_kernel, grid, block, 0, ctx->stream, a);
         hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(256), 0, ctx->stream, a.table, a.totals, num_ranges);
