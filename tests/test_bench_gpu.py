@@ -1,0 +1,62 @@
+"""bench.py contract on a GPU box: the JSON line of a small single-GPU run, and the N > 1 code
+path (sharding by rank, result gather, max-over-ranks timing) with two processes.  A 1-GPU box
+cannot host two RCCL ranks, so the two-process run uses bench.py's test hook
+PSS_BENCH_BACKEND=gloo: both ranks share GPU 0 and torch.distributed runs over gloo."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+REQUIRED = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+            'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline')
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_contract():
+    r = subprocess.run([sys.executable, 'bench.py', '--steps', '2', '--warmup', '1', '--logn', '22', '--queries', '500',
+                        '--cpu-sample-logn', '20'], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'weak'
+    assert d['unit'] == 'GB/s' and d['value'] > 0 and d['higher_is_better'] is True and d['vs_baseline'] is None
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    roof = d['roofline']
+    assert roof['bound'] == 'hbm' and roof['unit'] == 'GB/s' and roof['peak'] == 8000.0
+    assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
+    cpu = d['cpu_baseline']
+    assert cpu['cores'] == 1 and cpu['kind'] in ('reference', 'port') and cpu['value'] > 0 and cpu['sample']
+    assert d['entries_per_batch'] == d['search_stats']['entries']
+
+
+def test_bench_two_ranks_gloo_hook():
+    env = dict(os.environ, PSS_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--logn', '22',
+           '--queries', '500']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0
+    assert d['cpu_baseline'] is None and d['secondary'] is None     # rank 0, N = 1 only
+    # rank 1 holds a different chunk (seed + 1): the sampled half of the queries comes from rank
+    # 0's text, so the gathered batch has at least those hits
+    assert d['entries_per_batch'] >= 250
