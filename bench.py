@@ -159,11 +159,13 @@ def main():
         # Writer -> Reader hand-off through HBM (no file): the fresh text + SA replace the resident chunk
         _ffi.check(lib.pss_reader_set_chunk_device(h, 0, dT.data_ptr(), dSA.data_ptr(), n))
         t2 = time.perf_counter()
-        entries, counts = reader.search_batch_raw(queries)
         if world > 1:
-            merged = pdist.gather_results(entries, counts, dst=0)
-            if merged is not None:
-                entries = merged[0]
+            # packed local result -> gather to rank 0 -> one Python list there
+            pk = reader.search_batch_packed(queries)
+            merged = pdist.gather_packed(pk.data, np.diff(pk.offsets.astype(np.int64)), pk.counts, dst=0)
+            entries = merged[0] if merged is not None else []
+        else:
+            entries, counts = reader.search_batch_raw(queries)
         t3 = time.perf_counter()
         last['entries'] = len(entries)
         last['search_stats'] = reader.last_stats()

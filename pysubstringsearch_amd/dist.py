@@ -49,16 +49,21 @@ def merge_query_major(per_rank: typing.Sequence[typing.Tuple[np.ndarray, np.ndar
     return out, total
 
 
-def gather_results(entries: typing.Sequence[bytes], counts: typing.Sequence[int], group=None, dst: int = 0):
-    """Collective: every rank passes its local (entries, per-query counts);
-    rank ``dst`` gets (all entries query-major, total counts), others None."""
+def gather_packed(blob, lens, counts, group=None, dst: int = 0):
+    """Collective on packed local results: ``blob`` = this rank's entries back to
+    back (uint8), ``lens`` their lengths, ``counts`` the per-query entry counts,
+    all query-major.  Rank ``dst`` gets (all entries query-major, total counts),
+    the others None.  On the nccl (= RCCL) backend the three payloads travel as
+    device tensors; sizes are exchanged first so they can be padded to a common
+    shape."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
-    blob, lens = pack_entries(entries)
-    cnt = np.asarray(counts, dtype=np.int64)
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    lens = np.ascontiguousarray(lens, dtype=np.int64)
+    cnt = np.ascontiguousarray(counts, dtype=np.int64)
     sizes = torch.tensor([len(lens), len(blob)], dtype=torch.int64, device=dev)
     all_sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(all_sizes, sizes, group=group)
@@ -68,10 +73,10 @@ def gather_results(entries: typing.Sequence[bytes], counts: typing.Sequence[int]
     def padded(a, n, dtype):
         t = torch.zeros(max(n, 1), dtype=dtype)
         if len(a):
-            t[:len(a)] = torch.from_numpy(np.ascontiguousarray(a))
+            t[:len(a)] = torch.from_numpy(a.copy() if not a.flags.writeable else a)
         return t.to(dev)
 
-    t_cnt = torch.from_numpy(cnt).to(dev) if len(cnt) else torch.zeros(1, dtype=torch.int64, device=dev)
+    t_cnt = padded(cnt, len(cnt), torch.int64)
     t_len = padded(lens, max_e, torch.int64)
     t_blob = padded(blob, max_b, torch.uint8)
     # all_gather (not gather): supported by every backend/version; the payload is
@@ -92,6 +97,12 @@ def gather_results(entries: typing.Sequence[bytes], counts: typing.Sequence[int]
     return merge_query_major(per_rank)
 
 
+def gather_results(entries: typing.Sequence[bytes], counts: typing.Sequence[int], group=None, dst: int = 0):
+    """``gather_packed`` for a local result given as a list of entries."""
+    blob, lens = pack_entries(entries)
+    return gather_packed(blob, lens, counts, group, dst)
+
+
 class ShardedReader:
     """Reader over the chunks owned by this rank; ``search_multiple`` is a
     collective returning the full result on rank ``dst`` (None elsewhere)."""
@@ -107,7 +118,12 @@ class ShardedReader:
         self.local = reader
 
     def search_multiple_bytes(self, patterns: typing.Sequence[bytes], dst: int = 0):
-        entries, counts = self.local.search_batch_raw(list(patterns))
+        local = self.local
+        if hasattr(local, 'search_batch_packed'):
+            # no per-entry Python objects on the ranks that only contribute
+            pk = local.search_batch_packed(list(patterns))
+            return gather_packed(pk.data, np.diff(pk.offsets.astype(np.int64)), pk.counts, self.group, dst)
+        entries, counts = local.search_batch_raw(list(patterns))
         return gather_results(entries, counts, self.group, dst)
 
     def search_multiple(self, substrings: typing.List[str], dst: int = 0):
