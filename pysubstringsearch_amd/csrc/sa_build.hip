@@ -955,6 +955,79 @@ static int choose_key_chars(const u32 *counts, u32 n, int b, int kmax)
     return k;
 }
 
+// Environment switches of the builder (exploration and tests; read on every call so a test can
+// flip them between builds).  None of them changes the result.
+struct Knobs {
+    int key_chars = 0;          // PSS_KEY_CHARS  force the symbols packed into the initial key (0 = choose)
+    int key_drop = -1;          // PSS_KEY_DROP   force the low bits of the last symbol left out (-1 = choose)
+    bool no_sample = false;     // PSS_NO_SAMPLE  size the initial key from symbol counts even for large n
+    bool no_flags = false;      // PSS_NO_TIES_PASS  plain 8-byte-key passes + key comparison in the rerank
+    int mode = -1;              // PSS_MODE       dense / sparse / text tie resolution (-1 = choose)
+    int text_rounds_max = 5;    // PSS_TEXT_ROUNDS
+    bool timing = false;        // PSS_TIMING     per-round trace on stderr
+    static Knobs read()
+    {
+        Knobs k;
+        if (const char *e = getenv("PSS_KEY_CHARS")) k.key_chars = atoi(e);
+        if (const char *e = getenv("PSS_KEY_DROP")) k.key_drop = atoi(e);
+        k.no_sample = getenv("PSS_NO_SAMPLE") != nullptr;
+        k.no_flags = getenv("PSS_NO_TIES_PASS") != nullptr;
+        if (const char *e = getenv("PSS_MODE")) {
+            if (!strcmp(e, "dense")) k.mode = 0;
+            else if (!strcmp(e, "sparse")) k.mode = 1;
+            else if (!strcmp(e, "text")) k.mode = 2;
+        }
+        if (const char *e = getenv("PSS_TEXT_ROUNDS")) k.text_rounds_max = atoi(e);
+        k.timing = getenv("PSS_TIMING") != nullptr;
+        return k;
+    }
+};
+
+// start / stop events of one build, destroyed on every exit path
+struct BuildTimer {
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    ~BuildTimer()
+    {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    }
+};
+
+// Sizing of the initial sort from a sorted sample (see sample_keys_kernel): the fewest passes
+// that leave <= 2 % of the suffixes tied, else the full kmax symbols.  K / V are free scratch.
+static int size_initial_key(DeviceCtx *ctx, const u8 *codes, u32 n, int b, int kmax, int plus_one, u64 *K[2], u32 *V[2],
+                            void *work, u32 *d_tied, u32 *h_small, bool profile, SortStats *ss, int *key_chars,
+                            int *key_drop)
+{
+    hipStream_t s = ctx->stream;
+    const u32 S = 1u << 21;
+    const int bits_max = kmax * b, pmax = (bits_max + 7) / 8;
+    PSS_HIP(hipMemsetAsync(d_tied, 0, 32, s));
+    hipLaunchKernelGGL(sample_keys_kernel, dim3(S / 256), dim3(256), 0, s, codes, n, S, b, kmax, plus_one, K[0], V[0]);
+    u32 mask = 0;
+    for (int p = 0; p < 8; ++p)
+        if (8 * (p + 1) > 64 - 8 * (pmax - 1)) mask |= 1u << p;   // only the top 8 (pmax - 1) bits are ever compared
+    int sd = 0;
+    const u64 launches = ss->launches, elems = ss->elems;
+    PSS_TRY(radix_sort_pairs(ctx, K, V, S, 64, mask, nullptr, 0, work, &sd, profile, ss));
+    ss->launches = launches;   // not passes of the suffix sort (their profile figures stay in: same kernel, same stream)
+    ss->elems = elems;
+    hipLaunchKernelGGL(sample_ties_kernel, dim3(256), dim3(256), 0, s, K[sd], S, d_tied);
+    PSS_HIP(hipMemcpyAsync(h_small, d_tied, 32, hipMemcpyDeviceToHost, s));
+    PSS_HIP(hipStreamSynchronize(s));
+    *key_chars = kmax;
+    *key_drop = 0;
+    for (int p = 2; p < pmax; ++p) {
+        const double est = (double)h_small[p - 1] / S * ((double)n / S);
+        if (est <= 0.02) {
+            *key_chars = (8 * p + b - 1) / b;
+            *key_drop = *key_chars * b - 8 * p;
+            break;
+        }
+    }
+    return PSS_OK;
+}
+
 int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, uint32_t flags, pss_sa_stats *stats)
 {
     pss_sa_stats st;
@@ -965,6 +1038,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     }
     const u32 n = (u32)n_in;
     const bool profile = flags & 1u;
+    const Knobs knobs = Knobs::read();
     hipStream_t s = ctx->stream;
     if (n < 2) {
         if (n == 1) PSS_HIP(hipMemsetAsync(d_SA, 0, 4, s));
@@ -1004,10 +1078,10 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     u32 *GRP = ctx->slot[S_GRP].as<u32>();
     u32 *h_small = static_cast<u32 *>(ctx->pinned);
 
-    hipEvent_t ev0, ev1;
-    PSS_HIP(hipEventCreate(&ev0));
-    PSS_HIP(hipEventCreate(&ev1));
-    PSS_HIP(hipEventRecord(ev0, s));
+    BuildTimer timer;
+    PSS_HIP(hipEventCreate(&timer.ev0));
+    PSS_HIP(hipEventCreate(&timer.ev1));
+    PSS_HIP(hipEventRecord(timer.ev0, s));
 
     // ---- 0. alphabet ----
     const int grid_stream = ctx->num_cus * 8;
@@ -1031,10 +1105,8 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     int kmax = 64 / b;
     if (kmax > 16) kmax = 16;
     int key_chars = choose_key_chars(h_small + 256, n, b, kmax);
-    if (const char *e = getenv("PSS_KEY_CHARS")) {
-        const int v = atoi(e);
-        if (v >= 1 && v <= kmax) key_chars = v;
-    }
+    const bool forced_chars = knobs.key_chars >= 1 && knobs.key_chars <= kmax;
+    if (forced_chars) key_chars = knobs.key_chars;
     st.sigma = sigma;
     st.code_bits = (u32)b;
     st.key_chars = (u32)key_chars;
@@ -1045,38 +1117,12 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     // ---- 1. initial sort on the first key_chars symbols ----
     SortStats ss;
     int key_drop = 0;
-    if (n >= (1u << 24) && !getenv("PSS_KEY_CHARS") && !getenv("PSS_NO_SAMPLE")) {
-        // measured sizing (see sample_keys_kernel): the fewest passes that leave <= 2 % tied
-        const u32 S = 1u << 21;
-        const int bits_max = kmax * b, pmax = (bits_max + 7) / 8;
-        u32 *d_tied = d_counters + 16;
-        PSS_HIP(hipMemsetAsync(d_tied, 0, 32, s));
-        hipLaunchKernelGGL(sample_keys_kernel, dim3(S / 256), dim3(256), 0, s, codes, n, S, b, kmax, plus_one, K[0], V[0]);
-        u32 mask = 0;
-        for (int p = 0; p < 8; ++p)
-            if (8 * (p + 1) > 64 - 8 * (pmax - 1)) mask |= 1u << p;   // only the top 8 (pmax - 1) bits are ever compared
-        int sd = 0;
-        PSS_TRY(radix_sort_pairs(ctx, K, V, S, 64, mask, nullptr, 0, work, &sd, profile, &ss));
-        ss.launches = 0;   // (the profile figures of these launches stay in: same kernel, same stream)
-        ss.elems = 0;
-        hipLaunchKernelGGL(sample_ties_kernel, dim3(256), dim3(256), 0, s, K[sd], S, d_tied);
-        PSS_HIP(hipMemcpyAsync(h_small, d_tied, 32, hipMemcpyDeviceToHost, s));
-        PSS_HIP(hipStreamSynchronize(s));
-        key_chars = kmax;
-        for (int p = 2; p < pmax; ++p) {
-            const double est = (double)h_small[p - 1] / S * ((double)n / S);
-            if (est <= 0.02) {
-                key_chars = (8 * p + b - 1) / b;
-                key_drop = key_chars * b - 8 * p;
-                break;
-            }
-        }
+    if (n >= (1u << 24) && !forced_chars && knobs.key_chars == 0 && !knobs.no_sample) {
+        PSS_TRY(size_initial_key(ctx, codes, n, b, kmax, plus_one, K, V, work, d_counters + 16, h_small, profile, &ss,
+                                 &key_chars, &key_drop));
         st.key_chars = (u32)key_chars;
     }
-    if (const char *e = getenv("PSS_KEY_DROP")) {
-        const int v = atoi(e);
-        if (v >= 0 && v < b && key_chars > 1) key_drop = v;
-    }
+    if (knobs.key_drop >= 0 && knobs.key_drop < b && key_chars > 1) key_drop = knobs.key_drop;
     TextKeys tk{codes, b, key_chars, plus_one, key_drop};
     const int key_bits0 = key_chars * b - key_drop;
     st.key_bits = (u64)key_bits0;
@@ -1092,7 +1138,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     // With >= 2 passes the sort carries tie flags instead of consumed digits (radix_sort.hip, fs_*):
     // the last pass writes only the suffix indices with bit 31 = "tied with my predecessor", and
     // the rerank reads 4-byte flagged values instead of comparing 8-byte keys.
-    const bool ties = passes0 >= 2 && !getenv("PSS_NO_TIES_PASS");
+    const bool ties = passes0 >= 2 && !knobs.no_flags;
     if (ties) PSS_TRY(suffix_sort_flags(ctx, K, V, n, key_bits0, &tk, work, &cur, profile, &ss));
     else PSS_TRY(radix_sort_pairs(ctx, K, V, n, key_bits0, 0xffffffffu, &tk, 0, work, &cur, profile, &ss));
     st.initial_passes = (u32)ss.launches;
@@ -1123,8 +1169,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     bool keyed_grp = true;       // the sorted keys of the previous round carry the group rank in their high half
     u32 global_above = 0;        // rank rounds use ONE global (group, rank) sort while m stays above this
     double last_big_frac = 0.0;
-    int text_rounds_max = 5;
-    if (const char *e = getenv("PSS_TEXT_ROUNDS")) text_rounds_max = atoi(e);
+    const int text_rounds_max = knobs.text_rounds_max;
     int kt = 64 / b;             // symbols per text-round key
     if (kt > 16) kt = 16;
     const int k0buf = cur;       // K[k0buf] = sorted initial keys (kept intact in sparse mode)
@@ -1160,11 +1205,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         if (round == 0) {
             // few ties: sparse (hash + key search); otherwise extend the ties from the text first
             mode = ((u64)m_next * 1024 <= (u64)n) ? M_SPARSE : M_TEXT;
-            if (const char *e = getenv("PSS_MODE")) {
-                if (!strcmp(e, "dense")) mode = M_DENSE;
-                else if (!strcmp(e, "sparse")) mode = M_SPARSE;
-                else if (!strcmp(e, "text")) mode = M_TEXT;
-            }
+            if (knobs.mode >= 0) mode = (Mode)knobs.mode;
             if (mode == M_SPARSE && (u64)m_next * 16 > (u64)n) mode = M_TEXT;   // hash table must fit the ISA buffer
             if (m_next == 0) mode = M_SPARSE;                                   // nothing left: no ISA at all
             if (mode == M_TEXT && text_rounds_max <= 0) mode = M_DENSE;
@@ -1224,7 +1265,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
             PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
             PSS_HIP(hipStreamSynchronize(s));
             const u32 nbig = h_small[0];
-            if (getenv("PSS_TIMING"))
+            if (knobs.timing)
                 fprintf(stderr, "[pss] %s round: h=%llu m=%u large-group members=%u (%.1f%%)\n", use_text ? "text" : "rank",
                         (unsigned long long)h, m, nbig, 100.0 * nbig / m);
             last_big_frac = (double)nbig / (double)m;
@@ -1368,12 +1409,10 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         ss.pairs_elems += rs.pairs_elems;
         h *= 2;
     }
-    PSS_HIP(hipEventRecord(ev1, s));
+    PSS_HIP(hipEventRecord(timer.ev1, s));
     PSS_HIP(hipStreamSynchronize(s));
     float ms = 0.f;
-    PSS_HIP(hipEventElapsedTime(&ms, ev0, ev1));
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
+    PSS_HIP(hipEventElapsedTime(&ms, timer.ev0, timer.ev1));
     st.ms_total = ms;
     st.ms_sort = ss.ms;
     st.sort_launches = ss.launches;
