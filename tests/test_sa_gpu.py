@@ -106,6 +106,13 @@ def test_sampled_sizing_sizes(oracle):
     for kind, n in ((0, (1 << 24) + 12345), (1, 1 << 24)):
         t = gen_corpus(kind, n)
         assert (sa_gpu(t) == oracle.sa(t)).all()
+    rng = np.random.default_rng(17)
+    # all 256 byte values (9-bit codes computed on the fly, 5 of them dropped from a 5-symbol key),
+    # a binary alphabet (32-bit key at most) and a text whose second half repeats the first
+    half = rng.integers(97, 123, 1 << 23, dtype=np.uint8)
+    for t in (rng.integers(0, 256, (1 << 24) + 7, dtype=np.uint8), rng.integers(0, 2, 1 << 24, dtype=np.uint8),
+              np.concatenate([half, half])):
+        assert (sa_gpu(t) == oracle.sa(t)).all()
 
 
 def test_long_repeats(oracle):
