@@ -714,8 +714,8 @@ __global__ __launch_bounds__(1024) void fs_fix_kernel(const u32 *first_z, const 
 }
 
 // Tiny inputs (<= one tile): one workgroup, bitonic network in LDS over the
-// whole 64-bit key.  Not stable -- callers only use it where ties stay tied
-// (doubling rounds: equal keys remain one group and are re-sorted later).
+// whole 64-bit key, ties broken by value (so the order is fully determined and the
+// padding never overtakes a real element).
 __global__ __launch_bounds__(RS_BLOCK) void rs_small_sort_kernel(u64 *keys, u32 *vals, u32 n)
 {
     __shared__ u64 sk[RS_TILE];
@@ -735,12 +735,14 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_small_sort_kernel(u64 *keys, u32 
                 if (x > i) {
                     const bool up = (i & k) == 0;
                     const u64 a = sk[i], b = sk[x];
-                    if ((a > b) == up) {
+                    const u32 va = sv[i], vb = sv[x];
+                    // equal keys order by value: the padding (value 0xffffffff) must stay behind real
+                    // elements even when a real key is all ones (16 symbols of the largest 4-bit code)
+                    if ((a > b || (a == b && va > vb)) == up) {
                         sk[i] = b;
                         sk[x] = a;
-                        const u32 t = sv[i];
-                        sv[i] = sv[x];
-                        sv[x] = t;
+                        sv[i] = vb;
+                        sv[x] = va;
                     }
                 }
             }

@@ -115,6 +115,17 @@ def test_sampled_sizing_sizes(oracle):
         assert (sa_gpu(t) == oracle.sa(t)).all()
 
 
+def test_all_ones_key_in_small_sort(oracle):
+    """Regression (found by tools/fuzz.py, seed 1279): 15 symbols -> 4-bit codes, so 16 symbols of the
+    largest code pack to an all-ones 64-bit text key -- the value the one-workgroup sort pads with.
+    The padding overtook real elements and the chained sort of the large groups read out of bounds."""
+    import os
+    t = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'regress_small_sort_padding.npy'))
+    assert (sa_gpu(t) == oracle.sa(t)).all()
+    crafted = np.frombuffer(b'\x0f' * 3000 + bytes(range(1, 16)) * 20 + b'\x0e' * 700 + b'\x0f' * 900, dtype=np.uint8)
+    assert (sa_gpu(crafted) == oracle.sa(crafted)).all()
+
+
 def test_long_repeats(oracle):
     """Duplicated blocks with small edits: LCPs in the tens of thousands (text rounds must
     hand over to rank rounds; large and small groups mixed)."""
