@@ -22,7 +22,7 @@ from util import sa_gpu  # noqa: E402
 
 def make_text(rng):
     sigma = rng.choice([1, 2, 3, 4, 16, 40, 100, 255, 256])
-    n = int(2 ** rng.uniform(0, 20))
+    n = int(2 ** rng.uniform(0, 22 if rng.random() < 0.05 else 18))
     kind = rng.choice(['iid', 'repeat', 'runs', 'periodic', 'mixed'])
     nprng = np.random.default_rng(rng.getrandbits(32))
     syms = nprng.permutation(256)[:sigma].astype(np.uint8)
@@ -72,19 +72,71 @@ def build(path, entries, limit, W):
     return open(path, 'rb').read()
 
 
+KNOBS = ('PSS_MODE', 'PSS_KEY_CHARS', 'PSS_KEY_DROP', 'PSS_TEXT_ROUNDS', 'PSS_NO_TIES_PASS', 'PSS_NO_SMALL_PATH')
+
+
+def random_knobs(rng):
+    """Builder / search switches that must never change a result."""
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    if rng.random() < 0.5:
+        return
+    if rng.random() < 0.5:
+        os.environ['PSS_MODE'] = rng.choice(['dense', 'sparse', 'text'])
+    if rng.random() < 0.5:
+        os.environ['PSS_KEY_CHARS'] = str(rng.randint(1, 16))
+        if rng.random() < 0.6:
+            os.environ['PSS_KEY_DROP'] = str(rng.randint(0, 8))
+    if rng.random() < 0.3:
+        os.environ['PSS_TEXT_ROUNDS'] = str(rng.randint(0, 3))
+    if rng.random() < 0.15:
+        os.environ['PSS_NO_TIES_PASS'] = '1'
+    if rng.random() < 0.5:
+        os.environ['PSS_NO_SMALL_PATH'] = '1'
+
+
+def file_case(rng, tmp):
+    """add_entries_from_file_lines: LF / CRLF / lone CR / empty lines / no final newline, raw bytes."""
+    pieces = []
+    for _ in range(rng.randint(0, 300)):
+        body = bytes(rng.choice([97, 98, 99, 0, 13, 200, 255, 32]) for _ in range(rng.randint(0, 30)))
+        pieces.append(body + rng.choice([b'\n', b'\n', b'\r\n', b'\n\n', b'\r\r\n']))
+    blob = b''.join(pieces)
+    if rng.random() < 0.5 and blob.endswith(b'\n'):
+        blob = blob[:-1]
+    src = os.path.join(tmp, 'in.txt')
+    open(src, 'wb').write(blob)
+    limit = rng.choice([None, 40, 100, 1000])
+    tail = rng.random() < 0.3
+    out = []
+    for W, name in ((pysubstringsearch.Writer, 'g'), (O.OracleWriter, 'o')):
+        path = os.path.join(tmp, name + 'f.idx')
+        w = W(path, limit) if limit is not None else W(path)
+        w.add_entries_from_file_lines(src)
+        if tail:
+            w.add_entry('tail entry')
+        w.finalize()
+        if hasattr(w, 'close'):
+            w.close()
+        out.append(open(path, 'rb').read())
+    return out
+
+
 def one_case(seed, tmp):
     rng = random.Random(seed)
+    random_knobs(rng)
     t = make_text(rng)
     assert (sa_gpu(t) == O.sa(t)).all(), 'suffix array differs'
+    if rng.random() < 0.3:
+        state = rng.getstate()
+        g, o = file_case(random.Random(seed ^ 0x5bd1e995), tmp)
+        rng.setstate(state)
+        assert g == o, 'file ingest: container differs'
     alphabet, entries = entries_of(rng)
     limit = rng.choice([None, 64, 257, 5000, 70000])
     if limit is not None:
         limit = max(limit, max(len(e.encode()) for e in entries) + 1)
     p, q = os.path.join(tmp, 'g.idx'), os.path.join(tmp, 'o.idx')
-    if rng.random() < 0.5:
-        os.environ['PSS_NO_SMALL_PATH'] = '1'
-    else:
-        os.environ.pop('PSS_NO_SMALL_PATH', None)
     assert build(p, entries, limit, pysubstringsearch.Writer) == build(q, entries, limit, O.OracleWriter), 'container differs'
     text = '\n'.join(entries) + '\n'
     queries = ['', '\n']
