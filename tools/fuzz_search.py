@@ -1,0 +1,106 @@
+"""Time-boxed fuzzing of the search path on mid-size multi-chunk indexes: batch sizes from 1 to
+tens of thousands of queries (fused small-batch kernel, wave-per-pair and lane-per-pair interval
+search, arena overflow, > 1024 hits per (query, chunk)), long and newline-crossing patterns,
+sharded readers.  Everything is compared with the oracle's restatement of Reader::search.
+
+    python tools/fuzz_search.py [seconds=120] [seed0=<time>]"""
+import os
+import random
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, '.')
+import pysubstringsearch  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from pysubstringsearch_amd import Reader  # noqa: E402
+
+
+def one_case(seed, tmp):
+    rng = random.Random(seed)
+    alphabet = rng.choice(['ab', 'abc', 'abcdefgh', 'aé☃b', 'ab \t.', 'abcdefghijklmnopqrstuvwxyz'])
+    m = int(2 ** rng.uniform(3, 16))
+    L = rng.choice([3, 10, 40, 200])
+    pool = [''.join(rng.choice(alphabet) for _ in range(rng.randint(0, L))) for _ in range(max(1, m // rng.choice([1, 2, 20])))]
+    entries = [rng.choice(pool) for _ in range(m)]
+    total = sum(len(e.encode()) + 1 for e in entries)
+    chunks = rng.choice([1, 1, 2, 7, 40])
+    limit = max(total // chunks + 1, max(len(e.encode()) for e in entries) + 1)
+    p, q = os.path.join(tmp, 'g.idx'), os.path.join(tmp, 'o.idx')
+    for path, W in ((p, pysubstringsearch.Writer), (q, O.OracleWriter)):
+        w = W(path, limit)
+        for e in entries:
+            w.add_entry(e)
+        w.finalize()
+        if hasattr(w, 'close'):
+            w.close()
+    assert open(p, 'rb').read() == open(q, 'rb').read(), 'container differs'
+    text = '\n'.join(entries) + '\n'
+    nq = rng.choice([1, 3, 50, 1500, 40000 if total < 300000 else 3000])
+    queries = []
+    for _ in range(nq):
+        r = rng.random()
+        if r < 0.6:
+            s = rng.randrange(len(text))
+            queries.append(text[s:s + rng.choice([1, 2, 3, 5, 9, 17, 60])])
+        elif r < 0.9:
+            queries.append(''.join(rng.choice(alphabet) for _ in range(rng.randint(1, 7))))
+        else:
+            queries.append(rng.choice(['', '\n', alphabet[0], alphabet[0] + '\n', '\n' + alphabet[0]]))
+    if rng.random() < 0.5:
+        os.environ['PSS_NO_SMALL_PATH'] = '1'
+    else:
+        os.environ.pop('PSS_NO_SMALL_PATH', None)
+    if rng.random() < 0.3:
+        os.environ['PSS_WAVE_SEARCH'] = '1'
+    else:
+        os.environ.pop('PSS_WAVE_SEARCH', None)
+    qb = [s.encode() for s in queries]
+    o = O.OracleReader(q)
+    oe, oc = o.search_multiple_bytes(qb)
+    with Reader(p) as r:
+        ents, counts = r.search_batch_raw(qb)
+        assert counts == oc.tolist(), 'per-query counts differ'
+        pos = 0
+        for c in counts:
+            assert sorted(ents[pos:pos + c]) == sorted(oe[pos:pos + c]), 'multiset differs'
+            pos += c
+        pk = r.search_batch_packed(qb)
+        assert pk.counts.tolist() == counts and len(pk.offsets) == len(ents) + 1
+        assert bytes(pk.data) == b''.join(ents)
+    # shards: the union over ranks is the whole result, per query
+    k = rng.choice([2, 3, 8])
+    per = [0] * len(qb)
+    allents = []
+    for i in range(k):
+        with Reader(p, shard=(i, k)) as r:
+            e, c = r.search_batch_raw(qb[:200])
+            per = [a + b for a, b in zip(per, c + [0] * (len(per) - len(c)))]
+            allents += e
+    assert per[:min(200, len(qb))] == oc.tolist()[:200], 'sharded counts differ'
+    assert sorted(allents) == sorted(oe[:sum(oc.tolist()[:200])]), 'sharded multiset differs'
+    o.close()
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+    O.use_reference_sa(O.have_reference())
+    t0 = time.time()
+    cases = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        while time.time() - t0 < budget:
+            if os.environ.get('FUZZ_TRACE'):
+                print('seed', seed, file=sys.stderr, flush=True)
+            try:
+                one_case(seed, tmp)
+            except Exception as e:   # noqa: BLE001
+                print(f'FAIL seed={seed}: {type(e).__name__}: {e}')
+                raise
+            cases += 1
+            seed += 1
+    print(f'fuzz_search: {cases} cases in {time.time() - t0:.0f} s, all equal to the oracle (last seed {seed - 1})')
+
+
+if __name__ == '__main__':
+    main()
