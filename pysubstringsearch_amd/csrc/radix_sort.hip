@@ -470,12 +470,19 @@ template <> struct FsKey<4> { using type = u32; };
 
 // One tile.  KIN = bytes of the incoming key plane (0: packed from the text), KOUT = bytes of
 // the outgoing one (0: none, last pass).  zcarry = group heads seen in the earlier tiles of
-// the range (uniform over the workgroup).
+// the range (uniform over the workgroup); par = tile parity (s_tz / s_tv are double-buffered so
+// that the digit owners can publish this tile's last group numbers while the output loop still
+// reads the previous tile's).
+//
+// Four workgroup barriers per tile: keys, group numbers and values pass through separate LDS
+// buffers in ONE exchange, every wave clears its own counter row for the next tile, and the
+// next tile's barriers order everything else (its loads and ranking touch only per-wave state).
 template <int KIN, int KOUT, bool FULL>
 __device__ __forceinline__ void fs_tile(const PassArgs &a, u32 base, u32 valid_count,
-                                        typename FsKey<KIN == 4 ? 4 : 8>::type *exk, u32 *exz,
+                                        typename FsKey<KIN == 4 ? 4 : 8>::type *exk, u32 *exz, u32 *exv,
                                         u32 (*wave_hist)[256], u32 *s_off, u32 *s_delta, u32 *s_scr, u32 g,
-                                        u32 *s_dstart, u32 *s_cnt, u32 *s_tz, u32 *s_tv, u32 *s_zwave, u32 &zcarry)
+                                        u32 *s_dstart, u32 *s_cnt, u32 (*s_tz)[256], u32 (*s_tv)[256], u32 *s_zwave,
+                                        u32 &zcarry, u32 par)
 {
     constexpr bool FROM_TEXT = KIN == 0;
     constexpr int IPT = RS_IPT;
@@ -521,10 +528,8 @@ __device__ __forceinline__ void fs_tile(const PassArgs &a, u32 base, u32 valid_c
         }
         if (lane == 0) s_zwave[wave] = zwave_total;
     }
-    for (u32 i = tid; i < RS_WAVES * 256; i += RS_BLOCK) (&wave_hist[0][0])[i] = 0;
-    __syncthreads();
 
-    // ---- per-wave stable ranking (as rs scatter_tile) ----
+    // ---- per-wave stable ranking (as rs scatter_tile); the wave's counter row is zero on entry ----
     u32 prev[IPT];
 #pragma unroll
     for (int r = 0; r < IPT; ++r) {
@@ -542,6 +547,8 @@ __device__ __forceinline__ void fs_tile(const PassArgs &a, u32 base, u32 valid_c
         const u32 p = __shfl(prev[r], (int)(rank[r] >> 16));
         rank[r] = p + (rank[r] & 0xffffu);
     }
+    __syncthreads();                                            // (A) counters and s_zwave complete
+
     u32 zbase = zcarry, ztile = 0;
     if (!FROM_TEXT) {
 #pragma unroll
@@ -551,8 +558,6 @@ __device__ __forceinline__ void fs_tile(const PassArgs &a, u32 base, u32 valid_c
             ztile += c;
         }
     }
-    __syncthreads();
-
     // ---- workgroup prefix over digits (thread d < 256 owns digit d) ----
     {
         u32 c[RS_WAVES];
@@ -564,7 +569,13 @@ __device__ __forceinline__ void fs_tile(const PassArgs &a, u32 base, u32 valid_c
                 total += c[w];
             }
         }
-        const u32 dstart = block_excl_sum<RS_WAVES>(total, s_scr, nullptr);
+        const u32 incl = wave_incl_sum(total);
+        if (lane == kWave - 1) s_scr[wave] = incl;
+        __syncthreads();                                        // (P) wave totals of the digit counts
+        u32 dstart = incl - total;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w)
+            if (w < (int)wave) dstart += s_scr[w];
         if (tid < 256) {
             u32 run = dstart;
 #pragma unroll
@@ -579,83 +590,74 @@ __device__ __forceinline__ void fs_tile(const PassArgs &a, u32 base, u32 valid_c
             s_cnt[tid] = total;
         }
     }
-    __syncthreads();
+    __syncthreads();                                            // (B) digit offsets published
 
-    // ---- keys (and group numbers) through LDS in digit order ----
+    // ---- keys, group numbers and values through LDS in digit order ----
 #pragma unroll
     for (int r = 0; r < IPT; ++r) {
         const u32 d = (u32)key[r] & 0xffu;
         const u32 lp = wave_hist[wave][d] + rank[r];
-        rank[r] = lp;
         if (is_valid(r)) {
             exk[lp] = key[r];
             if (!FROM_TEXT) exz[lp] = zbase + zin[r];
+            exv[lp] = val[r] & 0x7fffffffu;
         }
     }
-    __syncthreads();
-    u32 gpos[IPT];
-    u32 tied = 0;   // bit i = element i continues the group of its predecessor in the output
+    __syncthreads();                                            // (C) exchange buffers complete
+    // the counter row is consumed: clear it for the next tile (own wave only)
+#pragma unroll
+    for (int q = 0; q < 256 / kWave; ++q) wave_hist[wave][q * kWave + lane] = 0;
+    // digit owners publish the last group number of their digit for the next tile
+    if (tid < 256) {
+        const u32 c = s_cnt[tid];
+        s_tz[par ^ 1u][tid] = c ? (FROM_TEXT ? 0u : exz[s_dstart[tid] + c - 1]) : s_tz[par][tid];
+        s_tv[par ^ 1u][tid] = c ? 1u : s_tv[par][tid];
+    }
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
         const u32 p = i * RS_BLOCK + tid;
-        gpos[i] = 0;
         if (FULL || p < valid_count) {
             const RK k = exk[p];
             const u32 d = (u32)k & 0xffu;
             const u32 z = FROM_TEXT ? 0u : exz[p];
-            gpos[i] = s_delta[d] + p;
+            const u32 gp = s_delta[d] + p;
             const u32 ds = s_dstart[d];
             bool t;
             if (p > ds) {
                 t = FROM_TEXT ? true : exz[p - 1] == z;
-            } else if (s_tv[d]) {
-                t = s_tz[d] == z;                              // last of this digit in an earlier tile
+            } else if (s_tv[par][d]) {
+                t = s_tz[par][d] == z;                         // last of this digit in an earlier tile
             } else {
                 t = false;                                     // first of its digit in the whole range:
                 a.first_z[(size_t)g * 256 + d] = z;            // settled by fs_fix
             }
-            tied |= (t ? 1u : 0u) << i;
-            if (KOUT == 8) a.kout[gpos[i]] = (u64)(k >> 8);
-            if (KOUT == 4) a.kout32[gpos[i]] = (u32)(k >> 8);
+            if (KOUT == 8) a.kout[gp] = (u64)(k >> 8);
+            if (KOUT == 4) a.kout32[gp] = (u32)(k >> 8);
+            a.vout[gp] = exv[p] | ((t ? 1u : 0u) << 31);
         }
     }
-    __syncthreads();
-    if (tid < 256 && s_cnt[tid]) {
-        s_tz[tid] = FROM_TEXT ? 0u : exz[s_dstart[tid] + s_cnt[tid] - 1];
-        s_tv[tid] = 1;
-    }
-    __syncthreads();
-    u32 *exv = reinterpret_cast<u32 *>(exk);
-#pragma unroll
-    for (int r = 0; r < IPT; ++r) {
-        if (is_valid(r)) exv[rank[r]] = val[r] & 0x7fffffffu;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-        const u32 p = i * RS_BLOCK + tid;
-        if (FULL || p < valid_count) a.vout[gpos[i]] = exv[p] | (((tied >> i) & 1u) << 31);
-    }
     zcarry += ztile;
-    __syncthreads();
 }
 
 template <int KIN, int KOUT>
 __global__ __launch_bounds__(RS_BLOCK, PSS_RS_MINWAVES) void fs_scatter_kernel(PassArgs a)
 {
     using RK = typename FsKey<KIN == 4 ? 4 : 8>::type;
-    __shared__ __attribute__((aligned(16))) RK exk[RS_TILE];           // reused for values
+    __shared__ __attribute__((aligned(16))) RK exk[RS_TILE];
     __shared__ u32 exz[KIN == 0 ? 1 : RS_TILE];
+    __shared__ u32 exv[RS_TILE];
     __shared__ u32 wave_hist[RS_WAVES][256];
-    __shared__ u32 s_off[256], s_delta[256], s_dstart[256], s_cnt[256], s_tz[256], s_tv[256];
-    __shared__ u32 s_scr[RS_WAVES + 1], s_zwave[RS_WAVES];
+    __shared__ u32 s_off[256], s_delta[256], s_dstart[256], s_cnt[256], s_tz[2][256], s_tv[2][256];
+    __shared__ u32 s_scr[RS_WAVES], s_zwave[RS_WAVES];
 
     const u32 tid = threadIdx.x;
     const u32 g = xcd_range_of_block(blockIdx.x, gridDim.x);
     if (tid < 256) {
         s_off[tid] = a.table[tid * a.num_ranges + g];
-        s_tv[tid] = 0;
+        s_tv[0][tid] = 0;
+        s_tz[0][tid] = 0;
     }
+    for (u32 i = tid; i < RS_WAVES * 256; i += RS_BLOCK) (&wave_hist[0][0])[i] = 0;
     const u32 tile0 = g * a.tiles_per_range;
     const u32 tile1 = min(tile0 + a.tiles_per_range, a.num_tiles);
     if (tile0 >= tile1) {
@@ -663,23 +665,25 @@ __global__ __launch_bounds__(RS_BLOCK, PSS_RS_MINWAVES) void fs_scatter_kernel(P
         if (tid == 0) a.zeros[g] = 0;
         return;
     }
+    __syncthreads();
     const u32 e0 = tile0 * (u32)RS_TILE;
     const u32 e1_full = tile1 * (u32)RS_TILE;
     const u32 e1 = e1_full < a.n ? e1_full : a.n;
-    u32 zcarry = 0;
-    for (u32 base = e0; base < e1; base += RS_TILE) {
+    u32 zcarry = 0, par = 0;
+    for (u32 base = e0; base < e1; base += RS_TILE, par ^= 1u) {
         const u32 left = e1 - base;
         const u32 valid_count = left < (u32)RS_TILE ? left : (u32)RS_TILE;
         if (valid_count == (u32)RS_TILE)
-            fs_tile<KIN, KOUT, true>(a, base, valid_count, exk, exz, wave_hist, s_off, s_delta, s_scr, g, s_dstart, s_cnt,
-                                     s_tz, s_tv, s_zwave, zcarry);
+            fs_tile<KIN, KOUT, true>(a, base, valid_count, exk, exz, exv, wave_hist, s_off, s_delta, s_scr, g, s_dstart, s_cnt,
+                                     s_tz, s_tv, s_zwave, zcarry, par);
         else
-            fs_tile<KIN, KOUT, false>(a, base, valid_count, exk, exz, wave_hist, s_off, s_delta, s_scr, g, s_dstart, s_cnt,
-                                      s_tz, s_tv, s_zwave, zcarry);
+            fs_tile<KIN, KOUT, false>(a, base, valid_count, exk, exz, exv, wave_hist, s_off, s_delta, s_scr, g, s_dstart,
+                                      s_cnt, s_tz, s_tv, s_zwave, zcarry, par);
     }
+    __syncthreads();                                            // the last tile's s_tz / s_tv [par]
     if (tid < 256) {
-        a.has[(size_t)g * 256 + tid] = s_tv[tid];
-        if (s_tv[tid]) a.last_z[(size_t)g * 256 + tid] = s_tz[tid];
+        a.has[(size_t)g * 256 + tid] = s_tv[par][tid];
+        if (s_tv[par][tid]) a.last_z[(size_t)g * 256 + tid] = s_tz[par][tid];
     }
     if (tid == 0) a.zeros[g] = zcarry;
 }
