@@ -170,6 +170,16 @@ typedef struct pss_search_stats {
  */
 int pss_reader_search_batch(pss_reader *r, const uint8_t *qbytes, const uint64_t *qoffsets,
                             uint32_t nq, pss_result **out);
+/*
+ * Beyond the reference surface: counts[q] = the number of
+ * entries pss_reader_search_batch would return for query q (after the per-chunk
+ * dedupe), without materialising a single entry -- the interval search, the
+ * dedupe flags and two scans; nothing but nq counters crosses PCIe.  For
+ * high-hit queries this is the part of Reader::search (src/lib.rs:254-278) that
+ * dominates on the CPU (README.md:57).
+ */
+int pss_reader_count_batch(pss_reader *r, const uint8_t *qbytes, const uint64_t *qoffsets,
+                           uint32_t nq, uint64_t *counts);
 int pss_reader_last_stats(const pss_reader *r, pss_search_stats *stats);
 /* Drops the chunks and closes the reader. */
 int pss_reader_close(pss_reader *r);

@@ -202,6 +202,23 @@ class Reader:
         finally:
             _lib.pss_result_free(res)
 
+    def count_multiple(self, substrings: typing.List[str]) -> typing.List[int]:
+        """Extension (not in the reference API): ``len(search(s))`` for every s, in one batched
+        device call that materialises no entry -- only the counters come back."""
+        import numpy as np
+        pats = [_utf8(s, 'substring') for s in substrings]
+        nq = len(pats)
+        offs = np.zeros(nq + 1, dtype=np.uint64)
+        if nq:
+            np.cumsum(np.fromiter(map(len, pats), dtype=np.uint64, count=nq), out=offs[1:])
+        counts = np.zeros(max(nq, 1), dtype=np.uint64)
+        _ffi.check(_lib.pss_reader_count_batch(self._handle(), b''.join(pats), offs.ctypes.data, nq, counts.ctypes.data))
+        return [int(c) for c in counts[:nq]]
+
+    def count(self, substring: str) -> int:
+        """Extension: ``len(search(substring))`` without building the entries."""
+        return self.count_multiple([substring])[0]
+
     def search_batch_packed(self, patterns: typing.Sequence[bytes]) -> 'PackedResult':
         """One batched device call, zero per-entry Python objects: numpy copies of
         the packed result (entry i of the batch = data[offsets[i]:offsets[i+1]],

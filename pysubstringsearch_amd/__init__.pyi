@@ -51,6 +51,10 @@ class Reader:
 
     def search_multiple(self, substrings: typing.List[str]) -> typing.List[str]: ...
 
+    def count(self, substring: str) -> int: ...
+
+    def count_multiple(self, substrings: typing.List[str]) -> typing.List[int]: ...
+
     def search_batch_raw(
         self, patterns: typing.Sequence[bytes],
     ) -> typing.Tuple[typing.List[bytes], typing.List[int]]: ...

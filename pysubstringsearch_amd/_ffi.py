@@ -116,6 +116,7 @@ def _load() -> ctypes.CDLL:
         'pss_reader_set_chunk_device': (ctypes.c_int, [vp, u64, vp, vp, u32]),
         'pss_reader_num_chunks': (u64, [vp]),
         'pss_reader_search_batch': (ctypes.c_int, [vp, vp, vp, u32, pvp]),
+        'pss_reader_count_batch': (ctypes.c_int, [vp, vp, vp, u32, vp]),
         'pss_reader_last_stats': (ctypes.c_int, [vp, ctypes.POINTER(SearchStats)]),
         'pss_reader_close': (ctypes.c_int, [vp]),
         'pss_result_num_queries': (u64, [vp]),

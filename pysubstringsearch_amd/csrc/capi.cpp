@@ -840,6 +840,28 @@ extern "C" int pss_reader_search_batch(pss_reader *r, const uint8_t *qbytes, con
     });
 }
 
+extern "C" int pss_reader_count_batch(pss_reader *r, const uint8_t *qbytes, const uint64_t *qoffsets, uint32_t nq,
+                                      uint64_t *counts)
+{
+    return guarded([&]() -> int {
+        if (!r || (nq && (!qoffsets || !counts))) {
+            set_error("pss_reader_count_batch: bad arguments");
+            return PSS_EINVAL;
+        }
+        std::lock_guard<std::recursive_mutex> lk(r->ctx->mu);
+        PSS_HIP(hipSetDevice(r->device));
+        const uint32_t nc = (uint32_t)r->chunks.size();
+        PSS_TRY(reader_sync_descs(r));
+        pss_result res;
+        const int rc = search_batch_device(r->ctx, r->d_descs, nc, qbytes, qoffsets, nq, &res.r, &r->last, true);
+        if (rc == PSS_OK && nq) memcpy(counts, res.r.qcount, (size_t)nq * sizeof(uint64_t));
+        free(res.r.qcount);
+        free(res.r.offsets);
+        free(res.r.bytes);
+        return rc;
+    });
+}
+
 extern "C" int pss_reader_last_stats(const pss_reader *r, pss_search_stats *stats)
 {
     if (!r || !stats) return PSS_EINVAL;

@@ -23,6 +23,8 @@ struct HostResult {
 };
 
 int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, uint32_t nc, const uint8_t *qbytes,
-                        const uint64_t *qoffsets, uint32_t nq, HostResult *res, pss_search_stats *st);
+                        const uint64_t *qoffsets, uint32_t nq, HostResult *res, pss_search_stats *st,
+                        bool counts_only = false);
+// counts_only: res->qcount only (entries each query would return); no entry is materialised.
 
 }  // namespace pss

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void query_counts_kernel(u32 nc, u32 nq, const
 enum SSlot { Q_BYTES = 10, Q_OFF, Q_LO, Q_CNT, Q_HITOFF, Q_START, Q_LEN, Q_EIDX, Q_BOFF, Q_ENTOFF, Q_OUT, Q_SMALL, Q_QCOUNT, Q_ARENA = 28 };
 
 int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const uint8_t *qbytes,
-                        const uint64_t *qoffsets, uint32_t nq, HostResult *res, pss_search_stats *st)
+                        const uint64_t *qoffsets, uint32_t nq, HostResult *res, pss_search_stats *st, bool counts_only)
 {
     hipStream_t s = ctx->stream;
     memset(st, 0, sizeof *st);
@@ -409,10 +409,16 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
     u64 *d_qcount = ctx->slot[Q_QCOUNT].as<u64>();
     u64 *h_small = static_cast<u64 *>(ctx->pinned);
 
-    hipEvent_t e0, e1, e2;
-    PSS_HIP(hipEventCreate(&e0));
-    PSS_HIP(hipEventCreate(&e1));
-    PSS_HIP(hipEventCreate(&e2));
+    struct Events {   // destroyed on every exit path
+        hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+        ~Events()
+        {
+            for (hipEvent_t x : e)
+                if (x) (void)hipEventDestroy(x);
+        }
+    } evs;
+    for (hipEvent_t &x : evs.e) PSS_HIP(hipEventCreate(&x));
+    const hipEvent_t e0 = evs.e[0], e1 = evs.e[1], e2 = evs.e[2];
     const size_t off_bytes = ((size_t)nq + 1) * 8;
     if (qtotal + 32 <= 8192 && off_bytes <= 8192) {
         // tiny batch: stage in pinned memory (pageable H2D copies are synchronous and slow to start)
@@ -429,7 +435,7 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
     }
     PSS_HIP(hipEventRecord(e0, s));
     const u64 waves_per_block = 256 / kWave;
-    if (nvq <= SM_MAX_VQ && !getenv("PSS_NO_SMALL_PATH")) {
+    if (nvq <= SM_MAX_VQ && !counts_only && !getenv("PSS_NO_SMALL_PATH")) {
         // ---- fused small-batch path: one kernel, two small copies ----
         const size_t rec_bytes = (size_t)SM_MAX_VQ * sizeof(SmallRecord);
         const size_t ent_bytes = (size_t)SM_ENT_CAP * sizeof(SmallEntry);
@@ -487,9 +493,6 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
             PSS_HIP(hipEventElapsedTime(&ms, e0, e2));
             st->ms_device = ms;
             st->ms_interval = ms;
-            (void)hipEventDestroy(e0);
-            (void)hipEventDestroy(e1);
-            (void)hipEventDestroy(e2);
             return PSS_OK;
         }
         // overflow: fall through to the general path (qcount is still all zero)
@@ -522,6 +525,23 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
                            d_hitoff, H, d_start, d_len);
         PSS_TRY(device_excl_scan(ctx, InKept{d_len}, H, d_partial, d_total, d_eidx));
         PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
+        if (counts_only) {
+            // entries per query without materialising one: interval search, dedupe flags, two scans
+            hipLaunchKernelGGL(query_counts_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, nc, nq, d_hitoff, d_eidx,
+                               d_qcount);
+            PSS_HIP(hipEventRecord(e2, s));
+            PSS_HIP(hipMemcpyAsync(res->qcount, d_qcount, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
+            PSS_HIP(hipStreamSynchronize(s));
+            res->offsets = (u64 *)calloc(1, sizeof(u64));
+            if (!res->offsets) return PSS_ENOMEM;
+            st->entries = h_small[0];
+            float msc = 0.f;
+            PSS_HIP(hipEventElapsedTime(&msc, e0, e2));
+            st->ms_device = msc;
+            PSS_HIP(hipEventElapsedTime(&msc, e0, e1));
+            st->ms_interval = msc;
+            return PSS_OK;
+        }
         PSS_TRY(device_excl_scan(ctx, InLen{d_len}, H, d_partial, d_total, d_boff));
         PSS_HIP(hipMemcpyAsync(h_small + 1, d_total, 8, hipMemcpyDeviceToHost, s));
         PSS_HIP(hipStreamSynchronize(s));
@@ -559,9 +579,6 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
     st->ms_device = ms;
     PSS_HIP(hipEventElapsedTime(&ms, e0, e1));
     st->ms_interval = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipEventDestroy(e2);
     return PSS_OK;
 }
 

@@ -359,3 +359,26 @@ def test_large_batch_lane_search(tmp_path, oracle):
         oe, oc = o.search_multiple_bytes(qs)
         assert counts == oc.tolist()
         assert sorted(ents) == sorted(oe)
+
+
+def test_count_only_matches_search(tmp_path, oracle):
+    """Extension API: count / count_multiple = len(search) per query, on a multi-chunk index, for
+    batches on both sides of the lane-search threshold; counts come from the oracle."""
+    rng = random.Random(4)
+    entries = [''.join(rng.choice('abc') for _ in range(rng.randint(0, 12))) for _ in range(3000)]
+    p, q = str(tmp_path / 'c.idx'), str(tmp_path / 'o.idx')
+    build(p, entries, 2000)
+    oracle.use_reference_sa(False)
+    build(q, entries, 2000, W=oracle.OracleWriter)
+    o = oracle.OracleReader(q)
+    text = '\n'.join(entries) + '\n'
+    with pysubstringsearch.Reader(p) as r:
+        assert r.count_multiple([]) == []
+        assert r.count('zzz') == 0 and r.count('') == len(entries)
+        for nq in (7, 4000):
+            qs = [text[s:s + rng.randint(1, 5)] for s in (rng.randrange(len(text)) for _ in range(nq))] + ['', 'a', 'q']
+            _, oc = o.search_multiple_bytes([s.encode() for s in qs])
+            assert r.count_multiple(qs) == oc.tolist()
+        assert r.count('ab') == len(r.search('ab'))
+        with pytest.raises(TypeError):
+            r.count(b'ab')
