@@ -22,7 +22,8 @@ from util import sa_gpu  # noqa: E402
 
 def make_text(rng):
     sigma = rng.choice([1, 2, 3, 4, 16, 40, 100, 255, 256])
-    n = int(2 ** rng.uniform(0, 22 if rng.random() < 0.05 else 18))
+    big = os.environ.get('FUZZ_BIG')      # SA only, sizes that reach the sampled sizing (n >= 2^24)
+    n = int(2 ** (rng.uniform(21, 25.3) if big else rng.uniform(0, 22 if rng.random() < 0.05 else 18)))
     kind = rng.choice(['iid', 'repeat', 'runs', 'periodic', 'mixed'])
     nprng = np.random.default_rng(rng.getrandbits(32))
     syms = nprng.permutation(256)[:sigma].astype(np.uint8)
@@ -127,6 +128,8 @@ def one_case(seed, tmp):
     random_knobs(rng)
     t = make_text(rng)
     assert (sa_gpu(t) == O.sa(t)).all(), 'suffix array differs'
+    if os.environ.get('FUZZ_BIG'):
+        return
     if rng.random() < 0.3:
         state = rng.getstate()
         g, o = file_case(random.Random(seed ^ 0x5bd1e995), tmp)
