@@ -122,6 +122,29 @@ class Writer:
             pass
 
 
+class _ResultOwner:
+    """Keeps a pss_result alive for the numpy views handed out by search_batch_packed."""
+
+    def __init__(self, handle) -> None:
+        self._h = handle
+
+    def view(self, ptr, count: int, dtype):
+        import numpy as np
+        if not count or not ptr:
+            return np.zeros(0, dtype=dtype)
+        nbytes = int(count) * np.dtype(dtype).itemsize
+        buf = (ctypes.c_uint8 * nbytes).from_address(ctypes.addressof(ptr.contents))
+        buf._owner = self               # numpy keeps `buf` as the array's base, `buf` keeps the result
+        a = np.frombuffer(buf, dtype=dtype, count=int(count))
+        a.flags.writeable = False
+        return a
+
+    def __del__(self):
+        h, self._h = self._h, None
+        if h:
+            _lib.pss_result_free(h)
+
+
 class PackedResult(typing.NamedTuple):
     data: typing.Any      # numpy uint8: all entries back to back
     offsets: typing.Any   # numpy uint64 [num_entries + 1]
@@ -220,9 +243,10 @@ class Reader:
         return self.count_multiple([substring])[0]
 
     def search_batch_packed(self, patterns: typing.Sequence[bytes]) -> 'PackedResult':
-        """One batched device call, zero per-entry Python objects: numpy copies of
-        the packed result (entry i of the batch = data[offsets[i]:offsets[i+1]],
-        entries are query-major, counts[q] of them belong to query q).  For
+        """One batched device call, zero per-entry Python objects: read-only numpy
+        views of the packed result, which lives as long as they do (entry i of the
+        batch = data[offsets[i]:offsets[i+1]], entries are query-major, counts[q] of
+        them belong to query q).  For
         hit-heavy batches the Python list of ``search_multiple`` costs more than
         the search itself (~50 ns per entry); this is the bulk alternative."""
         import numpy as np
@@ -233,17 +257,12 @@ class Reader:
             np.cumsum(np.fromiter(map(len, patterns), dtype=np.uint64, count=nq), out=offs[1:])
         res = ctypes.c_void_p()
         _ffi.check(_lib.pss_reader_search_batch(self._handle(), blob, offs.ctypes.data, nq, ctypes.byref(res)))
-        try:
-            n = _lib.pss_result_num_entries(res)
-            counts = np.ctypeslib.as_array(_lib.pss_result_query_counts(res), shape=(nq,)).copy() if nq else \
-                np.zeros(0, np.uint64)
-            offsets = np.ctypeslib.as_array(_lib.pss_result_offsets(res), shape=(n + 1,)).copy()
-            total = int(offsets[n])
-            data = np.ctypeslib.as_array(_lib.pss_result_bytes(res), shape=(total,)).copy() if total else \
-                np.zeros(0, np.uint8)
-            return PackedResult(data, offsets, counts)
-        finally:
-            _lib.pss_result_free(res)
+        owner = _ResultOwner(res)      # the arrays below are views of the C result; it lives as long as they do
+        n = _lib.pss_result_num_entries(res)
+        counts = owner.view(_lib.pss_result_query_counts(res), nq, np.uint64)
+        offsets = owner.view(_lib.pss_result_offsets(res), n + 1, np.uint64)
+        data = owner.view(_lib.pss_result_bytes(res), int(offsets[n]), np.uint8)
+        return PackedResult(data, offsets, counts)
 
     def search_batch_raw(self, patterns: typing.Sequence[bytes]):
         """One batched device call.  Returns (entries, per_query_counts): the

@@ -382,3 +382,28 @@ def test_count_only_matches_search(tmp_path, oracle):
         assert r.count('ab') == len(r.search('ab'))
         with pytest.raises(TypeError):
             r.count(b'ab')
+
+
+def test_packed_result_outlives_reader(tmp_path):
+    """search_batch_packed hands out views of the C result: they stay valid after the reader is
+    closed and collected, are read-only, and empty results are well-formed."""
+    import gc
+    p = str(tmp_path / 'p.idx')
+    build(p, ['alpha', 'beta', 'alphabet'], None)
+    r = pysubstringsearch.Reader(p)
+    pk = r.search_batch_packed([b'alpha', b'zzz', b'bet'])
+    none = r.search_batch_packed([b'zzz'])
+    r.close()
+    del r
+    gc.collect()
+    assert pk.counts.tolist() == [2, 0, 2]
+    ents = [bytes(pk.data[pk.offsets[i]:pk.offsets[i + 1]]) for i in range(len(pk.offsets) - 1)]
+    assert sorted(ents) == sorted([b'alpha', b'alphabet', b'beta', b'alphabet'])
+    assert not pk.data.flags.writeable
+    with pytest.raises(ValueError):
+        pk.data[0] = 0
+    assert none.counts.tolist() == [0] and none.data.size == 0 and none.offsets.tolist() == [0]
+    data = pk.data
+    del pk
+    gc.collect()
+    assert bytes(data[:5]) in (b'alpha', b'beta\x00'[:5], b'alpha')   # still backed by the result
