@@ -83,8 +83,6 @@ typedef struct pss_sa_stats {
     double fs_ms[9];
     uint64_t fs_launches[9];
     uint64_t fs_elems[9];
-    uint64_t sort_batches;     /* initial sort run bucket by bucket (most significant digit first): batches of
-                                  buckets its remaining passes ran in; 0 = one sweep over all suffixes per pass */
 } pss_sa_stats;
 
 /*

@@ -40,7 +40,6 @@ class SaStats(ctypes.Structure):
         ('fs_ms', ctypes.c_double * 9),
         ('fs_launches', ctypes.c_uint64 * 9),
         ('fs_elems', ctypes.c_uint64 * 9),
-        ('sort_batches', ctypes.c_uint64),
     ]
 
     def as_dict(self):

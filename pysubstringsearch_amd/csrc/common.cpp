@@ -57,17 +57,6 @@ int DeviceCtx::ensure_staging()
     return PSS_OK;
 }
 
-int DeviceCtx::ensure_aux(int count)
-{
-    if (!fork_ev) PSS_HIP(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
-    for (int i = 0; i < count && i < kAux; ++i) {
-        if (aux_stream[i]) continue;
-        PSS_HIP(hipStreamCreateWithFlags(&aux_stream[i], hipStreamNonBlocking));
-        PSS_HIP(hipEventCreateWithFlags(&aux_ev[i], hipEventDisableTiming));
-    }
-    return PSS_OK;
-}
-
 static constexpr int kMaxDevices = 64;
 static DeviceCtx g_ctx[kMaxDevices];
 static std::mutex g_ctx_mu;

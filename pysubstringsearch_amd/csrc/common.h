@@ -62,13 +62,6 @@ struct DeviceCtx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     int ensure_staging();
-    // Auxiliary compute streams (the bucketed suffix sort runs independent batches side by side)
-    // and the events that fork them off / join them back into `stream`.
-    static constexpr int kAux = 3;
-    hipStream_t aux_stream[kAux] = {nullptr, nullptr, nullptr};
-    hipEvent_t aux_ev[kAux] = {nullptr, nullptr, nullptr};
-    hipEvent_t fork_ev = nullptr;
-    int ensure_aux(int count);
 };
 
 // Validates `device`, makes it current, returns its context (created lazily).

@@ -34,7 +34,6 @@ struct SortStats {
     double fs_ms[9] = {};
     uint64_t fs_launches[9] = {};
     uint64_t fs_elems[9] = {};
-    uint32_t batches = 0;    // bucketed suffix sort: batches of buckets the remaining digits ran in
 };
 
 // Workspace the sort needs besides the ping-pong buffers.
@@ -60,19 +59,5 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
 // receives the buffer index of the final values.
 int suffix_sort_flags(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint32_t n, int key_bits,
                       const TextKeys *text, void *work, int *dst, bool profile, SortStats *stats);
-
-// The same sort, most significant digit first: the text pass splits the suffixes into 256 buckets
-// by the top 8 key bits, the remaining digits are sorted inside the buckets, a batch of whole
-// buckets (about opt.batch_elems elements) at a time, so that a batch's ping-pong buffers stay in
-// the 256 MiB Infinity Cache between its passes.  Same contract as suffix_sort_flags (the text
-// pass writes buffer 0, the passes alternate); needs key_bits >= 16.  `desc_slot` receives the
-// range descriptors.  opt.lanes > 1 runs batches side by side on auxiliary streams.
-struct BucketedOpts {
-    uint32_t batch_elems = 1u << 22;
-    int lanes = 1;
-};
-int suffix_sort_flags_bucketed(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint32_t n, int key_bits,
-                               const TextKeys *text, void *work, DevBuf *desc_slot, const BucketedOpts &opt, int *dst,
-                               bool profile, SortStats *stats);
 
 }  // namespace pss

@@ -31,8 +31,6 @@
 // key plane shrinks from 8 to 4 to 0 bytes per element.
 //
 // HBM-bound integer work: no MFMA anywhere by design.
-#include <vector>
-
 #include "prims.h"
 #include "radix_sort.h"
 
@@ -55,19 +53,6 @@ constexpr int RS_TILE = RS_BLOCK * RS_IPT;   // 4096 pairs per tile
 #define PSS_RS_MAX_RANGES 1024
 #endif
 constexpr u32 RS_MAX_RANGES = PSS_RS_MAX_RANGES;   // <= 1024 (one thread per range in the scan / fix kernels)
-
-// Bucketed passes: a batch holds up to FSB_MAX_BUCKETS whole buckets (contiguous in the buffers);
-// every range lies inside one bucket.
-constexpr u32 FSB_MAX_BUCKETS = 16;
-struct RangeDesc {
-    u32 start, end;   // elements [start, end) of the buffers
-    u32 bucket;       // bucket of the batch the range belongs to
-    u32 pad;
-};
-struct BucketDesc {
-    u32 base;         // first element of the bucket
-    u32 gfirst;       // its first range
-};
 
 struct PassArgs {
     const u64 *kin;
@@ -95,16 +80,6 @@ struct PassArgs {
     u32 *first_z;     // [num_ranges][256] group number of its first / last element of the digit
     u32 *last_z;
     u32 *zeros;       // [num_ranges] group heads seen in the range
-    // text passes: the histogram assembles symbols [hist_off, hist_off + hist_nch) of the suffix and
-    // takes 8 bits at hist_shift; msd_low_bits > 0 makes the text pass the MOST significant digit
-    // first (bucketed sort below): sort digit = top 8 bits, the low msd_low_bits are kept
-    int hist_off, hist_nch, hist_shift;
-    int msd_low_bits;
-    // bucketed passes (fsb_*): ranges of arbitrary extent, each inside one bucket of the batch
-    const RangeDesc *ranges;     // nullptr: uniform ranges of tiles_per_range tiles
-    const BucketDesc *buckets;   // [num_buckets] of the batch
-    u32 num_buckets;
-    u32 *btotals;                // [num_buckets][256] digit counts per bucket (zero on entry to the histogram)
 };
 
 // Packs the keys of 16 consecutive suffixes i0 .. i0+15 (i0 % 16 == 0) from the
@@ -455,9 +430,10 @@ __global__ __launch_bounds__(RS_BLOCK) void fs_hist_text_kernel(PassArgs a)
     const u32 g = blockIdx.x;
     if (tid < 256) h[tid] = 0;
     __syncthreads();
-    const int b = a.code_bits;
-    const int nch = a.hist_nch;                      // symbols covering the digit (<= 26 bits of window)
-    const u32 off = (u32)a.hist_off;                 // first of them, relative to the suffix start
+    const int b = a.code_bits, k = a.key_chars;
+    int nch = (a.key_drop + 8 + b - 1) / b;          // symbols covering the digit (<= 26 bits of window)
+    if (nch > k) nch = k;
+    const u32 off = (u32)(k - nch);                  // first of them, relative to the suffix start
     const u32 wmask = (nch * b >= 32) ? ~0u : ((1u << (nch * b)) - 1u);
     const u32 tile0 = g * a.tiles_per_range;
     const u32 tile1 = min(tile0 + a.tiles_per_range, a.num_tiles);
@@ -478,7 +454,7 @@ __global__ __launch_bounds__(RS_BLOCK) void fs_hist_text_kernel(PassArgs a)
 #pragma unroll
         for (int r = 0; r < RS_IPT; ++r) {
             if (r > 0) win = ((win << b) | sym(off + (u32)nch - 1u + (u32)r)) & wmask;
-            hist_add(h, (win >> a.hist_shift) & 0xffu, i0 + r < a.n);
+            hist_add(h, (win >> a.key_drop) & 0xffu, i0 + r < a.n);
         }
     }
     __syncthreads();
@@ -527,14 +503,6 @@ __device__ __forceinline__ void fs_tile(const PassArgs &a, u32 base, u32 valid_c
         if (FULL || i0 < a.n) {
             u64 (&k16)[RS_IPT] = reinterpret_cast<u64 (&)[RS_IPT]>(key);
             text_keys16(a.codes, i0, a.code_bits, a.key_chars, a.plus_one, a.key_drop, a.n, k16);
-            if (a.msd_low_bits) {
-                // most significant digit first: rotate the top 8 bits below the low ones, so that
-                // "digit = low byte, keep key >> 8" sorts by the top digit and keeps the rest
-                const int lb = a.msd_low_bits;
-                const u64 lmask = (1ull << lb) - 1ull;
-#pragma unroll
-                for (int r = 0; r < IPT; ++r) k16[r] = ((k16[r] & lmask) << 8) | (k16[r] >> lb);
-            }
         }
 #pragma unroll
         for (int r = 0; r < IPT; ++r) {
@@ -690,27 +658,17 @@ __global__ __launch_bounds__(RS_BLOCK, PSS_RS_MINWAVES) void fs_scatter_kernel(P
         s_tz[0][tid] = 0;
     }
     for (u32 i = tid; i < RS_WAVES * 256; i += RS_BLOCK) (&wave_hist[0][0])[i] = 0;
-    u32 e0, e1;
-    if (a.ranges) {
-        // bucketed pass: the histogram and the scan have consumed the per-bucket digit totals;
-        // clear them for the next user of the region
-        if (blockIdx.x == 0)
-            for (u32 i = tid; i < a.num_buckets * 256u; i += RS_BLOCK) a.btotals[i] = 0;
-        e0 = a.ranges[g].start;
-        e1 = a.ranges[g].end;
-    } else {
-        const u32 tile0 = g * a.tiles_per_range;
-        const u32 tile1 = min(tile0 + a.tiles_per_range, a.num_tiles);
-        e0 = tile0 * (u32)RS_TILE;
-        const u32 e1_full = tile1 * (u32)RS_TILE;
-        e1 = (tile0 >= tile1) ? e0 : (e1_full < a.n ? e1_full : a.n);
-    }
-    if (e0 >= e1) {
+    const u32 tile0 = g * a.tiles_per_range;
+    const u32 tile1 = min(tile0 + a.tiles_per_range, a.num_tiles);
+    if (tile0 >= tile1) {
         if (tid < 256) a.has[(size_t)g * 256 + tid] = 0;
         if (tid == 0) a.zeros[g] = 0;
         return;
     }
     __syncthreads();
+    const u32 e0 = tile0 * (u32)RS_TILE;
+    const u32 e1_full = tile1 * (u32)RS_TILE;
+    const u32 e1 = e1_full < a.n ? e1_full : a.n;
     u32 zcarry = 0, par = 0;
     for (u32 base = e0; base < e1; base += RS_TILE, par ^= 1u) {
         const u32 left = e1 - base;
@@ -735,8 +693,7 @@ __global__ __launch_bounds__(RS_BLOCK, PSS_RS_MINWAVES) void fs_scatter_kernel(P
 // heads of the ranges in between are added (exclusive scan of zeros[]).  One workgroup per digit,
 // one thread per range.
 __global__ __launch_bounds__(1024) void fs_fix_kernel(const u32 *first_z, const u32 *last_z, const u32 *has,
-                                                        const u32 *zeros, const u32 *table, u32 num_ranges, u32 *vout,
-                                                        const RangeDesc *ranges)
+                                                        const u32 *zeros, const u32 *table, u32 num_ranges, u32 *vout)
 {
     __shared__ u32 s_wave[16], s_zw[16];
     __shared__ u32 s_base[1024];
@@ -755,85 +712,8 @@ __global__ __launch_bounds__(1024) void fs_fix_kernel(const u32 *first_z, const 
     __syncthreads();
     if (mine && prev1) {
         const u32 gp = prev1 - 1;
-        // bucketed pass: a predecessor in another bucket is no predecessor (ranges of a bucket are
-        // consecutive, so the nearest earlier range with the digit decides)
-        const bool same_bucket = ranges == nullptr || ranges[gp].bucket == ranges[g].bucket;
-        if (same_bucket && last_z[(size_t)gp * 256 + d] + s_base[gp] == first_z[(size_t)g * 256 + d] + zb)
+        if (last_z[(size_t)gp * 256 + d] + s_base[gp] == first_z[(size_t)g * 256 + d] + zb)
             vout[table[d * num_ranges + g]] |= 0x80000000u;
-    }
-}
-
-// =====================================================================================
-// Bucketed initial suffix sort (suffix_sort_flags_bucketed): most significant digit first, then
-// the remaining digits bucket by bucket.
-//
-// A scatter pass whose ping-pong buffers fit the 256 MiB Infinity Cache runs 1.6x faster than
-// one that streams from HBM (tools/cache_micro.py: 4.0 vs 2.5 TB/s on (u64, u32) pairs).  So the
-// text pass sorts by the TOP 8 bits of the key (256 buckets, contiguous in the output), and the
-// remaining passes run least significant digit first INSIDE the buckets, a batch of whole buckets
-// (a few million elements) at a time: hist -> scan -> scatter -> fix per batch and pass, all
-// passes of a batch back to back so that its data never leaves the cache in between.
-// The flag algebra is the one above; a bucket is a closed world (its first element has no
-// predecessor, offsets restart at the bucket's base, fs_fix never links two buckets).
-// =====================================================================================
-
-// digit histogram (low 8 bits) of the key plane over the range's elements; KB = bytes per key
-template <int KB>
-__global__ __launch_bounds__(RS_BLOCK) void fsb_hist_kernel(PassArgs a)
-{
-    __shared__ u32 h[256];
-    const u32 tid = threadIdx.x;
-    const u32 g = blockIdx.x;
-    h[tid] = 0;
-    __syncthreads();
-    const RangeDesc rd = a.ranges[g];
-    constexpr u32 U = 8;
-    for (u32 base = rd.start; base < rd.end; base += U * RS_BLOCK) {
-        u32 d[U];
-#pragma unroll
-        for (u32 j = 0; j < U; ++j) {
-            const u32 i = base + j * RS_BLOCK + tid;
-            d[j] = 0;
-            if (i < rd.end) d[j] = KB == 4 ? a.kin32[i] & 0xffu : (u32)a.kin[i] & 0xffu;
-        }
-#pragma unroll
-        for (u32 j = 0; j < U; ++j) hist_add(h, d[j], base + j * RS_BLOCK + tid < rd.end);
-    }
-    __syncthreads();
-    const u32 c = h[tid];
-    a.table[tid * a.num_ranges + g] = c;
-    if (c) atomicAdd(&a.btotals[rd.bucket * 256u + tid], c);
-}
-
-// table[d][g] -> global offset of (digit d, range g): bucket base + the bucket's elements with a
-// smaller digit + the elements of digit d in the bucket's earlier ranges.  One workgroup per digit.
-__global__ __launch_bounds__(256) void fsb_scan_kernel(PassArgs a)
-{
-    __shared__ u32 s_x[RS_MAX_RANGES + 8];
-    __shared__ u32 s_bbase[FSB_MAX_BUCKETS];
-    __shared__ u32 scr[4 + 1];
-    const u32 tid = threadIdx.x, d = blockIdx.x;
-    const u32 num_ranges = a.num_ranges;
-    if (tid < FSB_MAX_BUCKETS) s_bbase[tid] = tid < a.num_buckets ? a.buckets[tid].base : 0u;
-    __syncthreads();
-    for (u32 b = 0; b < a.num_buckets; ++b) {
-        const u32 v = wave_incl_sum(tid < d ? a.btotals[b * 256u + tid] : 0u);
-        if ((tid & 63u) == 63u && v) atomicAdd(&s_bbase[b], v);
-    }
-    const u32 per = (num_ranges + 255) / 256;
-    u32 *row = a.table + (size_t)d * num_ranges;
-    const u32 i0 = min(tid * per, num_ranges), i1 = min(i0 + per, num_ranges);
-    u32 local = 0;
-    for (u32 i = i0; i < i1; ++i) local += row[i];
-    u32 run = block_excl_sum<4>(local, scr, nullptr);     // its barriers also publish s_bbase
-    for (u32 i = i0; i < i1; ++i) {
-        s_x[i] = run;
-        run += row[i];
-    }
-    __syncthreads();
-    for (u32 i = i0; i < i1; ++i) {
-        const u32 b = a.ranges[i].bucket;
-        row[i] = s_bbase[b] + s_x[i] - s_x[a.buckets[b].gfirst];
     }
 }
 
@@ -879,28 +759,11 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_small_sort_kernel(u64 *keys, u32 
     }
 }
 
-// One lane of workspace: digit table + 16 totals rows + the (first_z, last_z, has) tables and
-// zeros[] of the fs passes + the per-bucket digit totals of the bucketed passes.  Lane 0 is what
-// every sort uses; lanes 1.. serve the auxiliary streams of the bucketed suffix sort.
-static constexpr size_t kLaneTable = (size_t)256 * RS_MAX_RANGES * 4;
-static constexpr size_t kLaneBytes = kLaneTable + 256 * 4 * 16 + kLaneTable * 3 + RS_MAX_RANGES * 4 + FSB_MAX_BUCKETS * 256 * 4;
-struct Lane {
-    u32 *table, *totals, *first_z, *last_z, *has, *zeros, *btotals;
-    hipStream_t stream;
-    explicit Lane(void *work, int k, hipStream_t s) : stream(s)
-    {
-        u8 *base = static_cast<u8 *>(work) + (size_t)k * kLaneBytes;
-        table = reinterpret_cast<u32 *>(base);
-        totals = table + (size_t)256 * RS_MAX_RANGES;
-        first_z = totals + 256 * 16;
-        last_z = first_z + (size_t)256 * RS_MAX_RANGES;
-        has = last_z + (size_t)256 * RS_MAX_RANGES;
-        zeros = has + (size_t)256 * RS_MAX_RANGES;
-        btotals = zeros + RS_MAX_RANGES;
-    }
-};
-
-size_t radix_sort_workspace_bytes() { return kLaneBytes * (1 + DeviceCtx::kAux); }
+size_t radix_sort_workspace_bytes()
+{
+    // digit table + 16 totals rows + the (has, first_z, last_z) tables and zeros[] of the fs passes
+    return (size_t)256 * RS_MAX_RANGES * 4 + 256 * 4 * 16 + (size_t)256 * RS_MAX_RANGES * 12 + RS_MAX_RANGES * 4;
+}
 
 int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint32_t n, int key_bits,
                      uint32_t pass_mask, const TextKeys *text, int src, void *work, int *dst,
@@ -939,7 +802,6 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
     for (int p = 0; p < passes; ++p) {
         if (!((pass_mask >> p) & 1u)) continue;
         PassArgs a;
-        memset(&a, 0, sizeof a);
         a.n = n;
         a.num_tiles = num_tiles;
         a.tiles_per_range = tpr;
@@ -1059,12 +921,6 @@ int suffix_sort_flags(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint
             a.key_chars = text->key_chars;
             a.plus_one = text->plus_one;
             a.key_drop = text->drop;
-            // the symbols that reach into bits [drop, drop + 8) of the packed key
-            int nch = (text->drop + 8 + text->code_bits - 1) / text->code_bits;
-            if (nch > text->key_chars) nch = text->key_chars;
-            a.hist_nch = nch;
-            a.hist_off = text->key_chars - nch;
-            a.hist_shift = text->drop;
         } else {
             a.kin = keys[cur];
             a.kin32 = reinterpret_cast<const u32 *>(keys[cur]);
@@ -1094,7 +950,7 @@ int suffix_sort_flags(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint
         }
         if (profile && (nev & 1)) PSS_HIP(hipEventRecord(ev[nev++], ctx->stream));
         hipLaunchKernelGGL(fs_fix_kernel, dim3(256), dim3(1024), 0, ctx->stream, first_z, last_z, has, zeros, table,
-                           num_ranges, a.vout, (const RangeDesc *)nullptr);
+                           num_ranges, a.vout);
         PSS_HIP(hipGetLastError());
         cur = out;
         kin = kout;
@@ -1118,264 +974,6 @@ int suffix_sort_flags(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint
     }
     for (int i = 0; i < nev_created; ++i) (void)hipEventDestroy(ev[i]);
     *dst = cur;
-    return PSS_OK;
-}
-
-
-template <int KIN, int KOUT> static void launch_fs_scatter(const PassArgs &a, dim3 grid, hipStream_t st)
-{
-    hipLaunchKernelGGL((fs_scatter_kernel<KIN, KOUT>), grid, dim3(RS_BLOCK), 0, st, a);
-}
-static int launch_fs_scatter_dyn(int kin, int kout, const PassArgs &a, dim3 grid, hipStream_t st)
-{
-    if (kin == 0 && kout == 8) launch_fs_scatter<0, 8>(a, grid, st);
-    else if (kin == 0 && kout == 4) launch_fs_scatter<0, 4>(a, grid, st);
-    else if (kin == 8 && kout == 8) launch_fs_scatter<8, 8>(a, grid, st);
-    else if (kin == 8 && kout == 4) launch_fs_scatter<8, 4>(a, grid, st);
-    else if (kin == 4 && kout == 4) launch_fs_scatter<4, 4>(a, grid, st);
-    else if (kin == 4 && kout == 0) launch_fs_scatter<4, 0>(a, grid, st);
-    else {
-        set_error("suffix sort: no kernel for key planes %d -> %d", kin, kout);
-        return PSS_EINVAL;
-    }
-    return PSS_OK;
-}
-
-int suffix_sort_flags_bucketed(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint32_t n, int key_bits,
-                               const TextKeys *text, void *work, DevBuf *desc_slot, const BucketedOpts &opt, int *dst,
-                               bool profile, SortStats *stats)
-{
-    if (key_bits < 16 || text == nullptr || n == 0) {
-        set_error("suffix_sort_flags_bucketed: needs a text source, n > 0 and at least 16 key bits");
-        return PSS_EINVAL;
-    }
-    const int low_bits = key_bits - 8;
-    const int in_passes = (low_bits + 7) / 8;
-    int lanes = opt.lanes < 1 ? 1 : (opt.lanes > 1 + DeviceCtx::kAux ? 1 + DeviceCtx::kAux : opt.lanes);
-    if (profile) lanes = 1;      // per-kernel times are only meaningful when nothing runs beside the kernel
-    PSS_TRY(ctx->ensure_aux(lanes > 1 ? lanes - 1 : 1));   // aux stream 0 also carries the descriptor upload
-    hipStream_t s = ctx->stream;
-    Lane lane0(work, 0, s);
-
-    // ---- pass 0: the text, most significant digit first (uniform ranges) ----
-    const u32 num_tiles = (u32)(((u64)n + RS_TILE - 1) / RS_TILE);
-    const u32 tpr0 = (num_tiles + RS_MAX_RANGES - 1) / RS_MAX_RANGES;
-    u32 num_ranges0 = (num_tiles + tpr0 - 1) / tpr0;
-    num_ranges0 = (num_ranges0 + 7u) & ~7u;
-    PSS_HIP(hipMemsetAsync(lane0.totals, 0, 256 * 4, s));
-
-    std::vector<hipEvent_t> ev;
-    std::vector<int> ev_idx;
-    std::vector<u32> ev_elems;
-    struct EvGuard {
-        std::vector<hipEvent_t> &v;
-        ~EvGuard() { for (hipEvent_t e : v) (void)hipEventDestroy(e); }
-    } ev_guard{ev};
-    size_t nev = 0;
-
-    const int kout = low_bits > 32 ? 8 : 4;
-    {
-        PassArgs a;
-        memset(&a, 0, sizeof a);
-        a.n = n;
-        a.num_tiles = num_tiles;
-        a.tiles_per_range = tpr0;
-        a.num_ranges = num_ranges0;
-        a.table = lane0.table;
-        a.totals = lane0.totals;
-        a.first_z = lane0.first_z;
-        a.last_z = lane0.last_z;
-        a.has = lane0.has;
-        a.zeros = lane0.zeros;
-        a.codes = text->codes;
-        a.code_bits = text->code_bits;
-        a.key_chars = text->key_chars;
-        a.plus_one = text->plus_one;
-        a.key_drop = text->drop;
-        a.msd_low_bits = low_bits;
-        a.hist_nch = (8 + text->code_bits - 1) / text->code_bits;    // symbols covering the top 8 bits
-        a.hist_off = 0;
-        a.hist_shift = a.hist_nch * text->code_bits - 8;
-        a.kout = keys[0];
-        a.kout32 = reinterpret_cast<u32 *>(keys[0]);
-        a.vout = vals[0];
-        const dim3 grid(num_ranges0), block(RS_BLOCK);
-        hipLaunchKernelGGL(fs_hist_text_kernel, grid, block, 0, s, a);
-        u32 *h_totals = reinterpret_cast<u32 *>(static_cast<u8 *>(ctx->pinned) + 49152);
-        PSS_HIP(hipMemcpyAsync(h_totals, lane0.totals, 256 * 4, hipMemcpyDeviceToHost, s));
-        PSS_HIP(hipEventRecord(ctx->fork_ev, s));
-        hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(256), 0, s, a.table, a.totals, num_ranges0);
-        if (profile) {
-            // batches * passes is not known yet: the events of the bucket passes are created after the
-            // totals have arrived (the text scatter is running then, nothing idles)
-            ev.resize(2);
-            PSS_HIP(hipEventCreate(&ev[0]));
-            PSS_HIP(hipEventCreate(&ev[1]));
-            PSS_HIP(hipEventRecord(ev[nev++], s));
-        }
-        PSS_TRY(launch_fs_scatter_dyn(0, kout, a, grid, s));
-        if (profile) {
-            PSS_HIP(hipEventRecord(ev[nev++], s));
-            ev_idx.push_back(kout / 4);
-            ev_elems.push_back(n);
-        }
-        hipLaunchKernelGGL(fs_fix_kernel, dim3(256), dim3(1024), 0, s, lane0.first_z, lane0.last_z, lane0.has, lane0.zeros,
-                           lane0.table, num_ranges0, a.vout, (const RangeDesc *)nullptr);
-        PSS_HIP(hipGetLastError());
-        if (stats) {
-            stats->launches += 1;
-            stats->elems += n;
-        }
-
-        // ---- buckets -> batches of whole buckets -> ranges (host, while the text scatter runs) ----
-        PSS_HIP(hipEventSynchronize(ctx->fork_ev));
-        struct Batch { u32 r0, nr, b0, nb, elems; };
-        std::vector<Batch> batches;
-        std::vector<RangeDesc> ranges;
-        std::vector<BucketDesc> buckets;
-        const u32 target = opt.batch_elems < (u32)RS_TILE ? (u32)RS_TILE : opt.batch_elems;
-        u32 base = 0;
-        int d = 0;
-        while (d < 256) {
-            // gather consecutive non-empty buckets
-            u32 bb[FSB_MAX_BUCKETS], bc[FSB_MAX_BUCKETS], nb = 0;
-            u64 elems = 0;
-            while (d < 256 && nb < FSB_MAX_BUCKETS && (nb == 0 || elems + h_totals[d] <= target)) {
-                const u32 c = h_totals[d++];
-                if (c == 0) continue;
-                bb[nb] = base;
-                bc[nb] = c;
-                ++nb;
-                base += c;
-                elems += c;
-            }
-            if (nb == 0) continue;
-            const u64 tiles = (elems + RS_TILE - 1) / RS_TILE;
-            u32 tpr = (u32)((tiles + 999) / 1000);
-            if (tpr < 1) tpr = 1;
-            for (;; ++tpr) {
-                u64 nr = 0;
-                for (u32 i = 0; i < nb; ++i) nr += ((u64)bc[i] + (u64)tpr * RS_TILE - 1) / ((u64)tpr * RS_TILE);
-                if (nr <= RS_MAX_RANGES - 8) break;
-            }
-            Batch bt;
-            bt.r0 = (u32)ranges.size();
-            bt.b0 = (u32)buckets.size();
-            bt.nb = nb;
-            bt.elems = (u32)elems;
-            const u32 step = tpr * (u32)RS_TILE;
-            for (u32 i = 0; i < nb; ++i) {
-                buckets.push_back(BucketDesc{bb[i], (u32)ranges.size() - bt.r0});
-                const u32 end = bb[i] + bc[i];              // n < 2^31: no overflow
-                for (u32 st = bb[i]; st < end;) {
-                    const u32 e = (end - st > step) ? st + step : end;
-                    ranges.push_back(RangeDesc{st, e, i, 0});
-                    st = e;
-                }
-            }
-            while ((ranges.size() - bt.r0) & 7u) ranges.push_back(RangeDesc{base, base, nb - 1, 0});
-            bt.nr = (u32)ranges.size() - bt.r0;
-            batches.push_back(bt);
-        }
-        if (base != n) {
-            set_error("suffix_sort_flags_bucketed: bucket totals %u != n %u (internal error)", base, n);
-            return PSS_EDEVICE;
-        }
-        const size_t rbytes = ranges.size() * sizeof(RangeDesc), bbytes = buckets.size() * sizeof(BucketDesc);
-        PSS_TRY(desc_slot->reserve(rbytes + bbytes + 256));
-        RangeDesc *d_ranges = desc_slot->as<RangeDesc>();
-        BucketDesc *d_buckets = reinterpret_cast<BucketDesc *>(desc_slot->as<u8>() + rbytes);
-        // upload beside the running text scatter (its stream would queue the copy behind it)
-        PSS_HIP(hipMemcpyAsync(d_ranges, ranges.data(), rbytes, hipMemcpyHostToDevice, ctx->aux_stream[0]));
-        PSS_HIP(hipMemcpyAsync(d_buckets, buckets.data(), bbytes, hipMemcpyHostToDevice, ctx->aux_stream[0]));
-        PSS_HIP(hipStreamSynchronize(ctx->aux_stream[0]));
-
-        if (profile) {
-            const size_t want = 2 + 2 * batches.size() * (size_t)in_passes;
-            ev.resize(want, nullptr);
-            for (size_t i = 2; i < want; ++i) PSS_HIP(hipEventCreate(&ev[i]));
-        }
-
-        // ---- the remaining digits, batch by batch ----
-        std::vector<Lane> L;
-        L.emplace_back(work, 0, s);
-        for (int k = 1; k < lanes; ++k) L.emplace_back(work, k, ctx->aux_stream[k - 1]);
-        for (int k = 0; k < lanes; ++k) PSS_HIP(hipMemsetAsync(L[k].btotals, 0, FSB_MAX_BUCKETS * 256 * 4, L[k].stream));
-        if (lanes > 1) {
-            PSS_HIP(hipEventRecord(ctx->fork_ev, s));
-            for (int k = 1; k < lanes; ++k) PSS_HIP(hipStreamWaitEvent(L[k].stream, ctx->fork_ev, 0));
-        }
-        const int kout0 = kout;
-        for (size_t bi = 0; bi < batches.size(); ++bi) {
-            const Batch &bt = batches[bi];
-            const Lane &ln = L[bi % (size_t)lanes];
-            int bkin = kout0, cur = 0;
-            for (int j = 1; j <= in_passes; ++j) {
-                const int rem = low_bits - 8 * j;
-                const int bkout = rem <= 0 ? 0 : (rem <= 32 ? 4 : 8);
-                const int out = cur ^ 1;
-                PassArgs q;
-                memset(&q, 0, sizeof q);
-                q.n = n;
-                q.num_ranges = bt.nr;
-                q.table = ln.table;
-                q.first_z = ln.first_z;
-                q.last_z = ln.last_z;
-                q.has = ln.has;
-                q.zeros = ln.zeros;
-                q.btotals = ln.btotals;
-                q.ranges = d_ranges + bt.r0;
-                q.buckets = d_buckets + bt.b0;
-                q.num_buckets = bt.nb;
-                q.kin = keys[cur];
-                q.kin32 = reinterpret_cast<const u32 *>(keys[cur]);
-                q.vin = vals[cur];
-                q.kout = keys[out];
-                q.kout32 = reinterpret_cast<u32 *>(keys[out]);
-                q.vout = vals[out];
-                const dim3 bgrid(bt.nr);
-                if (bkin == 8) hipLaunchKernelGGL(fsb_hist_kernel<8>, bgrid, block, 0, ln.stream, q);
-                else hipLaunchKernelGGL(fsb_hist_kernel<4>, bgrid, block, 0, ln.stream, q);
-                hipLaunchKernelGGL(fsb_scan_kernel, dim3(256), dim3(256), 0, ln.stream, q);
-                if (profile) PSS_HIP(hipEventRecord(ev[nev++], ln.stream));
-                PSS_TRY(launch_fs_scatter_dyn(bkin, bkout, q, bgrid, ln.stream));
-                if (profile) {
-                    PSS_HIP(hipEventRecord(ev[nev++], ln.stream));
-                    ev_idx.push_back((bkin / 4) * 3 + bkout / 4);
-                    ev_elems.push_back(bt.elems);
-                }
-                hipLaunchKernelGGL(fs_fix_kernel, dim3(256), dim3(1024), 0, ln.stream, ln.first_z, ln.last_z, ln.has, ln.zeros,
-                                   ln.table, bt.nr, q.vout, q.ranges);
-                cur = out;
-                bkin = bkout;
-            }
-            PSS_HIP(hipGetLastError());
-        }
-        for (int k = 1; k < lanes; ++k) {
-            PSS_HIP(hipEventRecord(ctx->aux_ev[k - 1], L[k].stream));
-            PSS_HIP(hipStreamWaitEvent(s, ctx->aux_ev[k - 1], 0));
-        }
-        if (stats) {
-            stats->launches += (u64)in_passes;
-            stats->elems += (u64)n * in_passes;
-            stats->batches = (u32)batches.size();
-        }
-    }
-    if (nev) {
-        PSS_HIP(hipStreamSynchronize(s));
-        for (size_t i = 0; i + 1 < nev; i += 2) {
-            float ms = 0.f;
-            PSS_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
-            if (stats) {
-                const int idx = ev_idx[i / 2];
-                stats->ms += ms;
-                stats->fs_ms[idx] += ms;
-                stats->fs_launches[idx] += 1;
-                stats->fs_elems[idx] += ev_elems[i / 2];
-            }
-        }
-    }
-    *dst = in_passes & 1;
     return PSS_OK;
 }
 

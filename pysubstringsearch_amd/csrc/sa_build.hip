@@ -923,7 +923,7 @@ static void rerank_geometry(u32 m, RerankArgs &a)
     a.num_ranges = (a.num_tiles + a.tiles_per_range - 1) / a.tiles_per_range;
 }
 
-enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK, S_DESC = 23, S_GRP2 = 26, S_BIG = 27, S_SCR = 29 };
+enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK, S_GRP2 = 26, S_BIG = 27, S_SCR = 29 };
 
 // Initial key width.  Model the text as i.i.d. with per-symbol collision
 // probability c = sum p_i^2 (from the sampled counts): two suffixes agree on k
@@ -965,10 +965,6 @@ struct Knobs {
     int mode = -1;              // PSS_MODE       dense / sparse / text tie resolution (-1 = choose)
     int text_rounds_max = 5;    // PSS_TEXT_ROUNDS
     bool timing = false;        // PSS_TIMING     per-round trace on stderr
-    u32 bucket_min_n = 1u << 25;   // PSS_BUCKET_MIN_N   initial sort runs bucket by bucket (most significant digit
-                                   //                    first) from this many suffixes on; 0 = never
-    u32 batch_elems = 1u << 22;    // PSS_BATCH_ELEMS    elements per batch of buckets
-    int lanes = 1;                 // PSS_SORT_LANES     batches side by side (streams)
     static Knobs read()
     {
         Knobs k;
@@ -983,9 +979,6 @@ struct Knobs {
         }
         if (const char *e = getenv("PSS_TEXT_ROUNDS")) k.text_rounds_max = atoi(e);
         k.timing = getenv("PSS_TIMING") != nullptr;
-        if (const char *e = getenv("PSS_BUCKET_MIN_N")) k.bucket_min_n = (u32)strtoul(e, nullptr, 0);
-        if (const char *e = getenv("PSS_BATCH_ELEMS")) k.batch_elems = (u32)strtoul(e, nullptr, 0);
-        if (const char *e = getenv("PSS_SORT_LANES")) k.lanes = atoi(e);
         return k;
     }
 };
@@ -1146,14 +1139,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     // the last pass writes only the suffix indices with bit 31 = "tied with my predecessor", and
     // the rerank reads 4-byte flagged values instead of comparing 8-byte keys.
     const bool ties = passes0 >= 2 && !knobs.no_flags;
-    const bool bucketed = ties && key_bits0 >= 16 && knobs.bucket_min_n != 0 && n >= knobs.bucket_min_n;
-    if (bucketed) {
-        BucketedOpts bo;
-        bo.batch_elems = knobs.batch_elems;
-        bo.lanes = knobs.lanes;
-        PSS_TRY(suffix_sort_flags_bucketed(ctx, K, V, n, key_bits0, &tk, work, &ctx->slot[S_DESC], bo, &cur, profile, &ss));
-        st.sort_batches = ss.batches;
-    } else if (ties) PSS_TRY(suffix_sort_flags(ctx, K, V, n, key_bits0, &tk, work, &cur, profile, &ss));
+    if (ties) PSS_TRY(suffix_sort_flags(ctx, K, V, n, key_bits0, &tk, work, &cur, profile, &ss));
     else PSS_TRY(radix_sort_pairs(ctx, K, V, n, key_bits0, 0xffffffffu, &tk, 0, work, &cur, profile, &ss));
     st.initial_passes = (u32)ss.launches;
     const bool sa_in_place = (cur == final_buf);

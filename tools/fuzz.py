@@ -73,8 +73,7 @@ def build(path, entries, limit, W):
     return open(path, 'rb').read()
 
 
-KNOBS = ('PSS_MODE', 'PSS_KEY_CHARS', 'PSS_KEY_DROP', 'PSS_TEXT_ROUNDS', 'PSS_NO_TIES_PASS', 'PSS_NO_SMALL_PATH',
-         'PSS_BUCKET_MIN_N', 'PSS_BATCH_ELEMS', 'PSS_SORT_LANES')
+KNOBS = ('PSS_MODE', 'PSS_KEY_CHARS', 'PSS_KEY_DROP', 'PSS_TEXT_ROUNDS', 'PSS_NO_TIES_PASS', 'PSS_NO_SMALL_PATH')
 
 
 def random_knobs(rng):
@@ -95,11 +94,6 @@ def random_knobs(rng):
         os.environ['PSS_NO_TIES_PASS'] = '1'
     if rng.random() < 0.5:
         os.environ['PSS_NO_SMALL_PATH'] = '1'
-    if rng.random() < 0.6:
-        # initial sort bucket by bucket (normally only from 2^25 suffixes on), tiny batches, 1-4 streams
-        os.environ['PSS_BUCKET_MIN_N'] = '1'
-        os.environ['PSS_BATCH_ELEMS'] = str(rng.choice([1, 100, 4096, 20000, 1 << 22]))
-        os.environ['PSS_SORT_LANES'] = str(rng.randint(1, 4))
 
 
 def file_case(rng, tmp):
