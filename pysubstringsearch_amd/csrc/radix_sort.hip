@@ -310,6 +310,9 @@ __device__ __forceinline__ void scatter_tile(const PassArgs &a, u32 base, u32 va
         }
     }
     __syncthreads();
+#ifdef PSS_EXPERIMENT_NO_VALUES
+    return;                          // timing experiment only (wrong output): the key plane alone
+#endif
     u32 *exv = reinterpret_cast<u32 *>(exch);
     if (!FROM_TEXT) {
 #pragma unroll
