@@ -224,7 +224,8 @@ class OracleReader:
         if n:
             off = L.orc_result_offsets(res)
             base = L.orc_result_bytes(res)
-            blob = ctypes.string_at(base, off[n])
+            # not ctypes.string_at: its size argument is a C int (results beyond 2 GiB)
+            blob = bytes((ctypes.c_char * off[n]).from_address(ctypes.cast(base, ctypes.c_void_p).value)) if off[n] else b''
             out = [blob[off[i]:off[i + 1]] for i in range(n)]
         L.orc_result_free(res)
         return out

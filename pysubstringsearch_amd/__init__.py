@@ -216,7 +216,9 @@ class Reader:
                     entries = _pssglue.entries_to_list(ctypes.cast(base, ctypes.c_void_p).value,
                                                        ctypes.cast(off, ctypes.c_void_p).value, n, as_str)
                 else:
-                    data = ctypes.string_at(base, off[n])
+                    # not ctypes.string_at: its size argument is a C int (results beyond 2 GiB)
+                    addr = ctypes.cast(base, ctypes.c_void_p).value
+                    data = bytes((ctypes.c_char * off[n]).from_address(addr)) if off[n] else b''
                     o = off[:n + 1]
                     entries = [data[o[i]:o[i + 1]] for i in range(n)]
                     if as_str:

@@ -614,21 +614,41 @@ struct pss_result {
 
 namespace {
 
-int reader_alloc_chunk(pss_reader *r, uint32_t n, void **d_text, void **d_sa)
+// Text (zero padded) and suffix array of one chunk; the key-sample table (search.h) lives behind
+// the suffix array in the same allocation.
+int reader_alloc_chunk(pss_reader *r, uint32_t n, ChunkDesc *out)
 {
     PSS_HIP(hipSetDevice(r->device));
-    *d_text = nullptr;
-    *d_sa = nullptr;
-    hipError_t e = hipMalloc(d_text, (size_t)n + 32);
-    if (e == hipSuccess) e = hipMalloc(d_sa, (size_t)n * 4 + 16);
+    void *d_text = nullptr, *d_sa = nullptr;
+    const size_t sa_bytes = round_up((size_t)n * 4 + 16, 8);
+    const bool samples = getenv("PSS_NO_KEY_SAMPLES") == nullptr;
+    uint32_t shift = kSampleShift;
+    if (const char *ev = getenv("PSS_SAMPLE_SHIFT")) {      // tests: dense tables on small chunks
+        const int v = atoi(ev);
+        if (v >= 0 && v <= 20) shift = (uint32_t)v;
+    }
+    hipError_t e = hipMalloc(&d_text, (size_t)n + 32);
+    if (e == hipSuccess) e = hipMalloc(&d_sa, sa_bytes + (samples ? sample_count(n, shift) * 8 : 0));
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        if (*d_text) (void)hipFree(*d_text);
+        if (d_text) (void)hipFree(d_text);
         set_error("hipMalloc of a %u-byte chunk failed: %s", n, hipGetErrorString(e));
         return PSS_ENOMEM;
     }
-    PSS_HIP(hipMemsetAsync(static_cast<uint8_t *>(*d_text) + n, 0, 32, r->ctx->stream));
+    PSS_HIP(hipMemsetAsync(static_cast<uint8_t *>(d_text) + n, 0, 32, r->ctx->stream));
+    out->text = static_cast<uint8_t *>(d_text);
+    out->sa = static_cast<uint32_t *>(d_sa);
+    out->skeys = samples ? reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(d_sa) + sa_bytes) : nullptr;
+    out->n = n;
+    out->shift = shift;
     return PSS_OK;
+}
+
+// (Re)builds the key samples of a chunk whose text and suffix array are in place (stream-ordered).
+int reader_sample_chunk(pss_reader *r, const ChunkDesc &c)
+{
+    if (!c.skeys) return PSS_OK;
+    return build_key_samples(r->ctx, c.text, c.sa, c.n, c.shift, const_cast<uint64_t *>(c.skeys));
 }
 
 void reader_free(pss_reader *r)
@@ -737,12 +757,12 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
             if (fread(hdr, 1, 4, fp) != 4) { set_error("failed to fill whole buffer (truncated index file)"); rc = PSS_EFORMAT; break; }
             const uint32_t dlen = (uint32_t)hdr[0] | (uint32_t)hdr[1] << 8 | (uint32_t)hdr[2] << 16 | (uint32_t)hdr[3] << 24;
             const bool mine = (index % shard_count) == shard_index;
-            void *d_text = nullptr, *d_sa = nullptr;
+            ChunkDesc cd{};
             if (mine && dlen) {
-                rc = reader_alloc_chunk(r, dlen, &d_text, &d_sa);
+                rc = reader_alloc_chunk(r, dlen, &cd);
                 if (rc) break;
-                r->chunks.push_back(ChunkDesc{static_cast<uint8_t *>(d_text), static_cast<uint32_t *>(d_sa), dlen, 0});
-                rc = upload_from_file(r, fp, d_text, dlen);
+                r->chunks.push_back(cd);
+                rc = upload_from_file(r, fp, const_cast<uint8_t *>(cd.text), dlen);
                 if (rc) break;
             } else if (fseeko(fp, dlen, SEEK_CUR) != 0) { rc = io_error(path); break; }
             if (fread(hdr, 1, 4, fp) != 4) { set_error("failed to fill whole buffer (truncated index file)"); rc = PSS_EFORMAT; break; }
@@ -753,7 +773,9 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
                 break;
             }
             if (mine && dlen) {
-                rc = upload_from_file(r, fp, d_sa, (size_t)dlen * 4);
+                rc = upload_from_file(r, fp, const_cast<uint32_t *>(cd.sa), (size_t)dlen * 4);
+                if (rc) break;
+                rc = reader_sample_chunk(r, cd);     // uploads are complete (copy stream synchronised)
                 if (rc) break;
             } else {
                 if (bytes_read + 8 + dlen + (uint64_t)slen > flen) { set_error("failed to fill whole buffer (truncated index file)"); rc = PSS_EFORMAT; break; }
@@ -761,6 +783,10 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
             }
             bytes_read += 8 + (uint64_t)dlen + slen;   // lib.rs:184
             ++index;
+        }
+        if (rc == PSS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            set_error("key samples: %s", hipGetErrorString(hipGetLastError()));
+            rc = PSS_EDEVICE;
         }
         if (rc == PSS_OK) rc = reader_sync_descs(r);
         if (rc != PSS_OK) {
@@ -778,11 +804,12 @@ extern "C" int pss_reader_add_chunk_device(pss_reader *r, const void *d_text, co
         if (!r || (n && (!d_text || !d_sa))) return PSS_EINVAL;
         if (n == 0) return PSS_OK;
         std::lock_guard<std::recursive_mutex> lk(r->ctx->mu);
-        void *t = nullptr, *s = nullptr;
-        PSS_TRY(reader_alloc_chunk(r, n, &t, &s));
-        r->chunks.push_back(ChunkDesc{static_cast<uint8_t *>(t), static_cast<uint32_t *>(s), n, 0});
-        PSS_HIP(hipMemcpyAsync(t, d_text, n, hipMemcpyDeviceToDevice, r->ctx->stream));
-        PSS_HIP(hipMemcpyAsync(s, d_sa, (size_t)n * 4, hipMemcpyDeviceToDevice, r->ctx->stream));
+        ChunkDesc cd{};
+        PSS_TRY(reader_alloc_chunk(r, n, &cd));
+        r->chunks.push_back(cd);
+        PSS_HIP(hipMemcpyAsync(const_cast<uint8_t *>(cd.text), d_text, n, hipMemcpyDeviceToDevice, r->ctx->stream));
+        PSS_HIP(hipMemcpyAsync(const_cast<uint32_t *>(cd.sa), d_sa, (size_t)n * 4, hipMemcpyDeviceToDevice, r->ctx->stream));
+        PSS_TRY(reader_sample_chunk(r, cd));
         PSS_HIP(hipStreamSynchronize(r->ctx->stream));
         r->dirty = true;
         return reader_sync_descs(r);
@@ -801,15 +828,16 @@ extern "C" int pss_reader_set_chunk_device(pss_reader *r, uint64_t index, const 
         if (index == r->chunks.size()) return pss_reader_add_chunk_device(r, d_text, d_sa, n);
         ChunkDesc &c = r->chunks[index];
         if (c.n != n) {   // different size: fresh allocation
-            void *t = nullptr, *sa = nullptr;
-            PSS_TRY(reader_alloc_chunk(r, n, &t, &sa));
+            ChunkDesc fresh{};
+            PSS_TRY(reader_alloc_chunk(r, n, &fresh));
             (void)hipFree(const_cast<uint8_t *>(c.text));
             (void)hipFree(const_cast<uint32_t *>(c.sa));
-            c = ChunkDesc{static_cast<uint8_t *>(t), static_cast<uint32_t *>(sa), n, 0};
+            c = fresh;
             r->dirty = true;
         }
         PSS_HIP(hipMemcpyAsync(const_cast<uint8_t *>(c.text), d_text, n, hipMemcpyDeviceToDevice, r->ctx->stream));
         PSS_HIP(hipMemcpyAsync(const_cast<uint32_t *>(c.sa), d_sa, (size_t)n * 4, hipMemcpyDeviceToDevice, r->ctx->stream));
+        PSS_TRY(reader_sample_chunk(r, c));
         PSS_HIP(hipStreamSynchronize(r->ctx->stream));
         return reader_sync_descs(r);
     });

@@ -4,14 +4,26 @@
 
 namespace pss {
 
-// One resident chunk: text (n bytes, readable 16 bytes past the end) and its
-// suffix array (n x u32), both in HBM.
+// One resident chunk: text (n bytes, zero padded and readable 32 bytes past the end), its
+// suffix array (n x u32) and a table of key samples: skeys[j] = the first 8 bytes of suffix
+// sa[j << shift] as a big-endian integer (ceil(n / 2^shift) entries, nullptr = none).  The
+// keys are non-decreasing along the suffix array, so two searches in the small table (L2
+// resident) confine a query to a window of one or two strides before the suffix array and
+// the text are touched.
 struct ChunkDesc {
     const uint8_t *text;
     const uint32_t *sa;
+    const uint64_t *skeys;
     uint32_t n;
-    uint32_t pad;
+    uint32_t shift;
 };
+constexpr uint32_t kSampleShift = 11;   // one key sample per 2048 suffixes: 2 MiB per 512 MiB chunk
+
+// Entries of the key-sample table of an n-byte chunk, and the kernel launch that fills it
+// (stream-ordered on ctx->stream; `skeys` must hold sample_count(n, shift) entries).
+static inline uint64_t sample_count(uint32_t n, uint32_t shift) { return ((uint64_t)n + (1u << shift) - 1) >> shift; }
+int build_key_samples(DeviceCtx *ctx, const uint8_t *d_text, const uint32_t *d_sa, uint32_t n, uint32_t shift,
+                      uint64_t *d_skeys);
 
 // Host-side packed result of one batch (malloc'ed; owned by pss_result).
 struct HostResult {

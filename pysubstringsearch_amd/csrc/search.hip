@@ -77,6 +77,14 @@ __device__ __forceinline__ u32 wave_bound(const u8 *text, u32 n, const u32 *sa, 
                                           u32 hi, bool upper)
 {
     const u32 lane = lane_id();
+    if (upper && hi - lo > kWave) {
+        // the interval of a query is short far more often than not: look at the 64 suffixes
+        // right behind the lower bound first (one step when the query has < 64 hits here)
+        const int c = cmp_suffix(text, n, sa[lo + lane], pat, plen);
+        const u32 k = (u32)__popcll(__ballot(c <= 0));
+        if (k < kWave) return lo + k;
+        lo += kWave;
+    }
     while (hi > lo) {
         const u32 s = hi - lo;
         if (s <= kWave) {
@@ -99,6 +107,122 @@ __device__ __forceinline__ u32 wave_bound(const u8 *text, u32 n, const u32 *sa, 
     return lo;
 }
 
+// ---- key samples: confine a query to a window of the suffix array -----------------------
+//
+// key8(i) = first 8 bytes of suffix sa[i], big-endian, zero padded past the end of the text, is
+// non-decreasing in i (zero is the smallest byte, so the padding never breaks the order).  With
+// P8 = the query's first min(8, plen) bytes: every suffix whose key8 < P8|00.. is smaller than
+// the query and every suffix whose key8 > P8|ff.. is larger and does not start with it, so both
+// ends of the query's interval lie between A = first i with key8(i) >= P8|00.. and B = first i
+// with key8(i) > P8|ff...  The table holds key8 of every 2^shift-th suffix: jA / jB searched
+// there give A > (jA - 1) << shift and B <= jB << shift.
+
+__device__ __forceinline__ u64 key8_be(const u8 *p) { return __builtin_bswap64(load_u64_unaligned(p)); }
+
+// P8|00.. and P8|ff.. of a query (pat is readable 16 bytes past its end)
+__device__ __forceinline__ void query_keys(const u8 *pat, u32 plen, u64 &k_lo, u64 &k_hi)
+{
+    const u64 mask = plen >= 8 ? ~0ull : (plen ? ~0ull << (8 * (8 - plen)) : 0ull);
+    k_lo = key8_be(pat) & mask;
+    k_hi = k_lo | ~mask;
+}
+
+// first j in [lo, hi) with k[j] >= key (upper: > key); wave-cooperative 64-ary search
+__device__ __forceinline__ u32 wave_bound_key(const u64 *k, u32 lo, u32 hi, u64 key, bool upper)
+{
+    const u32 lane = lane_id();
+    while (hi > lo) {
+        const u32 s = hi - lo;
+        if (s <= kWave) {
+            bool before = false;
+            if (lane < s) {
+                const u64 v = k[lo + lane];
+                before = upper ? (v <= key) : (v < key);
+            }
+            return lo + (u32)__popcll(__ballot(before));
+        }
+        const u32 p = lo + (u32)(((u64)(lane + 1) * s) / (kWave + 1));
+        const u64 v = k[p];
+        const bool before = upper ? (v <= key) : (v < key);
+        const u32 c = (u32)__popcll(__ballot(before));
+        const u32 nlo = (c == 0) ? lo : (u32)__shfl((int)p, (int)c - 1) + 1;
+        const u32 nhi = (c == kWave) ? hi : (u32)__shfl((int)p, (int)c);
+        lo = nlo;
+        hi = nhi;
+    }
+    return lo;
+}
+
+// window [lo, hi) of the suffix array that holds the query's interval (whole array without a table)
+__device__ __forceinline__ void sample_window_wave(const ChunkDesc &ch, const u8 *pat, u32 plen, u32 &lo, u32 &hi)
+{
+    lo = 0;
+    hi = ch.n;
+    if (ch.skeys == nullptr) return;
+    const u32 ns = (u32)(((u64)ch.n + (1u << ch.shift) - 1) >> ch.shift);
+    u64 k_lo, k_hi;
+    query_keys(pat, plen, k_lo, k_hi);
+    const u32 ja = wave_bound_key(ch.skeys, 0, ns, k_lo, false);
+    u32 jb = ja;
+    if (ja < ns) {
+        // jB is jA or jA + 1 unless the query's first 8 bytes are frequent: 64 consecutive samples first
+        const u32 s = min(ns - ja, (u32)kWave);
+        const u32 lane = lane_id();
+        const bool before = lane < s && ch.skeys[ja + lane] <= k_hi;
+        const u32 c = (u32)__popcll(__ballot(before));
+        jb = ja + c;
+        if (c == kWave) jb = wave_bound_key(ch.skeys, ja + kWave, ns, k_hi, true);
+    }
+    lo = ja ? (ja - 1) << ch.shift : 0u;
+    hi = jb < ns ? jb << ch.shift : ch.n;
+}
+
+__device__ __forceinline__ void sample_window_lane(const ChunkDesc &ch, const u8 *pat, u32 plen, u32 &lo, u32 &hi)
+{
+    lo = 0;
+    hi = ch.n;
+    if (ch.skeys == nullptr) return;
+    const u32 ns = (u32)(((u64)ch.n + (1u << ch.shift) - 1) >> ch.shift);
+    u64 k_lo, k_hi;
+    query_keys(pat, plen, k_lo, k_hi);
+    u32 a = 0, b = ns;
+    while (a < b) {
+        const u32 mid = a + ((b - a) >> 1);
+        if (ch.skeys[mid] < k_lo) a = mid + 1; else b = mid;
+    }
+    const u32 ja = a;
+    b = ns;                                       // gallop: jB is almost always jA or jA + 1
+    for (u32 step = 1; a < b; step <<= 1) {
+        const u32 p = a + step - 1;
+        if (p >= b) break;
+        if (ch.skeys[p] <= k_hi) a = p + 1; else { b = p; break; }
+    }
+    while (a < b) {
+        const u32 mid = a + ((b - a) >> 1);
+        if (ch.skeys[mid] <= k_hi) a = mid + 1; else b = mid;
+    }
+    lo = ja ? (ja - 1) << ch.shift : 0u;
+    hi = a < ns ? a << ch.shift : ch.n;
+}
+
+__global__ __launch_bounds__(256) void key_samples_kernel(const u8 *text, const u32 *sa, u32 n, u32 shift, u64 *skeys)
+{
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 i = j << shift;
+    if (i < n) skeys[j] = key8_be(text + sa[i]);
+}
+
+int build_key_samples(DeviceCtx *ctx, const uint8_t *d_text, const uint32_t *d_sa, uint32_t n, uint32_t shift,
+                      uint64_t *d_skeys)
+{
+    if (n == 0) return PSS_OK;
+    const u64 ns = sample_count(n, shift);
+    hipLaunchKernelGGL(key_samples_kernel, dim3((u32)((ns + 255) / 256)), dim3(256), 0, ctx->stream, d_text, d_sa, n,
+                       shift, d_skeys);
+    PSS_HIP(hipGetLastError());
+    return PSS_OK;
+}
+
 // Large batches: one LANE per (query, chunk) and plain binary searches.  The 64-ary wave
 // search above minimises latency (5+5 dependent steps) but touches 64 random SA + text
 // sectors per step, ~80 KB per pair -- at 1.5 M pairs (100 k queries x 15 chunks) that is
@@ -115,13 +239,20 @@ __global__ __launch_bounds__(256) void search_interval_lane_kernel(const ChunkDe
     const ChunkDesc ch = chunks[c];
     const u8 *pat = qbytes + qoff[q];
     const u32 plen = (u32)(qoff[q + 1] - qoff[q]);
-    u32 lo = 0, hi = ch.n;                       // lower bound: first suffix not < pattern
+    u32 lo, hi0;
+    sample_window_lane(ch, pat, plen, lo, hi0);
+    u32 hi = hi0;                                // lower bound: first suffix not < pattern
     while (lo < hi) {
         const u32 mid = lo + ((hi - lo) >> 1);
         if (cmp_suffix(ch.text, ch.n, ch.sa[mid], pat, plen) < 0) lo = mid + 1; else hi = mid;
     }
     const u32 L = lo;
-    hi = ch.n;                                   // upper bound: first suffix > pattern and not prefixed by it
+    hi = hi0;                                    // upper bound: first suffix > pattern and not prefixed by it;
+    for (u32 step = 1; lo < hi; step <<= 1) {    // galloping from L (most intervals are short)
+        const u32 p = lo + step - 1;
+        if (p >= hi) break;
+        if (cmp_suffix(ch.text, ch.n, ch.sa[p], pat, plen) <= 0) lo = p + 1; else { hi = p; break; }
+    }
     while (lo < hi) {
         const u32 mid = lo + ((hi - lo) >> 1);
         if (cmp_suffix(ch.text, ch.n, ch.sa[mid], pat, plen) <= 0) lo = mid + 1; else hi = mid;
@@ -139,8 +270,10 @@ __global__ __launch_bounds__(256) void search_interval_kernel(const ChunkDesc *c
     const ChunkDesc ch = chunks[c];
     const u8 *pat = qbytes + qoff[q];
     const u32 plen = (u32)(qoff[q + 1] - qoff[q]);
-    const u32 L = wave_bound(ch.text, ch.n, ch.sa, pat, plen, 0, ch.n, false);
-    const u32 U = wave_bound(ch.text, ch.n, ch.sa, pat, plen, L, ch.n, true);
+    u32 w0, w1;
+    sample_window_wave(ch, pat, plen, w0, w1);
+    const u32 L = wave_bound(ch.text, ch.n, ch.sa, pat, plen, w0, w1, false);
+    const u32 U = wave_bound(ch.text, ch.n, ch.sa, pat, plen, L, w1, true);
     if (lane_id() == 0) {
         lo_out[vq] = L;
         cnt_out[vq] = U - L;
@@ -285,8 +418,10 @@ __global__ __launch_bounds__(256) void search_small_kernel(const ChunkDesc *chun
     const ChunkDesc ch = chunks[c];
     const u8 *pat = qbytes + qoff[q];
     const u32 plen = (u32)(qoff[q + 1] - qoff[q]);
-    const u32 L = wave_bound(ch.text, ch.n, ch.sa, pat, plen, 0, ch.n, false);
-    const u32 U = wave_bound(ch.text, ch.n, ch.sa, pat, plen, L, ch.n, true);
+    u32 w0, w1;
+    sample_window_wave(ch, pat, plen, w0, w1);
+    const u32 L = wave_bound(ch.text, ch.n, ch.sa, pat, plen, w0, w1, false);
+    const u32 U = wave_bound(ch.text, ch.n, ch.sa, pat, plen, L, w1, true);
     const u32 cnt = U - L;
     if (cnt == 0) {
         if (lane == 0) rec[vq] = SmallRecord{0, 0};

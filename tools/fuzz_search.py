@@ -55,6 +55,13 @@ def one_case(seed, tmp):
         os.environ['PSS_WAVE_SEARCH'] = '1'
     else:
         os.environ.pop('PSS_WAVE_SEARCH', None)
+    os.environ.pop('PSS_NO_KEY_SAMPLES', None)
+    os.environ.pop('PSS_SAMPLE_SHIFT', None)
+    r = rng.random()
+    if r < 0.15:
+        os.environ['PSS_NO_KEY_SAMPLES'] = '1'
+    elif r < 0.85:
+        os.environ['PSS_SAMPLE_SHIFT'] = str(rng.randint(0, 8))     # dense key-sample tables on these small chunks
     qb = [s.encode() for s in queries]
     o = O.OracleReader(q)
     oe, oc = o.search_multiple_bytes(qb)
