@@ -156,6 +156,7 @@ typedef struct pss_search_stats {
     uint64_t result_bytes;
     double ms_device;       /* HIP-event time of the kernels of the batch */
     double ms_interval;     /* ... of the interval-search kernel alone */
+    double ms_host;         /* wall time of the whole batch inside the library (host clock) */
 } pss_search_stats;
 
 /*

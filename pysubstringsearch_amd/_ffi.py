@@ -57,6 +57,7 @@ class SearchStats(ctypes.Structure):
         ('result_bytes', ctypes.c_uint64),
         ('ms_device', ctypes.c_double),
         ('ms_interval', ctypes.c_double),
+        ('ms_host', ctypes.c_double),
     ]
 
     def as_dict(self):

@@ -627,7 +627,7 @@ int reader_alloc_chunk(pss_reader *r, uint32_t n, ChunkDesc *out)
         const int v = atoi(ev);
         if (v >= 0 && v <= 20) shift = (uint32_t)v;
     }
-    hipError_t e = hipMalloc(&d_text, (size_t)n + 32);
+    hipError_t e = hipMalloc(&d_text, (size_t)n + 64);
     if (e == hipSuccess) e = hipMalloc(&d_sa, sa_bytes + (samples ? sample_count(n, shift) * 8 : 0));
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -635,7 +635,7 @@ int reader_alloc_chunk(pss_reader *r, uint32_t n, ChunkDesc *out)
         set_error("hipMalloc of a %u-byte chunk failed: %s", n, hipGetErrorString(e));
         return PSS_ENOMEM;
     }
-    PSS_HIP(hipMemsetAsync(static_cast<uint8_t *>(d_text) + n, 0, 32, r->ctx->stream));
+    PSS_HIP(hipMemsetAsync(static_cast<uint8_t *>(d_text) + n, 0, 64, r->ctx->stream));
     out->text = static_cast<uint8_t *>(d_text);
     out->sa = static_cast<uint32_t *>(d_sa);
     out->skeys = samples ? reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(d_sa) + sa_bytes) : nullptr;

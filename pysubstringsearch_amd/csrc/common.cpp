@@ -83,8 +83,10 @@ int get_ctx(int device, DeviceCtx **out)
         hipDeviceProp_t prop;
         PSS_HIP(hipGetDeviceProperties(&prop, device));
         c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        c.pinned_cap = 1 << 16;
+        c.pinned_cap = DeviceCtx::kPinnedBytes;
         PSS_HIP(hipHostMalloc(&c.pinned, c.pinned_cap, hipHostMallocDefault));
+        PSS_HIP(hipHostGetDevicePointer(&c.pinned_dev, c.pinned, 0));
+        for (hipEvent_t &e : c.search_ev) PSS_HIP(hipEventCreate(&e));
         c.device = device;
     }
     *out = &c;

@@ -53,8 +53,12 @@ struct DeviceCtx {
     int num_cus = 256;
     static constexpr int kSlots = 32;
     DevBuf slot[kSlots];
+    static constexpr size_t kPinnedBytes = (size_t)192 << 10;   // 64 KiB of counters / small tables + 128 KiB of result bytes
     void *pinned = nullptr;   // small pinned host scratch for D2H of counters
     size_t pinned_cap = 0;
+    void *pinned_dev = nullptr;          // the same memory as the device sees it (zero-copy reads / writes)
+    hipEvent_t search_ev[3] = {nullptr, nullptr, nullptr};   // timing events of the search path, created once
+    void *small_hdr_ready = nullptr;     // arena whose small-path cursors have been zeroed (search.hip)
     // Two pinned staging buffers + a copy stream: file <-> HBM transfers are
     // double-buffered so the PCIe copy of piece i overlaps the file I/O of piece i+1.
     static constexpr size_t kStage = (size_t)64 << 20;

@@ -28,6 +28,7 @@
 #include "scan.h"
 #include "search.h"
 
+#include <chrono>
 #include <vector>
 
 namespace pss {
@@ -296,13 +297,19 @@ __device__ __forceinline__ bool hit_entry(const ChunkDesc &ch, const u8 *pat, u3
                                           u32 &line_len)
 {
     const u64 NL = 0x0a0a0a0a0a0a0a0aull;
-    // Backwards, 8 bytes at a time, to the entry start (lib.rs:270-273); candidates for an
-    // earlier occurrence are the bytes equal to the query's first byte.
+    // The scans are chains of dependent loads from a random place in the text, so they move 32
+    // bytes per step (four independent 8-byte loads) and the first step forwards is issued
+    // before the backward scan starts.  text is zero padded 64 bytes past n.
+    u64 fw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) fw[k] = load_u64_unaligned(ch.text + di + 8 * k);
+    // Backwards to the entry start (lib.rs:270-273); candidates for an earlier occurrence are
+    // the bytes equal to the query's first byte.
     const u64 first = plen ? 0x0101010101010101ull * pat[0] : 0;
     u32 p = di;            // scan frontier: bytes [p, di) hold no newline
     bool dup = false, at_start = false;
-    while (p >= 8 && !dup && !at_start) {
-        const u64 w = load_u64_unaligned(ch.text + p - 8);      // byte k of w = text[p-8+k]
+    // one 8-byte word w = text[p-8, p): byte k of w = text[p-8+k]
+    auto word = [&](u64 w) {
         const u64 nlm = zero_bytes(w ^ NL);
         u32 keep_from = 0;                                       // first byte index of w inside the entry
         if (nlm) {
@@ -321,7 +328,16 @@ __device__ __forceinline__ bool hit_entry(const ChunkDesc &ch, const u8 *pat, u3
             }
         }
         p = at_start ? p - 8 + keep_from : p - 8;
+    };
+    while (p >= 32 && !dup && !at_start) {
+        u64 w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = load_u64_unaligned(ch.text + p - 8 * (k + 1));
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (!dup && !at_start) word(w[k]);
     }
+    while (p >= 8 && !dup && !at_start) word(load_u64_unaligned(ch.text + p - 8));
     while (p > 0 && !dup && !at_start) {                         // the first < 8 bytes of the chunk
         const u8 cb = ch.text[p - 1];
         if (cb == '\n') break;
@@ -330,16 +346,23 @@ __device__ __forceinline__ bool hit_entry(const ChunkDesc &ch, const u8 *pat, u3
     }
     if (dup) return false;
     line_start = p;
-    // forwards to the entry end (lib.rs:266-269; no newline: len - 1); text is zero padded past n
+    // forwards to the entry end (lib.rs:266-269; no newline: len - 1)
     u32 e = di;
     for (;;) {
-        const u64 nlm = zero_bytes(load_u64_unaligned(ch.text + e) ^ NL);
-        if (nlm) {
-            e += (u32)(__builtin_ctzll(nlm) >> 3);
-            break;
+        bool found = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const u64 nlm = zero_bytes(fw[k] ^ NL);
+            if (nlm && !found) {
+                e += 8 * k + (u32)(__builtin_ctzll(nlm) >> 3);
+                found = true;
+            }
         }
-        e += 8;
+        if (found) break;
+        e += 32;
         if (e >= ch.n) break;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fw[k] = load_u64_unaligned(ch.text + e + 8 * k);
     }
     if (e >= ch.n) e = ch.n - 1;
     line_len = e >= line_start ? e - line_start : 0;
@@ -385,20 +408,27 @@ __global__ __launch_bounds__(256) void hit_lines_kernel(const ChunkDesc *chunks,
 }
 
 // ---- fused path for small batches (single-query latency) ----------------------
-// One launch does everything for up to SM_MAX_VQ (query, chunk) pairs: interval
-// search, entry recovery, dedupe, and packing into a small arena whose space is
-// handed out with two atomic cursors.  A pair's entries are contiguous; the host
-// re-orders pairs query-major.  Anything that does not fit (arena full, more
-// than SM_MAX_HITS hits for one pair) sets the overflow flag and the general
+// One launch does everything for up to SM_MAX_VQ (query, chunk) pairs: interval search, entry
+// recovery, dedupe, and packing into a small arena whose space is handed out with two atomic
+// cursors.  A pair's entries are contiguous; the host re-orders pairs query-major.
+// No copy engine is involved: the kernel READS the queries from pinned host memory (once, into
+// LDS) and WRITES the per-pair records, the entry table and the first SM_BYTE_PREFIX result
+// bytes straight into pinned host memory, so a call is memcpy -> launch -> wait.  Results larger
+// than the prefix are fetched from the device arena with one copy.  Anything that does not fit
+// (arena full, more than SM_MAX_HITS hits for one pair) sets the overflow flag and the general
 // multi-kernel path runs instead.
 constexpr u32 SM_MAX_VQ = 1024;
 constexpr u32 SM_MAX_HITS = 1024;
 constexpr u32 SM_ENT_CAP = 4096;
-constexpr u32 SM_BYTE_PREFIX = 8000;   // result bytes fetched together with the header in the first copy
+#ifndef PSS_SM_BYTE_PREFIX
+#define PSS_SM_BYTE_PREFIX 65536
+#endif
+constexpr u32 SM_BYTE_PREFIX = PSS_SM_BYTE_PREFIX;   // result bytes that also go to pinned host memory
 constexpr u32 SM_BYTE_CAP = 2u << 20;
+constexpr u32 SM_MAX_PLEN = 256;       // longest query the path takes (kept in LDS)
 
-struct SmallHeader {
-    u32 ent_cursor, byte_cursor, overflow, pad;
+struct SmallHeader {   // device memory; all zero between launches (the last wave to finish resets it)
+    u32 ent_cursor, byte_cursor, done, pad;
 };
 struct SmallRecord {
     u32 ent_start, ent_count;
@@ -406,18 +436,20 @@ struct SmallRecord {
 struct SmallEntry {
     u32 byte_off, len;
 };
+// layout of the pinned scratch (DeviceCtx::pinned) on this path
+constexpr size_t SM_OFF_FLAGS = 0;                                              // u32 overflow
+constexpr size_t SM_OFF_REC = 64;
+constexpr size_t SM_OFF_ENT = SM_OFF_REC + SM_MAX_VQ * sizeof(SmallRecord);
+constexpr size_t SM_OFF_QUERY = 49152;                                          // query bytes, then offsets at + 8192
+constexpr size_t SM_OFF_BYTES = 65536;
+static_assert(SM_OFF_ENT + SM_ENT_CAP * sizeof(SmallEntry) <= SM_OFF_QUERY, "entry table must fit below the query staging");
+static_assert(SM_OFF_BYTES + SM_BYTE_PREFIX <= DeviceCtx::kPinnedBytes, "result prefix must fit the pinned scratch");
 
-__global__ __launch_bounds__(256) void search_small_kernel(const ChunkDesc *chunks, u32 nc, const u8 *qbytes,
-                                                             const u64 *qoff, u32 nvq, SmallHeader *hdr,
-                                                             SmallRecord *rec, SmallEntry *ent, u8 *bytes)
+__device__ __forceinline__ void small_pair(const ChunkDesc &ch, const u8 *pat, u32 plen, u32 vq, SmallHeader *hdr,
+                                           u32 *h_overflow, SmallRecord *rec, SmallEntry *ent, u8 *bytes, u8 *hbytes,
+                                           u32 *my_ls, u32 *my_ll)
 {
-    const u32 vq = blockIdx.x * (blockDim.x / kWave) + wave_id();
-    if (vq >= nvq) return;
     const u32 lane = lane_id();
-    const u32 q = vq / nc, c = vq % nc;
-    const ChunkDesc ch = chunks[c];
-    const u8 *pat = qbytes + qoff[q];
-    const u32 plen = (u32)(qoff[q + 1] - qoff[q]);
     u32 w0, w1;
     sample_window_wave(ch, pat, plen, w0, w1);
     const u32 L = wave_bound(ch.text, ch.n, ch.sa, pat, plen, w0, w1, false);
@@ -428,13 +460,10 @@ __global__ __launch_bounds__(256) void search_small_kernel(const ChunkDesc *chun
         return;
     }
     if (cnt > SM_MAX_HITS) {
-        if (lane == 0) hdr->overflow = 1;
+        if (lane == 0) *h_overflow = 1;
         return;
     }
     // pass 1: entry bounds of every hit (kept in LDS), entries / bytes this pair produces
-    __shared__ u32 s_ls[256 / kWave][SM_MAX_HITS];
-    __shared__ u32 s_ll[256 / kWave][SM_MAX_HITS];
-    u32 *my_ls = s_ls[wave_id()], *my_ll = s_ll[wave_id()];
     u32 n_ent = 0, n_bytes = 0;
     for (u32 base = 0; base < cnt; base += kWave) {
         const u32 j = base + lane;
@@ -452,8 +481,8 @@ __global__ __launch_bounds__(256) void search_small_kernel(const ChunkDesc *chun
     if (lane == 0) {
         e0 = atomicAdd(&hdr->ent_cursor, n_ent);
         b0 = atomicAdd(&hdr->byte_cursor, n_bytes);
-        if (e0 + n_ent > SM_ENT_CAP || b0 + n_bytes > SM_BYTE_CAP) hdr->overflow = 1;
-        rec[vq] = SmallRecord{e0, n_ent};
+        if (e0 + n_ent > SM_ENT_CAP || b0 + n_bytes > SM_BYTE_CAP) *h_overflow = 1;
+        else rec[vq] = SmallRecord{e0, n_ent};
     }
     e0 = __shfl(e0, 0);
     b0 = __shfl(b0, 0);
@@ -470,9 +499,161 @@ __global__ __launch_bounds__(256) void search_small_kernel(const ChunkDesc *chun
             const u32 o = b0 + incl - ll;
             ent[e] = SmallEntry{o, ll};
             copy_entry(bytes + o, ch.text + my_ls[j], ll);
+            if (o + ll <= SM_BYTE_PREFIX) copy_entry(hbytes + o, ch.text + my_ls[j], ll);
         }
         e0 += (u32)__popcll(km);
         b0 += __shfl(incl, 63);
+    }
+}
+
+// qbytes / qoff / h_overflow / rec / ent / hbytes: pinned host memory; hdr / bytes: device memory
+__global__ __launch_bounds__(256) void search_small_kernel(const ChunkDesc *chunks, u32 nc, const u8 *qbytes,
+                                                             const u64 *qoff, u32 nvq, SmallHeader *hdr,
+                                                             u32 *h_overflow, SmallRecord *rec, SmallEntry *ent,
+                                                             u8 *bytes, u8 *hbytes)
+{
+    __shared__ u32 s_ls[256 / kWave][SM_MAX_HITS];
+    __shared__ u32 s_ll[256 / kWave][SM_MAX_HITS];
+    __shared__ __attribute__((aligned(8))) u8 s_pat[256 / kWave][SM_MAX_PLEN + 32];
+    const u32 vq = blockIdx.x * (blockDim.x / kWave) + wave_id();
+    if (vq >= nvq) return;
+    const u32 lane = lane_id();
+    const u32 q = vq / nc, c = vq % nc;
+    const u64 o0 = qoff[q];
+    const u32 plen = (u32)(qoff[q + 1] - o0);
+    // the query crosses PCIe once; every comparison afterwards reads it from LDS (zero padded)
+    u8 *pat = s_pat[wave_id()];
+    for (u32 i = lane * 8; i < SM_MAX_PLEN + 32; i += kWave * 8) {
+        u64 v = 0;
+        if (i < plen) {
+            v = load_u64_unaligned(qbytes + o0 + i);
+            if (plen - i < 8) v &= (1ull << (8 * (plen - i))) - 1ull;
+        }
+        *reinterpret_cast<u64 *>(pat + i) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the wave reads what its other lanes wrote
+    __builtin_amdgcn_wave_barrier();
+    small_pair(chunks[c], pat, plen, vq, hdr, h_overflow, rec, ent, bytes, hbytes, s_ls[wave_id()], s_ll[wave_id()]);
+    if (lane == 0 && atomicAdd(&hdr->done, 1u) == nvq - 1) {
+        hdr->ent_cursor = 0;       // every pair has taken its space: leave the header zero for the next launch
+        hdr->byte_cursor = 0;
+        hdr->done = 0;
+    }
+}
+
+// The same for very few pairs (a single query over <= SM_BLOCK_MAX_VQ chunks): one WORKGROUP
+// of 16 wavefronts per pair.  Wave 0 finds the interval; then every thread recovers the entry of
+// one hit at a time, so up to 1024 hits cost one round of dependent loads instead of sixteen
+// (a query with 245 hits: 137 -> ~45 us of device time).  Entry order inside the pair stays the
+// suffix-array order of the kept hits.
+constexpr u32 SM_BLOCK = 1024;
+constexpr u32 SM_BLOCK_MAX_VQ = 64;
+constexpr u32 SM_BLOCK_MAX_HITS = 4096;
+
+__global__ __launch_bounds__(SM_BLOCK) void search_block_kernel(const ChunkDesc *chunks, u32 nc, const u8 *qbytes,
+                                                                  const u64 *qoff, u32 nvq, SmallHeader *hdr,
+                                                                  u32 *h_overflow, SmallRecord *rec, SmallEntry *ent,
+                                                                  u8 *bytes, u8 *hbytes)
+{
+    __shared__ u32 s_ls[SM_BLOCK_MAX_HITS];
+    __shared__ u32 s_ll[SM_BLOCK_MAX_HITS];
+    __shared__ __attribute__((aligned(8))) u8 s_pat[SM_MAX_PLEN + 32];
+    __shared__ u32 s_L, s_cnt, s_e0, s_b0;
+    __shared__ u32 s_we[SM_BLOCK / kWave], s_wb[SM_BLOCK / kWave];
+    const u32 vq = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+    const u32 q = vq / nc, c = vq % nc;
+    const ChunkDesc ch = chunks[c];
+    const u64 o0 = qoff[q];
+    const u32 plen = (u32)(qoff[q + 1] - o0);
+    for (u32 i = tid * 8; i < SM_MAX_PLEN + 32; i += SM_BLOCK * 8) {
+        u64 v = 0;
+        if (i < plen) {
+            v = load_u64_unaligned(qbytes + o0 + i);
+            if (plen - i < 8) v &= (1ull << (8 * (plen - i))) - 1ull;
+        }
+        *reinterpret_cast<u64 *>(s_pat + i) = v;
+    }
+    __syncthreads();
+    const u8 *pat = s_pat;
+    if (wave == 0) {
+        u32 w0, w1;
+        sample_window_wave(ch, pat, plen, w0, w1);
+        const u32 L = wave_bound(ch.text, ch.n, ch.sa, pat, plen, w0, w1, false);
+        const u32 U = wave_bound(ch.text, ch.n, ch.sa, pat, plen, L, w1, true);
+        if (lane == 0) {
+            s_L = L;
+            s_cnt = U - L;
+        }
+    }
+    __syncthreads();
+    const u32 L = s_L, cnt = s_cnt;
+    if (cnt == 0) {
+        if (tid == 0) rec[vq] = SmallRecord{0, 0};
+    } else if (cnt > SM_BLOCK_MAX_HITS) {
+        if (tid == 0) *h_overflow = 1;
+    } else {
+        // pass 1: entry bounds of every hit, one hit per thread and round
+        for (u32 j = tid; j < cnt; j += SM_BLOCK) {
+            u32 ls = 0, ll = 0;
+            const bool keep = hit_entry(ch, pat, plen, ch.sa[L + j], ls, ll);
+            s_ls[j] = ls;
+            s_ll[j] = keep ? ll : kSkip;
+        }
+        __syncthreads();
+        // entries / bytes before each thread's run of consecutive hits (suffix-array order)
+        const u32 per = (cnt + SM_BLOCK - 1) / SM_BLOCK;
+        const u32 j0 = min(tid * per, cnt), j1 = min(j0 + per, cnt);
+        u32 my_e = 0, my_b = 0;
+        for (u32 j = j0; j < j1; ++j) {
+            const u32 ll = s_ll[j];
+            if (ll != kSkip) {
+                ++my_e;
+                my_b += ll;
+            }
+        }
+        const u32 ie = wave_incl_sum(my_e), ib = wave_incl_sum(my_b);
+        if (lane == kWave - 1) {
+            s_we[wave] = ie;
+            s_wb[wave] = ib;
+        }
+        __syncthreads();
+        u32 e_before = ie - my_e, b_before = ib - my_b, n_ent = 0, n_bytes = 0;
+#pragma unroll
+        for (u32 w = 0; w < SM_BLOCK / kWave; ++w) {
+            if (w < wave) {
+                e_before += s_we[w];
+                b_before += s_wb[w];
+            }
+            n_ent += s_we[w];
+            n_bytes += s_wb[w];
+        }
+        if (tid == 0) {
+            const u32 e0 = atomicAdd(&hdr->ent_cursor, n_ent);
+            const u32 b0 = atomicAdd(&hdr->byte_cursor, n_bytes);
+            s_e0 = e0;
+            s_b0 = b0;
+            if (e0 + n_ent > SM_ENT_CAP || b0 + n_bytes > SM_BYTE_CAP) *h_overflow = 1;
+            else rec[vq] = SmallRecord{e0, n_ent};
+        }
+        __syncthreads();
+        const u32 e0 = s_e0, b0 = s_b0;
+        if (e0 + n_ent <= SM_ENT_CAP && b0 + n_bytes <= SM_BYTE_CAP) {
+            // pass 2: pack
+            u32 e = e0 + e_before, o = b0 + b_before;
+            for (u32 j = j0; j < j1; ++j) {
+                const u32 ll = s_ll[j];
+                if (ll == kSkip) continue;
+                ent[e++] = SmallEntry{o, ll};
+                copy_entry(bytes + o, ch.text + s_ls[j], ll);
+                if (o + ll <= SM_BYTE_PREFIX) copy_entry(hbytes + o, ch.text + s_ls[j], ll);
+                o += ll;
+            }
+        }
+    }
+    if (tid == 0 && atomicAdd(&hdr->done, 1u) == nvq - 1) {
+        hdr->ent_cursor = 0;
+        hdr->byte_cursor = 0;
+        hdr->done = 0;
     }
 }
 
@@ -544,67 +725,66 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
     u64 *d_qcount = ctx->slot[Q_QCOUNT].as<u64>();
     u64 *h_small = static_cast<u64 *>(ctx->pinned);
 
-    struct Events {   // destroyed on every exit path
-        hipEvent_t e[3] = {nullptr, nullptr, nullptr};
-        ~Events()
-        {
-            for (hipEvent_t x : e)
-                if (x) (void)hipEventDestroy(x);
-        }
-    } evs;
-    for (hipEvent_t &x : evs.e) PSS_HIP(hipEventCreate(&x));
-    const hipEvent_t e0 = evs.e[0], e1 = evs.e[1], e2 = evs.e[2];
+    const hipEvent_t e0 = ctx->search_ev[0], e1 = ctx->search_ev[1], e2 = ctx->search_ev[2];
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto host_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     const size_t off_bytes = ((size_t)nq + 1) * 8;
-    if (qtotal + 32 <= 8192 && off_bytes <= 8192) {
-        // tiny batch: stage in pinned memory (pageable H2D copies are synchronous and slow to start)
-        u8 *stg = static_cast<u8 *>(ctx->pinned) + 49152;          // last 16 KiB of the pinned scratch
+    const bool tiny = qtotal + 32 <= 8192 && off_bytes <= 8192;
+    u8 *stg = static_cast<u8 *>(ctx->pinned) + SM_OFF_QUERY;          // last 16 KiB of the pinned scratch
+    if (tiny) {
         memcpy(stg, qbytes, qtotal);
         memset(stg + qtotal, 0, 32);
         memcpy(stg + 8192, qoffsets, off_bytes);
-        PSS_HIP(hipMemcpyAsync(d_q, stg, qtotal + 32, hipMemcpyHostToDevice, s));
-        PSS_HIP(hipMemcpyAsync(d_qoff, stg + 8192, off_bytes, hipMemcpyHostToDevice, s));
-    } else {
-        PSS_HIP(hipMemsetAsync(d_q + qtotal, 0, 32, s));
-        if (qtotal) PSS_HIP(hipMemcpyAsync(d_q, qbytes, qtotal, hipMemcpyHostToDevice, s));
-        PSS_HIP(hipMemcpyAsync(d_qoff, qoffsets, off_bytes, hipMemcpyHostToDevice, s));
     }
-    PSS_HIP(hipEventRecord(e0, s));
+    bool small = tiny && nvq <= SM_MAX_VQ && !counts_only && !getenv("PSS_NO_SMALL_PATH");
+    for (u32 i = 0; small && i < nq; ++i) small = qoffsets[i + 1] - qoffsets[i] <= SM_MAX_PLEN;
     const u64 waves_per_block = 256 / kWave;
-    if (nvq <= SM_MAX_VQ && !counts_only && !getenv("PSS_NO_SMALL_PATH")) {
-        // ---- fused small-batch path: one kernel, two small copies ----
-        const size_t rec_bytes = (size_t)SM_MAX_VQ * sizeof(SmallRecord);
-        const size_t ent_bytes = (size_t)SM_ENT_CAP * sizeof(SmallEntry);
-        PSS_TRY(ctx->slot[Q_ARENA].reserve(64 + rec_bytes + ent_bytes + SM_BYTE_CAP + 64));
+    if (small) {
+        // ---- fused small-batch path: one kernel, queries and results through pinned host memory ----
+        PSS_TRY(ctx->slot[Q_ARENA].reserve(64 + SM_BYTE_CAP + 64));
         u8 *arena = ctx->slot[Q_ARENA].as<u8>();
         SmallHeader *d_hdr = reinterpret_cast<SmallHeader *>(arena);
-        SmallRecord *d_rec = reinterpret_cast<SmallRecord *>(arena + 64);
-        SmallEntry *d_ent = reinterpret_cast<SmallEntry *>(arena + 64 + rec_bytes);
-        u8 *d_bytes = arena + 64 + rec_bytes + ent_bytes;
-        PSS_HIP(hipMemsetAsync(d_hdr, 0, 64, s));
-        hipLaunchKernelGGL(search_small_kernel, dim3((u32)((nvq + waves_per_block - 1) / waves_per_block)), dim3(256), 0,
-                           s, d_chunks, nc, d_q, d_qoff, (u32)nvq, d_hdr, d_rec, d_ent, d_bytes);
-        PSS_HIP(hipEventRecord(e2, s));
-        // first copy: header + records + entry table + the first SM_BYTE_PREFIX result bytes
-        // (48 KiB of the pinned scratch); most small results need nothing more
+        u8 *d_bytes = arena + 64;
+        if (ctx->small_hdr_ready != arena) {
+            PSS_HIP(hipMemsetAsync(d_hdr, 0, 64, s));
+            ctx->small_hdr_ready = arena;
+        }
         u8 *h_arena = static_cast<u8 *>(ctx->pinned);
-        const size_t prefix = 64 + rec_bytes + ent_bytes + SM_BYTE_PREFIX;
-        static_assert(64 + SM_MAX_VQ * sizeof(SmallRecord) + SM_ENT_CAP * sizeof(SmallEntry) + SM_BYTE_PREFIX <= 49152,
-                      "first copy must fit the pinned scratch");
-        PSS_HIP(hipMemcpyAsync(h_arena, arena, prefix, hipMemcpyDeviceToHost, s));
+        u8 *v_arena = static_cast<u8 *>(ctx->pinned_dev);               // the same bytes, device view
+        volatile u32 *h_overflow = reinterpret_cast<volatile u32 *>(h_arena + SM_OFF_FLAGS);
+        *h_overflow = 0;
+        PSS_HIP(hipEventRecord(e0, s));
+        const u8 *v_q = v_arena + SM_OFF_QUERY;
+        const u64 *v_qoff = reinterpret_cast<const u64 *>(v_arena + SM_OFF_QUERY + 8192);
+        u32 *v_flags = reinterpret_cast<u32 *>(v_arena + SM_OFF_FLAGS);
+        SmallRecord *v_rec = reinterpret_cast<SmallRecord *>(v_arena + SM_OFF_REC);
+        SmallEntry *v_ent = reinterpret_cast<SmallEntry *>(v_arena + SM_OFF_ENT);
+        if (nvq <= SM_BLOCK_MAX_VQ && !getenv("PSS_NO_BLOCK_PATH"))
+            hipLaunchKernelGGL(search_block_kernel, dim3((u32)nvq), dim3(SM_BLOCK), 0, s, d_chunks, nc, v_q, v_qoff,
+                               (u32)nvq, d_hdr, v_flags, v_rec, v_ent, d_bytes, v_arena + SM_OFF_BYTES);
+        else
+            hipLaunchKernelGGL(search_small_kernel, dim3((u32)((nvq + waves_per_block - 1) / waves_per_block)), dim3(256),
+                               0, s, d_chunks, nc, v_q, v_qoff, (u32)nvq, d_hdr, v_flags, v_rec, v_ent, d_bytes,
+                               v_arena + SM_OFF_BYTES);
+        PSS_HIP(hipEventRecord(e2, s));
         PSS_HIP(hipStreamSynchronize(s));
-        const SmallHeader hh = *reinterpret_cast<SmallHeader *>(h_arena);
-        if (!hh.overflow) {
-            const u32 E = hh.ent_cursor, B = hh.byte_cursor;
-            const SmallEntry *h_ent = reinterpret_cast<const SmallEntry *>(h_arena + 64 + rec_bytes);
+        if (!*h_overflow) {
+            const SmallRecord *h_rec = reinterpret_cast<const SmallRecord *>(h_arena + SM_OFF_REC);
+            const SmallEntry *h_ent = reinterpret_cast<const SmallEntry *>(h_arena + SM_OFF_ENT);
+            u64 E = 0, B = 0;
+            for (u64 vq = 0; vq < nvq; ++vq) {
+                const SmallRecord r = h_rec[vq];
+                E += r.ent_count;
+                for (u32 k = 0; k < r.ent_count; ++k) B += h_ent[r.ent_start + k].len;
+            }
             std::vector<u8> h_more;
-            const u8 *h_bytes = h_arena + 64 + rec_bytes + ent_bytes;
+            const u8 *h_bytes = h_arena + SM_OFF_BYTES;
             if (B > SM_BYTE_PREFIX) {
                 h_more.resize(B);
                 PSS_HIP(hipMemcpyAsync(h_more.data(), d_bytes, B, hipMemcpyDeviceToHost, s));
                 PSS_HIP(hipStreamSynchronize(s));
                 h_bytes = h_more.data();
             }
-            const SmallRecord *h_rec = reinterpret_cast<const SmallRecord *>(h_arena + 64);
             res->offsets = (u64 *)malloc(((size_t)E + 1) * sizeof(u64));
             res->bytes = (u8 *)malloc(B ? B : 1);
             if (!res->offsets || !res->bytes) return PSS_ENOMEM;
@@ -628,11 +808,21 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
             PSS_HIP(hipEventElapsedTime(&ms, e0, e2));
             st->ms_device = ms;
             st->ms_interval = ms;
+            st->ms_host = host_ms();
             return PSS_OK;
         }
         // overflow: fall through to the general path (qcount is still all zero)
-        for (u32 i = 0; i < nq; ++i) res->qcount[i] = 0;
     }
+    if (tiny) {
+        // pageable H2D copies are synchronous and slow to start: tiny batches go up from the pinned staging
+        PSS_HIP(hipMemcpyAsync(d_q, stg, qtotal + 32, hipMemcpyHostToDevice, s));
+        PSS_HIP(hipMemcpyAsync(d_qoff, stg + 8192, off_bytes, hipMemcpyHostToDevice, s));
+    } else {
+        PSS_HIP(hipMemsetAsync(d_q + qtotal, 0, 32, s));
+        if (qtotal) PSS_HIP(hipMemcpyAsync(d_q, qbytes, qtotal, hipMemcpyHostToDevice, s));
+        PSS_HIP(hipMemcpyAsync(d_qoff, qoffsets, off_bytes, hipMemcpyHostToDevice, s));
+    }
+    PSS_HIP(hipEventRecord(e0, s));
     if (nvq >= 32768 && !getenv("PSS_WAVE_SEARCH"))
         hipLaunchKernelGGL(search_interval_lane_kernel, dim3((u32)((nvq + 255) / 256)), dim3(256), 0, s, d_chunks, nc,
                            d_q, d_qoff, nvq, d_lo, d_cnt);
@@ -675,6 +865,7 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
             st->ms_device = msc;
             PSS_HIP(hipEventElapsedTime(&msc, e0, e1));
             st->ms_interval = msc;
+            st->ms_host = host_ms();
             return PSS_OK;
         }
         PSS_TRY(device_excl_scan(ctx, InLen{d_len}, H, d_partial, d_total, d_boff));
@@ -714,6 +905,7 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
     st->ms_device = ms;
     PSS_HIP(hipEventElapsedTime(&ms, e0, e1));
     st->ms_interval = ms;
+    st->ms_host = host_ms();
     return PSS_OK;
 }
 

@@ -55,6 +55,10 @@ def one_case(seed, tmp):
         os.environ['PSS_WAVE_SEARCH'] = '1'
     else:
         os.environ.pop('PSS_WAVE_SEARCH', None)
+    if rng.random() < 0.4:
+        os.environ['PSS_NO_BLOCK_PATH'] = '1'
+    else:
+        os.environ.pop('PSS_NO_BLOCK_PATH', None)
     os.environ.pop('PSS_NO_KEY_SAMPLES', None)
     os.environ.pop('PSS_SAMPLE_SHIFT', None)
     r = rng.random()
