@@ -147,6 +147,12 @@ int pss_reader_add_chunk_device(pss_reader *r, const void *d_text, const void *d
 int pss_reader_set_chunk_device(pss_reader *r, uint64_t index, const void *d_text, const void *d_sa, uint32_t n);
 /* Chunks resident in this reader. */
 uint64_t pss_reader_num_chunks(const pss_reader *r);
+/* Where the resident index lives.  The text of every chunk is in HBM; a suffix array is too while it
+ * fits (PSS_READER_HBM_BUDGET bytes when set, else until 2 GiB of HBM are left), otherwise it stays in
+ * pinned host memory and the kernels read it over PCIe (the key samples in HBM confine a query to a few
+ * dozen such reads).  host_chunks = chunks whose suffix array is on the host.  No reference counterpart:
+ * Reader::new keeps the text in RAM and every suffix array on disk (src/lib.rs:176-189). */
+int pss_reader_residency(const pss_reader *r, uint64_t *hbm_bytes, uint64_t *host_bytes, uint64_t *host_chunks);
 
 /* Per-batch statistics of the last pss_reader_search_batch call. */
 typedef struct pss_search_stats {

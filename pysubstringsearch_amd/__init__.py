@@ -184,6 +184,14 @@ class Reader:
     def num_chunks(self) -> int:
         return _lib.pss_reader_num_chunks(self._handle())
 
+    @property
+    def residency(self) -> dict:
+        """Extension: where the resident index lives -- bytes in HBM, bytes of suffix arrays kept in
+        pinned host memory (chunks beyond the HBM budget) and how many chunks that concerns."""
+        hbm, host, nhost = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        _ffi.check(_lib.pss_reader_residency(self._handle(), ctypes.byref(hbm), ctypes.byref(host), ctypes.byref(nhost)))
+        return {'hbm_bytes': hbm.value, 'host_bytes': host.value, 'host_chunks': nhost.value}
+
     def _search_batch(self, patterns: typing.Sequence[bytes], as_str: bool):
         nq = len(patterns)
         if _pssglue is not None:

@@ -47,6 +47,9 @@ class Reader:
     @property
     def num_chunks(self) -> int: ...
 
+    @property
+    def residency(self) -> typing.Dict[str, int]: ...
+
     def search(self, substring: str) -> typing.List[str]: ...
 
     def search_multiple(self, substrings: typing.List[str]) -> typing.List[str]: ...

@@ -116,6 +116,7 @@ def _load() -> ctypes.CDLL:
         'pss_reader_add_chunk_device': (ctypes.c_int, [vp, vp, vp, u32]),
         'pss_reader_set_chunk_device': (ctypes.c_int, [vp, u64, vp, vp, u32]),
         'pss_reader_num_chunks': (u64, [vp]),
+        'pss_reader_residency': (ctypes.c_int, [vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64)]),
         'pss_reader_search_batch': (ctypes.c_int, [vp, vp, vp, u32, pvp]),
         'pss_reader_count_batch': (ctypes.c_int, [vp, vp, vp, u32, vp]),
         'pss_reader_last_stats': (ctypes.c_int, [vp, ctypes.POINTER(SearchStats)]),

@@ -602,6 +602,17 @@ struct pss_reader {
     int device = 0;
     DeviceCtx *ctx = nullptr;
     std::vector<ChunkDesc> chunks;      // device pointers of resident chunks
+    // Residency of chunk i.  The text always lives in HBM.  The suffix array does too while it fits;
+    // past the HBM budget it stays in pinned host memory that the kernels read over PCIe (tier 2:
+    // the key-sample table, kept in HBM, confines every query to a few dozen such reads).
+    struct Mem {
+        void *text = nullptr;
+        void *sa = nullptr;        // hipMalloc or (sa_host) hipHostMalloc
+        void *skeys = nullptr;     // own hipMalloc when the suffix array is on the host, else inside `sa`
+        bool sa_host = false;
+        uint64_t hbm_bytes = 0, host_bytes = 0;
+    };
+    std::vector<Mem> mem;
     ChunkDesc *d_descs = nullptr;
     size_t d_descs_cap = 0;
     bool dirty = true;
@@ -614,12 +625,25 @@ struct pss_result {
 
 namespace {
 
+// HBM the reader may still take for suffix arrays: PSS_READER_HBM_BUDGET (bytes, over all chunks of
+// this reader; tests use it to force the host tier), else whatever hipMalloc grants while
+// kHbmReserve stays free for the search and build workspaces.
+constexpr size_t kHbmReserve = (size_t)2 << 30;
+
+void reader_free_mem(pss_reader::Mem &m)
+{
+    if (m.text) (void)hipFree(m.text);
+    if (m.sa) (void)(m.sa_host ? hipHostFree(m.sa) : hipFree(m.sa));
+    if (m.skeys) (void)hipFree(m.skeys);
+    m = pss_reader::Mem{};
+}
+
 // Text (zero padded) and suffix array of one chunk; the key-sample table (search.h) lives behind
-// the suffix array in the same allocation.
-int reader_alloc_chunk(pss_reader *r, uint32_t n, ChunkDesc *out)
+// the suffix array in the same allocation (or on its own in HBM when the suffix array is on the host).
+int reader_alloc_chunk(pss_reader *r, uint32_t n, ChunkDesc *out, pss_reader::Mem *mem)
 {
     PSS_HIP(hipSetDevice(r->device));
-    void *d_text = nullptr, *d_sa = nullptr;
+    pss_reader::Mem m;
     const size_t sa_bytes = round_up((size_t)n * 4 + 16, 8);
     const bool samples = getenv("PSS_NO_KEY_SAMPLES") == nullptr;
     uint32_t shift = kSampleShift;
@@ -627,20 +651,65 @@ int reader_alloc_chunk(pss_reader *r, uint32_t n, ChunkDesc *out)
         const int v = atoi(ev);
         if (v >= 0 && v <= 20) shift = (uint32_t)v;
     }
-    hipError_t e = hipMalloc(&d_text, (size_t)n + 64);
-    if (e == hipSuccess) e = hipMalloc(&d_sa, sa_bytes + (samples ? sample_count(n, shift) * 8 : 0));
+    const size_t sk_bytes = samples ? sample_count(n, shift) * 8 : 0;
+    hipError_t e = hipMalloc(&m.text, (size_t)n + 64);
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        if (d_text) (void)hipFree(d_text);
-        set_error("hipMalloc of a %u-byte chunk failed: %s", n, hipGetErrorString(e));
+        set_error("hipMalloc of the text of a %u-byte chunk failed: %s", n, hipGetErrorString(e));
         return PSS_ENOMEM;
     }
-    PSS_HIP(hipMemsetAsync(static_cast<uint8_t *>(d_text) + n, 0, 64, r->ctx->stream));
-    out->text = static_cast<uint8_t *>(d_text);
-    out->sa = static_cast<uint32_t *>(d_sa);
-    out->skeys = samples ? reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(d_sa) + sa_bytes) : nullptr;
+    m.hbm_bytes = (size_t)n + 64;
+    // tier 1: suffix array (+ samples) in HBM
+    uint64_t used = 0;
+    for (const auto &x : r->mem) used += x.hbm_bytes;
+    bool want_hbm = true;
+    if (const char *ev = getenv("PSS_READER_HBM_BUDGET"))
+        want_hbm = used + m.hbm_bytes + sa_bytes + sk_bytes <= strtoull(ev, nullptr, 0);
+    if (want_hbm) {
+        e = hipMalloc(&m.sa, sa_bytes + sk_bytes);
+        if (e == hipSuccess) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < kHbmReserve && !getenv("PSS_READER_HBM_BUDGET")) {
+                (void)hipFree(m.sa);                  // it fits, but would starve the workspaces
+                m.sa = nullptr;
+            }
+        } else {
+            (void)hipGetLastError();
+            m.sa = nullptr;
+        }
+    }
+    if (m.sa) {
+        m.hbm_bytes += sa_bytes + sk_bytes;
+        out->skeys = samples ? reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(m.sa) + sa_bytes) : nullptr;
+    } else {
+        // tier 2: suffix array in pinned host memory, samples in HBM
+        e = hipHostMalloc(&m.sa, sa_bytes, hipHostMallocDefault);
+        if (e == hipSuccess && sk_bytes) e = hipMalloc(&m.skeys, sk_bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            m.sa_host = m.sa != nullptr;
+            reader_free_mem(m);
+            set_error("no room for the suffix array of a %u-byte chunk in HBM or pinned host memory: %s", n,
+                      hipGetErrorString(e));
+            return PSS_ENOMEM;
+        }
+        m.sa_host = true;
+        m.host_bytes = sa_bytes;
+        m.hbm_bytes += sk_bytes;
+        out->skeys = static_cast<uint64_t *>(m.skeys);
+    }
+    PSS_HIP(hipMemsetAsync(static_cast<uint8_t *>(m.text) + n, 0, 64, r->ctx->stream));
+    out->text = static_cast<uint8_t *>(m.text);
+    if (m.sa_host) {
+        void *dp = nullptr;
+        PSS_HIP(hipHostGetDevicePointer(&dp, m.sa, 0));
+        out->sa = static_cast<uint32_t *>(dp);
+    } else {
+        out->sa = static_cast<uint32_t *>(m.sa);
+    }
     out->n = n;
     out->shift = shift;
+    *mem = m;
     return PSS_OK;
 }
 
@@ -655,10 +724,7 @@ void reader_free(pss_reader *r)
 {
     if (!r) return;
     if (r->ctx) (void)hipSetDevice(r->device);
-    for (auto &c : r->chunks) {
-        (void)hipFree(const_cast<uint8_t *>(c.text));
-        (void)hipFree(const_cast<uint32_t *>(c.sa));
-    }
+    for (auto &m : r->mem) reader_free_mem(m);
     if (r->d_descs) (void)hipFree(r->d_descs);
     delete r;
 }
@@ -758,10 +824,12 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
             const uint32_t dlen = (uint32_t)hdr[0] | (uint32_t)hdr[1] << 8 | (uint32_t)hdr[2] << 16 | (uint32_t)hdr[3] << 24;
             const bool mine = (index % shard_count) == shard_index;
             ChunkDesc cd{};
+            pss_reader::Mem cm;
             if (mine && dlen) {
-                rc = reader_alloc_chunk(r, dlen, &cd);
+                rc = reader_alloc_chunk(r, dlen, &cd, &cm);
                 if (rc) break;
                 r->chunks.push_back(cd);
+                r->mem.push_back(cm);
                 rc = upload_from_file(r, fp, const_cast<uint8_t *>(cd.text), dlen);
                 if (rc) break;
             } else if (fseeko(fp, dlen, SEEK_CUR) != 0) { rc = io_error(path); break; }
@@ -773,7 +841,14 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
                 break;
             }
             if (mine && dlen) {
-                rc = upload_from_file(r, fp, const_cast<uint32_t *>(cd.sa), (size_t)dlen * 4);
+                if (cm.sa_host) {      // host tier: the file is read straight into the pinned buffer
+                    if (fread(cm.sa, 1, (size_t)dlen * 4, fp) != (size_t)dlen * 4) {
+                        set_error("failed to fill whole buffer (truncated index file)");
+                        rc = PSS_EFORMAT;
+                    }
+                } else {
+                    rc = upload_from_file(r, fp, cm.sa, (size_t)dlen * 4);
+                }
                 if (rc) break;
                 rc = reader_sample_chunk(r, cd);     // uploads are complete (copy stream synchronised)
                 if (rc) break;
@@ -805,10 +880,13 @@ extern "C" int pss_reader_add_chunk_device(pss_reader *r, const void *d_text, co
         if (n == 0) return PSS_OK;
         std::lock_guard<std::recursive_mutex> lk(r->ctx->mu);
         ChunkDesc cd{};
-        PSS_TRY(reader_alloc_chunk(r, n, &cd));
+        pss_reader::Mem cm;
+        PSS_TRY(reader_alloc_chunk(r, n, &cd, &cm));
         r->chunks.push_back(cd);
-        PSS_HIP(hipMemcpyAsync(const_cast<uint8_t *>(cd.text), d_text, n, hipMemcpyDeviceToDevice, r->ctx->stream));
-        PSS_HIP(hipMemcpyAsync(const_cast<uint32_t *>(cd.sa), d_sa, (size_t)n * 4, hipMemcpyDeviceToDevice, r->ctx->stream));
+        r->mem.push_back(cm);
+        PSS_HIP(hipMemcpyAsync(cm.text, d_text, n, hipMemcpyDeviceToDevice, r->ctx->stream));
+        PSS_HIP(hipMemcpyAsync(cm.sa, d_sa, (size_t)n * 4, cm.sa_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
+                               r->ctx->stream));
         PSS_TRY(reader_sample_chunk(r, cd));
         PSS_HIP(hipStreamSynchronize(r->ctx->stream));
         r->dirty = true;
@@ -829,14 +907,18 @@ extern "C" int pss_reader_set_chunk_device(pss_reader *r, uint64_t index, const 
         ChunkDesc &c = r->chunks[index];
         if (c.n != n) {   // different size: fresh allocation
             ChunkDesc fresh{};
-            PSS_TRY(reader_alloc_chunk(r, n, &fresh));
-            (void)hipFree(const_cast<uint8_t *>(c.text));
-            (void)hipFree(const_cast<uint32_t *>(c.sa));
+            pss_reader::Mem fm;
+            reader_free_mem(r->mem[index]);            // first: its HBM may be what the new one needs
+            c = ChunkDesc{};
+            PSS_TRY(reader_alloc_chunk(r, n, &fresh, &fm));
             c = fresh;
+            r->mem[index] = fm;
             r->dirty = true;
         }
-        PSS_HIP(hipMemcpyAsync(const_cast<uint8_t *>(c.text), d_text, n, hipMemcpyDeviceToDevice, r->ctx->stream));
-        PSS_HIP(hipMemcpyAsync(const_cast<uint32_t *>(c.sa), d_sa, (size_t)n * 4, hipMemcpyDeviceToDevice, r->ctx->stream));
+        const pss_reader::Mem &cm = r->mem[index];
+        PSS_HIP(hipMemcpyAsync(cm.text, d_text, n, hipMemcpyDeviceToDevice, r->ctx->stream));
+        PSS_HIP(hipMemcpyAsync(cm.sa, d_sa, (size_t)n * 4, cm.sa_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
+                               r->ctx->stream));
         PSS_TRY(reader_sample_chunk(r, c));
         PSS_HIP(hipStreamSynchronize(r->ctx->stream));
         return reader_sync_descs(r);
@@ -844,6 +926,21 @@ extern "C" int pss_reader_set_chunk_device(pss_reader *r, uint64_t index, const 
 }
 
 extern "C" uint64_t pss_reader_num_chunks(const pss_reader *r) { return r ? r->chunks.size() : 0; }
+
+extern "C" int pss_reader_residency(const pss_reader *r, uint64_t *hbm_bytes, uint64_t *host_bytes, uint64_t *host_chunks)
+{
+    if (!r) return PSS_EINVAL;
+    uint64_t hb = 0, pb = 0, hc = 0;
+    for (const auto &m : r->mem) {
+        hb += m.hbm_bytes;
+        pb += m.host_bytes;
+        hc += m.sa_host ? 1 : 0;
+    }
+    if (hbm_bytes) *hbm_bytes = hb;
+    if (host_bytes) *host_bytes = pb;
+    if (host_chunks) *host_chunks = hc;
+    return PSS_OK;
+}
 
 extern "C" int pss_reader_search_batch(pss_reader *r, const uint8_t *qbytes, const uint64_t *qoffsets, uint32_t nq,
                                        pss_result **out)

@@ -407,3 +407,39 @@ def test_packed_result_outlives_reader(tmp_path):
     del pk
     gc.collect()
     assert bytes(data[:5]) in (b'alpha', b'beta\x00'[:5], b'alpha')   # still backed by the result
+
+
+@pytest.mark.parametrize('budget_chunks', [0, 2])
+def test_suffix_arrays_beyond_the_hbm_budget_stay_on_the_host(tmp_path, oracle, monkeypatch, budget_chunks):
+    """Residency tiers: with PSS_READER_HBM_BUDGET exhausted the suffix arrays of the later chunks
+    live in pinned host memory (read over PCIe by the kernels); every search path (fused single
+    query, wave-per-pair, lane-per-pair, count-only) must return what the oracle returns."""
+    from tests.util import gen_corpus
+    src = tmp_path / 'c.txt'
+    src.write_bytes(gen_corpus(0, 1 << 18).tobytes())
+    p = str(tmp_path / 'c.idx')
+    w = pysubstringsearch.Writer(p, 1 << 16)
+    w.add_entries_from_file_lines(str(src))
+    w.close()
+    text = src.read_bytes()
+    rng = np.random.default_rng(12)
+    qs = [b'', b'e', b'\n', b'zzzzzz', b'a\n']
+    while len(qs) < 9000:
+        s = int(rng.integers(0, len(text) - 20))
+        qs.append(text[s:s + int(rng.integers(1, 14))])
+    o = oracle.OracleReader(p)
+    # one chunk: 64 KiB text + 256 KiB suffix array + samples
+    monkeypatch.setenv('PSS_READER_HBM_BUDGET', str(budget_chunks * ((1 << 16) * 5 + 4096)))
+    with pysubstringsearch.Reader(p) as r:
+        res = r.residency
+        assert r.num_chunks >= 4
+        assert res['host_chunks'] == r.num_chunks - budget_chunks and res['host_bytes'] > 0
+        for batch in (qs[:1], qs[5:6], qs[:40], qs):           # fused paths, then the general pipeline
+            ents, counts = r.search_batch_raw(batch)
+            oe, oc = o.search_multiple_bytes(batch)
+            assert counts == oc.tolist()
+            assert sorted(ents) == sorted(oe)
+        assert r.count_multiple([q.decode() for q in qs[:50]]) == o.search_multiple_bytes(qs[:50])[1].tolist()
+    monkeypatch.delenv('PSS_READER_HBM_BUDGET')
+    with pysubstringsearch.Reader(p) as r:
+        assert r.residency['host_chunks'] == 0

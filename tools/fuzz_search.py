@@ -59,6 +59,11 @@ def one_case(seed, tmp):
         os.environ['PSS_NO_BLOCK_PATH'] = '1'
     else:
         os.environ.pop('PSS_NO_BLOCK_PATH', None)
+    if rng.random() < 0.3:
+        # suffix arrays beyond this many bytes of HBM stay in pinned host memory
+        os.environ['PSS_READER_HBM_BUDGET'] = str(rng.choice([0, total * 2, total * 4]))
+    else:
+        os.environ.pop('PSS_READER_HBM_BUDGET', None)
     os.environ.pop('PSS_NO_KEY_SAMPLES', None)
     os.environ.pop('PSS_SAMPLE_SHIFT', None)
     r = rng.random()
