@@ -379,10 +379,104 @@ __device__ __forceinline__ void copy_entry(u8 *dst, const u8 *src, u32 l)
     for (; i < l; ++i) dst[i] = src[i];
 }
 
+// ---- mid pipeline: batches of <= MID_MAX pairs with <= MID_MAX hits -----------------------
+// The general pipeline waits for the host twice in the middle (hit total, then entry / byte totals:
+// sizes of the next allocations and grids) and spends nine launches on three scans.  When the pairs
+// and the hits fit one workgroup's scan, the totals stay on the device (MidState), every scan is one
+// launch, the buffers are sized for the caps, and the host waits once for the totals and once for the
+// result.  More hits or bytes than the caps raise `flag`; the later kernels then do nothing and the
+// general pipeline runs instead.
+constexpr u32 MID_MAX = 65536;
+constexpr u32 MID_BLOCK = 1024;
+struct MidState {
+    u64 hits, entries, bytes;
+    u32 flag, pad;
+};
+
+// exclusive sum of one value per thread over a MID_BLOCK workgroup (u64); *total = block sum
+__device__ __forceinline__ u64 mid_block_excl(u64 v, u64 *scr /* [16] */, u64 *total)
+{
+    const u64 incl = wave_incl_sum64(v);
+    if (lane_id() == kWave - 1) scr[wave_id()] = incl;
+    __syncthreads();
+    u64 base = 0, tot = 0;
+#pragma unroll
+    for (u32 w = 0; w < MID_BLOCK / kWave; ++w) {
+        const u64 x = scr[w];
+        if (w < (u32)wave_id()) base += x;
+        tot += x;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+// hit counts -> hit offsets (nvq + 1 entries); total and overflow flag into MidState
+__global__ __launch_bounds__(MID_BLOCK) void mid_hitoff_kernel(const u32 *cnt, u32 nvq, u64 *hit_off, MidState *ms)
+{
+    __shared__ u64 scr[MID_BLOCK / kWave];
+    const u32 per = (nvq + MID_BLOCK - 1) / MID_BLOCK;
+    const u32 i0 = min(threadIdx.x * per, nvq), i1 = min(i0 + per, nvq);
+    u64 local = 0;
+    for (u32 i = i0; i < i1; ++i) local += cnt[i];
+    u64 total;
+    u64 run = mid_block_excl(local, scr, &total);
+    for (u32 i = i0; i < i1; ++i) {
+        hit_off[i] = run;
+        run += cnt[i];
+    }
+    if (threadIdx.x == 0) {
+        hit_off[nvq] = total;
+        ms->hits = total;
+        ms->entries = 0;
+        ms->bytes = 0;
+        ms->flag = total > MID_MAX ? 1u : 0u;
+    }
+}
+
+// kept flags -> entry index, entry lengths -> byte offset (both hits + 1 entries), in one launch
+__global__ __launch_bounds__(MID_BLOCK) void mid_hit_scans_kernel(const u32 *len, MidState *ms, u64 byte_cap, u64 *eidx,
+                                                                    u64 *boff)
+{
+    __shared__ u64 scr[MID_BLOCK / kWave];
+    if (ms->flag) return;
+    const u32 H = (u32)ms->hits;
+    const u32 per = (H + MID_BLOCK - 1) / MID_BLOCK;
+    const u32 i0 = min(threadIdx.x * per, H), i1 = min(i0 + per, H);
+    u64 le = 0, lb = 0;
+    for (u32 i = i0; i < i1; ++i) {
+        const u32 l = len[i];
+        if (l != kSkip) {
+            ++le;
+            lb += l;
+        }
+    }
+    u64 te, tb;
+    u64 re = mid_block_excl(le, scr, &te);
+    u64 rb = mid_block_excl(lb, scr, &tb);
+    for (u32 i = i0; i < i1; ++i) {
+        const u32 l = len[i];
+        eidx[i] = re;
+        boff[i] = rb;
+        if (l != kSkip) {
+            ++re;
+            rb += l;
+        }
+    }
+    if (threadIdx.x == 0) {
+        eidx[H] = te;
+        boff[H] = tb;
+        ms->entries = te;
+        ms->bytes = tb;
+        if (tb > byte_cap) ms->flag = 1u;
+    }
+}
+
 __global__ __launch_bounds__(256) void hit_lines_kernel(const ChunkDesc *chunks, u32 nc, const u8 *qbytes,
                                                           const u64 *qoff, u64 nvq, const u32 *lo, const u64 *hit_off,
-                                                          u64 H, u32 *start_out, u32 *len_out)
+                                                          u64 H, const MidState *mid, u32 *start_out, u32 *len_out)
 {
+    if (mid) H = mid->flag ? 0 : mid->hits;      // mid pipeline: the hit count never visits the host
     for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < H; t += (u64)gridDim.x * blockDim.x) {
         // owning (query, chunk): last vq with hit_off[vq] <= t
         u64 a = 0, b = nvq;
@@ -658,9 +752,10 @@ __global__ __launch_bounds__(SM_BLOCK) void search_block_kernel(const ChunkDesc 
 }
 
 __global__ __launch_bounds__(256) void emit_kernel(const ChunkDesc *chunks, u32 nc, u64 nvq, const u64 *hit_off, u64 H,
-                                                     const u32 *start, const u32 *len, const u64 *eidx,
-                                                     const u64 *boff, u64 *ent_off, u8 *out)
+                                                     const MidState *mid, const u32 *start, const u32 *len,
+                                                     const u64 *eidx, const u64 *boff, u64 *ent_off, u8 *out)
 {
+    if (mid) H = mid->flag ? 0 : mid->hits;
     for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < H; t += (u64)gridDim.x * blockDim.x) {
         const u32 l = len[t];
         if (l == kSkip) continue;
@@ -678,10 +773,10 @@ __global__ __launch_bounds__(256) void emit_kernel(const ChunkDesc *chunks, u32 
 
 // entries per query = sum over its chunks of kept hits
 __global__ __launch_bounds__(256) void query_counts_kernel(u32 nc, u32 nq, const u64 *hit_off, const u64 *eidx,
-                                                             u64 *qcount)
+                                                             u64 *qcount, const MidState *mid)
 {
     const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
+    if (q >= nq || (mid && mid->flag)) return;      // mid pipeline over its caps: eidx is not filled
     const u64 v0 = (u64)q * nc, v1 = v0 + nc;
     qcount[q] = eidx[hit_off[v1]] - eidx[hit_off[v0]];
 }
@@ -713,7 +808,7 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
     PSS_TRY(ctx->slot[Q_LO].reserve(nvq * 4));
     PSS_TRY(ctx->slot[Q_CNT].reserve(nvq * 4));
     PSS_TRY(ctx->slot[Q_HITOFF].reserve((nvq + 1) * 8));
-    PSS_TRY(ctx->slot[Q_SMALL].reserve(SC_MAX_BLOCKS * 8 + 64));
+    PSS_TRY(ctx->slot[Q_SMALL].reserve(SC_MAX_BLOCKS * 8 + 256));      // scan partials, totals, MidState
     PSS_TRY(ctx->slot[Q_QCOUNT].reserve((size_t)nq * 8));
     u8 *d_q = ctx->slot[Q_BYTES].as<u8>();
     u64 *d_qoff = ctx->slot[Q_OFF].as<u64>();
@@ -830,6 +925,59 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
         hipLaunchKernelGGL(search_interval_kernel, dim3((u32)((nvq + waves_per_block - 1) / waves_per_block)), dim3(256),
                            0, s, d_chunks, nc, d_q, d_qoff, nvq, d_lo, d_cnt);
     PSS_HIP(hipEventRecord(e1, s));
+    if (nvq <= MID_MAX && !counts_only && !getenv("PSS_NO_MID_PIPELINE")) {
+        // ---- mid pipeline: totals stay on the device, one wait for them, one for the result ----
+        const u64 byte_cap = (u64)16 << 20;
+        PSS_TRY(ctx->slot[Q_START].reserve((size_t)MID_MAX * 4));
+        PSS_TRY(ctx->slot[Q_LEN].reserve((size_t)MID_MAX * 4));
+        PSS_TRY(ctx->slot[Q_EIDX].reserve(((size_t)MID_MAX + 1) * 8));
+        PSS_TRY(ctx->slot[Q_BOFF].reserve(((size_t)MID_MAX + 1) * 8));
+        PSS_TRY(ctx->slot[Q_ENTOFF].reserve(((size_t)MID_MAX + 1) * 8));
+        PSS_TRY(ctx->slot[Q_OUT].reserve(byte_cap + 16));
+        u32 *d_start = ctx->slot[Q_START].as<u32>();
+        u32 *d_len = ctx->slot[Q_LEN].as<u32>();
+        u64 *d_eidx = ctx->slot[Q_EIDX].as<u64>();
+        u64 *d_boff = ctx->slot[Q_BOFF].as<u64>();
+        u64 *d_entoff = ctx->slot[Q_ENTOFF].as<u64>();
+        u8 *d_out = ctx->slot[Q_OUT].as<u8>();
+        MidState *d_ms = reinterpret_cast<MidState *>(d_total + 8);         // behind the scan partials
+        const u32 grid = (u32)ctx->num_cus * 4;
+        hipLaunchKernelGGL(mid_hitoff_kernel, dim3(1), dim3(MID_BLOCK), 0, s, d_cnt, (u32)nvq, d_hitoff, d_ms);
+        hipLaunchKernelGGL(hit_lines_kernel, dim3(grid), dim3(256), 0, s, d_chunks, nc, d_q, d_qoff, nvq, d_lo, d_hitoff,
+                           (u64)0, d_ms, d_start, d_len);
+        hipLaunchKernelGGL(mid_hit_scans_kernel, dim3(1), dim3(MID_BLOCK), 0, s, d_len, d_ms, byte_cap, d_eidx, d_boff);
+        hipLaunchKernelGGL(emit_kernel, dim3(grid), dim3(256), 0, s, d_chunks, nc, nvq, d_hitoff, (u64)0, d_ms, d_start,
+                           d_len, d_eidx, d_boff, d_entoff, d_out);
+        hipLaunchKernelGGL(query_counts_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, nc, nq, d_hitoff, d_eidx, d_qcount,
+                           (const MidState *)d_ms);
+        PSS_HIP(hipEventRecord(e2, s));
+        MidState *h_ms = reinterpret_cast<MidState *>(h_small);
+        PSS_HIP(hipMemcpyAsync(h_ms, d_ms, sizeof(MidState), hipMemcpyDeviceToHost, s));
+        PSS_HIP(hipStreamSynchronize(s));
+        if (!h_ms->flag) {
+            const u64 H = h_ms->hits, E = h_ms->entries, B = h_ms->bytes;
+            res->offsets = (u64 *)malloc((E + 1) * sizeof(u64));
+            res->bytes = (u8 *)malloc(B ? B : 1);
+            if (!res->offsets || !res->bytes) return PSS_ENOMEM;
+            if (E) PSS_HIP(hipMemcpyAsync(res->offsets, d_entoff, E * 8, hipMemcpyDeviceToHost, s));
+            if (B) PSS_HIP(hipMemcpyAsync(res->bytes, d_out, B, hipMemcpyDeviceToHost, s));
+            PSS_HIP(hipMemcpyAsync(res->qcount, d_qcount, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
+            PSS_HIP(hipStreamSynchronize(s));
+            res->offsets[E] = B;
+            res->n_entries = E;
+            st->hits = H;
+            st->entries = E;
+            st->result_bytes = B;
+            float ms = 0.f;
+            PSS_HIP(hipEventElapsedTime(&ms, e0, e2));
+            st->ms_device = ms;
+            PSS_HIP(hipEventElapsedTime(&ms, e0, e1));
+            st->ms_interval = ms;
+            st->ms_host = host_ms();
+            return PSS_OK;
+        }
+        // more hits or bytes than the caps: the general pipeline below takes over (intervals are kept)
+    }
     PSS_TRY(device_excl_scan(ctx, InU32{d_cnt}, nvq, d_partial, d_total, d_hitoff));
     PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
     PSS_HIP(hipStreamSynchronize(s));
@@ -847,13 +995,13 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
         u64 *d_boff = ctx->slot[Q_BOFF].as<u64>();
         const u32 grid = (u32)std::min<u64>((u64)ctx->num_cus * 16, (H + 255) / 256);
         hipLaunchKernelGGL(hit_lines_kernel, dim3(grid), dim3(256), 0, s, d_chunks, nc, d_q, d_qoff, nvq, d_lo,
-                           d_hitoff, H, d_start, d_len);
+                           d_hitoff, H, (const MidState *)nullptr, d_start, d_len);
         PSS_TRY(device_excl_scan(ctx, InKept{d_len}, H, d_partial, d_total, d_eidx));
         PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
         if (counts_only) {
             // entries per query without materialising one: interval search, dedupe flags, two scans
             hipLaunchKernelGGL(query_counts_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, nc, nq, d_hitoff, d_eidx,
-                               d_qcount);
+                               d_qcount, (const MidState *)nullptr);
             PSS_HIP(hipEventRecord(e2, s));
             PSS_HIP(hipMemcpyAsync(res->qcount, d_qcount, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
             PSS_HIP(hipStreamSynchronize(s));
@@ -877,10 +1025,10 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
         PSS_TRY(ctx->slot[Q_OUT].reserve(B + 16));
         u64 *d_entoff = ctx->slot[Q_ENTOFF].as<u64>();
         u8 *d_out = ctx->slot[Q_OUT].as<u8>();
-        hipLaunchKernelGGL(emit_kernel, dim3(grid), dim3(256), 0, s, d_chunks, nc, nvq, d_hitoff, H, d_start, d_len,
-                           d_eidx, d_boff, d_entoff, d_out);
+        hipLaunchKernelGGL(emit_kernel, dim3(grid), dim3(256), 0, s, d_chunks, nc, nvq, d_hitoff, H,
+                           (const MidState *)nullptr, d_start, d_len, d_eidx, d_boff, d_entoff, d_out);
         hipLaunchKernelGGL(query_counts_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, nc, nq, d_hitoff, d_eidx,
-                           d_qcount);
+                           d_qcount, (const MidState *)nullptr);
         PSS_HIP(hipEventRecord(e2, s));
         res->offsets = (u64 *)malloc((E + 1) * sizeof(u64));
         res->bytes = (u8 *)malloc(B ? B : 1);

@@ -64,6 +64,10 @@ def one_case(seed, tmp):
         os.environ['PSS_READER_HBM_BUDGET'] = str(rng.choice([0, total * 2, total * 4]))
     else:
         os.environ.pop('PSS_READER_HBM_BUDGET', None)
+    if rng.random() < 0.3:
+        os.environ['PSS_NO_MID_PIPELINE'] = '1'
+    else:
+        os.environ.pop('PSS_NO_MID_PIPELINE', None)
     os.environ.pop('PSS_NO_KEY_SAMPLES', None)
     os.environ.pop('PSS_SAMPLE_SHIFT', None)
     r = rng.random()
