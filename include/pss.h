@@ -115,6 +115,14 @@ int32_t pss_sort_pairs_device(void *d_keys, void *d_vals, uint32_t n, int32_t ke
 /* Writer::new, src/lib.rs:50-65.  Creates/truncates `path`.  max_chunk_len < 0
  * means None (512 MiB, src/lib.rs:57).  Suffix arrays are built on `device`. */
 int pss_writer_open(const char *path, int64_t max_chunk_len, int32_t device, pss_writer **out);
+/* The same with the container format chosen (no reference counterpart).
+ * 1 = the reference's records, u32le len | text | u32le 4n | n x i32le (src/lib.rs:112-119), whose
+ *     u32 at lib.rs:116 limits a chunk to < 1 GiB of text;
+ * 2 = "PSSIDX\x02\x00" | u32le flags (0) | u32le reserved (0), then records with 64-bit lengths,
+ *     u64le n | text | u64le 4n | n x i32le: chunks of up to 2^31 - 1 bytes (max_chunk_len beyond
+ *     that is PSS_EINVAL).  pss_reader_open recognises either format by the magic. */
+int pss_writer_open_format(const char *path, int64_t max_chunk_len, int32_t device, int32_t format_version,
+                           pss_writer **out);
 /* Writer::add_entry, src/lib.rs:88-103.  PSS_ETOOBIG when len > limit. */
 int pss_writer_add_entry(pss_writer *w, const uint8_t *text, uint64_t len);
 /* Writer::add_entries_from_file_lines, src/lib.rs:67-86 (bstr for_byte_line rule). */

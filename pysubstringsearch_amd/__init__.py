@@ -70,7 +70,12 @@ class Writer:
         max_chunk_len: typing.Optional[int] = None,
         *,
         device: typing.Optional[int] = None,
+        format_version: int = 1,
     ) -> None:
+        """``format_version=2`` (extension, opt-in) writes the container with 64-bit lengths: chunks of
+        up to 2^31 - 1 bytes instead of the reference format's < 1 GiB.  Reader opens either."""
+        if format_version not in (1, 2):
+            raise ValueError('format_version must be 1 (the reference container) or 2')
         if max_chunk_len is not None:
             if not isinstance(max_chunk_len, int) or isinstance(max_chunk_len, bool):
                 raise TypeError("argument 'max_chunk_len': must be an int or None")
@@ -78,9 +83,9 @@ class Writer:
                 raise OverflowError("can't convert negative int to unsigned")   # Option<usize>
         self._h = ctypes.c_void_p()
         path = _path(index_file_path, 'index_file_path')
-        rc = _lib.pss_writer_open(
+        rc = _lib.pss_writer_open_format(
             path, -1 if max_chunk_len is None else max_chunk_len,
-            _default_device() if device is None else device, ctypes.byref(self._h))
+            _default_device() if device is None else device, format_version, ctypes.byref(self._h))
         _ffi.check(rc, index_file_path)
         self.writer = self   # the reference wrapper exposes `.writer` (__init__.py:12)
 

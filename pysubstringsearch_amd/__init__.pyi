@@ -10,6 +10,7 @@ class Writer:
         max_chunk_len: typing.Optional[int] = None,
         *,
         device: typing.Optional[int] = None,
+        format_version: int = 1,
     ) -> None: ...
 
     def add_entries_from_file_lines(self, input_file_path: str) -> None: ...

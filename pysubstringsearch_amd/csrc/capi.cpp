@@ -205,6 +205,7 @@ struct pss_writer {
     DevBuf d_sa[2];               // suffix arrays in HBM: one being written out, one being built
     int sa_next = 0;
     WriterIo *io = nullptr;
+    int version = 1;              // container format: 1 = the reference's (lib.rs:112-119), 2 = 64-bit lengths
 };
 
 namespace {
@@ -246,6 +247,19 @@ int w_append(pss_writer *w, const uint8_t *p, size_t l)
     return PSS_OK;
 }
 
+// Container format 2 (opt-in; the reference format stays the default):
+//   file   = "PSSIDX\x02\x00" | u32le flags (0) | u32le reserved (0) | record*
+//   record = u64le n | n bytes of text | u64le 4n | n x i32le
+// i.e. the reference's record with 64-bit lengths: the u32 at lib.rs:116 wraps from 1 GiB of text on,
+// here a chunk may hold up to 2^31 - 1 bytes (the suffix array stays int32).
+constexpr uint8_t kMagicV2[8] = {'P', 'S', 'S', 'I', 'D', 'X', 2, 0};
+constexpr size_t kHeaderV2 = 16;
+
+void put_u64le(uint8_t *p, uint64_t v)
+{
+    for (int i = 0; i < 8; ++i) p[i] = (uint8_t)(v >> (8 * i));
+}
+
 void put_u32le(uint8_t *p, uint32_t v)
 {
     p[0] = (uint8_t)v;
@@ -281,16 +295,19 @@ int download_to_file(WriterIo *io, const void *src, size_t bytes, FILE *fp)
 // One chunk record: u32le len | data | u32le 4n | n x i32le  (src/lib.rs:112-119)
 int write_record(pss_writer *w, const uint8_t *text, size_t n, const void *d_sa)
 {
-    uint8_t hdr[4];
+    uint8_t hdr[8];
+    const size_t hl = w->version == 2 ? 8 : 4;
     errno = 0;
-    put_u32le(hdr, (uint32_t)n);
+    if (w->version == 2) put_u64le(hdr, (uint64_t)n);
+    else put_u32le(hdr, (uint32_t)n);
     {
         Phase ph("record: write text");
-        if (fwrite(hdr, 1, 4, w->fp) != 4) return io_error("write");
+        if (fwrite(hdr, 1, hl, w->fp) != hl) return io_error("write");
         if (fwrite(text, 1, n, w->fp) != n) return io_error("write");
     }
-    put_u32le(hdr, (uint32_t)(n * 4));   // wraps like `as u32` at n >= 2^30 (lib.rs:116)
-    if (fwrite(hdr, 1, 4, w->fp) != 4) return io_error("write");
+    if (w->version == 2) put_u64le(hdr, (uint64_t)n * 4);
+    else put_u32le(hdr, (uint32_t)(n * 4));   // wraps like `as u32` at n >= 2^30 (lib.rs:116)
+    if (fwrite(hdr, 1, hl, w->fp) != hl) return io_error("write");
     // x86-64 / little-endian host: int32 in memory == i32le on disk (lib.rs:117-119)
     Phase ph("record: SA -> file");
     return download_to_file(w->io, d_sa, n * 4, w->fp);
@@ -389,13 +406,16 @@ int w_dump(pss_writer *w)
     if (n < 2) {
         // libsais.c:6603-6607: n == 1 -> SA[0] = 0; written by the caller once the thread is idle
         PSS_TRY(io_wait(w));
-        uint8_t hdr[4];
+        uint8_t hdr[8];
+        const size_t hl = w->version == 2 ? 8 : 4;
         errno = 0;
-        put_u32le(hdr, (uint32_t)n);
-        if (fwrite(hdr, 1, 4, w->fp) != 4 || fwrite(w->buf, 1, n, w->fp) != n) return io_error("write");
-        put_u32le(hdr, 4);
+        if (w->version == 2) put_u64le(hdr, (uint64_t)n);
+        else put_u32le(hdr, (uint32_t)n);
+        if (fwrite(hdr, 1, hl, w->fp) != hl || fwrite(w->buf, 1, n, w->fp) != n) return io_error("write");
+        if (w->version == 2) put_u64le(hdr, 4);
+        else put_u32le(hdr, 4);
         const uint8_t zero[4] = {0, 0, 0, 0};
-        if (fwrite(hdr, 1, 4, w->fp) != 4 || fwrite(zero, 1, 4, w->fp) != 4) return io_error("write");
+        if (fwrite(hdr, 1, hl, w->fp) != hl || fwrite(zero, 1, 4, w->fp) != 4) return io_error("write");
         w->len = 0;
         return PSS_OK;
     }
@@ -436,23 +456,43 @@ int w_dump(pss_writer *w)
 
 }  // namespace
 
-extern "C" int pss_writer_open(const char *path, int64_t max_chunk_len, int32_t device, pss_writer **out)
+extern "C" int pss_writer_open_format(const char *path, int64_t max_chunk_len, int32_t device, int32_t format_version,
+                                      pss_writer **out)
 {
     return guarded([&]() -> int {
-        if (!path || !out) {
-            set_error("pss_writer_open: bad arguments");
+        if (!path || !out || (format_version != 1 && format_version != 2)) {
+            set_error("pss_writer_open: bad arguments (format_version must be 1 or 2)");
+            return PSS_EINVAL;
+        }
+        if (format_version == 2 && max_chunk_len > (int64_t)INT32_MAX) {
+            set_error("max_chunk_len %lld: a chunk holds at most 2^31 - 1 bytes (32-bit suffix array)", (long long)max_chunk_len);
             return PSS_EINVAL;
         }
         errno = 0;
         FILE *fp = fopen(path, "wb");   // File::create truncates, lib.rs:55
         if (!fp) return io_error(path);
+        if (format_version == 2) {
+            uint8_t hdr[kHeaderV2] = {};
+            memcpy(hdr, kMagicV2, 8);
+            if (fwrite(hdr, 1, kHeaderV2, fp) != kHeaderV2) {
+                const int rc = io_error(path);
+                fclose(fp);
+                return rc;
+            }
+        }
         pss_writer *w = new pss_writer();
         w->fp = fp;
         w->limit = max_chunk_len < 0 ? (size_t)512 * 1024 * 1024 : (size_t)max_chunk_len;   // lib.rs:57
         w->device = device;
+        w->version = format_version;
         *out = w;
         return PSS_OK;
     });
+}
+
+extern "C" int pss_writer_open(const char *path, int64_t max_chunk_len, int32_t device, pss_writer **out)
+{
+    return pss_writer_open_format(path, max_chunk_len, device, 1, out);
 }
 
 extern "C" int pss_writer_add_entry(pss_writer *w, const uint8_t *text, uint64_t len)
@@ -818,10 +858,40 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
         uint64_t bytes_read = 0;
         int64_t index = 0;
         int rc = PSS_OK;
+        // format 2 announces itself (a reference file starts with the u32 length of its first chunk,
+        // < 2^30, which these bytes are not): 64-bit lengths, otherwise the same records
+        bool v2 = false;
+        if (flen >= kHeaderV2) {
+            uint8_t fh[kHeaderV2];
+            if (fread(fh, 1, kHeaderV2, fp) == kHeaderV2 && memcmp(fh, kMagicV2, 8) == 0) {
+                v2 = true;
+                bytes_read = kHeaderV2;
+            } else {
+                fseeko(fp, 0, SEEK_SET);
+            }
+        }
+        const size_t hl = v2 ? 8 : 4;
+        auto get_len = [&](uint64_t *out_len) -> bool {
+            uint8_t hdr[8];
+            if (fread(hdr, 1, hl, fp) != hl) return false;
+            uint64_t v = 0;
+            for (size_t i = 0; i < hl; ++i) v |= (uint64_t)hdr[i] << (8 * i);
+            *out_len = v;
+            return true;
+        };
+        const char *kTrunc = "failed to fill whole buffer (truncated index file)";
         while (bytes_read < flen) {   // lib.rs:174
-            uint8_t hdr[4];
-            if (fread(hdr, 1, 4, fp) != 4) { set_error("failed to fill whole buffer (truncated index file)"); rc = PSS_EFORMAT; break; }
-            const uint32_t dlen = (uint32_t)hdr[0] | (uint32_t)hdr[1] << 8 | (uint32_t)hdr[2] << 16 | (uint32_t)hdr[3] << 24;
+            uint64_t dlen64 = 0, slen = 0;
+            if (!get_len(&dlen64)) { set_error("%s", kTrunc); rc = PSS_EFORMAT; break; }
+            if (dlen64 > (uint64_t)INT32_MAX || bytes_read + 2 * hl + dlen64 > flen) {
+                if (dlen64 > (uint64_t)INT32_MAX && bytes_read + 2 * hl + dlen64 <= flen)
+                    set_error("chunk %lld: %llu bytes of text exceed the 32-bit suffix array", (long long)index, (unsigned long long)dlen64);
+                else
+                    set_error("%s", kTrunc);
+                rc = PSS_EFORMAT;
+                break;
+            }
+            const uint32_t dlen = (uint32_t)dlen64;
             const bool mine = (index % shard_count) == shard_index;
             ChunkDesc cd{};
             pss_reader::Mem cm;
@@ -833,30 +903,31 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
                 rc = upload_from_file(r, fp, const_cast<uint8_t *>(cd.text), dlen);
                 if (rc) break;
             } else if (fseeko(fp, dlen, SEEK_CUR) != 0) { rc = io_error(path); break; }
-            if (fread(hdr, 1, 4, fp) != 4) { set_error("failed to fill whole buffer (truncated index file)"); rc = PSS_EFORMAT; break; }
-            const uint32_t slen = (uint32_t)hdr[0] | (uint32_t)hdr[1] << 8 | (uint32_t)hdr[2] << 16 | (uint32_t)hdr[3] << 24;
-            if ((uint64_t)slen != (uint64_t)dlen * 4 && dlen < (1u << 30)) {
-                set_error("chunk %lld: suffix array of %u bytes does not match %u bytes of text", (long long)index, slen, dlen);
+            if (!get_len(&slen)) { set_error("%s", kTrunc); rc = PSS_EFORMAT; break; }
+            // the reference format stores (4n) as u32, which wraps from 2^30 bytes of text on (lib.rs:116)
+            const uint64_t want = v2 ? (uint64_t)dlen * 4 : (uint64_t)(uint32_t)((uint64_t)dlen * 4);
+            if (slen != want) {
+                set_error("chunk %lld: suffix array of %llu bytes does not match %u bytes of text", (long long)index,
+                          (unsigned long long)slen, dlen);
                 rc = PSS_EFORMAT;
                 break;
             }
+            const uint64_t sa_bytes_file = (uint64_t)dlen * 4;
+            if (bytes_read + 2 * hl + dlen + sa_bytes_file > flen) { set_error("%s", kTrunc); rc = PSS_EFORMAT; break; }
             if (mine && dlen) {
                 if (cm.sa_host) {      // host tier: the file is read straight into the pinned buffer
-                    if (fread(cm.sa, 1, (size_t)dlen * 4, fp) != (size_t)dlen * 4) {
-                        set_error("failed to fill whole buffer (truncated index file)");
+                    if (fread(cm.sa, 1, (size_t)sa_bytes_file, fp) != (size_t)sa_bytes_file) {
+                        set_error("%s", kTrunc);
                         rc = PSS_EFORMAT;
                     }
                 } else {
-                    rc = upload_from_file(r, fp, cm.sa, (size_t)dlen * 4);
+                    rc = upload_from_file(r, fp, cm.sa, (size_t)sa_bytes_file);
                 }
                 if (rc) break;
                 rc = reader_sample_chunk(r, cd);     // uploads are complete (copy stream synchronised)
                 if (rc) break;
-            } else {
-                if (bytes_read + 8 + dlen + (uint64_t)slen > flen) { set_error("failed to fill whole buffer (truncated index file)"); rc = PSS_EFORMAT; break; }
-                if (fseeko(fp, slen, SEEK_CUR) != 0) { rc = io_error(path); break; }
-            }
-            bytes_read += 8 + (uint64_t)dlen + slen;   // lib.rs:184
+            } else if (fseeko(fp, (off_t)sa_bytes_file, SEEK_CUR) != 0) { rc = io_error(path); break; }
+            bytes_read += 2 * hl + (uint64_t)dlen + sa_bytes_file;   // lib.rs:184
             ++index;
         }
         if (rc == PSS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {

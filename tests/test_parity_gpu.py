@@ -443,3 +443,47 @@ def test_suffix_arrays_beyond_the_hbm_budget_stay_on_the_host(tmp_path, oracle, 
     monkeypatch.delenv('PSS_READER_HBM_BUDGET')
     with pysubstringsearch.Reader(p) as r:
         assert r.residency['host_chunks'] == 0
+
+
+def test_container_format_2(tmp_path, oracle):
+    """Opt-in container with 64-bit lengths (no reference counterpart): same chunks, same suffix
+    arrays, same search results as the reference container of the same entries; the Reader tells the
+    two apart by the magic; truncation is reported like the reference's UnexpectedEof."""
+    rng = random.Random(11)
+    entries = [''.join(rng.choice('abcd \t') for _ in range(rng.randint(0, 30))) for _ in range(4000)] + ['', 'x']
+    p1, p2 = str(tmp_path / 'v1.idx'), str(tmp_path / 'v2.idx')
+    b1 = build(p1, entries, 3000)
+    w = pysubstringsearch.Writer(p2, 3000, format_version=2)
+    for e in entries:
+        w.add_entry(e)
+    w.close()
+    b2 = open(p2, 'rb').read()
+    assert b2[:8] == b'PSSIDX\x02\x00' and b2[8:16] == bytes(8)
+    # walk both files: identical text and suffix array bytes, chunk by chunk
+    o1, o2, chunks = 0, 16, 0
+    while o1 < len(b1):
+        n = int.from_bytes(b1[o1:o1 + 4], 'little')
+        assert int.from_bytes(b2[o2:o2 + 8], 'little') == n
+        assert b1[o1 + 4:o1 + 4 + n] == b2[o2 + 8:o2 + 8 + n]
+        s1, s2 = o1 + 4 + n, o2 + 8 + n
+        assert int.from_bytes(b1[s1:s1 + 4], 'little') == 4 * n == int.from_bytes(b2[s2:s2 + 8], 'little')
+        assert b1[s1 + 4:s1 + 4 + 4 * n] == b2[s2 + 8:s2 + 8 + 4 * n]
+        o1, o2, chunks = s1 + 4 + 4 * n, s2 + 8 + 4 * n, chunks + 1
+    assert o2 == len(b2) and chunks > 3
+    text = '\n'.join(entries) + '\n'
+    qs = [text[s:s + rng.randint(1, 6)] for s in (rng.randrange(len(text)) for _ in range(300))] + ['', 'zz', '\n']
+    o = oracle.OracleReader(p1)
+    oe, oc = o.search_multiple_bytes([q.encode() for q in qs])
+    with pysubstringsearch.Reader(p2) as r:
+        assert r.num_chunks == chunks
+        ents, counts = r.search_batch_raw([q.encode() for q in qs])
+        assert counts == oc.tolist() and sorted(ents) == sorted(oe)
+    with pysubstringsearch.Reader(p2, shard=(1, 3)) as r:
+        assert r.num_chunks == len(range(1, chunks, 3))
+    open(str(tmp_path / 'cut.idx'), 'wb').write(b2[:len(b2) - 5])
+    with pytest.raises(OSError):
+        pysubstringsearch.Reader(str(tmp_path / 'cut.idx'))
+    with pytest.raises(ValueError):
+        pysubstringsearch.Writer(str(tmp_path / 'bad.idx'), 1 << 31, format_version=2)
+    with pytest.raises(ValueError):
+        pysubstringsearch.Writer(str(tmp_path / 'bad.idx'), format_version=3)
