@@ -297,15 +297,25 @@ __device__ __forceinline__ bool hit_entry(const ChunkDesc &ch, const u8 *pat, u3
                                           u32 &line_len)
 {
     const u64 NL = 0x0a0a0a0a0a0a0a0aull;
-    // The scans are chains of dependent loads from a random place in the text, so they move 32
-    // bytes per step (four independent 8-byte loads) and the first step forwards is issued
-    // before the backward scan starts.  text is zero padded 64 bytes past n.
-    u64 fw[4];
+    // The scans are chains of dependent loads from a random place in the text, and the slowest lane
+    // of a wave sets the pace, so they move HE_W * 8 = 64 bytes per step (independent 8-byte loads)
+    // and the first step forwards is issued before the backward scan starts.  text is zero padded
+    // 64 bytes past n and the loads stay inside [.., n + 64): di < n, so di + 64 + 3 <= n + 66 -- the
+    // last word of a step is clamped to the padding.
+    constexpr int HE_W = 8;
+    u64 fw[HE_W];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) fw[k] = load_u64_unaligned(ch.text + di + 8 * k);
+    for (int k = 0; k < HE_W; ++k) fw[k] = (di + 8 * k < ch.n) ? load_u64_unaligned(ch.text + di + 8 * k) : 0ull;
     // Backwards to the entry start (lib.rs:270-273); candidates for an earlier occurrence are
-    // the bytes equal to the query's first byte.
+    // the bytes equal to the query's first byte.  A candidate is checked against the query's first
+    // min(8, plen) bytes IN REGISTERS (the word just scanned plus the word after it in the text, which
+    // the scan has seen before); only a query longer than 8 bytes whose first 8 match goes back to
+    // memory.  (Checking every candidate with a load made the slowest lane of a wave pay one memory
+    // round trip per candidate and word: 20 us for 70 hits.)
     const u64 first = plen ? 0x0101010101010101ull * pat[0] : 0;
+    const u64 pmask = plen >= 8 ? ~0ull : (plen ? (1ull << (8 * plen)) - 1ull : 0ull);
+    const u64 pk = load_u64_unaligned(pat) & pmask;            // pat is readable 16 bytes past its end
+    u64 nxt = fw[0];       // the 8 bytes behind the word being scanned: text[p, p + 8)
     u32 p = di;            // scan frontier: bytes [p, di) hold no newline
     bool dup = false, at_start = false;
     // one 8-byte word w = text[p-8, p): byte k of w = text[p-8+k]
@@ -324,17 +334,19 @@ __device__ __forceinline__ bool hit_entry(const ChunkDesc &ch, const u8 *pat, u3
             while (cand && !dup) {
                 const u32 k = (u32)(__builtin_ctzll(cand) >> 3);
                 cand &= cand - 1;
-                dup = cmp_suffix(ch.text, ch.n, p - 8 + k, pat, plen) == 0;
+                const u64 x = k ? (w >> (8 * k)) | (nxt << (64 - 8 * k)) : w;     // text[p-8+k, p+k)
+                if ((x & pmask) == pk) dup = plen <= 8 || cmp_suffix(ch.text, ch.n, p - 8 + k, pat, plen) == 0;
             }
         }
+        nxt = w;
         p = at_start ? p - 8 + keep_from : p - 8;
     };
-    while (p >= 32 && !dup && !at_start) {
-        u64 w[4];
+    while (p >= 8 * HE_W && !dup && !at_start) {
+        u64 w[HE_W];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = load_u64_unaligned(ch.text + p - 8 * (k + 1));
+        for (int k = 0; k < HE_W; ++k) w[k] = load_u64_unaligned(ch.text + p - 8 * (k + 1));
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < HE_W; ++k)
             if (!dup && !at_start) word(w[k]);
     }
     while (p >= 8 && !dup && !at_start) word(load_u64_unaligned(ch.text + p - 8));
@@ -351,7 +363,7 @@ __device__ __forceinline__ bool hit_entry(const ChunkDesc &ch, const u8 *pat, u3
     for (;;) {
         bool found = false;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < HE_W; ++k) {
             const u64 nlm = zero_bytes(fw[k] ^ NL);
             if (nlm && !found) {
                 e += 8 * k + (u32)(__builtin_ctzll(nlm) >> 3);
@@ -359,24 +371,54 @@ __device__ __forceinline__ bool hit_entry(const ChunkDesc &ch, const u8 *pat, u3
             }
         }
         if (found) break;
-        e += 32;
+        e += 8 * HE_W;
         if (e >= ch.n) break;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) fw[k] = load_u64_unaligned(ch.text + e + 8 * k);
+        for (int k = 0; k < HE_W; ++k) fw[k] = (e + 8 * k < ch.n) ? load_u64_unaligned(ch.text + e + 8 * k) : 0ull;
     }
     if (e >= ch.n) e = ch.n - 1;
     line_len = e >= line_start ? e - line_start : 0;
     return true;
 }
 
-__device__ __forceinline__ void copy_entry(u8 *dst, const u8 *src, u32 l)
+// Copies one entry (l bytes, unaligned on both sides) to dst and, when dst2 is given, to a second
+// destination from the same loads.  64 bytes per step: eight independent loads are in flight at
+// once, so a long entry costs a few memory round trips instead of one per 8 bytes (the slowest
+// lane of a wave sets the pace: 150-byte entries took 19 dependent steps).
+__device__ __forceinline__ void copy_entry(u8 *dst, const u8 *src, u32 l, u8 *dst2 = nullptr)
 {
     u32 i = 0;
-    for (; i + 8 <= l; i += 8) {                       // 8 bytes per step, unaligned on both sides
-        const u64 v = load_u64_unaligned(src + i);
-        __builtin_memcpy(dst + i, &v, 8);
+    for (; i + 64 <= l; i += 64) {
+        u64 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = load_u64_unaligned(src + i + 8 * k);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) __builtin_memcpy(dst + i + 8 * k, &v[k], 8);
+        if (dst2) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) __builtin_memcpy(dst2 + i + 8 * k, &v[k], 8);
+        }
     }
-    for (; i < l; ++i) dst[i] = src[i];
+    if (i < l) {
+        // tail of < 64 bytes: the same eight loads (the text is readable past the entry), stores by length
+        u64 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (i + 8 * k < l) ? load_u64_unaligned(src + i + 8 * k) : 0ull;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const u32 at = i + 8 * k;
+            if (at + 8 <= l) {
+                __builtin_memcpy(dst + at, &v[k], 8);
+                if (dst2) __builtin_memcpy(dst2 + at, &v[k], 8);
+            } else if (at < l) {
+                for (u32 b = 0; b < l - at; ++b) {
+                    const u8 x = (u8)(v[k] >> (8 * b));
+                    dst[at + b] = x;
+                    if (dst2) dst2[at + b] = x;
+                }
+            }
+        }
+    }
 }
 
 // ---- mid pipeline: batches of <= MID_MAX pairs with <= MID_MAX hits -----------------------
@@ -592,8 +634,7 @@ __device__ __forceinline__ void small_pair(const ChunkDesc &ch, const u8 *pat, u
             const u32 e = e0 + mbcnt(km);
             const u32 o = b0 + incl - ll;
             ent[e] = SmallEntry{o, ll};
-            copy_entry(bytes + o, ch.text + my_ls[j], ll);
-            if (o + ll <= SM_BYTE_PREFIX) copy_entry(hbytes + o, ch.text + my_ls[j], ll);
+            copy_entry(bytes + o, ch.text + my_ls[j], ll, o + ll <= SM_BYTE_PREFIX ? hbytes + o : nullptr);
         }
         e0 += (u32)__popcll(km);
         b0 += __shfl(incl, 63);
@@ -738,8 +779,7 @@ __global__ __launch_bounds__(SM_BLOCK) void search_block_kernel(const ChunkDesc 
                 const u32 ll = s_ll[j];
                 if (ll == kSkip) continue;
                 ent[e++] = SmallEntry{o, ll};
-                copy_entry(bytes + o, ch.text + s_ls[j], ll);
-                if (o + ll <= SM_BYTE_PREFIX) copy_entry(hbytes + o, ch.text + s_ls[j], ll);
+                copy_entry(bytes + o, ch.text + s_ls[j], ll, o + ll <= SM_BYTE_PREFIX ? hbytes + o : nullptr);
                 o += ll;
             }
         }
