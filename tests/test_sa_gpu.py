@@ -116,7 +116,7 @@ def test_sampled_sizing_sizes(oracle):
 
 
 def test_all_ones_key_in_small_sort(oracle):
-    """Regression (found by tools/fuzz.py, seed 1279): 15 symbols -> 4-bit codes, so 16 symbols of the
+    """Regression (found by tests/tools/fuzz.py, seed 1279): 15 symbols -> 4-bit codes, so 16 symbols of the
     largest code pack to an all-ones 64-bit text key -- the value the one-workgroup sort pads with.
     The padding overtook real elements and the chained sort of the large groups read out of bounds."""
     import os

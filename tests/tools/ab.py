@@ -1,5 +1,5 @@
 """Interleaved A/B of libpss variants (one process per (lib, round); min / median over rounds).
-usage: python tools/ab.py <corpus> <logn> <rounds> lib1.so lib2.so ..."""
+usage: python tests/tools/ab.py <corpus> <logn> <rounds> lib1.so lib2.so ..."""
 import ast
 import os
 import statistics
@@ -12,7 +12,7 @@ res = {l: [] for l in libs}
 for _ in range(rounds):
     for l in libs:
         env = dict(os.environ, PSS_LIBPSS=os.path.abspath(l), PSS_PROFILE_ALL='1')
-        out = subprocess.run([sys.executable, 'tools/sa_perf.py', corpus, logn, '4'], env=env, capture_output=True, text=True).stdout
+        out = subprocess.run([sys.executable, 'tests/tools/sa_perf.py', corpus, logn, '4'], env=env, capture_output=True, text=True).stdout
         for line in out.splitlines():
             if line.startswith('rep') and not line.startswith('rep 0'):
                 d = ast.literal_eval(line[line.index('{'):])

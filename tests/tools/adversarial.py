@@ -6,7 +6,7 @@ corpora, checked exactly.
             otherwise identical suffixes first).
   runs      against libsais (oracle/_ref, one host thread) -- about a minute at 2^29.
 
-    python tools/adversarial.py [logn=29] [--no-libsais]
+    python tests/tools/adversarial.py [logn=29] [--no-libsais]
 """
 import ctypes
 import json

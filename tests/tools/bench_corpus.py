@@ -7,7 +7,7 @@ keeps all of them resident in one Reader, then times
 Optionally checks a sample of the queries against the CPU oracle on chunk 0 and
 times the oracle (SA in RAM, one thread, one query at a time) on that chunk.
 
-    python tools/bench_corpus.py --chunks 15 --logn 29 --queries 100000
+    python tests/tools/bench_corpus.py --chunks 15 --logn 29 --queries 100000
 """
 import argparse
 import ctypes
@@ -18,7 +18,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 ALPHA = b'abcdefghijklmnopqrstuvwxyz0123456789 .'
 KINDS = {'lines': 0, 'words': 1}

@@ -2,7 +2,7 @@
 (default 1.25 GiB) through Writer(format_version=2) -> .idx -> Reader, checked by brute force:
 every sampled query must return exactly the lines of the text that contain it.
 
-    python tools/big_chunk.py [bytes=1342177280]"""
+    python tests/tools/big_chunk.py [bytes=1342177280]"""
 import os
 import sys
 import tempfile

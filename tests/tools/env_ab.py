@@ -1,4 +1,4 @@
-"""Interleaved A/B of one environment switch: python tools/env_ab.py VAR corpus logn rounds"""
+"""Interleaved A/B of one environment switch: python tests/tools/env_ab.py VAR corpus logn rounds"""
 import ast, os, statistics, subprocess, sys
 var, corpus, logn, rounds = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 res = {'unset': [], 'set': []}
@@ -8,7 +8,7 @@ for _ in range(rounds):
         env.pop(var, None)
         if mode == 'set':
             env[var] = '1'
-        out = subprocess.run([sys.executable, 'tools/sa_perf.py', corpus, logn, '4'], env=env, capture_output=True, text=True).stdout
+        out = subprocess.run([sys.executable, 'tests/tools/sa_perf.py', corpus, logn, '4'], env=env, capture_output=True, text=True).stdout
         for line in out.splitlines():
             if line.startswith('rep') and not line.startswith('rep 0'):
                 res[mode].append(ast.literal_eval(line[line.index('{'):])['ms_total'])

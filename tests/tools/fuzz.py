@@ -1,7 +1,7 @@
 """Time-boxed fuzzing of the whole path against the oracle (libsais + the CPU restatement of the
 reference's Writer / Reader): random alphabets, repeat structure, chunk limits and queries.
 
-    python tools/fuzz.py [seconds=120] [seed0=<time>]
+    python tests/tools/fuzz.py [seconds=120] [seed0=<time>]
 
 Every case checks (1) the suffix array of the raw text, (2) the .idx container byte for byte,
 (3) search / search_multiple multisets and per-query counts.  Prints the failing seed and stops."""

@@ -3,7 +3,7 @@ import os
 import sys
 import tempfile
 
-sys.path.insert(0, 'tools')
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, '.')
 import fuzz_search as F  # noqa: E402
 from oracle import oracle as O  # noqa: E402

@@ -3,7 +3,7 @@ tens of thousands of queries (fused small-batch kernel, wave-per-pair and lane-p
 search, arena overflow, > 1024 hits per (query, chunk)), long and newline-crossing patterns,
 sharded readers.  Everything is compared with the oracle's restatement of Reader::search.
 
-    python tools/fuzz_search.py [seconds=120] [seed0=<time>]"""
+    python tests/tools/fuzz_search.py [seconds=120] [seed0=<time>]"""
 import os
 import random
 import sys

@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC collection, one counter group per run (rocprofv3 --pmc, no trace domains besides kernel-trace).
-# usage: tools/pmc.sh <outdir> -- <program and args>
+# usage: tests/tools/pmc.sh <outdir> -- <program and args>
 out=$1; shift; shift
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 i=0

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Build a libpss variant with extra -D flags for interleaved A/B runs (tools/ab.py):
-#   tools/variant.sh name "-DPSS_RR_ROWS=16"   ->  variants/libpss_name.so   (git-ignored, travels with gpurun)
+# Build a libpss variant with extra -D flags for interleaved A/B runs (tests/tools/ab.py):
+#   tests/tools/variant.sh name "-DPSS_RR_ROWS=16"   ->  variants/libpss_name.so   (git-ignored, travels with gpurun)
 set -e
 name=$1; flags=$2
-root=$(cd "$(dirname "$0")/.." && pwd)
+root=$(cd "$(dirname "$0")/../.." && pwd)
 src=$root/pysubstringsearch_amd/csrc
 obj=$root/variants/obj_$name
 mkdir -p $obj
