@@ -57,6 +57,13 @@ int DeviceCtx::ensure_staging()
     return PSS_OK;
 }
 
+int DeviceCtx::ensure_search_stage()
+{
+    if (search_stage) return PSS_OK;
+    PSS_HIP(hipHostMalloc(&search_stage, kStageQ + kStageR, hipHostMallocDefault));
+    return PSS_OK;
+}
+
 static constexpr int kMaxDevices = 64;
 static DeviceCtx g_ctx[kMaxDevices];
 static std::mutex g_ctx_mu;

@@ -57,6 +57,11 @@ struct DeviceCtx {
     void *pinned = nullptr;   // small pinned host scratch for D2H of counters
     size_t pinned_cap = 0;
     void *pinned_dev = nullptr;          // the same memory as the device sees it (zero-copy reads / writes)
+    // Pinned staging of the batched search (queries up, results down): copies from / to pageable
+    // memory are synchronous and slow to start, DMA from / to pinned memory is not.
+    static constexpr size_t kStageQ = (size_t)2 << 20, kStageR = (size_t)4 << 20;
+    void *search_stage = nullptr;        // kStageQ + kStageR bytes, allocated on first use
+    int ensure_search_stage();
     hipEvent_t search_ev[3] = {nullptr, nullptr, nullptr};   // timing events of the search path, created once
     void *small_hdr_ready = nullptr;     // arena whose small-path cursors have been zeroed (search.hip)
     // Two pinned staging buffers + a copy stream: file <-> HBM transfers are

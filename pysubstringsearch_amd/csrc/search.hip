@@ -952,6 +952,16 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
         // pageable H2D copies are synchronous and slow to start: tiny batches go up from the pinned staging
         PSS_HIP(hipMemcpyAsync(d_q, stg, qtotal + 32, hipMemcpyHostToDevice, s));
         PSS_HIP(hipMemcpyAsync(d_qoff, stg + 8192, off_bytes, hipMemcpyHostToDevice, s));
+    } else if (qtotal + 32 + off_bytes + 64 <= DeviceCtx::kStageQ && !getenv("PSS_NO_SEARCH_STAGE")) {
+        // mid-size batch: the same through the larger pinned staging
+        PSS_TRY(ctx->ensure_search_stage());
+        u8 *sq = static_cast<u8 *>(ctx->search_stage);
+        u8 *so = sq + round_up(qtotal + 32, 64);
+        memcpy(sq, qbytes, qtotal);
+        memset(sq + qtotal, 0, 32);
+        memcpy(so, qoffsets, off_bytes);
+        PSS_HIP(hipMemcpyAsync(d_q, sq, qtotal + 32, hipMemcpyHostToDevice, s));
+        PSS_HIP(hipMemcpyAsync(d_qoff, so, off_bytes, hipMemcpyHostToDevice, s));
     } else {
         PSS_HIP(hipMemsetAsync(d_q + qtotal, 0, 32, s));
         if (qtotal) PSS_HIP(hipMemcpyAsync(d_q, qbytes, qtotal, hipMemcpyHostToDevice, s));
@@ -999,10 +1009,25 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
             res->offsets = (u64 *)malloc((E + 1) * sizeof(u64));
             res->bytes = (u8 *)malloc(B ? B : 1);
             if (!res->offsets || !res->bytes) return PSS_ENOMEM;
-            if (E) PSS_HIP(hipMemcpyAsync(res->offsets, d_entoff, E * 8, hipMemcpyDeviceToHost, s));
-            if (B) PSS_HIP(hipMemcpyAsync(res->bytes, d_out, B, hipMemcpyDeviceToHost, s));
-            PSS_HIP(hipMemcpyAsync(res->qcount, d_qcount, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
-            PSS_HIP(hipStreamSynchronize(s));
+            const size_t need = round_up(E * 8, 64) + round_up(B, 64) + (size_t)nq * 8;
+            if (need <= DeviceCtx::kStageR && !getenv("PSS_NO_SEARCH_STAGE")) {
+                // down through pinned staging (three DMA copies, one wait), then plain memcpy
+                PSS_TRY(ctx->ensure_search_stage());
+                u8 *r0 = static_cast<u8 *>(ctx->search_stage) + DeviceCtx::kStageQ;
+                u8 *r1 = r0 + round_up(E * 8, 64), *r2 = r1 + round_up(B, 64);
+                if (E) PSS_HIP(hipMemcpyAsync(r0, d_entoff, E * 8, hipMemcpyDeviceToHost, s));
+                if (B) PSS_HIP(hipMemcpyAsync(r1, d_out, B, hipMemcpyDeviceToHost, s));
+                PSS_HIP(hipMemcpyAsync(r2, d_qcount, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
+                PSS_HIP(hipStreamSynchronize(s));
+                if (E) memcpy(res->offsets, r0, E * 8);
+                if (B) memcpy(res->bytes, r1, B);
+                memcpy(res->qcount, r2, (size_t)nq * 8);
+            } else {
+                if (E) PSS_HIP(hipMemcpyAsync(res->offsets, d_entoff, E * 8, hipMemcpyDeviceToHost, s));
+                if (B) PSS_HIP(hipMemcpyAsync(res->bytes, d_out, B, hipMemcpyDeviceToHost, s));
+                PSS_HIP(hipMemcpyAsync(res->qcount, d_qcount, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
+                PSS_HIP(hipStreamSynchronize(s));
+            }
             res->offsets[E] = B;
             res->n_entries = E;
             st->hits = H;

@@ -68,6 +68,10 @@ def one_case(seed, tmp):
         os.environ['PSS_NO_MID_PIPELINE'] = '1'
     else:
         os.environ.pop('PSS_NO_MID_PIPELINE', None)
+    if rng.random() < 0.3:
+        os.environ['PSS_NO_SEARCH_STAGE'] = '1'
+    else:
+        os.environ.pop('PSS_NO_SEARCH_STAGE', None)
     os.environ.pop('PSS_NO_KEY_SAMPLES', None)
     os.environ.pop('PSS_SAMPLE_SHIFT', None)
     r = rng.random()
