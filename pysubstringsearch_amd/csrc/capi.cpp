@@ -692,13 +692,13 @@ int reader_alloc_chunk(pss_reader *r, uint32_t n, ChunkDesc *out, pss_reader::Me
         if (v >= 0 && v <= 20) shift = (uint32_t)v;
     }
     const size_t sk_bytes = samples ? sample_count(n, shift) * 8 : 0;
-    hipError_t e = hipMalloc(&m.text, (size_t)n + 64);
+    hipError_t e = hipMalloc(&m.text, (size_t)n + 128);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         set_error("hipMalloc of the text of a %u-byte chunk failed: %s", n, hipGetErrorString(e));
         return PSS_ENOMEM;
     }
-    m.hbm_bytes = (size_t)n + 64;
+    m.hbm_bytes = (size_t)n + 128;
     // tier 1: suffix array (+ samples) in HBM
     uint64_t used = 0;
     for (const auto &x : r->mem) used += x.hbm_bytes;
@@ -738,7 +738,7 @@ int reader_alloc_chunk(pss_reader *r, uint32_t n, ChunkDesc *out, pss_reader::Me
         m.hbm_bytes += sk_bytes;
         out->skeys = static_cast<uint64_t *>(m.skeys);
     }
-    PSS_HIP(hipMemsetAsync(static_cast<uint8_t *>(m.text) + n, 0, 64, r->ctx->stream));
+    PSS_HIP(hipMemsetAsync(static_cast<uint8_t *>(m.text) + n, 0, 128, r->ctx->stream));
     out->text = static_cast<uint8_t *>(m.text);
     if (m.sa_host) {
         void *dp = nullptr;

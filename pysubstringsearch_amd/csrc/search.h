@@ -4,7 +4,7 @@
 
 namespace pss {
 
-// One resident chunk: text (n bytes, zero padded and readable 64 bytes past the end), its
+// One resident chunk: text (n bytes, zero padded and readable 128 bytes past the end), its
 // suffix array (n x u32) and a table of key samples: skeys[j] = the first 8 bytes of suffix
 // sa[j << shift] as a big-endian integer (ceil(n / 2^shift) entries, nullptr = none).  The
 // keys are non-decreasing along the suffix array, so two searches in the small table (L2
