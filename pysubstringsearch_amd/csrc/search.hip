@@ -411,8 +411,7 @@ __device__ __forceinline__ void copy_entry(u8 *dst, const u8 *src, u32 l, u8 *ds
     u32 i = 0;
     for (; i + 64 <= l; i += 64) {
         u64 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = load_u64_unaligned(src + i + 8 * k);
+        load_words64(src + i, v);
 #pragma unroll
         for (int k = 0; k < 8; ++k) __builtin_memcpy(dst + i + 8 * k, &v[k], 8);
         if (dst2) {
@@ -421,10 +420,9 @@ __device__ __forceinline__ void copy_entry(u8 *dst, const u8 *src, u32 l, u8 *ds
         }
     }
     if (i < l) {
-        // tail of < 64 bytes: the same eight loads (the text is readable past the entry), stores by length
+        // tail of < 64 bytes: the same loads (the text is readable 128 bytes past its end), stores by length
         u64 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = (i + 8 * k < l) ? load_u64_unaligned(src + i + 8 * k) : 0ull;
+        load_words64(src + i, v);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const u32 at = i + 8 * k;
