@@ -884,7 +884,7 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
     auto host_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     const size_t off_bytes = ((size_t)nq + 1) * 8;
     const bool tiny = qtotal + 32 <= 8192 && off_bytes <= 8192;
-    u8 *stg = static_cast<u8 *>(ctx->pinned) + SM_OFF_QUERY;          // last 16 KiB of the pinned scratch
+    u8 *stg = static_cast<u8 *>(ctx->pinned) + SM_OFF_QUERY;          // 16 KiB of the pinned scratch
     if (tiny) {
         memcpy(stg, qbytes, qtotal);
         memset(stg + qtotal, 0, 32);
