@@ -262,6 +262,98 @@ __global__ __launch_bounds__(256) void search_interval_lane_kernel(const ChunkDe
     cnt_out[vq] = lo - L;
 }
 
+// Mid-size batches (thousands of pairs): SG = 16 lanes per (query, chunk) pair, four pairs per
+// wavefront, 17-ary searches.  One wave per pair finishes in the fewest dependent steps but probes 64
+// suffixes per step -- with ten thousand pairs in flight the address units and the random sectors are
+// the limit, not the latency; 16 lanes per pair need ~1.5x the steps for a quarter of the probes
+// (10 000 queries on a 512 MiB chunk: 76 -> ~40 us).  All 64 lanes run every step together; the
+// groups of a wave that are done idle.
+constexpr u32 SG = 16;
+
+// first index in [lo, hi) for which before(i) is false (before is monotone: true ... true false ...);
+// `near`: look at the SG positions right behind lo first (short intervals end there in one step)
+template <typename Before>
+__device__ __forceinline__ u32 group_search(u32 lo, u32 hi, bool active, bool near, u32 gl, u32 gbase, Before before)
+{
+    bool done = !active;
+    u32 res = lo;
+    for (;;) {
+        if (!done && hi <= lo) {
+            res = lo;
+            done = true;
+        }
+        const bool work = !done;
+        if (__ballot(work) == 0) break;
+        const u32 s = work ? hi - lo : 0;
+        const bool last = s <= SG;                  // the remaining range fits the group: one probe each
+        const bool first_near = near && !last;
+        u32 p = lo;
+        bool b = false;
+        if (work) {
+            p = (last || first_near) ? lo + gl : lo + (u32)(((u64)(gl + 1) * s) / (SG + 1));
+            b = (!last || gl < s) && before(p);
+        }
+        const u32 k = (u32)__popc((u32)((__ballot(b) >> gbase) & 0xffffu));
+        const u32 p_below = (u32)__shfl((int)p, (int)(gbase + (k ? k - 1 : 0)));     // last probe that is "before"
+        const u32 p_at = (u32)__shfl((int)p, (int)(gbase + (k < SG ? k : SG - 1)));   // first probe that is not
+        if (work) {
+            if (last) {
+                res = lo + k;
+                done = true;
+            } else if (first_near) {
+                if (k < SG) {
+                    res = lo + k;
+                    done = true;
+                } else {
+                    lo += SG;
+                }
+            } else {
+                const u32 nlo = k ? p_below + 1 : lo;
+                hi = (k == SG) ? hi : p_at;
+                lo = nlo;
+            }
+        }
+        near = false;
+    }
+    return res;
+}
+
+__global__ __launch_bounds__(256) void search_interval_group_kernel(const ChunkDesc *chunks, u32 nc, const u8 *qbytes,
+                                                                      const u64 *qoff, u64 nvq, u32 *lo_out, u32 *cnt_out)
+{
+    const u32 lane = lane_id(), gl = lane & (SG - 1), gbase = lane & ~(SG - 1);
+    const u64 vq0 = ((u64)blockIdx.x * (blockDim.x / kWave) + wave_id()) * (kWave / SG);
+    if (vq0 >= nvq) return;                                   // wave-uniform
+    const u64 vq = vq0 + (lane / SG);
+    const bool active = vq < nvq;
+    const u64 vqc = active ? vq : vq0;                        // idle groups read valid memory
+    const u32 q = (u32)(vqc / nc), c = (u32)(vqc % nc);
+    const ChunkDesc ch = chunks[c];
+    const u8 *pat = qbytes + qoff[q];
+    const u32 plen = (u32)(qoff[q + 1] - qoff[q]);
+    u32 w0 = 0, w1 = ch.n;
+    const bool tab = active && ch.skeys != nullptr;
+    {
+        const u32 ns = (u32)(((u64)ch.n + (1u << ch.shift) - 1) >> ch.shift);
+        u64 k_lo, k_hi;
+        query_keys(pat, plen, k_lo, k_hi);
+        const u32 ja = group_search(0, ns, tab, false, gl, gbase, [&](u32 j) { return ch.skeys[j] < k_lo; });
+        const u32 jb = group_search(ja, ns, tab, true, gl, gbase, [&](u32 j) { return ch.skeys[j] <= k_hi; });
+        if (tab) {
+            w0 = ja ? (ja - 1) << ch.shift : 0u;
+            w1 = jb < ns ? jb << ch.shift : ch.n;
+        }
+    }
+    const u32 L = group_search(w0, w1, active, false, gl, gbase,
+                               [&](u32 i) { return cmp_suffix(ch.text, ch.n, ch.sa[i], pat, plen) < 0; });
+    const u32 U = group_search(L, w1, active, true, gl, gbase,
+                               [&](u32 i) { return cmp_suffix(ch.text, ch.n, ch.sa[i], pat, plen) <= 0; });
+    if (active && gl == 0) {
+        lo_out[vq] = L;
+        cnt_out[vq] = U - L;
+    }
+}
+
 __global__ __launch_bounds__(256) void search_interval_kernel(const ChunkDesc *chunks, u32 nc, const u8 *qbytes,
                                                                 const u64 *qoff, u64 nvq, u32 *lo_out, u32 *cnt_out)
 {
@@ -990,6 +1082,9 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
     if (nvq >= 32768 && !getenv("PSS_WAVE_SEARCH"))
         hipLaunchKernelGGL(search_interval_lane_kernel, dim3((u32)((nvq + 255) / 256)), dim3(256), 0, s, d_chunks, nc,
                            d_q, d_qoff, nvq, d_lo, d_cnt);
+    else if (nvq >= 2048 && !getenv("PSS_WAVE_SEARCH") && !getenv("PSS_NO_GROUP_SEARCH"))
+        hipLaunchKernelGGL(search_interval_group_kernel, dim3((u32)((nvq + 15) / 16)), dim3(256), 0, s, d_chunks, nc, d_q,
+                           d_qoff, nvq, d_lo, d_cnt);
     else
         hipLaunchKernelGGL(search_interval_kernel, dim3((u32)((nvq + waves_per_block - 1) / waves_per_block)), dim3(256),
                            0, s, d_chunks, nc, d_q, d_qoff, nvq, d_lo, d_cnt);

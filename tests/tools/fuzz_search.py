@@ -72,6 +72,10 @@ def one_case(seed, tmp):
         os.environ['PSS_NO_SEARCH_STAGE'] = '1'
     else:
         os.environ.pop('PSS_NO_SEARCH_STAGE', None)
+    if rng.random() < 0.3:
+        os.environ['PSS_NO_GROUP_SEARCH'] = '1'
+    else:
+        os.environ.pop('PSS_NO_GROUP_SEARCH', None)
     os.environ.pop('PSS_NO_KEY_SAMPLES', None)
     os.environ.pop('PSS_SAMPLE_SHIFT', None)
     r = rng.random()
