@@ -338,7 +338,7 @@ def test_concurrent_handles_from_threads(tmp_path, oracle):
 
 
 def test_large_batch_lane_search(tmp_path, oracle):
-    """>= 32768 (query, chunk) pairs switch the interval search to one lane per pair."""
+    """>= 8192 (query, chunk) pairs switch the interval search to one lane per pair."""
     from tests.util import gen_corpus
     src = tmp_path / 'c.txt'
     src.write_bytes(gen_corpus(1, 1 << 19).tobytes())
@@ -434,7 +434,8 @@ def test_suffix_arrays_beyond_the_hbm_budget_stay_on_the_host(tmp_path, oracle, 
         res = r.residency
         assert r.num_chunks >= 4
         assert res['host_chunks'] == r.num_chunks - budget_chunks and res['host_bytes'] > 0
-        for batch in (qs[:1], qs[5:6], qs[:40], qs):           # fused paths, then the general pipeline
+        # fused paths (<= 64, <= 1024 pairs), 16 lanes per pair (2048 .. 8191 pairs), one lane per pair
+        for batch in (qs[:1], qs[5:6], qs[:40], qs[:1000], qs):
             ents, counts = r.search_batch_raw(batch)
             oe, oc = o.search_multiple_bytes(batch)
             assert counts == oc.tolist()
