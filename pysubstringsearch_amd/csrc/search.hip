@@ -48,14 +48,28 @@ struct InLen {
 // -1: suffix < pattern, 0: pattern is a prefix of the suffix, +1: suffix > pattern
 // (unsigned bytes, a proper prefix sorts first -- Rust slice cmp, lib.rs:224,246).
 // text and pat must be readable 16 bytes past their ends.
-__device__ __forceinline__ int cmp_suffix(const u8 *text, u32 n, u32 s, const u8 *pat, u32 plen)
+// 8 bytes at the unaligned address p of the TEXT as two aligned 8-byte loads (every lane probes its
+// own random suffix, and a scattered load costs the address unit a cycle per lane and instruction
+// whatever its width: 2 instead of 3).  Reads up to 15 bytes past p (the text is zero padded).
+__device__ __forceinline__ u64 load_text8(const u8 *p)
+{
+    const uintptr_t a = (uintptr_t)p;
+    const u64 *q = reinterpret_cast<const u64 *>(a & ~(uintptr_t)7);
+    const u32 sh = (u32)(a & 7) * 8;
+    const u64 w0 = q[0], w1 = q[1];
+    return sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+}
+
+// pat0 = the query's first 8 bytes (load_u64_unaligned(pat)), fetched once per pair by the caller
+// instead of once per probe
+__device__ __forceinline__ int cmp_suffix(const u8 *text, u32 n, u32 s, const u8 *pat, u32 plen, u64 pat0)
 {
     const u32 avail = n - s;
     const u32 L = plen < avail ? plen : avail;
     u32 i = 0;
     while (i < L) {
-        u64 a = load_u64_unaligned(text + s + i);
-        u64 b = load_u64_unaligned(pat + i);
+        u64 a = load_text8(text + s + i);
+        u64 b = i ? load_u64_unaligned(pat + i) : pat0;
         const u32 rem = L - i;
         if (rem < 8) {
             const u64 mask = (1ull << (8 * rem)) - 1ull;
@@ -69,6 +83,10 @@ __device__ __forceinline__ int cmp_suffix(const u8 *text, u32 n, u32 s, const u8
         i += 8;
     }
     return (L == plen) ? 0 : -1;
+}
+__device__ __forceinline__ int cmp_suffix(const u8 *text, u32 n, u32 s, const u8 *pat, u32 plen)
+{
+    return cmp_suffix(text, n, s, pat, plen, load_u64_unaligned(pat));
 }
 
 // First index in [lo, hi) whose suffix is NOT before the bound; wave-cooperative.
@@ -240,23 +258,24 @@ __global__ __launch_bounds__(256) void search_interval_lane_kernel(const ChunkDe
     const ChunkDesc ch = chunks[c];
     const u8 *pat = qbytes + qoff[q];
     const u32 plen = (u32)(qoff[q + 1] - qoff[q]);
+    const u64 pat0 = load_u64_unaligned(pat);
     u32 lo, hi0;
     sample_window_lane(ch, pat, plen, lo, hi0);
     u32 hi = hi0;                                // lower bound: first suffix not < pattern
     while (lo < hi) {
         const u32 mid = lo + ((hi - lo) >> 1);
-        if (cmp_suffix(ch.text, ch.n, ch.sa[mid], pat, plen) < 0) lo = mid + 1; else hi = mid;
+        if (cmp_suffix(ch.text, ch.n, ch.sa[mid], pat, plen, pat0) < 0) lo = mid + 1; else hi = mid;
     }
     const u32 L = lo;
     hi = hi0;                                    // upper bound: first suffix > pattern and not prefixed by it;
     for (u32 step = 1; lo < hi; step <<= 1) {    // galloping from L (most intervals are short)
         const u32 p = lo + step - 1;
         if (p >= hi) break;
-        if (cmp_suffix(ch.text, ch.n, ch.sa[p], pat, plen) <= 0) lo = p + 1; else { hi = p; break; }
+        if (cmp_suffix(ch.text, ch.n, ch.sa[p], pat, plen, pat0) <= 0) lo = p + 1; else { hi = p; break; }
     }
     while (lo < hi) {
         const u32 mid = lo + ((hi - lo) >> 1);
-        if (cmp_suffix(ch.text, ch.n, ch.sa[mid], pat, plen) <= 0) lo = mid + 1; else hi = mid;
+        if (cmp_suffix(ch.text, ch.n, ch.sa[mid], pat, plen, pat0) <= 0) lo = mid + 1; else hi = mid;
     }
     lo_out[vq] = L;
     cnt_out[vq] = lo - L;
@@ -344,10 +363,11 @@ __global__ __launch_bounds__(256) void search_interval_group_kernel(const ChunkD
             w1 = jb < ns ? jb << ch.shift : ch.n;
         }
     }
+    const u64 pat0 = load_u64_unaligned(pat);
     const u32 L = group_search(w0, w1, active, false, gl, gbase,
-                               [&](u32 i) { return cmp_suffix(ch.text, ch.n, ch.sa[i], pat, plen) < 0; });
+                               [&](u32 i) { return cmp_suffix(ch.text, ch.n, ch.sa[i], pat, plen, pat0) < 0; });
     const u32 U = group_search(L, w1, active, true, gl, gbase,
-                               [&](u32 i) { return cmp_suffix(ch.text, ch.n, ch.sa[i], pat, plen) <= 0; });
+                               [&](u32 i) { return cmp_suffix(ch.text, ch.n, ch.sa[i], pat, plen, pat0) <= 0; });
     if (active && gl == 0) {
         lo_out[vq] = L;
         cnt_out[vq] = U - L;
