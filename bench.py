@@ -162,8 +162,8 @@ def main():
         if world > 1:
             # packed local result -> gather to rank 0 -> one Python list there
             pk = reader.search_batch_packed(queries)
-            merged = pdist.gather_packed(pk.data, np.diff(pk.offsets.astype(np.int64)), pk.counts, dst=0)
-            entries = merged[0] if merged is not None else []
+            merged = pdist.gather_packed(pk.data, np.diff(pk.offsets.astype(np.int64)), pk.counts, dst=0, packed=True)
+            entries = merged[1][:-1] if merged is not None else []      # one offset per entry (packed result)
         else:
             entries, counts = reader.search_batch_raw(queries)
         t3 = time.perf_counter()

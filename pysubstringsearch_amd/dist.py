@@ -25,34 +25,58 @@ def pack_entries(entries: typing.Sequence[bytes]) -> typing.Tuple[np.ndarray, np
     return blob, lens
 
 
-def merge_query_major(per_rank: typing.Sequence[typing.Tuple[np.ndarray, np.ndarray, np.ndarray]]
-                      ) -> typing.Tuple[typing.List[bytes], np.ndarray]:
-    """per_rank[r] = (blob uint8, lens int64[E_r], counts int64[nq]) with rank
-    r's entries query-major.  Returns all entries query-major (inside a query:
-    rank-major) and the summed per-query counts."""
+def merge_packed(per_rank: typing.Sequence[typing.Tuple[np.ndarray, np.ndarray, np.ndarray]]
+                 ) -> typing.Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """per_rank[r] = (blob uint8, lens int64[E_r], counts int64[nq]) with rank r's entries
+    query-major.  Returns the merged result packed the same way -- (blob, offsets int64[E + 1],
+    summed per-query counts) -- query-major, inside a query rank-major, inside a rank in its
+    local order.  Vectorised: no Python object per entry."""
     nq = len(per_rank[0][2])
-    qid, rk, start, length = [], [], [], []
+    qid, rk, src, length = [], [], [], []
+    base = 0
     for r, (blob, lens, counts) in enumerate(per_rank):
+        lens = np.asarray(lens, dtype=np.int64)
+        counts = np.asarray(counts, dtype=np.int64)
         assert len(counts) == nq and int(counts.sum()) == len(lens)
         qid.append(np.repeat(np.arange(nq, dtype=np.int64), counts))
         rk.append(np.full(len(lens), r, dtype=np.int64))
         off = np.zeros(len(lens) + 1, dtype=np.int64)
         np.cumsum(lens, out=off[1:])
-        start.append(off[:-1])
+        src.append(off[:-1] + base)          # position in the concatenation of all blobs
         length.append(lens)
+        base += len(blob)
     qid, rk = np.concatenate(qid), np.concatenate(rk)
-    start, length = np.concatenate(start), np.concatenate(length)
-    order = np.lexsort((rk, qid))          # stable: keeps each rank's local order inside (query, rank)
-    blobs = [bytes(p[0].tobytes()) for p in per_rank]
-    out = [blobs[rk[i]][start[i]:start[i] + length[i]] for i in order]
-    total = np.sum([p[2] for p in per_rank], axis=0).astype(np.int64)
-    return out, total
+    src, length = np.concatenate(src), np.concatenate(length)
+    order = np.lexsort((rk, qid))            # stable: keeps each rank's local order inside (query, rank)
+    src, length = src[order], length[order]
+    offsets = np.zeros(len(length) + 1, dtype=np.int64)
+    np.cumsum(length, out=offsets[1:])
+    total_bytes = int(offsets[-1])
+    big = np.concatenate([np.asarray(p[0], dtype=np.uint8) for p in per_rank]) if base else np.zeros(0, np.uint8)
+    if total_bytes:
+        # byte i of the output comes from big[src[e] + (i - offsets[e])] for the entry e that holds it
+        idx = np.repeat(src - offsets[:-1], length) + np.arange(total_bytes, dtype=np.int64)
+        out = big[idx]
+    else:
+        out = np.zeros(0, dtype=np.uint8)
+    total = np.sum([np.asarray(p[2], dtype=np.int64) for p in per_rank], axis=0).astype(np.int64)
+    return out, offsets, total
 
 
-def gather_packed(blob, lens, counts, group=None, dst: int = 0):
+def merge_query_major(per_rank: typing.Sequence[typing.Tuple[np.ndarray, np.ndarray, np.ndarray]]
+                      ) -> typing.Tuple[typing.List[bytes], np.ndarray]:
+    """``merge_packed`` with the entries as a list of bytes."""
+    blob, offsets, total = merge_packed(per_rank)
+    data = blob.tobytes()
+    o = offsets.tolist()
+    return [data[o[i]:o[i + 1]] for i in range(len(o) - 1)], total
+
+
+def gather_packed(blob, lens, counts, group=None, dst: int = 0, packed: bool = False):
     """Collective on packed local results: ``blob`` = this rank's entries back to
     back (uint8), ``lens`` their lengths, ``counts`` the per-query entry counts,
-    all query-major.  Rank ``dst`` gets (all entries query-major, total counts),
+    all query-major.  Rank ``dst`` gets (all entries query-major, total counts)
+    -- with ``packed=True`` (blob, offsets, total counts), no Python object per entry --,
     the others None.  On the nccl (= RCCL) backend the three payloads travel as
     device tensors; sizes are exchanged first so they can be padded to a common
     shape."""
@@ -94,7 +118,7 @@ def gather_packed(blob, lens, counts, group=None, dst: int = 0):
         e, b = int(all_sizes[r, 0]), int(all_sizes[r, 1])
         per_rank.append((g_blob[r].cpu().numpy()[:b], g_len[r].cpu().numpy()[:e],
                          g_cnt[r].cpu().numpy()[:len(cnt)]))
-    return merge_query_major(per_rank)
+    return merge_packed(per_rank) if packed else merge_query_major(per_rank)
 
 
 def gather_results(entries: typing.Sequence[bytes], counts: typing.Sequence[int], group=None, dst: int = 0):
