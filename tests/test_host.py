@@ -231,3 +231,31 @@ def test_cabi_argument_contract_without_gpu():
     assert lib.pss_result_num_entries(None) == 0 and lib.pss_reader_num_chunks(None) == 0
     lib.pss_result_free(None)
     assert lib.pss_reader_close(None) == _ffi.PSS_OK and lib.pss_writer_close(None) == _ffi.PSS_OK
+
+
+def test_merge_packed_random():
+    """The vectorised merge of per-rank packed results equals the naive one: query-major, inside a
+    query rank-major, inside a rank the local order; empty blobs, empty entries, one rank."""
+    import random
+    from pysubstringsearch_amd import dist as pdist
+    rng = random.Random(1)
+    for _ in range(100):
+        nq, world = rng.randint(1, 6), rng.randint(1, 4)
+        per, naive = [], [[[] for _ in range(world)] for _ in range(nq)]
+        for r in range(world):
+            ents, counts = [], []
+            for q in range(nq):
+                k = rng.randint(0, 3)
+                counts.append(k)
+                for _ in range(k):
+                    e = bytes(rng.randrange(256) for _ in range(rng.randint(0, 5)))
+                    ents.append(e)
+                    naive[q][r].append(e)
+            blob, lens = pdist.pack_entries(ents)
+            per.append((blob, lens, np.array(counts)))
+        want = [e for q in range(nq) for r in range(world) for e in naive[q][r]]
+        out, total = pdist.merge_query_major(per)
+        assert out == want
+        assert total.tolist() == [sum(len(naive[q][r]) for r in range(world)) for q in range(nq)]
+        blob, offsets, total2 = pdist.merge_packed(per)
+        assert bytes(blob) == b''.join(want) and len(offsets) == len(want) + 1 and total2.tolist() == total.tolist()
