@@ -77,9 +77,8 @@ def gather_packed(blob, lens, counts, group=None, dst: int = 0, packed: bool = F
     back (uint8), ``lens`` their lengths, ``counts`` the per-query entry counts,
     all query-major.  Rank ``dst`` gets (all entries query-major, total counts)
     -- with ``packed=True`` (blob, offsets, total counts), no Python object per entry --,
-    the others None.  On the nccl (= RCCL) backend the three payloads travel as
-    device tensors; sizes are exchanged first so they can be padded to a common
-    shape."""
+    the others None.  On the nccl (= RCCL) backend the payload travels as one device
+    tensor per rank; sizes are exchanged first so that it can be padded to a common shape."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -88,36 +87,29 @@ def gather_packed(blob, lens, counts, group=None, dst: int = 0, packed: bool = F
     blob = np.ascontiguousarray(blob, dtype=np.uint8)
     lens = np.ascontiguousarray(lens, dtype=np.int64)
     cnt = np.ascontiguousarray(counts, dtype=np.int64)
+    nq = len(cnt)
+    # two collectives: the sizes, then ONE payload per rank (counts | lengths | bytes) padded to the largest
     sizes = torch.tensor([len(lens), len(blob)], dtype=torch.int64, device=dev)
     all_sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(all_sizes, sizes, group=group)
     all_sizes = torch.stack(all_sizes).cpu().numpy()
-    max_e, max_b = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max())
-
-    def padded(a, n, dtype):
-        t = torch.zeros(max(n, 1), dtype=dtype)
-        if len(a):
-            t[:len(a)] = torch.from_numpy(a.copy() if not a.flags.writeable else a)
-        return t.to(dev)
-
-    t_cnt = padded(cnt, len(cnt), torch.int64)
-    t_len = padded(lens, max_e, torch.int64)
-    t_blob = padded(blob, max_b, torch.uint8)
+    width = int((nq * 8 + all_sizes[:, 0] * 8 + all_sizes[:, 1]).max())
+    payload = np.zeros(max(width, 1), dtype=np.uint8)
+    mine = np.concatenate([cnt.view(np.uint8), lens.view(np.uint8), blob])
+    payload[:len(mine)] = mine
+    t = torch.from_numpy(payload).to(dev)
     # all_gather (not gather): supported by every backend/version; the payload is
     # small (result strings), so the extra copies to non-destination ranks are noise
-    g_cnt = [torch.empty_like(t_cnt) for _ in range(world)]
-    g_len = [torch.empty_like(t_len) for _ in range(world)]
-    g_blob = [torch.empty_like(t_blob) for _ in range(world)]
-    dist.all_gather(g_cnt, t_cnt, group=group)
-    dist.all_gather(g_len, t_len, group=group)
-    dist.all_gather(g_blob, t_blob, group=group)
+    g = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(g, t, group=group)
     if rank != dst:
         return None
     per_rank = []
     for r in range(world):
         e, b = int(all_sizes[r, 0]), int(all_sizes[r, 1])
-        per_rank.append((g_blob[r].cpu().numpy()[:b], g_len[r].cpu().numpy()[:e],
-                         g_cnt[r].cpu().numpy()[:len(cnt)]))
+        raw = g[r].cpu().numpy()
+        o1, o2 = nq * 8, nq * 8 + e * 8
+        per_rank.append((raw[o2:o2 + b], raw[o1:o2].view(np.int64), raw[:o1].view(np.int64)))
     return merge_packed(per_rank) if packed else merge_query_major(per_rank)
 
 
