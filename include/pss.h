@@ -138,10 +138,14 @@ uint64_t pss_writer_chunk_limit(const pss_writer *w);
 
 /* ---- Reader (src/lib.rs:146-288; pysubstringsearch/__init__.py:44-73) --- */
 
-/* Reader::new, src/lib.rs:162-199.  Parses the chunk records of `path` and
+/* Reader::new, src/lib.rs:162-199.  Parses the chunk records of `path` (the reference
+ * container, or format 2 -- recognised by its magic, see pss_writer_open_format) and
  * makes the text AND suffix array of every chunk c with
- * c % shard_count == shard_index resident in the HBM of `device`
- * (shard_index 0, shard_count 1 = whole file). */
+ * c % shard_count == shard_index resident on `device`: in HBM, the suffix arrays
+ * beyond the HBM budget in pinned host memory (pss_reader_residency)
+ * (shard_index 0, shard_count 1 = whole file).  Every resident chunk also gets a
+ * table of key samples (first 8 bytes of every 2048th suffix) that the searches
+ * consult before the suffix array. */
 int pss_reader_open(const char *path, int32_t device, int32_t shard_index, int32_t shard_count,
                     pss_reader **out);
 /* An empty reader on `device`, to be filled with pss_reader_add_chunk_device
