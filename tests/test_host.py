@@ -259,3 +259,14 @@ def test_merge_packed_random():
         assert total.tolist() == [sum(len(naive[q][r]) for r in range(world)) for q in range(nq)]
         blob, offsets, total2 = pdist.merge_packed(per)
         assert bytes(blob) == b''.join(want) and len(offsets) == len(want) + 1 and total2.tolist() == total.tolist()
+
+
+def test_tools_compile():
+    """The measurement / fuzzing helpers under tests/tools are not imported by any test: at least
+    keep them syntactically valid."""
+    import glob
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools')
+    files = sorted(glob.glob(os.path.join(root, '*.py')))
+    assert len(files) > 10
+    for f in files:
+        compile(open(f, encoding='utf-8').read(), f, 'exec')
