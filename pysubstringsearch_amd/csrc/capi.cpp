@@ -980,7 +980,8 @@ extern "C" int pss_reader_set_chunk_device(pss_reader *r, uint64_t index, const 
             ChunkDesc fresh{};
             pss_reader::Mem fm;
             reader_free_mem(r->mem[index]);            // first: its HBM may be what the new one needs
-            c = ChunkDesc{};
+            c = ChunkDesc{};                           // (an empty chunk if the allocation below fails)
+            r->dirty = true;
             PSS_TRY(reader_alloc_chunk(r, n, &fresh, &fm));
             c = fresh;
             r->mem[index] = fm;
