@@ -1,32 +1,50 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path on N MI355X of one node.
 
-One "step" = one pass of the hot path over one batch of synthetic input per
-GPU (BASELINE.json configs[1]): build the 32-bit suffix array of one 512 MiB
-`lines` chunk that is already resident in HBM (pss_sa_build_device), hand the
-chunk to a device-resident Reader, and answer one batch of 10 000 8-byte
-queries (5 000 sampled from the text, 5 000 random) through the batched search.
+--config chunk (default; BASELINE.json configs[1], weak scaling)
+    One "step" = one pass of the hot path over one batch of synthetic input per GPU:
+    build the 32-bit suffix array of one 512 MiB `lines` chunk that is already resident
+    in HBM (pss_sa_build_device), hand the chunk to a device-resident Reader, and answer
+    one batch of 10 000 8-byte queries (5 000 sampled from the text, 5 000 random).
 
-  value            index-build GB/s  = chunk bytes of all ranks / build time
-  queries_per_sec  batched queries/s = queries / (H2D queries + kernels + D2H
-                   results + Python list construction [+ gather to rank 0])
-  roofline         dominant kernel (the scatter instantiation with the largest summed
-                   duration; `lines`: fs_scatter_kernel<4, 4>, 4 B key + 4 B value in,
-                   same out = 16 algorithmic bytes per element) over its HIP-event
-                   duration, against the 8 TB/s HBM peak
-  build_roofline   the whole build against the same peak: modelled algorithmic bytes
-                   (A_model) / build time, beside A_min = 5 n and the PMC-measured bytes
-  cpu_baseline     the reference's libsais (oracle/_ref) on a bounded sample,
-                   rank 0, N = 1 only
+      value            index-build GB/s  = chunk bytes of all ranks / build time
+      queries_per_sec  batched queries/s = queries / (H2D queries + kernels + D2H
+                       results + Python list construction [+ gather to rank 0])
+      verified         the suffix array of the LAST TIMED STEP equals libsais' (the
+                       reference's builder, src/lib.rs:30-36): positional checksum on the
+                       GPU + sha256 of the 2 GiB array against tests/golden/sa_big.json
+                       (or against libsais run on the spot for small --logn).  A build
+                       whose result is wrong prints no value.
+      roofline         dominant kernel (the scatter instantiation with the largest summed
+                       duration) over its HIP-event duration, against the 8 TB/s HBM peak
+      build_roofline   the whole build against the same peak
+      cpu_baseline     the reference's libsais (oracle/_ref) on a bounded sample,
+                       rank 0, N = 1 only
 
-N > 1: one process per GPU (torch.distributed, RCCL); chunk r lives on rank r,
-no collective on the build path, results of every rank are gathered to rank 0
-(weak scaling: corpus grows with N).
+    N > 1: one process per GPU (torch.distributed, RCCL); chunk r lives on rank r, no
+    collective on the build path, results of every rank are gathered to rank 0.
+
+--config corpus15 (BASELINE.json configs[2] / [3], strong scaling)
+    The 7.5 GB corpus: 15 `lines` chunks of 512 MiB, chunk c on rank c mod N (built there,
+    every suffix array verified against libsais' checksum, then resident).  One "step" =
+    one batch of 100 000 queries of 4..32 bytes (50 % sampled from the corpus) answered
+    through the drop-in list API -- every rank searches its chunks, results are gathered
+    to rank 0 (device buffers over RCCL), which builds the Python list.
+
+      value            batched queries/s through the list API (what search_multiple returns)
+      packed_queries_per_sec   the same batch through the packed (numpy) result API
+      single_query_us  latency of Reader.search for one query over all chunks (N = 1)
+      index_build_gbs  15 chunks / max over ranks of the summed build time
+      cpu_baseline     SURVEY 8(d)(ii): the oracle's restatement of Reader::search, queries
+                       one at a time, one thread per chunk, suffix arrays in RAM and -- like
+                       the reference -- probed on disk with lseek + read(8 KiB)
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
+import shutil
 import sys
 import tempfile
 import time
@@ -39,7 +57,66 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 KINDS = {'lines': 0, 'words': 1, 'runs': 2, 'periodic': 3}
 ALPHA = b'abcdefghijklmnopqrstuvwxyz0123456789 .'
+METRIC = 'queries/sec (batched) + index-build GB/s on 512MB chunk, 1/2/4/8 GPU'
+MASK64 = (1 << 64) - 1
 
+
+# ----------------------------------------------------------------------------- verification --
+
+def load_big_goldens():
+    """(kind, chunk_index, n) -> libsais known answers (tests/golden/make_golden_big.py)."""
+    p = os.path.join(ROOT, 'tests', 'golden', 'sa_big.json')
+    if not os.path.exists(p):
+        return {}
+    return {(r['kind'], r['chunk_index'], r['n']): r for r in json.load(open(p))['chunks']}
+
+
+def sa_poly64_torch(d_sa) -> int:
+    """sum (SA[i] + 1) * (2 i + 1) mod 2^64 of a device int32 tensor (int64 arithmetic wraps)."""
+    import torch
+    acc, n, blk = 0, d_sa.numel(), 1 << 26
+    for s in range(0, n, blk):
+        v = d_sa[s:s + blk].to(torch.int64) + 1
+        w = torch.arange(s, s + v.numel(), device=d_sa.device, dtype=torch.int64) * 2 + 1
+        acc = (acc + int((v * w).sum().item())) & MASK64
+    return acc
+
+
+def sa_poly64_numpy(sa: np.ndarray) -> int:
+    acc, blk = 0, 1 << 24
+    with np.errstate(over='ignore'):
+        for s in range(0, sa.size, blk):
+            v = sa[s:s + blk].astype(np.uint64) + np.uint64(1)
+            w = np.arange(s, s + v.size, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+            acc = (acc + int((v * w).sum(dtype=np.uint64))) & MASK64
+    return acc
+
+
+def verify_sa(d_sa, host_text: np.ndarray, kind: str, chunk_index: int, goldens, want_sha: bool):
+    """Is the device suffix array libsais' (the reference's) suffix array of this chunk?
+    Returns (verified, how): True / False when it could be decided, None when no known answer exists
+    for this input and it is too large to run libsais on the spot."""
+    n = host_text.size
+    g = goldens.get((kind, chunk_index, n))
+    if g is not None:
+        ok = sa_poly64_torch(d_sa) == g['sa_poly64']
+        how = 'positional checksum vs libsais golden (tests/golden/sa_big.json)'
+        if ok and want_sha:
+            ok = hashlib.sha256(d_sa.cpu().numpy().astype('<i4', copy=False)).hexdigest() == g['sa_sha256']
+            how = 'sha256 of the int32 array + positional checksum vs libsais golden (tests/golden/sa_big.json)'
+        return bool(ok), how
+    if n <= (1 << 25):
+        from oracle import oracle as O
+        if O.have_reference():
+            ref = O.sa_reference(host_text)
+            return bool(sa_poly64_torch(d_sa) == sa_poly64_numpy(ref) and
+                        (not want_sha or np.array_equal(d_sa.cpu().numpy(), ref))), 'libsais (oracle/_ref) run on the same text'
+        ref = O.sa_restatement(host_text)
+        return bool(np.array_equal(d_sa.cpu().numpy(), ref)), 'oracle restatement run on the same text (libsais not built)'
+    return None, 'no libsais known answer for this input (add it with tests/golden/make_golden_big.py)'
+
+
+# ----------------------------------------------------------------------------- queries --
 
 def make_queries(text: np.ndarray, nq: int, qlen: int, seed: int = 1):
     """SURVEY 8(d) config #2: half sampled from the chunk (no newline inside), half uniform over ALPHA."""
@@ -56,7 +133,34 @@ def make_queries(text: np.ndarray, nq: int, qlen: int, seed: int = 1):
     return out
 
 
-def cpu_baseline(host: np.ndarray, queries, sample_logn: int):
+def sample_chunk_queries(text: np.ndarray, chunk_index: int, count: int, qmin: int, qmax: int):
+    """SURVEY 8(d) config #4, the sampled half: `count` substrings of 4..32 bytes at uniform offsets of
+    one chunk (no newline inside).  Seeded by the chunk index alone, so the query set does not depend
+    on how the chunks are spread over ranks."""
+    rng = np.random.default_rng(1000 + chunk_index)
+    out = []
+    while len(out) < count:
+        s = int(rng.integers(0, text.size - qmax - 1))
+        ln = int(rng.integers(qmin, qmax + 1))
+        cand = text[s:s + ln].tobytes()
+        if b'\n' not in cand:
+            out.append(cand)
+    return out
+
+
+def mixed_queries(sampled, nq: int, qmin: int, qmax: int):
+    rng = np.random.default_rng(1)
+    queries = list(sampled[:nq // 2])
+    while len(queries) < nq:
+        ln = int(rng.integers(qmin, qmax + 1))
+        queries.append(bytes(ALPHA[int(i)] for i in rng.integers(0, len(ALPHA), ln)))
+    order = rng.permutation(len(queries))
+    return [queries[i] for i in order]
+
+
+# ----------------------------------------------------------------------------- CPU baselines --
+
+def cpu_baseline_chunk(host: np.ndarray, queries, sample_logn: int):
     """Reference CPU path on a bounded sample: libsais exactly as src/lib.rs:30-36
     calls it (1 thread), then the oracle's restatement of Reader::search, one
     query at a time like the reference's search_multiple loop."""
@@ -68,82 +172,143 @@ def cpu_baseline(host: np.ndarray, queries, sample_logn: int):
     t0 = time.perf_counter()
     sa = O.sa_reference(sample) if kind == 'reference' else O.sa_restatement(sample)
     t_sa = time.perf_counter() - t0
-    qps = None
-    try:
-        with tempfile.TemporaryDirectory() as d:
-            p = os.path.join(d, 'sample.idx')
-            with open(p, 'wb') as f:   # chunk record layout, src/lib.rs:112-119
-                f.write(np.uint32(m).tobytes())
-                f.write(sample.tobytes())
-                f.write(np.uint32(4 * m).tobytes())
-                f.write(sa.astype('<i4').tobytes())
-            r = O.OracleReader(p)
-            t0 = time.perf_counter()
-            total = 0
-            for q in queries:
-                total += len(r.search_bytes(q))
-            qps = len(queries) / (time.perf_counter() - t0)
-            r.close()
-    except OSError:
-        pass
+    r = O.OracleReader.from_arrays([sample], [sa])
+    b = r.bench_search(queries, 1)
+    r.close()
     return {
         'value': round(m / t_sa / 1e9, 6), 'unit': 'GB/s', 'cores': 1, 'kind': kind,
         'sample': f'SA build of the first {m >> 20} MiB of the same chunk '
                   f'({"libsais from oracle/_ref" if kind == "reference" else "oracle restatement"}, 1 thread, {t_sa:.1f} s); '
                   f'queries/s = oracle Reader::search restatement, SA in RAM, 1 thread, the same {len(queries)} queries one at a time',
-        'queries_per_sec': None if qps is None else round(qps, 1),
+        'queries_per_sec': round(len(queries) / b['seconds'], 1),
         'host_cpus': os.cpu_count(),
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--corpus', default='lines', choices=sorted(KINDS))
-    ap.add_argument('--logn', type=int, default=29, help='log2 of the chunk size (29 = the 512 MiB default chunk)')
-    ap.add_argument('--queries', type=int, default=10000)
-    ap.add_argument('--qlen', type=int, default=8)
-    ap.add_argument('--cpu-sample-logn', type=int, default=26)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    args = ap.parse_args()
-
-    import torch
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    dist = None
-    # Test hook for 1-GPU boxes: PSS_BENCH_BACKEND=gloo lets every rank share GPU 0
-    # so the N > 1 code path (sharding, gather, max-over-ranks timing) can be exercised.
-    backend = os.environ.get('PSS_BENCH_BACKEND', 'nccl')
-    if backend != 'nccl':
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+def cpu_baseline_corpus(texts, sas, queries, sample_queries: int, want_disk: bool):
+    """SURVEY 8(d)(ii) on the resident corpus: queries one at a time, one thread per chunk (up to
+    nproc), suffix arrays in RAM -- and, like the reference (src/lib.rs:216-217), left in the index
+    file and probed with lseek + read(8 KiB).  `sas` are the GPU-built suffix arrays, each already
+    verified against libsais' checksum."""
+    from oracle import oracle as O
+    qs = queries[:sample_queries]
+    nchunks, nproc = len(texts), os.cpu_count() or 1
+    threads = min(nchunks, nproc)
+    out = {'unit': 'queries/s', 'kind': 'port', 'cores': threads, 'host_cpus': nproc,
+           'sample': f'the first {len(qs)} queries of the batch, one at a time, fanned out over the {nchunks} chunks on '
+                     f'{threads} threads (oracle/pss_oracle.c orc_bench_search: rayon par_iter_mut of src/lib.rs:207 restated)'}
+    r = O.OracleReader.from_arrays(texts, sas)
+    b = r.bench_search(qs, threads)
+    out['value'] = round(len(qs) / b['seconds'], 1)
+    out['value_is'] = 'suffix arrays in RAM (kinder than the reference, which probes them on disk)'
+    out['entries_per_query'] = round(b['entries'] / max(len(qs), 1), 2)
+    b1 = r.bench_search(qs[:max(len(qs) // 10, 1)], 1)
+    out['one_thread_queries_per_sec'] = round(max(len(qs) // 10, 1) / b1['seconds'], 1)
+    counts = b['counts']
+    r.close()
+    if want_disk:
+        total = sum(int(t.size) * 5 + 8 for t in texts)
+        tmp = tempfile.gettempdir()
+        if shutil.disk_usage(tmp).free > total + (8 << 30):
+            d = tempfile.mkdtemp(prefix='pss_bench_')
+            try:
+                p = os.path.join(d, 'corpus.idx')
+                t0 = time.perf_counter()
+                with open(p, 'wb') as f:   # chunk record layout, src/lib.rs:112-119
+                    for t, s in zip(texts, sas):
+                        f.write(np.uint32(t.size).tobytes())
+                        f.write(memoryview(t))
+                        f.write(np.uint32((4 * t.size) & 0xffffffff).tobytes())
+                        f.write(memoryview(s))
+                t_write = time.perf_counter() - t0
+                rd = O.OracleReader(p, load_sa=False)
+                bd = rd.bench_search(qs, threads, disk=True)
+                rd.close()
+                assert np.array_equal(bd['counts'], counts)
+                out['disk_queries_per_sec'] = round(len(qs) / bd['seconds'], 1)
+                out['disk_is'] = (f'the reference\'s access path: suffix arrays in the {total >> 30} GiB index file (page cache hot, '
+                                  f'written in {t_write:.0f} s), lseek + read(8 KiB) per probe, src/lib.rs:216-217')
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
         else:
-            dist.init_process_group(backend)
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+            out['disk_queries_per_sec'] = None
+            out['disk_is'] = f'skipped: {tmp} has less than {(total >> 30) + 8} GiB free'
+    return out, counts
 
+
+# ----------------------------------------------------------------------------- distributed --
+
+class Dist:
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        self.dist = None
+        # Test hook for 1-GPU boxes: PSS_BENCH_BACKEND=gloo lets every rank share GPU 0
+        # so the N > 1 code path (sharding, gather, max-over-ranks timing) can be exercised.
+        self.backend = os.environ.get('PSS_BENCH_BACKEND', 'nccl')
+        if self.backend != 'nccl':
+            self.local_rank = 0
+        torch.cuda.set_device(self.local_rank)
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            if self.backend == 'nccl':
+                dist.init_process_group('nccl', device_id=torch.device('cuda', self.local_rank))
+            else:
+                dist.init_process_group(self.backend)
+        assert self.world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={self.world}'
+
+    def sync_all(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, values):
+        t = self.torch.tensor(values, dtype=self.torch.float64, device='cuda' if self.backend == 'nccl' else 'cpu')
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t.tolist()
+
+    def all_true(self, flag):
+        """True / False / None (undecided anywhere and false nowhere) over all ranks."""
+        code = 1 if flag is True else (0 if flag is False else 2)
+        t = self.torch.tensor([code == 0, code == 2], dtype=self.torch.float64, device='cuda' if self.backend == 'nccl' else 'cpu')
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        bad, unknown = t.tolist()
+        return False if bad else (None if unknown else True)
+
+    def finish(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------- configs[1] --
+
+def run_chunk(args, D):
+    import torch
     from pysubstringsearch_amd import Reader, _ffi
     from pysubstringsearch_amd import dist as pdist
     lib = _ffi.lib
+    rank, world, dist = D.rank, D.world, D.dist
     n = 1 << args.logn
-    dev = local_rank
+    dev = D.local_rank
+    nq = args.queries or 10000
 
     host = np.empty(n, dtype=np.uint8)
     _ffi.check(lib.pss_gen_corpus(KINDS[args.corpus], host.ctypes.data, n, rank))
     dT = torch.from_numpy(host).cuda()
     dSA = torch.empty(n, dtype=torch.int32, device='cuda')
     if world > 1:
-        box = [make_queries(host, args.queries, args.qlen) if rank == 0 else None]
+        box = [make_queries(host, nq, args.qlen) if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         queries = box[0]
     else:
-        queries = make_queries(host, args.queries, args.qlen)
+        queries = make_queries(host, nq, args.qlen)
     torch.cuda.synchronize()
 
     st = _ffi.SaStats()
@@ -160,9 +325,8 @@ def main():
         _ffi.check(lib.pss_reader_set_chunk_device(h, 0, dT.data_ptr(), dSA.data_ptr(), n))
         t2 = time.perf_counter()
         if world > 1:
-            # packed local result -> gather to rank 0 -> one Python list there
-            pk = reader.search_batch_packed(queries)
-            merged = pdist.gather_packed(pk.data, np.diff(pk.offsets.astype(np.int64)), pk.counts, dst=0, packed=True)
+            # local result stays on the device -> gather to rank 0 -> one packed result there
+            merged = pdist.gather_device(reader.search_batch_device(queries), dst=0)
             entries = merged[1][:-1] if merged is not None else []      # one offset per entry (packed result)
         else:
             entries, counts = reader.search_batch_raw(queries)
@@ -171,27 +335,23 @@ def main():
         last['search_stats'] = reader.last_stats()
         return t1 - t0, t3 - t2
 
-    def sync_all():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
-    sync_all()
+    D.sync_all()
     t_begin = time.perf_counter()
     build_s = search_s = 0.0
     for _ in range(args.steps):
         b, s = step()
         build_s += b
         search_s += s
-    sync_all()
+    D.sync_all()
     total_s = time.perf_counter() - t_begin
     sa_stats = st.as_dict()
-    t = torch.tensor([build_s, search_s, total_s], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    build_s, search_s, total_s = t.tolist()
+    build_s, search_s, total_s = D.max_over_ranks([build_s, search_s, total_s])
+
+    # the suffix array the last timed step left in dSA: is it the reference's?
+    verified, how = verify_sa(dSA, host, args.corpus, rank, load_big_goldens(), want_sha=(world == 1))
+    verified = D.all_true(verified)
 
     # roofline of the dominant kernel: one extra build in profile mode (HIP events
     # on the engine's own stream around every radix-pass launch), outside the timed region
@@ -210,8 +370,9 @@ def main():
             _ffi.check(lib.pss_sa_build_device(w_dT.data_ptr(), dSA.data_ptr(), n, dev, 0, ctypes.byref(wst)))
             best = wst.ms_total if best is None else min(best, wst.ms_total)
         wd = wst.as_dict()
+        w_ok, w_how = verify_sa(dSA, w_host, 'words', 0, load_big_goldens(), want_sha=False)
         secondary = {'corpus': 'words', 'chunk_bytes': n, 'build_ms': round(best, 3),
-                     'index_build_gbs': round(n / best / 1e6, 4),
+                     'index_build_gbs': round(n / best / 1e6, 4), 'verified': w_ok, 'verified_by': w_how,
                      'sa_stats': {k: wd[k] for k in ('key_chars', 'initial_passes', 'rounds', 'text_rounds', 'round_passes',
                                                      'sum_active', 'big_elems', 'mode')}}
         del w_dT
@@ -278,15 +439,17 @@ def main():
                       'passes': sa_stats['initial_passes'], 'rounds': sa_stats['rounds'], 'sum_active': sa_stats['sum_active']}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(host, queries, args.cpu_sample_logn)
+            cpu = cpu_baseline_chunk(host, queries, args.cpu_sample_logn)
         out = {
-            'metric': 'queries/sec (batched) + index-build GB/s on 512MB chunk, 1/2/4/8 GPU',
-            'value': round(world * n * args.steps / build_s / 1e9, 4),
+            'metric': METRIC,
+            # a build whose suffix array is not the reference's has no throughput worth reporting
+            'value': None if verified is False else round(world * n * args.steps / build_s / 1e9, 4),
             'unit': 'GB/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(total_s / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'u64', 'data': 'synthetic',
+            'verified': verified, 'verified_by': how,
             'config': {
                 'workload': f'configs[1]: one {n >> 20} MiB synthetic `{args.corpus}` chunk per GPU, suffix-array build + '
                             f'{len(queries)} {args.qlen}-byte queries (50% sampled from the text) in one batch',
@@ -307,9 +470,181 @@ def main():
         }
         print(json.dumps(out))
     reader.close()
+    return 1 if verified is False else 0
+
+
+# ----------------------------------------------------------------------------- configs[2] / [3] --
+
+def run_corpus(args, D):
+    import torch
+    from pysubstringsearch_amd import Reader, _ffi
+    from pysubstringsearch_amd import dist as pdist
+    lib = _ffi.lib
+    rank, world, dist = D.rank, D.world, D.dist
+    n = 1 << args.logn
+    dev = D.local_rank
+    nq = args.queries or 100000
+    chunks = args.chunks
+    mine = [c for c in range(chunks) if pdist.chunk_owner(c, world) == rank]
+    goldens = load_big_goldens()
+    keep_host = world == 1 and not args.no_cpu_baseline      # the CPU baseline needs text + SA of every chunk
+
+    h = ctypes.c_void_p()
+    _ffi.check(lib.pss_reader_create(dev, ctypes.byref(h)))
+    reader = Reader._from_handle(h)
+    dSA = torch.empty(n, dtype=torch.int32, device='cuda')
+    st = _ffi.SaStats()
+    per_chunk = (nq // 2 + chunks - 1) // chunks
+    sampled, texts, sas = {}, [], []
+    build_s, verified, how = 0.0, True, ''
+    for c in mine:
+        host = np.empty(n, dtype=np.uint8)
+        _ffi.check(lib.pss_gen_corpus(KINDS[args.corpus], host.ctypes.data, n, c))
+        dT = torch.from_numpy(host).cuda()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _ffi.check(lib.pss_sa_build_device(dT.data_ptr(), dSA.data_ptr(), n, dev, 0, ctypes.byref(st)))
+        build_s += time.perf_counter() - t0
+        ok, how = verify_sa(dSA, host, args.corpus, c, goldens, want_sha=False)
+        verified = False if (ok is False or verified is False) else (None if (ok is None or verified is None) else True)
+        _ffi.check(lib.pss_reader_add_chunk_device(h, dT.data_ptr(), dSA.data_ptr(), n))
+        sampled[c] = sample_chunk_queries(host, c, per_chunk, args.qmin, args.qmax)
+        if keep_host:
+            texts.append(host)
+            sas.append(dSA.cpu().numpy())
+        del dT
+    verified = D.all_true(verified)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        boxes = [None] * world
+        dist.all_gather_object(boxes, sampled)
+        sampled = {c: q for b in boxes for c, q in b.items()}
+    queries = mixed_queries([q for c in range(chunks) for q in sampled[c]], nq, args.qmin, args.qmax)
+
+    last = {}
+
+    def step(packed=False):
+        t0 = time.perf_counter()
+        if world > 1:
+            merged = pdist.gather_device(reader.search_batch_device(queries), dst=0)
+            if merged is not None:
+                blob, offsets, counts = merged
+                last['entries'] = len(offsets) - 1
+                if not packed:
+                    last['list'] = pdist.packed_to_list(blob, offsets, as_str=True)
+        elif packed:
+            pk = reader.search_batch_packed(queries)
+            last['entries'] = len(pk.offsets) - 1
+            last['bytes'] = int(pk.data.size)
+        else:
+            last['list'] = reader.search_multiple_bytes_as_str(queries)
+            last['entries'] = len(last['list'])
+        dt = time.perf_counter() - t0
+        last.pop('list', None)
+        return dt
+
+    for _ in range(args.warmup):
+        step()
+    D.sync_all()
+    t_begin = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    D.sync_all()
+    total_s = time.perf_counter() - t_begin
+    stats = reader.last_stats()
+    D.sync_all()
+    t_p = time.perf_counter()
+    for _ in range(args.steps):
+        step(packed=True)
+    D.sync_all()
+    packed_s = time.perf_counter() - t_p
+    total_s, packed_s, build_s = D.max_over_ranks([total_s, packed_s, build_s])
+
+    lat = None
+    if world == 1:
+        ts = []
+        for q in queries[:1000]:
+            t0 = time.perf_counter()
+            reader.search_batch_raw([q])
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        lat = {'median': round(ts[len(ts) // 2] * 1e6, 1), 'p90': round(ts[int(len(ts) * 0.9)] * 1e6, 1),
+               'queries_per_sec': round(len(ts) / sum(ts), 1)}
+
+    rc = 0
+    if rank == 0:
+        cpu = None
+        if keep_host:
+            cpu, cpu_counts = cpu_baseline_corpus(texts, sas, queries, args.cpu_sample_queries, not args.no_disk_baseline)
+            got = reader.count_multiple_bytes(queries[:args.cpu_sample_queries])
+            if not np.array_equal(np.asarray(got, dtype=np.uint64), cpu_counts):
+                verified = False            # per-query entry counts differ from the oracle's
+                how = 'per-query entry counts differ from the CPU oracle'
+        hits_q = stats['hits'] / max(stats['queries'], 1)
+        # A_query = chunks touched x 7.4 KB (58 dependent probes x 128 B) + 132 B per hit
+        a_query = len(mine) * len(queries) * 7424 + stats['hits'] * 132
+        ms_dev = stats['ms_device']
+        roof = {'bound': 'hbm', 'achieved': round(a_query / ms_dev / 1e6, 1) if ms_dev else None, 'peak': HBM_PEAK_GBS,
+                'unit': 'GB/s', 'frac': round(a_query / ms_dev / 1e6 / HBM_PEAK_GBS, 4) if ms_dev else None, 'traffic': None,
+                'kernel': 'search pipeline of one batch on rank 0 (interval search, entry recovery, emit)',
+                'ms_device': round(ms_dev, 3), 'ms_interval': round(stats['ms_interval'], 3),
+                'algorithmic_bytes': int(a_query),
+                'note': 'latency / transaction bound by construction (SURVEY 8(d)): graded on queries/s against the CPU path'}
+        qps = len(queries) * args.steps / total_s
+        out = {
+            'metric': METRIC, 'value': None if verified is False else round(qps, 1), 'unit': 'queries/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(total_s / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
+            'verified': verified, 'verified_by': how + ('; per-query entry counts of a sample equal to the CPU oracle' if cpu else ''),
+            'config': {
+                'workload': f'configs[2]/[3]: {chunks} x {n >> 20} MiB `{args.corpus}` chunks ({chunks * n / 1e9:.2f} GB) resident, chunk c on '
+                            f'rank c mod {world}; one batch of {len(queries)} queries of {args.qmin}..{args.qmax} bytes (50% sampled)',
+                'corpus': args.corpus, 'chunks': chunks, 'chunk_bytes': n, 'queries': len(queries),
+                'value_is': 'batched queries/s through the drop-in list API (Reader.search_multiple semantics: '
+                            'list[str] on rank 0), including H2D, kernels, D2H / gather and Python list construction',
+                'imbalance': f'{max(len([c for c in range(chunks) if c % world == r]) for r in range(world))} chunks on the '
+                             f'fullest rank: best-case speed-up {chunks / max(len([c for c in range(chunks) if c % world == r]) for r in range(world)):.2f}x',
+            },
+            'entries_per_batch': last.get('entries'), 'hits_per_query': round(hits_q, 2),
+            'packed_queries_per_sec': round(len(queries) * args.steps / packed_s, 1),
+            'single_query_us': lat,
+            'index_build_gbs': round(chunks * n / build_s / 1e9, 3),
+            'search_stats': stats,
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        if cpu and cpu.get('value'):
+            out['gpu_over_cpu'] = {'list_api': round(qps / cpu['value'], 2),
+                                   'packed_api': round(out['packed_queries_per_sec'] / cpu['value'], 2)}
+            if cpu.get('disk_queries_per_sec'):
+                out['gpu_over_cpu']['list_api_vs_disk_probes'] = round(qps / cpu['disk_queries_per_sec'], 2)
+        print(json.dumps(out))
+        rc = 1 if verified is False else 0
+    reader.close()
+    return rc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--config', default='chunk', choices=['chunk', 'corpus15'])
+    ap.add_argument('--corpus', default='lines', choices=sorted(KINDS))
+    ap.add_argument('--logn', type=int, default=29, help='log2 of the chunk size (29 = the 512 MiB default chunk)')
+    ap.add_argument('--queries', type=int, default=0, help='queries per batch (default 10 000 / 100 000 by config)')
+    ap.add_argument('--qlen', type=int, default=8)
+    ap.add_argument('--chunks', type=int, default=15, help='corpus15: chunks of the corpus')
+    ap.add_argument('--qmin', type=int, default=4)
+    ap.add_argument('--qmax', type=int, default=32)
+    ap.add_argument('--cpu-sample-logn', type=int, default=26)
+    ap.add_argument('--cpu-sample-queries', type=int, default=5000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-disk-baseline', action='store_true')
+    args = ap.parse_args()
+    D = Dist(args)
+    rc = run_chunk(args, D) if args.config == 'chunk' else run_corpus(args, D)
+    D.finish()
+    sys.exit(rc)
 
 
 if __name__ == '__main__':

@@ -45,6 +45,10 @@ int pss_device_count(void);
  * truncated to cap); returns the untruncated length. */
 size_t pss_last_error(char *buf, size_t cap);
 
+/* Test hook: re-reads the PSS_* environment switches of the search path, which the library reads
+ * once (when it first needs them) rather than on every call. */
+int pss_reload_env(void);
+
 /* Frees the grow-only HBM workspace of every device (the builder keeps ~45 n
  * bytes around for reuse; resident Reader chunks are not touched). */
 int pss_release_workspace(void);
@@ -199,6 +203,34 @@ int pss_reader_search_batch(pss_reader *r, const uint8_t *qbytes, const uint64_t
  */
 int pss_reader_count_batch(pss_reader *r, const uint8_t *qbytes, const uint64_t *qoffsets,
                            uint32_t nq, uint64_t *counts);
+/*
+ * The same search with the packed result LEFT ON THE DEVICE: the multi-GPU gather (RCCL send / recv of
+ * device buffers to the collecting rank, pysubstringsearch_amd/dist.py) takes it from there, so a
+ * contributing rank never moves an entry through its host.  Replaces, across GPUs, what
+ * `results.lock().extend(local_results)` does across chunk threads in src/lib.rs:280-284.  The pointers
+ * are workspace of the device context: valid until the next search or build on that device.
+ */
+typedef struct pss_device_result {
+    uint64_t num_queries;
+    uint64_t num_entries;
+    uint64_t num_bytes;
+    const void *d_counts;    /* u64 [num_queries]  entries per query */
+    const void *d_offsets;   /* u64 [num_entries]  start of every entry in d_bytes (entry e ends where e + 1 starts,
+                                the last one at num_bytes) */
+    const void *d_bytes;     /* u8  [num_bytes]    entries back to back, query-major, chunk-major inside a query */
+    int32_t device;
+} pss_device_result;
+int pss_reader_search_batch_device(pss_reader *r, const uint8_t *qbytes, const uint64_t *qoffsets,
+                                   uint32_t nq, pss_device_result *out);
+/*
+ * Host merge of `world` packed results of the same nq queries (one per rank, each query-major) into one:
+ * query-major, rank-major inside a query -- the cross-chunk concatenation of src/lib.rs:280-286 across
+ * ranks.  counts[r] = u64[nq], offsets[r] = u64[num_entries[r]] entry starts, bytes[r] = num_bytes[r]
+ * bytes.  out_counts[nq], out_offsets[sum(num_entries) + 1], out_bytes[sum(num_bytes)] are the caller's.
+ */
+int pss_merge_packed(uint32_t world, uint64_t nq, const uint64_t *const *counts, const uint64_t *const *offsets,
+                     const uint8_t *const *bytes, const uint64_t *num_entries, const uint64_t *num_bytes,
+                     uint64_t *out_counts, uint64_t *out_offsets, uint8_t *out_bytes);
 int pss_reader_last_stats(const pss_reader *r, pss_search_stats *stats);
 /* Drops the chunks and closes the reader. */
 int pss_reader_close(pss_reader *r);

@@ -53,6 +53,11 @@ def lib() -> ctypes.CDLL:
         L.orc_writer_capacity.argtypes = [vp]
         L.orc_writer_capacity.restype = ctypes.c_size_t
         L.orc_reader_open.argtypes = [u8p, ctypes.POINTER(vp)]
+        L.orc_reader_open_ex.argtypes = [u8p, ctypes.c_int, ctypes.POINTER(vp)]
+        L.orc_reader_from_arrays.argtypes = [ctypes.c_size_t, vp, vp, vp, ctypes.POINTER(vp)]
+        L.orc_bench_search.argtypes = [vp, vp, vp, ctypes.c_uint32, ctypes.c_int, ctypes.c_int,
+                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),
+                                       ctypes.POINTER(ctypes.c_uint64), vp]
         L.orc_reader_close.argtypes = [vp]
         L.orc_reader_close.restype = None
         L.orc_reader_num_chunks.argtypes = [vp]
@@ -198,11 +203,54 @@ class OracleWriter:
 
 
 class OracleReader:
-    def __init__(self, index_file_path: str) -> None:
+    def __init__(self, index_file_path: str, load_sa: bool = True) -> None:
+        """load_sa=False leaves the suffix arrays in the file, as the reference does
+        (lib.rs:179-182); such a reader only serves bench_search(disk=True)."""
         self._h = ctypes.c_void_p()
-        rc = lib().orc_reader_open(os.fsencode(index_file_path), ctypes.byref(self._h))
+        self._keep = None
+        rc = lib().orc_reader_open_ex(os.fsencode(index_file_path), 1 if load_sa else 0, ctypes.byref(self._h))
         if rc:
             _raise(rc, index_file_path)
+
+    @classmethod
+    def from_arrays(cls, texts: typing.Sequence[np.ndarray], sas: typing.Sequence[np.ndarray]) -> 'OracleReader':
+        """Reader over in-memory chunks (uint8 text + int32 suffix array each); the arrays
+        are borrowed and kept alive by the reader object."""
+        assert len(texts) == len(sas)
+        texts = [np.ascontiguousarray(t, dtype=np.uint8) for t in texts]
+        sas = [np.ascontiguousarray(s, dtype=np.int32) for s in sas]
+        for t, s in zip(texts, sas):
+            assert t.size == s.size
+        k = len(texts)
+        tp = (ctypes.c_void_p * max(k, 1))(*[t.ctypes.data for t in texts])
+        sp = (ctypes.c_void_p * max(k, 1))(*[s.ctypes.data for s in sas])
+        ln = (ctypes.c_uint64 * max(k, 1))(*[t.size for t in texts])
+        r = cls.__new__(cls)
+        r._h = ctypes.c_void_p()
+        r._keep = (texts, sas)
+        rc = lib().orc_reader_from_arrays(k, tp, ln, sp, ctypes.byref(r._h))
+        if rc:
+            _raise(rc, 'from_arrays')
+        return r
+
+    def bench_search(self, patterns: typing.Sequence[bytes], threads: int, disk: bool = False) -> dict:
+        """The reference-shaped CPU baseline: queries one at a time, each
+        fanned out over the chunks on `threads` workers (lib.rs:207), suffix array probed in
+        RAM or -- disk=True -- in the index file with lseek + read(8 KiB) per probe
+        (lib.rs:216-217).  Returns seconds, entries, bytes and the per-query counts."""
+        blob = b''.join(patterns)
+        off = np.zeros(len(patterns) + 1, dtype=np.uint64)
+        if patterns:
+            off[1:] = np.cumsum([len(p) for p in patterns], dtype=np.uint64)
+        buf = np.frombuffer(blob + b'\0', dtype=np.uint8)
+        counts = np.zeros(max(len(patterns), 1), dtype=np.uint64)
+        sec, ent, byt = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
+        rc = lib().orc_bench_search(self._h, buf.ctypes.data, off.ctypes.data, len(patterns), threads, 1 if disk else 0,
+                                    ctypes.byref(sec), ctypes.byref(ent), ctypes.byref(byt), counts.ctypes.data)
+        if rc:
+            _raise(rc, 'bench_search')
+        return {'seconds': sec.value, 'entries': ent.value, 'bytes': byt.value, 'counts': counts[:len(patterns)],
+                'threads': min(threads, max(self.num_chunks, 1)), 'disk': bool(disk)}
 
     @property
     def num_chunks(self) -> int:
@@ -262,6 +310,7 @@ class OracleReader:
         if self._h:
             lib().orc_reader_close(self._h)
             self._h = ctypes.c_void_p()
+        self._keep = None
 
     def __del__(self):
         try:

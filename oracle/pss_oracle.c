@@ -17,6 +17,10 @@
  *   - Reader::search               src/lib.rs:201-287   (two binary searches,
  *                                   newline scan, per-chunk dedupe on line start)
  *   - Reader.search_multiple       pysubstringsearch/__init__.py:61-73
+ *   - the chunk fan-out of Reader::search (rayon par_iter_mut + Mutex<Vec>, src/lib.rs:205-207,
+ *     280-284) and its on-disk suffix-array probes (BufReader seek + read_i32,
+ *     src/lib.rs:216-217, 238-239, 257-260): orc_bench_search, the CPU baseline that
+ *     bench.py times beside the GPU path
  *
  * Parity pinning: the suffix-array routine here is an independent O(n log n)
  * prefix-doubling sort (NOT libsais); it is checked byte-for-byte against the
@@ -27,11 +31,17 @@
  * (file ingest CR/LF rule, Vec growth quirk, multi-chunk) is labelled
  * "parity unpinned" where it is restated below.
  */
+#define _GNU_SOURCE   /* memrchr */
 #include <errno.h>
+#include <fcntl.h>
+#include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
 
 #define ORC_OK 0
 #define ORC_EINVAL (-1)
@@ -299,14 +309,39 @@ typedef struct orc_chunk {
     uint8_t *data;     /* SubIndex.data, lib.rs:147 */
     size_t dlen;
     int32_t *sa;       /* the reference leaves this on disk (lib.rs:179-182);
-                          values are identical, only the access path differs */
+                          values are identical, only the access path differs.
+                          NULL when the reader was opened with load_sa == 0: then
+                          every probe goes to the file like the reference's */
     size_t n_sa;
+    uint64_t sa_file_off;  /* suffixes_file_start, lib.rs:180 (0 for in-memory readers) */
+    int borrowed;          /* data / sa belong to the caller (orc_reader_from_arrays) */
 } orc_chunk;
 
 typedef struct orc_reader {
     orc_chunk *chunks;
     size_t n_chunks;
+    char *path;            /* index file (NULL for in-memory readers) */
 } orc_reader;
+
+/* How one search reads the suffix array: from RAM (fd < 0), or like the reference --
+ * BufReader<File> per chunk (lib.rs:189), `seek` + `read_i32` per probe (lib.rs:216-217,
+ * 238-239).  BufReader::seek discards the buffer and calls lseek; the 4-byte read that
+ * follows refills the 8 KiB buffer with one read(2): two system calls per probe. */
+typedef struct orc_sa_src {
+    int fd;
+    uint8_t buf[8192];
+} orc_sa_src;
+
+static int sa_probe(const orc_chunk *ch, orc_sa_src *src, int64_t idx, int32_t *out)
+{
+    if (src == NULL || src->fd < 0) { *out = ch->sa[idx]; return ORC_OK; }
+    if (lseek(src->fd, (off_t)(ch->sa_file_off + (uint64_t)idx * 4), SEEK_SET) < 0) return ORC_EIO;
+    ssize_t got = read(src->fd, src->buf, sizeof src->buf);
+    if (got < 4) return ORC_EIO;
+    *out = (int32_t)((uint32_t)src->buf[0] | (uint32_t)src->buf[1] << 8 | (uint32_t)src->buf[2] << 16 |
+                     (uint32_t)src->buf[3] << 24);
+    return ORC_OK;
+}
 
 typedef struct orc_result {
     uint8_t *bytes;      /* concatenated entries */
@@ -323,13 +358,17 @@ static uint32_t get_u32le(const uint8_t *p)
 void orc_reader_close(orc_reader *r)
 {
     if (!r) return;
-    for (size_t i = 0; i < r->n_chunks; i++) { free(r->chunks[i].data); free(r->chunks[i].sa); }
+    for (size_t i = 0; i < r->n_chunks; i++)
+        if (!r->chunks[i].borrowed) { free(r->chunks[i].data); free(r->chunks[i].sa); }
     free(r->chunks);
+    free(r->path);
     free(r);
 }
 
-/* lib.rs:162-199; truncated file -> UnexpectedEof -> OSError */
-int orc_reader_open(const char *path, orc_reader **out)
+/* lib.rs:162-199; truncated file -> UnexpectedEof -> OSError.  load_sa == 0 leaves the
+ * suffix arrays on disk exactly as the reference does (lib.rs:179-182: only their byte
+ * range is recorded); searches must then go through orc_bench_search(disk = 1). */
+int orc_reader_open_ex(const char *path, int load_sa, orc_reader **out)
 {
     FILE *fp = fopen(path, "rb");
     if (!fp) return ORC_EIO;
@@ -338,6 +377,7 @@ int orc_reader_open(const char *path, orc_reader **out)
     fseeko(fp, 0, SEEK_SET);
     orc_reader *r = (orc_reader *)calloc(1, sizeof *r);
     if (!r) { fclose(fp); return ORC_ENOMEM; }
+    r->path = strdup(path);
     uint64_t bytes_read = 0;
     int rc = ORC_OK;
     while (bytes_read < flen) {
@@ -352,11 +392,18 @@ int orc_reader_open(const char *path, orc_reader **out)
         ch.dlen = dlen;
         if (fread(hdr, 1, 4, fp) != 4) { free(ch.data); rc = ORC_EIO; errno = EIO; break; }
         uint32_t slen = get_u32le(hdr);
-        ch.sa = (int32_t *)malloc(slen ? slen : 4);
-        if (!ch.sa) { free(ch.data); rc = ORC_ENOMEM; break; }
-        /* the reference only seeks past the SA (lib.rs:182); a short file is
-         * detected there lazily.  We read it, and report short files here. */
-        if (fread(ch.sa, 1, slen, fp) != slen) { free(ch.data); free(ch.sa); rc = ORC_EIO; errno = EIO; break; }
+        ch.sa_file_off = bytes_read + 8 + (uint64_t)dlen;
+        if (load_sa) {
+            ch.sa = (int32_t *)malloc(slen ? slen : 4);
+            if (!ch.sa) { free(ch.data); rc = ORC_ENOMEM; break; }
+            /* the reference only seeks past the SA (lib.rs:182); a short file is
+             * detected there lazily.  We read it, and report short files here. */
+            if (fread(ch.sa, 1, slen, fp) != slen) { free(ch.data); free(ch.sa); rc = ORC_EIO; errno = EIO; break; }
+        } else {
+            if (ch.sa_file_off + slen > flen || fseeko(fp, (off_t)slen, SEEK_CUR) != 0) {
+                free(ch.data); rc = ORC_EIO; errno = EIO; break;
+            }
+        }
         ch.n_sa = slen / 4;
         bytes_read += 8 + (uint64_t)dlen + slen;
         orc_chunk *nc = (orc_chunk *)realloc(r->chunks, (r->n_chunks + 1) * sizeof(orc_chunk));
@@ -366,6 +413,30 @@ int orc_reader_open(const char *path, orc_reader **out)
     }
     fclose(fp);
     if (rc) { orc_reader_close(r); return rc; }
+    *out = r;
+    return ORC_OK;
+}
+
+int orc_reader_open(const char *path, orc_reader **out) { return orc_reader_open_ex(path, 1, out); }
+
+/* A reader over chunks that already sit in memory (text + suffix array per chunk, both
+ * BORROWED: the caller keeps them alive).  Lets the full-size parity tests check the HIP
+ * search against this restatement without writing a 40 GB index file first. */
+int orc_reader_from_arrays(size_t n_chunks, const uint8_t *const *data, const uint64_t *dlen,
+                           const int32_t *const *sa, orc_reader **out)
+{
+    orc_reader *r = (orc_reader *)calloc(1, sizeof *r);
+    if (!r) return ORC_ENOMEM;
+    r->chunks = (orc_chunk *)calloc(n_chunks ? n_chunks : 1, sizeof(orc_chunk));
+    if (!r->chunks) { free(r); return ORC_ENOMEM; }
+    for (size_t i = 0; i < n_chunks; i++) {
+        r->chunks[i].data = (uint8_t *)data[i];
+        r->chunks[i].dlen = (size_t)dlen[i];
+        r->chunks[i].sa = (int32_t *)sa[i];
+        r->chunks[i].n_sa = (size_t)dlen[i];
+        r->chunks[i].borrowed = 1;
+    }
+    r->n_chunks = n_chunks;
     *out = r;
     return ORC_OK;
 }
@@ -414,14 +485,16 @@ static int u64_cmp(const void *a, const void *b)
 /* lib.rs:209-278 for one chunk.  Offsets below are SA *element* indices; the
  * reference works on byte offsets = 4*index + file start, with the same
  * midpoint: left + ((right-left)/4/2*4)  ==  4*(l + (r-l)/2). */
-static int search_chunk(const orc_chunk *ch, const uint8_t *pat, size_t plen, orc_result *res)
+static int search_chunk_src(const orc_chunk *ch, orc_sa_src *src, const uint8_t *pat, size_t plen, orc_result *res)
 {
     if (ch->n_sa == 0) return ORC_OK;
+    int32_t probe = 0;
     int64_t left = 0, right = (int64_t)ch->n_sa - 1;
     int64_t start = -1, end = -1;
     while (left <= right) {                                   /* lib.rs:212-230 */
         int64_t mid = left + (right - left) / 2;
-        size_t di = (size_t)ch->sa[mid];
+        if (sa_probe(ch, src, mid, &probe)) return ORC_EIO;
+        size_t di = (size_t)probe;
         const uint8_t *line = ch->data + di;
         size_t ll = ch->dlen - di;
         if (ll >= plen && memcmp(line, pat, plen) == 0) { start = mid; right = mid - 1; }
@@ -434,7 +507,8 @@ static int search_chunk(const orc_chunk *ch, const uint8_t *pat, size_t plen, or
     right = (int64_t)ch->n_sa - 1;                            /* lib.rs:235 */
     while (left <= right) {                                   /* lib.rs:236-252 */
         int64_t mid = left + (right - left) / 2;
-        size_t di = (size_t)ch->sa[mid];
+        if (sa_probe(ch, src, mid, &probe)) return ORC_EIO;
+        size_t di = (size_t)probe;
         const uint8_t *line = ch->data + di;
         size_t ll = ch->dlen - di;
         if (ll >= plen && memcmp(line, pat, plen) == 0) { end = mid; left = mid + 1; }
@@ -447,20 +521,33 @@ static int search_chunk(const orc_chunk *ch, const uint8_t *pat, size_t plen, or
      * first hit.  A set is order-free; we keep first-hit order with a sorted
      * scratch list of seen line starts (results compared as multisets). */
     size_t nh = (size_t)(end - start + 1);
+    const int32_t *hits = ch->sa ? ch->sa + start : NULL;
+    int32_t *hits_read = NULL;
+    if (src != NULL && src->fd >= 0) {                        /* lib.rs:255-260: one seek + read_exact */
+        hits_read = (int32_t *)malloc(nh * sizeof(int32_t));
+        if (!hits_read) return ORC_ENOMEM;
+        if (pread(src->fd, hits_read, nh * 4, (off_t)(ch->sa_file_off + (uint64_t)start * 4)) != (ssize_t)(nh * 4)) {
+            free(hits_read);
+            return ORC_EIO;
+        }
+        hits = hits_read;                                      /* host is little-endian, like the file */
+    }
     uint64_t *seen = (uint64_t *)malloc(nh * sizeof(uint64_t));
     uint64_t *order = (uint64_t *)malloc(nh * 2 * sizeof(uint64_t));
-    if (!seen || !order) { free(seen); free(order); return ORC_ENOMEM; }
+    if (!seen || !order) { free(seen); free(order); free(hits_read); return ORC_ENOMEM; }
     for (size_t k = 0; k < nh; k++) {
-        size_t di = (size_t)ch->sa[start + (int64_t)k];
+        size_t di = (size_t)hits[k];
         const uint8_t *nl = (const uint8_t *)memchr(ch->data + di, '\n', ch->dlen - di);
         size_t line_head = nl ? (size_t)(nl - ch->data) : ch->dlen - 1;   /* lib.rs:266-269 */
         size_t line_tail = 0;                                              /* lib.rs:270-273 */
-        for (size_t p = di; p > 0; p--) if (ch->data[p - 1] == '\n') { line_tail = p; break; }
+        const uint8_t *pnl = di ? (const uint8_t *)memrchr(ch->data, '\n', di) : NULL;
+        if (pnl) line_tail = (size_t)(pnl - ch->data) + 1;
         seen[k] = (uint64_t)line_tail;
         order[2 * k] = (uint64_t)line_tail;
         order[2 * k + 1] = (uint64_t)line_head;
     }
     /* first-occurrence filter: sort a copy, then mark */
+    free(hits_read);
     uint64_t *sorted = (uint64_t *)malloc(nh * sizeof(uint64_t));
     if (!sorted) { free(seen); free(order); return ORC_ENOMEM; }
     memcpy(sorted, seen, nh * sizeof(uint64_t));
@@ -479,6 +566,12 @@ static int search_chunk(const orc_chunk *ch, const uint8_t *pat, size_t plen, or
     }
     free(used); free(sorted); free(seen); free(order);
     return rc;
+}
+
+static int search_chunk(const orc_chunk *ch, const uint8_t *pat, size_t plen, orc_result *res)
+{
+    if (ch->sa == NULL && ch->n_sa) return ORC_EINVAL;       /* opened with load_sa == 0 */
+    return search_chunk_src(ch, NULL, pat, plen, res);
 }
 
 /* Reader::search over all chunks (lib.rs:201-287; inter-chunk order is
@@ -512,6 +605,149 @@ int orc_reader_search_multiple(const orc_reader *r, const uint8_t *qbytes, const
     }
     *out = res;
     return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Reference-shaped CPU baseline for multi-chunk search.    */
+/* Reader::search fans one query out over the chunks with rayon              */
+/* (`par_iter_mut`, lib.rs:207: one task per chunk on the global pool), every */
+/* task extends a Mutex<Vec> with its local results (lib.rs:280), and         */
+/* search_multiple is a Python loop over single queries (__init__.py:61-73).  */
+/* Restated: a pool of min(nthreads, chunks) workers, queries ONE AT A TIME,  */
+/* worker t takes chunks t, t + T, ...; results appended under one mutex; the */
+/* caller waits for all workers before the next query.  disk = 1: the suffix  */
+/* array is probed in the index file (lseek + read(8 KiB) per probe, one file */
+/* descriptor per chunk like lib.rs:189), else in RAM (kinder than the        */
+/* reference).  Workers spin between queries (cheaper hand-off than rayon's   */
+/* sleeping workers: this baseline errs on the fast side).                    */
+/* ------------------------------------------------------------------------ */
+typedef struct orc_pool {
+    const orc_reader *r;
+    int nthreads, disk;
+    volatile uint64_t gen;          /* bumped by the caller to start a query */
+    volatile int stop;
+    volatile uint32_t done;         /* workers finished with the current query */
+    const uint8_t *pat;
+    size_t plen;
+    orc_result *shared;
+    pthread_mutex_t mu;
+    volatile int rc;
+} orc_pool;
+
+typedef struct orc_worker {
+    orc_pool *pool;
+    int t;
+    orc_sa_src *src;                /* one per chunk this worker owns (disk mode) */
+} orc_worker;
+
+static void *pool_worker(void *arg)
+{
+    orc_worker *w = (orc_worker *)arg;
+    orc_pool *p = w->pool;
+    uint64_t seen = 0;
+    for (;;) {
+        unsigned spins = 0;
+        while (__atomic_load_n(&p->gen, __ATOMIC_ACQUIRE) == seen && !__atomic_load_n(&p->stop, __ATOMIC_ACQUIRE)) {
+            if (++spins > 20000) { sched_yield(); spins = 0; }
+            else __builtin_ia32_pause();
+        }
+        if (__atomic_load_n(&p->stop, __ATOMIC_ACQUIRE)) return NULL;
+        seen = __atomic_load_n(&p->gen, __ATOMIC_ACQUIRE);
+        size_t k = 0;
+        for (size_t c = (size_t)w->t; c < p->r->n_chunks; c += (size_t)p->nthreads, k++) {
+            orc_result local;
+            memset(&local, 0, sizeof local);
+            int rc = search_chunk_src(&p->r->chunks[c], p->disk ? &w->src[k] : NULL, p->pat, p->plen, &local);
+            if (rc == ORC_OK && local.n_entries) {             /* results.lock().extend(local_results) */
+                pthread_mutex_lock(&p->mu);
+                for (size_t e = 0; e < local.n_entries && rc == ORC_OK; e++)
+                    rc = res_push(p->shared, local.bytes + local.offsets[e], (size_t)(local.offsets[e + 1] - local.offsets[e]));
+                pthread_mutex_unlock(&p->mu);
+            }
+            free(local.bytes);
+            free(local.offsets);
+            if (rc) p->rc = rc;
+        }
+        __atomic_add_fetch(&p->done, 1, __ATOMIC_ACQ_REL);
+    }
+}
+
+/* Runs the nq queries one at a time through the pool; *seconds = wall time of the loop
+ * (pool start-up and file opens excluded), *entries / *bytes = totals over all queries,
+ * counts[q] (optional) = entries of query q. */
+int orc_bench_search(const orc_reader *r, const uint8_t *qbytes, const uint64_t *qoff, uint32_t nq, int nthreads,
+                     int disk, double *seconds, uint64_t *entries, uint64_t *bytes, uint64_t *counts)
+{
+    if (nthreads < 1) nthreads = 1;
+    if ((size_t)nthreads > r->n_chunks) nthreads = (int)(r->n_chunks ? r->n_chunks : 1);
+    if (disk && r->path == NULL) return ORC_EINVAL;
+    for (size_t c = 0; !disk && c < r->n_chunks; c++)
+        if (r->chunks[c].sa == NULL && r->chunks[c].n_sa) return ORC_EINVAL;
+    orc_pool pool;
+    memset(&pool, 0, sizeof pool);
+    pool.r = r;
+    pool.nthreads = nthreads;
+    pool.disk = disk;
+    pthread_mutex_init(&pool.mu, NULL);
+    orc_worker *ws = (orc_worker *)calloc((size_t)nthreads, sizeof *ws);
+    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof *th);
+    int rc = (ws && th) ? ORC_OK : ORC_ENOMEM;
+    for (int t = 0; t < nthreads && rc == ORC_OK; t++) {
+        ws[t].pool = &pool;
+        ws[t].t = t;
+        size_t mine = (r->n_chunks + (size_t)nthreads - 1 - (size_t)t) / (size_t)nthreads;
+        ws[t].src = (orc_sa_src *)calloc(mine ? mine : 1, sizeof(orc_sa_src));
+        if (!ws[t].src) { rc = ORC_ENOMEM; break; }
+        for (size_t k = 0; k < mine; k++) {
+            ws[t].src[k].fd = -1;
+            if (disk) {
+                ws[t].src[k].fd = open(r->path, O_RDONLY);     /* File::open per chunk, lib.rs:189 */
+                if (ws[t].src[k].fd < 0) rc = ORC_EIO;
+            }
+        }
+    }
+    int started = 0;
+    for (; started < nthreads && rc == ORC_OK; started++)
+        if (pthread_create(&th[started], NULL, pool_worker, &ws[started]) != 0) { rc = ORC_ENOMEM; break; }
+    uint64_t tot_e = 0, tot_b = 0;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint32_t q = 0; q < nq && rc == ORC_OK && started == nthreads; q++) {
+        orc_result shared;
+        memset(&shared, 0, sizeof shared);
+        pool.shared = &shared;
+        pool.pat = qbytes + qoff[q];
+        pool.plen = (size_t)(qoff[q + 1] - qoff[q]);
+        __atomic_store_n(&pool.done, 0, __ATOMIC_RELEASE);
+        __atomic_add_fetch(&pool.gen, 1, __ATOMIC_ACQ_REL);
+        unsigned spins = 0;
+        while (__atomic_load_n(&pool.done, __ATOMIC_ACQUIRE) < (uint32_t)nthreads) {
+            if (++spins > 20000) { sched_yield(); spins = 0; }
+            else __builtin_ia32_pause();
+        }
+        tot_e += shared.n_entries;                             /* results.lock().to_vec() */
+        tot_b += shared.bytes_len;
+        if (counts) counts[q] = shared.n_entries;
+        free(shared.bytes);
+        free(shared.offsets);
+        if (pool.rc) rc = pool.rc;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    __atomic_store_n(&pool.stop, 1, __ATOMIC_RELEASE);
+    for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+    for (int t = 0; ws && t < nthreads; t++) {
+        size_t mine = (r->n_chunks + (size_t)nthreads - 1 - (size_t)t) / (size_t)nthreads;
+        for (size_t k = 0; ws[t].src && k < mine; k++)
+            if (ws[t].src[k].fd >= 0) close(ws[t].src[k].fd);
+        free(ws[t].src);
+    }
+    free(ws);
+    free(th);
+    pthread_mutex_destroy(&pool.mu);
+    if (seconds) *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    if (entries) *entries = tot_e;
+    if (bytes) *bytes = tot_b;
+    return rc;
 }
 
 size_t orc_result_count(const orc_result *res) { return res->n_entries; }

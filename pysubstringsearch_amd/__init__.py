@@ -26,7 +26,7 @@ try:   # C loop for result lists (csrc/pyglue.c); plain Python slicing if it was
 except ImportError:   # pragma: no cover
     _pssglue = None
 
-__all__ = ['Writer', 'Reader', 'PackedResult', 'device_count', 'release_workspace']
+__all__ = ['Writer', 'Reader', 'PackedResult', 'DeviceResult', 'device_count', 'release_workspace']
 
 
 def device_count() -> int:
@@ -156,6 +156,22 @@ class PackedResult(typing.NamedTuple):
     counts: typing.Any    # numpy uint64 [num_queries]
 
 
+class _DevicePtr:
+    """A raw HBM range as an object torch.as_tensor understands (CUDA array interface)."""
+
+    def __init__(self, ptr: int, nbytes: int) -> None:
+        self.__cuda_array_interface__ = {'shape': (nbytes,), 'typestr': '|u1', 'data': (ptr, True), 'version': 2}
+
+
+class DeviceResult(typing.NamedTuple):
+    """Packed result of one batch left in HBM (torch tensors over the engine's workspace: valid until
+    the next search or build on that device -- consume or clone them first)."""
+    data: typing.Any      # torch uint8 [num_bytes]
+    starts: typing.Any    # torch int64 [num_entries]: start of every entry in data
+    counts: typing.Any    # torch int64 [num_queries]
+    num_bytes: int
+
+
 class Reader:
     """Reference: pysubstringsearch/__init__.py:44-73, src/lib.rs:146-288."""
 
@@ -244,14 +260,7 @@ class Reader:
         """Extension (not in the reference API): ``len(search(s))`` for every s, in one batched
         device call that materialises no entry -- only the counters come back."""
         import numpy as np
-        pats = [_utf8(s, 'substring') for s in substrings]
-        nq = len(pats)
-        offs = np.zeros(nq + 1, dtype=np.uint64)
-        if nq:
-            np.cumsum(np.fromiter(map(len, pats), dtype=np.uint64, count=nq), out=offs[1:])
-        counts = np.zeros(max(nq, 1), dtype=np.uint64)
-        _ffi.check(_lib.pss_reader_count_batch(self._handle(), b''.join(pats), offs.ctypes.data, nq, counts.ctypes.data))
-        return [int(c) for c in counts[:nq]]
+        return self.count_multiple_bytes([_utf8(s, 'substring') for s in substrings])
 
     def count(self, substring: str) -> int:
         """Extension: ``len(search(substring))`` without building the entries."""
@@ -278,6 +287,43 @@ class Reader:
         offsets = owner.view(_lib.pss_result_offsets(res), n + 1, np.uint64)
         data = owner.view(_lib.pss_result_bytes(res), int(offsets[n]), np.uint8)
         return PackedResult(data, offsets, counts)
+
+    def search_batch_device(self, patterns: typing.Sequence[bytes]) -> 'DeviceResult':
+        """One batched device call whose packed result STAYS in HBM (torch tensors, no copy): what the
+        multi-GPU gather sends over RCCL (``dist.gather_device``).  Needs torch."""
+        import numpy as np
+        import torch
+        nq = len(patterns)
+        blob = b''.join(patterns)
+        offs = np.zeros(nq + 1, dtype=np.uint64)
+        if nq:
+            np.cumsum(np.fromiter(map(len, patterns), dtype=np.uint64, count=nq), out=offs[1:])
+        dr = _ffi.DeviceResult()
+        _ffi.check(_lib.pss_reader_search_batch_device(self._handle(), blob, offs.ctypes.data, nq, ctypes.byref(dr)))
+        dev = torch.device('cuda', dr.device)
+
+        def wrap(ptr, nbytes, dtype):
+            if not nbytes or not ptr:
+                return torch.empty(0, dtype=dtype, device=dev)
+            return torch.as_tensor(_DevicePtr(ptr, nbytes), device=dev).view(dtype)
+
+        return DeviceResult(wrap(dr.d_bytes, dr.num_bytes, torch.uint8), wrap(dr.d_offsets, dr.num_entries * 8, torch.int64),
+                            wrap(dr.d_counts, nq * 8, torch.int64), int(dr.num_bytes))
+
+    def search_multiple_bytes_as_str(self, patterns: typing.Sequence[bytes]) -> typing.List[str]:
+        """``search_multiple`` for queries that are already UTF-8 bytes."""
+        return self._search_batch(patterns, True)[0]
+
+    def count_multiple_bytes(self, patterns: typing.Sequence[bytes]) -> typing.List[int]:
+        """``count_multiple`` for queries that are already bytes."""
+        import numpy as np
+        nq = len(patterns)
+        offs = np.zeros(nq + 1, dtype=np.uint64)
+        if nq:
+            np.cumsum(np.fromiter(map(len, patterns), dtype=np.uint64, count=nq), out=offs[1:])
+        counts = np.zeros(max(nq, 1), dtype=np.uint64)
+        _ffi.check(_lib.pss_reader_count_batch(self._handle(), b''.join(patterns), offs.ctypes.data, nq, counts.ctypes.data))
+        return [int(c) for c in counts[:nq]]
 
     def search_batch_raw(self, patterns: typing.Sequence[bytes]):
         """One batched device call.  Returns (entries, per_query_counts): the

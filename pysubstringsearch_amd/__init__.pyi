@@ -34,6 +34,13 @@ class PackedResult(typing.NamedTuple):
     counts: typing.Any    # numpy uint64 array [num_queries]
 
 
+class DeviceResult(typing.NamedTuple):
+    data: typing.Any      # torch uint8 tensor in HBM: all entries back to back
+    starts: typing.Any    # torch int64 tensor [num_entries]: start of every entry
+    counts: typing.Any    # torch int64 tensor [num_queries]
+    num_bytes: int
+
+
 class Reader:
     reader: 'Reader'
 
@@ -65,6 +72,12 @@ class Reader:
 
     def search_batch_packed(self, patterns: typing.Sequence[bytes]) -> PackedResult: ...
 
+    def search_batch_device(self, patterns: typing.Sequence[bytes]) -> DeviceResult: ...
+
+    def search_multiple_bytes_as_str(self, patterns: typing.Sequence[bytes]) -> typing.List[str]: ...
+
+    def count_multiple_bytes(self, patterns: typing.Sequence[bytes]) -> typing.List[int]: ...
+
     def last_stats(self) -> typing.Dict[str, float]: ...
 
     def close(self) -> None: ...
@@ -75,3 +88,6 @@ class Reader:
 
 
 def device_count() -> int: ...
+
+
+def release_workspace() -> None: ...

@@ -64,6 +64,19 @@ class SearchStats(ctypes.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class DeviceResult(ctypes.Structure):
+    """pss_device_result (include/pss.h): packed result of one batch left in HBM."""
+    _fields_ = [
+        ('num_queries', ctypes.c_uint64),
+        ('num_entries', ctypes.c_uint64),
+        ('num_bytes', ctypes.c_uint64),
+        ('d_counts', ctypes.c_void_p),
+        ('d_offsets', ctypes.c_void_p),
+        ('d_bytes', ctypes.c_void_p),
+        ('device', ctypes.c_int32),
+    ]
+
+
 def _preload_hip_runtime() -> None:
     """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own
     libamdhip64.so (SONAME libamdhip64.so.7) and libhsa-runtime64.so; if libpss
@@ -120,6 +133,9 @@ def _load() -> ctypes.CDLL:
         'pss_reader_residency': (ctypes.c_int, [vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64)]),
         'pss_reader_search_batch': (ctypes.c_int, [vp, vp, vp, u32, pvp]),
         'pss_reader_count_batch': (ctypes.c_int, [vp, vp, vp, u32, vp]),
+        'pss_reader_search_batch_device': (ctypes.c_int, [vp, vp, vp, u32, ctypes.POINTER(DeviceResult)]),
+        'pss_merge_packed': (ctypes.c_int, [u32, u64, vp, vp, vp, vp, vp, vp, vp, vp]),
+        'pss_reload_env': (ctypes.c_int, []),
         'pss_reader_last_stats': (ctypes.c_int, [vp, ctypes.POINTER(SearchStats)]),
         'pss_reader_close': (ctypes.c_int, [vp]),
         'pss_result_num_queries': (u64, [vp]),

@@ -1050,13 +1050,86 @@ extern "C" int pss_reader_count_batch(pss_reader *r, const uint8_t *qbytes, cons
         const uint32_t nc = (uint32_t)r->chunks.size();
         PSS_TRY(reader_sync_descs(r));
         pss_result res;
-        const int rc = search_batch_device(r->ctx, r->d_descs, nc, qbytes, qoffsets, nq, &res.r, &r->last, true);
+        const int rc = search_batch_device(r->ctx, r->d_descs, nc, qbytes, qoffsets, nq, &res.r, &r->last, SEARCH_COUNTS);
         if (rc == PSS_OK && nq) memcpy(counts, res.r.qcount, (size_t)nq * sizeof(uint64_t));
-        free(res.r.qcount);
-        free(res.r.offsets);
-        free(res.r.bytes);
+        res.r.release();
         return rc;
     });
+}
+
+extern "C" int pss_reader_search_batch_device(pss_reader *r, const uint8_t *qbytes, const uint64_t *qoffsets, uint32_t nq,
+                                              pss_device_result *out)
+{
+    return guarded([&]() -> int {
+        if (!r || !out || (nq && !qoffsets)) {
+            set_error("pss_reader_search_batch_device: bad arguments");
+            return PSS_EINVAL;
+        }
+        std::lock_guard<std::recursive_mutex> lk(r->ctx->mu);
+        PSS_HIP(hipSetDevice(r->device));
+        const uint32_t nc = (uint32_t)r->chunks.size();
+        PSS_TRY(reader_sync_descs(r));
+        HostResult hr;
+        const int rc = search_batch_device(r->ctx, r->d_descs, nc, qbytes, qoffsets, nq, &hr, &r->last, SEARCH_DEVICE);
+        if (rc == PSS_OK) {
+            out->num_queries = nq;
+            out->num_entries = hr.n_entries;
+            out->num_bytes = hr.n_bytes;
+            out->d_counts = hr.d_qcount;
+            out->d_offsets = hr.d_offsets;
+            out->d_bytes = hr.d_bytes;
+            out->device = r->device;
+        }
+        hr.release();
+        return rc;
+    });
+}
+
+// Host merge of per-rank packed results into one, query-major (reference: every chunk task extends one
+// Mutex<Vec>, src/lib.rs:280-284; here the ranks' results are concatenated per query, rank-major inside
+// a query).  One memcpy per (query, rank) segment -- a rank's entries of one query are contiguous.
+extern "C" int pss_merge_packed(uint32_t world, uint64_t nq, const uint64_t *const *counts, const uint64_t *const *offsets,
+                                const uint8_t *const *bytes, const uint64_t *num_entries, const uint64_t *num_bytes,
+                                uint64_t *out_counts, uint64_t *out_offsets, uint8_t *out_bytes)
+{
+    return guarded([&]() -> int {
+        if (!world || !counts || !offsets || !bytes || !num_entries || !num_bytes || !out_counts || !out_offsets) {
+            set_error("pss_merge_packed: bad arguments");
+            return PSS_EINVAL;
+        }
+        std::vector<uint64_t> cursor(world, 0);      // next entry of each rank
+        uint64_t e_out = 0, b_out = 0;
+        for (uint64_t q = 0; q < nq; ++q) {
+            uint64_t tot = 0;
+            for (uint32_t r = 0; r < world; ++r) {
+                const uint64_t k = counts[r][q];
+                if (!k) continue;
+                const uint64_t e0 = cursor[r], e1 = e0 + k;
+                if (e1 > num_entries[r]) {
+                    set_error("pss_merge_packed: rank %u counts exceed its %llu entries", r, (unsigned long long)num_entries[r]);
+                    return PSS_EINVAL;
+                }
+                const uint64_t b0 = offsets[r][e0];
+                const uint64_t b1 = e1 < num_entries[r] ? offsets[r][e1] : num_bytes[r];
+                for (uint64_t e = e0; e < e1; ++e) out_offsets[e_out++] = b_out + (offsets[r][e] - b0);
+                if (b1 > b0) memcpy(out_bytes + b_out, bytes[r] + b0, (size_t)(b1 - b0));
+                b_out += b1 - b0;
+                cursor[r] = e1;
+                tot += k;
+            }
+            out_counts[q] = tot;
+        }
+        out_offsets[e_out] = b_out;
+        return PSS_OK;
+    });
+}
+
+// Test hook: re-reads the PSS_* environment switches of the search path (they are read once, when the
+// library first needs them -- not on every call).
+extern "C" int pss_reload_env(void)
+{
+    reload_search_knobs();
+    return PSS_OK;
 }
 
 extern "C" int pss_reader_last_stats(const pss_reader *r, pss_search_stats *stats)
@@ -1082,8 +1155,6 @@ extern "C" const uint8_t *pss_result_bytes(const pss_result *res) { return res ?
 extern "C" void pss_result_free(pss_result *res)
 {
     if (!res) return;
-    free(res->r.qcount);
-    free(res->r.offsets);
-    free(res->r.bytes);
+    res->r.release();
     delete res;
 }

@@ -2,6 +2,7 @@
 #include "common.h"
 
 #include <mutex>
+#include <vector>
 
 namespace pss {
 
@@ -64,6 +65,94 @@ int DeviceCtx::ensure_search_stage()
     return PSS_OK;
 }
 
+void SearchKnobs::load()
+{
+    *this = SearchKnobs{};
+    no_small_path = getenv("PSS_NO_SMALL_PATH") != nullptr;
+    no_block_path = getenv("PSS_NO_BLOCK_PATH") != nullptr;
+    no_search_stage = getenv("PSS_NO_SEARCH_STAGE") != nullptr;
+    wave_search = getenv("PSS_WAVE_SEARCH") != nullptr;
+    no_group_search = getenv("PSS_NO_GROUP_SEARCH") != nullptr;
+    no_mid_pipeline = getenv("PSS_NO_MID_PIPELINE") != nullptr;
+    no_pinned_results = getenv("PSS_NO_PINNED_RESULTS") != nullptr;
+    no_spread = getenv("PSS_NO_SPREAD") != nullptr;
+    if (const char *e = getenv("PSS_LANE_SEARCH_MIN")) lane_search_min = strtoull(e, nullptr, 0);
+}
+
+static SearchKnobs g_knobs;
+static std::once_flag g_knobs_once;
+const SearchKnobs &search_knobs()
+{
+    std::call_once(g_knobs_once, []() { g_knobs.load(); });
+    return g_knobs;
+}
+void reload_search_knobs()
+{
+    (void)search_knobs();
+    g_knobs.load();
+}
+
+// ---- pinned result blocks -------------------------------------------------------------------
+namespace {
+struct PinnedBlock {
+    void *p;
+    size_t bytes;
+};
+std::mutex g_pool_mu;
+std::vector<PinnedBlock> g_pool;            // free blocks
+constexpr size_t kPoolMaxBlocks = 4;
+constexpr size_t kPoolMaxBytes = (size_t)12 << 30;
+}  // namespace
+
+void *pinned_pool_alloc(size_t bytes, size_t *granted)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        int best = -1;
+        for (int i = 0; i < (int)g_pool.size(); ++i)
+            if (g_pool[i].bytes >= bytes && (best < 0 || g_pool[i].bytes < g_pool[best].bytes)) best = i;
+        if (best >= 0 && g_pool[best].bytes <= 2 * bytes + ((size_t)64 << 20)) {
+            PinnedBlock b = g_pool[best];
+            g_pool.erase(g_pool.begin() + best);
+            *granted = b.bytes;
+            return b.p;
+        }
+    }
+    void *p = nullptr;
+    const size_t want = round_up(bytes + bytes / 8, (size_t)2 << 20);   // headroom: the next batch is rarely the same size
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    *granted = want;
+    return p;
+}
+
+void pinned_pool_free(void *p, size_t granted)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        size_t held = 0;
+        for (const auto &b : g_pool) held += b.bytes;
+        if (g_pool.size() < kPoolMaxBlocks && held + granted <= kPoolMaxBytes) {
+            g_pool.push_back({p, granted});
+            return;
+        }
+    }
+    (void)hipHostFree(p);
+}
+
+void pinned_pool_trim()
+{
+    std::vector<PinnedBlock> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        drop.swap(g_pool);
+    }
+    for (auto &b : drop) (void)hipHostFree(b.p);
+}
+
 static constexpr int kMaxDevices = 64;
 static DeviceCtx g_ctx[kMaxDevices];
 static std::mutex g_ctx_mu;
@@ -108,7 +197,11 @@ void trim_all()
         std::lock_guard<std::recursive_mutex> lk2(c.mu);
         (void)hipSetDevice(c.device);
         for (auto &s : c.slot) s.release();
+        // the fused small-batch path keeps its cursors in one of the slots and only zeroes them when the
+        // arena's address changes: a fresh allocation may come back at the old address with garbage in it
+        c.small_hdr_ready = nullptr;
     }
+    pinned_pool_trim();
 }
 
 }  // namespace pss

@@ -42,6 +42,31 @@ struct DevBuf {
     template <typename T> T *as() const { return static_cast<T *>(p); }
 };
 
+// Environment switches of the search path (exploration and tests).  Read ONCE, when the library first
+// touches a device -- a getenv() per search call is measurable on the single-query latency path --
+// and again only when a test calls pss_reload_env().  None of them changes a result.
+struct SearchKnobs {
+    bool no_small_path = false;     // PSS_NO_SMALL_PATH     skip the fused small-batch kernels
+    bool no_block_path = false;     // PSS_NO_BLOCK_PATH     small batches: one wave per pair instead of one workgroup
+    bool no_search_stage = false;   // PSS_NO_SEARCH_STAGE   no pinned staging of queries / results
+    bool wave_search = false;       // PSS_WAVE_SEARCH       interval search: one wave per pair at every batch size
+    bool no_group_search = false;   // PSS_NO_GROUP_SEARCH   never 16 lanes per pair
+    bool no_mid_pipeline = false;   // PSS_NO_MID_PIPELINE   always the general multi-kernel pipeline
+    bool no_pinned_results = false; // PSS_NO_PINNED_RESULTS large results into pageable memory
+    bool no_spread = false;         // PSS_NO_SPREAD         single pairs with many hits stay in one workgroup
+    uint64_t lane_search_min = 8192;   // PSS_LANE_SEARCH_MIN  pairs from which one lane per pair searches
+    void load();
+};
+const SearchKnobs &search_knobs();
+void reload_search_knobs();
+
+// Pinned host blocks for large results (bytes + offsets of one batch): pinning is what makes the D2H
+// copy run at link speed instead of ~10 GB/s through the runtime's bounce buffers, but pinning a
+// gigabyte costs more than copying it, so freed blocks are kept (a few, bounded) and handed out again.
+void *pinned_pool_alloc(size_t bytes, size_t *granted);
+void pinned_pool_free(void *p, size_t granted);
+void pinned_pool_trim();
+
 // One per (process, device): a stream and named workspace slots.
 struct DeviceCtx {
     // Workspace slots, staging buffers and the stream are shared by every handle on the

@@ -1,8 +1,10 @@
 // corpus.cpp -- deterministic synthetic corpora for bench.py and the tests
 // (generator spec: SURVEY.md section 8(d)).  Integer-only xorshift64, so any
 // re-implementation (tests carry a Python one) agrees bit for bit.
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/pss.h"
@@ -23,14 +25,71 @@ struct Xs64 {
 
 constexpr uint64_t kSeed = 88172645463325252ULL;
 
-void gen_lines(uint8_t *out, uint64_t n, uint64_t chunk)
+// xorshift64 is linear over GF(2): one step is a 64 x 64 bit matrix M (col[j] = image of bit j), so the
+// state after k steps is M^k s.  `lines` draws exactly one step per byte, which lets the generator jump
+// to the start of every block and fill the blocks on several threads -- same bytes as the serial loop.
+struct BitMat {
+    uint64_t col[64];
+    uint64_t apply(uint64_t v) const
+    {
+        uint64_t r = 0;
+        for (int j = 0; v; ++j, v >>= 1)
+            if (v & 1u) r ^= col[j];
+        return r;
+    }
+};
+
+BitMat xs64_power(uint64_t k)
+{
+    BitMat result, base;
+    for (int j = 0; j < 64; ++j) {
+        result.col[j] = 1ull << j;
+        Xs64 g{1ull << j};
+        base.col[j] = g.step();
+    }
+    for (; k; k >>= 1) {
+        if (k & 1u) {
+            BitMat t;
+            for (int j = 0; j < 64; ++j) t.col[j] = base.apply(result.col[j]);
+            result = t;
+        }
+        BitMat sq;
+        for (int j = 0; j < 64; ++j) sq.col[j] = base.apply(base.col[j]);
+        base = sq;
+    }
+    return result;
+}
+
+void fill_lines(uint8_t *out, uint64_t count, uint64_t state)
 {
     static const char ALPHA[] = "abcdefghijklmnopqrstuvwxyz0123456789 .";
-    Xs64 g{kSeed + chunk};
-    for (uint64_t i = 0; i < n; ++i) {
+    Xs64 g{state};
+    for (uint64_t i = 0; i < count; ++i) {
         const uint32_t r = g.nx();
         out[i] = (r % 40 == 0) ? '\n' : (uint8_t)ALPHA[(r >> 8) % 38];
     }
+}
+
+void gen_lines(uint8_t *out, uint64_t n, uint64_t chunk)
+{
+    constexpr uint64_t kBlock = 1ull << 20;
+    const uint64_t blocks = (n + kBlock - 1) / kBlock;
+    unsigned nthreads = std::min<uint64_t>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u), blocks);
+    if (blocks < 4 || nthreads < 2) {
+        fill_lines(out, n, kSeed + chunk);
+        return;
+    }
+    const BitMat jump = xs64_power(kBlock);
+    std::vector<uint64_t> start(blocks);
+    start[0] = kSeed + chunk;
+    for (uint64_t b = 1; b < blocks; ++b) start[b] = jump.apply(start[b - 1]);
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nthreads; ++t)
+        pool.emplace_back([&, t]() {
+            for (uint64_t b = t; b < blocks; b += nthreads)
+                fill_lines(out + b * kBlock, std::min(kBlock, n - b * kBlock), start[b]);
+        });
+    for (auto &th : pool) th.join();
 }
 
 void gen_words(uint8_t *out, uint64_t n, uint64_t chunk)

@@ -25,18 +25,33 @@ static inline uint64_t sample_count(uint32_t n, uint32_t shift) { return ((uint6
 int build_key_samples(DeviceCtx *ctx, const uint8_t *d_text, const uint32_t *d_sa, uint32_t n, uint32_t shift,
                       uint64_t *d_skeys);
 
-// Host-side packed result of one batch (malloc'ed; owned by pss_result).
+// Host-side packed result of one batch (owned by pss_result).  Small results are malloc'ed; large
+// ones (offsets + bytes) share ONE pinned block from the pool in common.h, so the D2H copy runs at
+// link speed.  In SEARCH_DEVICE mode nothing but the totals comes down: d_* point into the device
+// context's workspace and stay valid until the next search on that device.
 struct HostResult {
     uint64_t nq = 0;
     uint64_t n_entries = 0;
+    uint64_t n_bytes = 0;
     uint64_t *qcount = nullptr;    // [nq]
     uint64_t *offsets = nullptr;   // [n_entries + 1]
     uint8_t *bytes = nullptr;
+    void *pinned = nullptr;        // when set: offsets and bytes live inside this block
+    size_t pinned_bytes = 0;
+    const uint64_t *d_qcount = nullptr;    // SEARCH_DEVICE: [nq]
+    const uint64_t *d_offsets = nullptr;   //                [n_entries] entry starts
+    const uint8_t *d_bytes = nullptr;      //                [n_bytes]
+    void release();
+};
+
+enum SearchMode {
+    SEARCH_FULL = 0,     // packed result on the host
+    SEARCH_COUNTS = 1,   // res->qcount only (entries each query would return); no entry is materialised
+    SEARCH_DEVICE = 2,   // packed result left on the device (multi-GPU gather over RCCL takes it from there)
 };
 
 int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, uint32_t nc, const uint8_t *qbytes,
                         const uint64_t *qoffsets, uint32_t nq, HostResult *res, pss_search_stats *st,
-                        bool counts_only = false);
-// counts_only: res->qcount only (entries each query would return); no entry is materialised.
+                        SearchMode mode = SEARCH_FULL);
 
 }  // namespace pss

@@ -956,9 +956,44 @@ __global__ __launch_bounds__(256) void query_counts_kernel(u32 nc, u32 nq, const
 
 enum SSlot { Q_BYTES = 10, Q_OFF, Q_LO, Q_CNT, Q_HITOFF, Q_START, Q_LEN, Q_EIDX, Q_BOFF, Q_ENTOFF, Q_OUT, Q_SMALL, Q_QCOUNT, Q_ARENA = 28 };
 
-int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const uint8_t *qbytes,
-                        const uint64_t *qoffsets, uint32_t nq, HostResult *res, pss_search_stats *st, bool counts_only)
+void HostResult::release()
 {
+    free(qcount);
+    if (pinned) {
+        pinned_pool_free(pinned, pinned_bytes);
+    } else {
+        free(offsets);
+        free(bytes);
+    }
+    *this = HostResult{};
+}
+
+// Room for E + 1 offsets and B bytes: one pinned block when the result is large, else malloc.
+static int alloc_result(HostResult *res, u64 E, u64 B, bool allow_pinned)
+{
+    const size_t off_bytes = round_up((size_t)(E + 1) * sizeof(u64), 64);
+    if (allow_pinned && off_bytes + B >= ((size_t)8 << 20)) {
+        size_t granted = 0;
+        void *blk = pinned_pool_alloc(off_bytes + (size_t)B + 64, &granted);
+        if (blk) {
+            res->pinned = blk;
+            res->pinned_bytes = granted;
+            res->offsets = static_cast<u64 *>(blk);
+            res->bytes = static_cast<u8 *>(blk) + off_bytes;
+            return PSS_OK;
+        }
+    }
+    res->offsets = (u64 *)malloc((size_t)(E + 1) * sizeof(u64));
+    res->bytes = (u8 *)malloc(B ? (size_t)B : 1);
+    return (res->offsets && res->bytes) ? PSS_OK : PSS_ENOMEM;
+}
+
+int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const uint8_t *qbytes,
+                        const uint64_t *qoffsets, uint32_t nq, HostResult *res, pss_search_stats *st, SearchMode mode)
+{
+    const bool counts_only = mode == SEARCH_COUNTS;
+    const bool device_only = mode == SEARCH_DEVICE;
+    const SearchKnobs &knobs = search_knobs();
     hipStream_t s = ctx->stream;
     memset(st, 0, sizeof *st);
     st->queries = nq;
@@ -969,6 +1004,15 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
     res->n_entries = 0;
     if (!res->qcount) return PSS_ENOMEM;
     if (nq == 0 || nc == 0) {
+        if (device_only) {        // a rank that owns no chunk still answers: nq zero counters, no entries
+            if (nq) {
+                PSS_TRY(ctx->slot[Q_QCOUNT].reserve((size_t)nq * 8));
+                PSS_HIP(hipMemsetAsync(ctx->slot[Q_QCOUNT].p, 0, (size_t)nq * 8, s));
+                PSS_HIP(hipStreamSynchronize(s));
+                res->d_qcount = ctx->slot[Q_QCOUNT].as<u64>();
+            }
+            return PSS_OK;
+        }
         res->offsets = (u64 *)calloc(1, sizeof(u64));
         return res->offsets ? PSS_OK : PSS_ENOMEM;
     }
@@ -1002,7 +1046,7 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
         memset(stg + qtotal, 0, 32);
         memcpy(stg + 8192, qoffsets, off_bytes);
     }
-    bool small = tiny && nvq <= SM_MAX_VQ && !counts_only && !getenv("PSS_NO_SMALL_PATH");
+    bool small = tiny && nvq <= SM_MAX_VQ && !counts_only && !device_only && !knobs.no_small_path;
     for (u32 i = 0; small && i < nq; ++i) small = qoffsets[i + 1] - qoffsets[i] <= SM_MAX_PLEN;
     const u64 waves_per_block = 256 / kWave;
     if (small) {
@@ -1025,7 +1069,7 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
         u32 *v_flags = reinterpret_cast<u32 *>(v_arena + SM_OFF_FLAGS);
         SmallRecord *v_rec = reinterpret_cast<SmallRecord *>(v_arena + SM_OFF_REC);
         SmallEntry *v_ent = reinterpret_cast<SmallEntry *>(v_arena + SM_OFF_ENT);
-        if (nvq <= SM_BLOCK_MAX_VQ && !getenv("PSS_NO_BLOCK_PATH"))
+        if (nvq <= SM_BLOCK_MAX_VQ && !knobs.no_block_path)
             hipLaunchKernelGGL(search_block_kernel, dim3((u32)nvq), dim3(SM_BLOCK), 0, s, d_chunks, nc, v_q, v_qoff,
                                (u32)nvq, d_hdr, v_flags, v_rec, v_ent, d_bytes, v_arena + SM_OFF_BYTES);
         else
@@ -1051,9 +1095,7 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
                 PSS_HIP(hipStreamSynchronize(s));
                 h_bytes = h_more.data();
             }
-            res->offsets = (u64 *)malloc(((size_t)E + 1) * sizeof(u64));
-            res->bytes = (u8 *)malloc(B ? B : 1);
-            if (!res->offsets || !res->bytes) return PSS_ENOMEM;
+            PSS_TRY(alloc_result(res, E, B, false));
             u64 e_out = 0, b_out = 0;
             for (u64 vq = 0; vq < nvq; ++vq) {               // pairs in (query, chunk) order
                 const SmallRecord r = h_rec[vq];
@@ -1067,6 +1109,7 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
             }
             res->offsets[e_out] = b_out;
             res->n_entries = e_out;
+            res->n_bytes = b_out;
             st->entries = e_out;
             st->result_bytes = b_out;
             st->hits = e_out;   // hits before dedupe are not counted on this path
@@ -1083,7 +1126,7 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
         // pageable H2D copies are synchronous and slow to start: tiny batches go up from the pinned staging
         PSS_HIP(hipMemcpyAsync(d_q, stg, qtotal + 32, hipMemcpyHostToDevice, s));
         PSS_HIP(hipMemcpyAsync(d_qoff, stg + 8192, off_bytes, hipMemcpyHostToDevice, s));
-    } else if (qtotal + 32 + off_bytes + 64 <= DeviceCtx::kStageQ && !getenv("PSS_NO_SEARCH_STAGE")) {
+    } else if (qtotal + 32 + off_bytes + 64 <= DeviceCtx::kStageQ && !knobs.no_search_stage) {
         // mid-size batch: the same through the larger pinned staging
         PSS_TRY(ctx->ensure_search_stage());
         u8 *sq = static_cast<u8 *>(ctx->search_stage);
@@ -1099,20 +1142,19 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
         PSS_HIP(hipMemcpyAsync(d_qoff, qoffsets, off_bytes, hipMemcpyHostToDevice, s));
     }
     PSS_HIP(hipEventRecord(e0, s));
-    u64 lane_min = 8192;                        // pairs from which one lane per pair is at least as fast as 16
-                                                // (10 000 pairs: 0.039 ms either way; 30 000: 0.044 vs 0.078 ms)
-    if (const char *e = getenv("PSS_LANE_SEARCH_MIN")) lane_min = strtoull(e, nullptr, 0);
-    if (nvq >= lane_min && !getenv("PSS_WAVE_SEARCH"))
+    const u64 lane_min = knobs.lane_search_min;   // pairs from which one lane per pair is at least as fast as 16
+                                                  // (10 000 pairs: 0.039 ms either way; 30 000: 0.044 vs 0.078 ms)
+    if (nvq >= lane_min && !knobs.wave_search)
         hipLaunchKernelGGL(search_interval_lane_kernel, dim3((u32)((nvq + 255) / 256)), dim3(256), 0, s, d_chunks, nc,
                            d_q, d_qoff, nvq, d_lo, d_cnt);
-    else if (nvq >= 2048 && !getenv("PSS_WAVE_SEARCH") && !getenv("PSS_NO_GROUP_SEARCH"))
+    else if (nvq >= 2048 && !knobs.wave_search && !knobs.no_group_search)
         hipLaunchKernelGGL(search_interval_group_kernel, dim3((u32)((nvq + 15) / 16)), dim3(256), 0, s, d_chunks, nc, d_q,
                            d_qoff, nvq, d_lo, d_cnt);
     else
         hipLaunchKernelGGL(search_interval_kernel, dim3((u32)((nvq + waves_per_block - 1) / waves_per_block)), dim3(256),
                            0, s, d_chunks, nc, d_q, d_qoff, nvq, d_lo, d_cnt);
     PSS_HIP(hipEventRecord(e1, s));
-    if (nvq <= MID_MAX && !counts_only && !getenv("PSS_NO_MID_PIPELINE")) {
+    if (nvq <= MID_MAX && !counts_only && !knobs.no_mid_pipeline) {
         // ---- mid pipeline: totals stay on the device, one wait for them, one for the result ----
         const u64 byte_cap = (u64)16 << 20;
         PSS_TRY(ctx->slot[Q_START].reserve((size_t)MID_MAX * 4));
@@ -1143,11 +1185,26 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
         PSS_HIP(hipStreamSynchronize(s));
         if (!h_ms->flag) {
             const u64 H = h_ms->hits, E = h_ms->entries, B = h_ms->bytes;
-            res->offsets = (u64 *)malloc((E + 1) * sizeof(u64));
-            res->bytes = (u8 *)malloc(B ? B : 1);
-            if (!res->offsets || !res->bytes) return PSS_ENOMEM;
+            if (device_only) {
+                res->d_qcount = d_qcount;
+                res->d_offsets = d_entoff;
+                res->d_bytes = d_out;
+                res->n_entries = E;
+                res->n_bytes = B;
+                st->hits = H;
+                st->entries = E;
+                st->result_bytes = B;
+                float msd = 0.f;
+                PSS_HIP(hipEventElapsedTime(&msd, e0, e2));
+                st->ms_device = msd;
+                PSS_HIP(hipEventElapsedTime(&msd, e0, e1));
+                st->ms_interval = msd;
+                st->ms_host = host_ms();
+                return PSS_OK;
+            }
+            PSS_TRY(alloc_result(res, E, B, false));
             const size_t need = round_up(E * 8, 64) + round_up(B, 64) + (size_t)nq * 8;
-            if (need <= DeviceCtx::kStageR && !getenv("PSS_NO_SEARCH_STAGE")) {
+            if (need <= DeviceCtx::kStageR && !knobs.no_search_stage) {
                 // down through pinned staging (three DMA copies, one wait), then plain memcpy
                 PSS_TRY(ctx->ensure_search_stage());
                 u8 *r0 = static_cast<u8 *>(ctx->search_stage) + DeviceCtx::kStageQ;
@@ -1167,6 +1224,7 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
             }
             res->offsets[E] = B;
             res->n_entries = E;
+            res->n_bytes = B;
             st->hits = H;
             st->entries = E;
             st->result_bytes = B;
@@ -1232,22 +1290,34 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
         hipLaunchKernelGGL(query_counts_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, nc, nq, d_hitoff, d_eidx,
                            d_qcount, (const MidState *)nullptr);
         PSS_HIP(hipEventRecord(e2, s));
-        res->offsets = (u64 *)malloc((E + 1) * sizeof(u64));
-        res->bytes = (u8 *)malloc(B ? B : 1);
-        if (!res->offsets || !res->bytes) return PSS_ENOMEM;
-        if (E) PSS_HIP(hipMemcpyAsync(res->offsets, d_entoff, E * 8, hipMemcpyDeviceToHost, s));
-        if (B) PSS_HIP(hipMemcpyAsync(res->bytes, d_out, B, hipMemcpyDeviceToHost, s));
-        PSS_HIP(hipMemcpyAsync(res->qcount, d_qcount, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
-        PSS_HIP(hipStreamSynchronize(s));
-        res->offsets[E] = B;
+        if (device_only) {
+            res->d_qcount = d_qcount;
+            res->d_offsets = d_entoff;
+            res->d_bytes = d_out;
+            PSS_HIP(hipStreamSynchronize(s));
+        } else {
+            PSS_TRY(alloc_result(res, E, B, !knobs.no_pinned_results));
+            if (E) PSS_HIP(hipMemcpyAsync(res->offsets, d_entoff, E * 8, hipMemcpyDeviceToHost, s));
+            if (B) PSS_HIP(hipMemcpyAsync(res->bytes, d_out, B, hipMemcpyDeviceToHost, s));
+            PSS_HIP(hipMemcpyAsync(res->qcount, d_qcount, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
+            PSS_HIP(hipStreamSynchronize(s));
+            res->offsets[E] = B;
+        }
     } else {
         PSS_HIP(hipEventRecord(e2, s));
+        if (device_only) {
+            PSS_HIP(hipMemsetAsync(d_qcount, 0, (size_t)nq * 8, s));
+            res->d_qcount = d_qcount;
+        }
         PSS_HIP(hipStreamSynchronize(s));
-        res->offsets = (u64 *)calloc(1, sizeof(u64));
-        if (!res->offsets) return PSS_ENOMEM;
+        if (!device_only) {
+            res->offsets = (u64 *)calloc(1, sizeof(u64));
+            if (!res->offsets) return PSS_ENOMEM;
+        }
     }
     PSS_HIP(hipGetLastError());
     res->n_entries = E;
+    res->n_bytes = B;
     st->entries = E;
     st->result_bytes = B;
     float ms = 0.f;

@@ -29,3 +29,22 @@ def oracle():
 def pss():
     import pysubstringsearch_amd as P
     return P
+
+
+@pytest.fixture
+def search_env(monkeypatch):
+    """Sets PSS_* switches of the search path for one test.  The library reads them once, not on
+    every call (single-query latency), so a change must be followed by pss_reload_env()."""
+    from pysubstringsearch_amd import _ffi
+
+    def set_(**kv):
+        for k, v in kv.items():
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, str(v))
+        _ffi.lib.pss_reload_env()
+
+    yield set_
+    monkeypatch.undo()
+    _ffi.lib.pss_reload_env()

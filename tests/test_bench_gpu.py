@@ -45,6 +45,7 @@ def test_bench_single_gpu_contract():
     cpu = d['cpu_baseline']
     assert cpu['cores'] == 1 and cpu['kind'] in ('reference', 'port') and cpu['value'] > 0 and cpu['sample']
     assert d['entries_per_batch'] == d['search_stats']['entries']
+    assert d['verified'] is True and 'libsais' in d['verified_by']      # small n: libsais run on the spot
 
 
 def test_bench_two_ranks_gloo_hook():

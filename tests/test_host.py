@@ -270,3 +270,25 @@ def test_tools_compile():
     assert len(files) > 10
     for f in files:
         compile(open(f, encoding='utf-8').read(), f, 'exec')
+
+
+def test_drop_in_name_ships_type_stubs():
+    """The reference ships pysubstringsearch/pysubstringsearch.pyi and py.typed beside its __init__.py."""
+    pkg = os.path.join(ROOT, 'pysubstringsearch')
+    assert os.path.exists(os.path.join(pkg, 'py.typed')) and os.path.exists(os.path.join(pkg, '__init__.pyi'))
+    stub = open(os.path.join(ROOT, 'pysubstringsearch_amd', '__init__.pyi')).read()
+    for name in ('add_entries_from_file_lines', 'add_entry', 'dump_data', 'finalize', 'search', 'search_multiple'):
+        assert f'def {name}(' in stub, name
+
+
+def test_merge_packed_c_helper_rejects_inconsistent_input():
+    from pysubstringsearch_amd import _ffi
+    counts = np.array([2, 1], dtype=np.uint64)
+    starts = np.array([0, 3], dtype=np.uint64)          # 2 entries, but the counts claim 3
+    blob = np.frombuffer(b'abcdef', dtype=np.uint8)
+    arr = ctypes.c_void_p * 1
+    ne, nb = np.array([2], dtype=np.uint64), np.array([6], dtype=np.uint64)
+    oc, oo, ob = np.zeros(2, np.uint64), np.zeros(4, np.uint64), np.zeros(6, np.uint8)
+    rc = _ffi.lib.pss_merge_packed(1, 2, arr(counts.ctypes.data), arr(starts.ctypes.data), arr(blob.ctypes.data),
+                                   ne.ctypes.data, nb.ctypes.data, oc.ctypes.data, oo.ctypes.data, ob.ctypes.data)
+    assert rc == _ffi.PSS_EINVAL

@@ -136,3 +136,59 @@ def test_generator_golden(oracle):
     assert hashlib.sha256(t.tobytes()).hexdigest() == \
         '33246a0e40f61c2a592fd16dc644ade2e25eae811ca2d7457ce4154000485e99'
     assert (t == oracle.gen_lines(1 << 20)).all()   # independent C restatement of the generator
+
+
+def test_thread_per_chunk_baseline_equals_plain_search(oracle, tmp_path):
+    """orc_bench_search (the reference-shaped CPU baseline of SURVEY 8(d)(ii): queries one at a time,
+    one worker per chunk, results appended under a mutex, suffix arrays in RAM or probed in the index
+    file with lseek + read(8 KiB)) returns, per query, exactly what the plain restatement returns."""
+    texts = [oracle.gen_lines(1 << 16, c) for c in range(5)]
+    sas = [oracle.sa(t) for t in texts]
+    r = oracle.OracleReader.from_arrays(texts, sas)
+    assert r.num_chunks == 5
+    rng = np.random.default_rng(2)
+    qs = [b'', b'\n', b'zzzzzz', b'e']
+    for _ in range(600):
+        c, s, ln = int(rng.integers(0, 5)), int(rng.integers(0, (1 << 16) - 40)), int(rng.integers(2, 12))
+        qs.append(texts[c][s:s + ln].tobytes())
+    ents, counts = r.search_multiple_bytes(qs)
+    for threads in (1, 2, 5, 64):
+        b = r.bench_search(qs, threads)
+        assert np.array_equal(b['counts'], counts) and b['entries'] == len(ents) and b['bytes'] == sum(map(len, ents))
+        assert b['threads'] == min(threads, 5) and b['seconds'] > 0
+    p = str(tmp_path / 'five.idx')
+    with open(p, 'wb') as f:            # chunk records, src/lib.rs:112-119
+        for t, s in zip(texts, sas):
+            f.write(np.uint32(t.size).tobytes() + t.tobytes() + np.uint32(4 * t.size).tobytes() + s.astype('<i4').tobytes())
+    on_disk = oracle.OracleReader(p, load_sa=False)     # suffix arrays stay in the file (src/lib.rs:179-182)
+    for threads in (1, 5):
+        b = on_disk.bench_search(qs, threads, disk=True)
+        assert np.array_equal(b['counts'], counts) and b['entries'] == len(ents)
+    with pytest.raises(RuntimeError):
+        on_disk.search_bytes(b'a')                      # no suffix array in RAM: only the disk path serves it
+    loaded = oracle.OracleReader(p)
+    e2, c2 = loaded.search_multiple_bytes(qs)
+    assert np.array_equal(c2, counts) and sorted(e2) == sorted(ents)
+
+
+def test_big_goldens_are_well_formed_and_the_checksum_is_libsais(oracle):
+    """tests/golden/sa_big.json (libsais on full 512 MiB chunks, generated by make_golden_big.py):
+    every BASELINE chunk is present; the positional checksum formula the GPU side evaluates in torch
+    is the one the generator evaluated in numpy (re-derived here on 1 MiB with the real libsais)."""
+    import bench
+    gold = bench.load_big_goldens()
+    n = 1 << 29
+    for c in range(15):
+        assert ('lines', c, n) in gold, c
+    for kind in ('words', 'runs', 'periodic'):
+        assert (kind, 0, n) in gold
+    for g in gold.values():
+        assert len(g['sa_sha256']) == 64 and len(g['sa_stride']) == 256 and 0 <= g['sa_poly64'] < 1 << 64
+        assert sorted(set(g['sa_stride'])) == sorted(g['sa_stride'])      # distinct suffixes
+    if not oracle.have_reference():
+        pytest.skip('oracle/_ref/libsais.so not present')
+    from tests.golden.make_golden_big import poly64
+    t = oracle.gen_lines(1 << 20, 3)
+    sa = oracle.sa_reference(t)
+    assert poly64(sa) == bench.sa_poly64_numpy(sa)
+    assert hashlib.sha256(sa.astype('<i4').tobytes()).hexdigest() != hashlib.sha256(np.sort(sa).tobytes()).hexdigest()

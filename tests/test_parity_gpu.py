@@ -104,10 +104,10 @@ def _fuzz_corpus(rng, alphabet, n_entries, max_len):
 
 @pytest.mark.parametrize('small_path', [True, False])
 @pytest.mark.parametrize('seed', range(6))
-def test_fuzz_against_oracle(tmp_path, oracle, seed, small_path, monkeypatch):
+def test_fuzz_against_oracle(tmp_path, oracle, seed, small_path, search_env):
     # both search paths: the fused small-batch kernel and the general multi-kernel pipeline
     if not small_path:
-        monkeypatch.setenv('PSS_NO_SMALL_PATH', '1')
+        search_env(PSS_NO_SMALL_PATH=1)
     rng = random.Random(seed)
     alphabet = rng.choice(['ab', 'abc', 'ab \n'.replace('\n', ''), 'abcdefgh', 'aé☃', '\x00a'])
     entries = _fuzz_corpus(rng, alphabet, rng.randint(1, 400), rng.choice([3, 12, 60]))

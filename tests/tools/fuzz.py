@@ -78,8 +78,10 @@ KNOBS = ('PSS_MODE', 'PSS_KEY_CHARS', 'PSS_KEY_DROP', 'PSS_TEXT_ROUNDS', 'PSS_NO
 
 def random_knobs(rng):
     """Builder / search switches that must never change a result."""
+    from pysubstringsearch_amd import _ffi
     for k in KNOBS:
         os.environ.pop(k, None)
+    _ffi.lib.pss_reload_env()        # the search switches are read once, not per call
     if rng.random() < 0.5:
         return
     if rng.random() < 0.5:
@@ -94,6 +96,7 @@ def random_knobs(rng):
         os.environ['PSS_NO_TIES_PASS'] = '1'
     if rng.random() < 0.5:
         os.environ['PSS_NO_SMALL_PATH'] = '1'
+    _ffi.lib.pss_reload_env()
 
 
 def file_case(rng, tmp):

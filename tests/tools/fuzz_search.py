@@ -83,6 +83,8 @@ def one_case(seed, tmp):
         os.environ['PSS_NO_KEY_SAMPLES'] = '1'
     elif r < 0.85:
         os.environ['PSS_SAMPLE_SHIFT'] = str(rng.randint(0, 8))     # dense key-sample tables on these small chunks
+    from pysubstringsearch_amd import _ffi
+    _ffi.lib.pss_reload_env()        # the search switches are read once, not per call
     qb = [s.encode() for s in queries]
     o = O.OracleReader(q)
     oe, oc = o.search_multiple_bytes(qb)
