@@ -160,7 +160,7 @@ class _DevicePtr:
     """A raw HBM range as an object torch.as_tensor understands (CUDA array interface)."""
 
     def __init__(self, ptr: int, nbytes: int) -> None:
-        self.__cuda_array_interface__ = {'shape': (nbytes,), 'typestr': '|u1', 'data': (ptr, True), 'version': 2}
+        self.__cuda_array_interface__ = {'shape': (nbytes,), 'typestr': '|u1', 'data': (ptr, False), 'version': 2}
 
 
 class DeviceResult(typing.NamedTuple):
