@@ -127,6 +127,13 @@ int pss_writer_open(const char *path, int64_t max_chunk_len, int32_t device, pss
  *     that is PSS_EINVAL).  pss_reader_open recognises either format by the magic. */
 int pss_writer_open_format(const char *path, int64_t max_chunk_len, int32_t device, int32_t format_version,
                            pss_writer **out);
+/* The same over several devices ("each GPU builds its chunks; host writes records in chunk
+ * order"): chunk k of the file is built on devices[k % n_devices], up to 2 n_devices chunks are in flight
+ * (G being built, the records of the earlier ones streaming to the file in chunk order), and the file
+ * is byte-identical to the single-device one.  The reference builds one chunk at a time inside
+ * dump_data (src/lib.rs:105-124).  The same device may be listed more than once. */
+int pss_writer_open_multi(const char *path, int64_t max_chunk_len, const int32_t *devices, int32_t n_devices,
+                          int32_t format_version, pss_writer **out);
 /* Writer::add_entry, src/lib.rs:88-103.  PSS_ETOOBIG when len > limit. */
 int pss_writer_add_entry(pss_writer *w, const uint8_t *text, uint64_t len);
 /* Writer::add_entries_from_file_lines, src/lib.rs:67-86 (bstr for_byte_line rule). */

@@ -70,10 +70,14 @@ class Writer:
         max_chunk_len: typing.Optional[int] = None,
         *,
         device: typing.Optional[int] = None,
+        devices: typing.Optional[typing.Sequence[int]] = None,
         format_version: int = 1,
     ) -> None:
         """``format_version=2`` (extension, opt-in) writes the container with 64-bit lengths: chunks of
-        up to 2^31 - 1 bytes instead of the reference format's < 1 GiB.  Reader opens either."""
+        up to 2^31 - 1 bytes instead of the reference format's < 1 GiB.  Reader opens either.
+        ``devices=[0, 1, ...]`` (extension) builds chunk k of the file on ``devices[k % len(devices)]``,
+        several chunks at once; the records are still written in chunk order, so the file is
+        byte-identical to the single-device one."""
         if format_version not in (1, 2):
             raise ValueError('format_version must be 1 (the reference container) or 2')
         if max_chunk_len is not None:
@@ -83,9 +87,17 @@ class Writer:
                 raise OverflowError("can't convert negative int to unsigned")   # Option<usize>
         self._h = ctypes.c_void_p()
         path = _path(index_file_path, 'index_file_path')
-        rc = _lib.pss_writer_open_format(
-            path, -1 if max_chunk_len is None else max_chunk_len,
-            _default_device() if device is None else device, format_version, ctypes.byref(self._h))
+        if devices is not None:
+            if device is not None:
+                raise ValueError('pass either device or devices')
+            devs = [int(d) for d in devices]
+            if not devs:
+                raise ValueError('devices must not be empty')
+        else:
+            devs = [_default_device() if device is None else device]
+        arr = (ctypes.c_int32 * len(devs))(*devs)
+        rc = _lib.pss_writer_open_multi(
+            path, -1 if max_chunk_len is None else max_chunk_len, arr, len(devs), format_version, ctypes.byref(self._h))
         _ffi.check(rc, index_file_path)
         self.writer = self   # the reference wrapper exposes `.writer` (__init__.py:12)
 

@@ -10,6 +10,7 @@ class Writer:
         max_chunk_len: typing.Optional[int] = None,
         *,
         device: typing.Optional[int] = None,
+        devices: typing.Optional[typing.Sequence[int]] = None,
         format_version: int = 1,
     ) -> None: ...
 

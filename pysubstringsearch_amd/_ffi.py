@@ -119,6 +119,7 @@ def _load() -> ctypes.CDLL:
         'pss_sort_pairs_device': (i32, [vp, vp, u32, i32, i32, ctypes.POINTER(ctypes.c_double)]),
         'pss_writer_open': (ctypes.c_int, [cp, i64, i32, pvp]),
         'pss_writer_open_format': (ctypes.c_int, [cp, i64, i32, i32, pvp]),
+        'pss_writer_open_multi': (ctypes.c_int, [cp, i64, ctypes.POINTER(i32), i32, i32, pvp]),
         'pss_writer_add_entry': (ctypes.c_int, [vp, cp, u64]),
         'pss_writer_add_file_lines': (ctypes.c_int, [vp, cp]),
         'pss_writer_dump': (ctypes.c_int, [vp]),

@@ -4,6 +4,7 @@
 #include <cerrno>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -171,26 +172,34 @@ extern "C" int32_t pss_sort_pairs_device(void *d_keys, void *d_vals, uint32_t n,
 
 // ------------------------------------------------------------------- Writer --
 
-// Chunk records are written by a background thread: while chunk k streams from
-// HBM to the file, the caller already fills (and the GPU builds) chunk k+1.
-// One job in flight; the file is only ever touched by that thread or, when it is
-// idle, by the caller -- so records stay in order.
-struct WriterIo {
-    std::thread th;
-    std::mutex mu;
-    std::condition_variable cv;
-    bool have_job = false, busy = false, stop = false;
-    uint8_t *text = nullptr;      // job: host text (owned by the job until done)
+// The Writer is a three-stage pipeline so that ingest, suffix-array builds and the file never wait for
+// one another more than the data dependencies demand:
+//
+//   caller thread     fills the host text buffer of chunk k (add_entry / add_entries_from_file_lines) and,
+//                     when the chunk is full, queues it as job k and goes on with a fresh buffer;
+//   builder threads   one per device of the writer: chunk k is built on device k mod G (upload, device
+//                     suffix-array build into one of that device's two SA buffers) -- with G devices, G
+//                     chunks are being built at once (reference: one libsais call at a time, lib.rs:105-124);
+//   record thread     writes the records strictly in chunk order (lib.rs:112-119), streaming each suffix
+//                     array HBM -> pinned double buffer -> file, so the file is byte-identical whatever G is.
+//
+// A device's SA buffer is reused two chunks of that device later, hence at most 2 G jobs are in flight.
+// The first failure (build or write) is sticky: nothing is written after it and every later dump /
+// finalize / close reports it.
+struct WJob {
+    uint64_t seq = 0;
+    uint8_t *text = nullptr;      // host text, owned by the job until its record is written
     size_t text_alloc = 0;
     size_t n = 0;
-    const void *d_sa = nullptr;   // job: suffix array in HBM
-    int rc = PSS_OK;              // first failure of any job
-    int err_no = 0;
-    std::string err;
-    // staging owned by the thread (pinned double buffer + copy stream)
-    void *stage[2] = {nullptr, nullptr};
-    hipStream_t stream = nullptr;
+    enum State { QUEUED, BUILDING, BUILT } state = QUEUED;
+};
+
+struct WDevice {
+    int device = 0;
+    DevBuf sa[2];                 // suffix arrays in HBM: one being written out, one being built
+    hipStream_t io_stream = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
+    std::thread builder;
 };
 
 struct pss_writer {
@@ -199,13 +208,20 @@ struct pss_writer {
     size_t len = 0;
     size_t limit = 0;    // the reference's Vec capacity (src/lib.rs:62), see reserve()
     size_t alloc = 0;
-    int device = 0;
-    uint8_t *spare = nullptr;     // second host text buffer (swapped with buf at every dump)
-    size_t spare_alloc = 0;
-    DevBuf d_sa[2];               // suffix arrays in HBM: one being written out, one being built
-    int sa_next = 0;
-    WriterIo *io = nullptr;
     int version = 1;              // container format: 1 = the reference's (lib.rs:112-119), 2 = 64-bit lengths
+    std::vector<WDevice> devs;    // chunk k is built on devs[k % devs.size()]
+    // pipeline state, guarded by mu
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<WJob> jobs;        // jobs[i].seq == written + i
+    uint64_t next_seq = 0, written = 0;
+    bool started = false, stop = false;
+    int rc = PSS_OK;              // first failure of any stage (sticky)
+    int err_no = 0;
+    std::string err;
+    std::vector<std::pair<uint8_t *, size_t>> free_text;   // host text buffers back from written jobs
+    std::thread record_thread;
+    void *stage[2] = {nullptr, nullptr};                    // pinned staging of the record thread
 };
 
 namespace {
@@ -269,126 +285,195 @@ void put_u32le(uint8_t *p, uint32_t v)
 }
 
 // Streams `bytes` of device memory to fp: the D2H copy of piece i+1 (pinned
-// staging, copy stream) runs while piece i is written to the file.
-int download_to_file(WriterIo *io, const void *src, size_t bytes, FILE *fp)
+// staging, the owning device's copy stream) runs while piece i is written to the file.
+int download_to_file(pss_writer *w, WDevice &d, const void *src, size_t bytes)
 {
     const size_t piece = DeviceCtx::kStage;
     const size_t pieces = (bytes + piece - 1) / piece;
     auto issue = [&](size_t i) -> int {
         const size_t off = i * piece, k = std::min(piece, bytes - off);
-        PSS_HIP(hipMemcpyAsync(io->stage[i & 1], static_cast<const uint8_t *>(src) + off, k, hipMemcpyDeviceToHost,
-                               io->stream));
-        PSS_HIP(hipEventRecord(io->ev[i & 1], io->stream));
+        PSS_HIP(hipMemcpyAsync(w->stage[i & 1], static_cast<const uint8_t *>(src) + off, k, hipMemcpyDeviceToHost,
+                               d.io_stream));
+        PSS_HIP(hipEventRecord(d.ev[i & 1], d.io_stream));
         return PSS_OK;
     };
     if (pieces) PSS_TRY(issue(0));
     for (size_t i = 0; i < pieces; ++i) {
-        PSS_HIP(hipEventSynchronize(io->ev[i & 1]));
+        PSS_HIP(hipEventSynchronize(d.ev[i & 1]));
         if (i + 1 < pieces) PSS_TRY(issue(i + 1));
         const size_t off = i * piece, k = std::min(piece, bytes - off);
         errno = 0;
-        if (fwrite(io->stage[i & 1], 1, k, fp) != k) return io_error("write");
+        if (fwrite(w->stage[i & 1], 1, k, w->fp) != k) return io_error("write");
     }
     return PSS_OK;
 }
 
 // One chunk record: u32le len | data | u32le 4n | n x i32le  (src/lib.rs:112-119)
-int write_record(pss_writer *w, const uint8_t *text, size_t n, const void *d_sa)
+int write_record(pss_writer *w, const WJob &job)
 {
     uint8_t hdr[8];
     const size_t hl = w->version == 2 ? 8 : 4;
+    const size_t n = job.n;
     errno = 0;
     if (w->version == 2) put_u64le(hdr, (uint64_t)n);
     else put_u32le(hdr, (uint32_t)n);
     {
         Phase ph("record: write text");
         if (fwrite(hdr, 1, hl, w->fp) != hl) return io_error("write");
-        if (fwrite(text, 1, n, w->fp) != n) return io_error("write");
+        if (fwrite(job.text, 1, n, w->fp) != n) return io_error("write");
     }
     if (w->version == 2) put_u64le(hdr, (uint64_t)n * 4);
     else put_u32le(hdr, (uint32_t)(n * 4));   // wraps like `as u32` at n >= 2^30 (lib.rs:116)
     if (fwrite(hdr, 1, hl, w->fp) != hl) return io_error("write");
+    if (n < 2) {                               // libsais.c:6603-6607: n == 1 -> SA[0] = 0, no device involved
+        const uint8_t zero[4] = {0, 0, 0, 0};
+        if (fwrite(zero, 1, 4, w->fp) != 4) return io_error("write");
+        return PSS_OK;
+    }
     // x86-64 / little-endian host: int32 in memory == i32le on disk (lib.rs:117-119)
     Phase ph("record: SA -> file");
-    return download_to_file(w->io, d_sa, n * 4, w->fp);
+    const size_t G = w->devs.size();
+    WDevice &d = w->devs[job.seq % G];
+    PSS_HIP(hipSetDevice(d.device));
+    return download_to_file(w, d, d.sa[(job.seq / G) & 1].p, n * 4);
 }
 
-void io_thread_main(pss_writer *w)
+void w_fail(pss_writer *w, int rc)      // with w->mu held
 {
-    WriterIo *io = w->io;
-    (void)hipSetDevice(w->device);
-    std::unique_lock<std::mutex> lk(io->mu);
-    for (;;) {
-        io->cv.wait(lk, [&] { return io->have_job || io->stop; });
-        if (!io->have_job && io->stop) return;
-        io->have_job = false;
-        lk.unlock();
-        const int rc = write_record(w, io->text, io->n, io->d_sa);
-        const int e = errno;
-        const std::string msg = rc != PSS_OK ? last_error() : std::string();
-        lk.lock();
-        if (rc != PSS_OK && io->rc == PSS_OK) {
-            io->rc = rc;
-            io->err_no = e;
-            io->err = msg;
-        }
-        io->busy = false;
-        io->cv.notify_all();
+    if (w->rc == PSS_OK && rc != PSS_OK) {
+        w->rc = rc;
+        w->err_no = errno;
+        w->err = last_error();
     }
 }
 
-// Blocks until the record in flight (if any) is on its way to the file; reports the
-// first background failure (once).
+// Builder of device slot `di`: takes the jobs with seq % G == di in order.
+void builder_main(pss_writer *w, size_t di)
+{
+    const size_t G = w->devs.size();
+    WDevice &d = w->devs[di];
+    std::unique_lock<std::mutex> lk(w->mu);
+    for (;;) {
+        WJob *job = nullptr;
+        w->cv.wait(lk, [&] {
+            for (auto &j : w->jobs)
+                if (j.seq % G == di && j.state == WJob::QUEUED) {
+                    job = &j;
+                    return true;
+                }
+            return w->stop;
+        });
+        if (!job) return;
+        job->state = WJob::BUILDING;
+        const uint64_t seq = job->seq;
+        const uint8_t *text = job->text;
+        const size_t n = job->n;
+        const bool skip = w->rc != PSS_OK || n < 2;
+        lk.unlock();
+        int rc = PSS_OK;
+        if (!skip) {
+            rc = guarded([&]() -> int {
+                DeviceCtx *ctx;
+                PSS_TRY(get_ctx(d.device, &ctx));
+                std::lock_guard<std::recursive_mutex> dl(ctx->mu);     // the device workspace is shared by every handle
+                PSS_HIP(hipSetDevice(d.device));
+                DevBuf &sa = d.sa[(seq / G) & 1];
+                PSS_TRY(ctx->slot[W_TEXT].reserve(n + 64));
+                PSS_TRY(sa.reserve(n * 4));
+                Phase ph("build: upload+build");
+                PSS_HIP(hipMemcpyAsync(ctx->slot[W_TEXT].p, text, n, hipMemcpyHostToDevice, ctx->stream));
+                return sa_build_device(ctx, ctx->slot[W_TEXT].p, sa.p, (int32_t)n, 0, nullptr);
+            });
+        }
+        lk.lock();
+        w_fail(w, rc);
+        for (auto &j : w->jobs)          // the deque may have shifted (front jobs written meanwhile)
+            if (j.seq == seq) j.state = WJob::BUILT;
+        w->cv.notify_all();
+    }
+}
+
+void record_main(pss_writer *w)
+{
+    std::unique_lock<std::mutex> lk(w->mu);
+    for (;;) {
+        w->cv.wait(lk, [&] { return (!w->jobs.empty() && w->jobs.front().state == WJob::BUILT) || w->stop; });
+        if (w->jobs.empty() || w->jobs.front().state != WJob::BUILT) {
+            if (w->stop) return;
+            continue;
+        }
+        const WJob job = w->jobs.front();
+        const bool skip = w->rc != PSS_OK;       // after a failure nothing more is written: no record follows a broken one
+        lk.unlock();
+        int rc = PSS_OK;
+        if (!skip) rc = guarded([&]() -> int { return write_record(w, job); });
+        lk.lock();
+        w_fail(w, rc);
+        w->free_text.emplace_back(job.text, job.text_alloc);
+        w->jobs.pop_front();
+        w->written += 1;
+        w->cv.notify_all();
+    }
+}
+
+int w_report(pss_writer *w)              // with w->mu held: the sticky failure, if any
+{
+    if (w->rc == PSS_OK) return PSS_OK;
+    set_error("%s", w->err.c_str());
+    errno = w->err_no;
+    return w->rc;
+}
+
+// Blocks until every queued record is in the file; reports the first failure (every time).
 int io_wait(pss_writer *w)
 {
-    WriterIo *io = w->io;
-    if (!io) return PSS_OK;
-    std::unique_lock<std::mutex> lk(io->mu);
-    io->cv.wait(lk, [&] { return !io->busy; });
-    if (io->rc != PSS_OK) {
-        const int rc = io->rc;
-        set_error("%s", io->err.c_str());
-        errno = io->err_no;
-        io->rc = PSS_OK;
-        return rc;
+    std::unique_lock<std::mutex> lk(w->mu);
+    w->cv.wait(lk, [&] { return w->written == w->next_seq; });
+    return w_report(w);
+}
+
+int pipe_start(pss_writer *w)
+{
+    if (w->started) return PSS_OK;
+    for (int i = 0; i < 2; ++i)
+        if (!w->stage[i]) PSS_HIP(hipHostMalloc(&w->stage[i], DeviceCtx::kStage, hipHostMallocPortable));
+    for (auto &d : w->devs) {
+        PSS_HIP(hipSetDevice(d.device));
+        if (!d.io_stream) PSS_HIP(hipStreamCreateWithFlags(&d.io_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i)
+            if (!d.ev[i]) PSS_HIP(hipEventCreateWithFlags(&d.ev[i], hipEventDisableTiming));
     }
+    w->started = true;
+    for (size_t di = 0; di < w->devs.size(); ++di) w->devs[di].builder = std::thread(builder_main, w, di);
+    w->record_thread = std::thread(record_main, w);
     return PSS_OK;
 }
 
-int io_start(pss_writer *w)
+void pipe_stop(pss_writer *w)
 {
-    if (w->io) return PSS_OK;
-    PSS_HIP(hipSetDevice(w->device));
-    WriterIo *io = new WriterIo();
-    PSS_HIP(hipStreamCreateWithFlags(&io->stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
-        PSS_HIP(hipHostMalloc(&io->stage[i], DeviceCtx::kStage, hipHostMallocDefault));
-        PSS_HIP(hipEventCreateWithFlags(&io->ev[i], hipEventDisableTiming));
+    if (w->started) {
+        {
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [&] { return w->written == w->next_seq; });
+            w->stop = true;
+            w->cv.notify_all();
+        }
+        for (auto &d : w->devs)
+            if (d.builder.joinable()) d.builder.join();
+        if (w->record_thread.joinable()) w->record_thread.join();
     }
-    w->io = io;
-    io->th = std::thread(io_thread_main, w);
-    return PSS_OK;
-}
-
-void io_stop(pss_writer *w)
-{
-    WriterIo *io = w->io;
-    if (!io) return;
-    {
-        std::unique_lock<std::mutex> lk(io->mu);
-        io->cv.wait(lk, [&] { return !io->busy; });
-        io->stop = true;
-        io->cv.notify_all();
+    for (auto &d : w->devs) {
+        bool touched = d.io_stream || d.sa[0].p || d.sa[1].p;
+        if (touched) (void)hipSetDevice(d.device);
+        for (int i = 0; i < 2; ++i)
+            if (d.ev[i]) (void)hipEventDestroy(d.ev[i]);
+        if (d.io_stream) (void)hipStreamDestroy(d.io_stream);
+        for (auto &b : d.sa) b.release();
     }
-    if (io->th.joinable()) io->th.join();
-    (void)hipSetDevice(w->device);
-    for (int i = 0; i < 2; ++i) {
-        if (io->stage[i]) (void)hipHostFree(io->stage[i]);
-        if (io->ev[i]) (void)hipEventDestroy(io->ev[i]);
-    }
-    if (io->stream) (void)hipStreamDestroy(io->stream);
-    delete io;
-    w->io = nullptr;
+    for (int i = 0; i < 2; ++i)
+        if (w->stage[i]) (void)hipHostFree(w->stage[i]);
+    for (auto &t : w->free_text) free(t.first);
+    w->free_text.clear();
 }
 
 // src/lib.rs:105-124
@@ -399,71 +484,61 @@ int w_dump(pss_writer *w)
         set_error("chunk of %zu bytes exceeds the 32-bit suffix array", w->len);
         return PSS_EINVAL;
     }
-    DeviceCtx *ctx;
-    PSS_TRY(get_ctx(w->device, &ctx));
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    const size_t n = w->len;
-    if (n < 2) {
-        // libsais.c:6603-6607: n == 1 -> SA[0] = 0; written by the caller once the thread is idle
-        PSS_TRY(io_wait(w));
-        uint8_t hdr[8];
-        const size_t hl = w->version == 2 ? 8 : 4;
-        errno = 0;
-        if (w->version == 2) put_u64le(hdr, (uint64_t)n);
-        else put_u32le(hdr, (uint32_t)n);
-        if (fwrite(hdr, 1, hl, w->fp) != hl || fwrite(w->buf, 1, n, w->fp) != n) return io_error("write");
-        if (w->version == 2) put_u64le(hdr, 4);
-        else put_u32le(hdr, 4);
-        const uint8_t zero[4] = {0, 0, 0, 0};
-        if (fwrite(hdr, 1, hl, w->fp) != hl || fwrite(zero, 1, 4, w->fp) != 4) return io_error("write");
+    const size_t G = w->devs.size();
+    if (w->len >= 2) {
+        // no usable device is reported here and now, not by a later call
+        DeviceCtx *ctx;
+        PSS_TRY(get_ctx(w->devs[w->next_seq % G].device, &ctx));
+    }
+    if (w->len >= 2 || w->started) PSS_TRY(pipe_start(w));
+    if (!w->started) {
+        // a one-byte chunk before anything touched a device: written in place (libsais.c:6603-6607)
+        WJob job;
+        job.text = w->buf;
+        job.n = w->len;
+        PSS_TRY(write_record(w, job));
         w->len = 0;
         return PSS_OK;
     }
-    // upload + build into the SA buffer the background writer is NOT reading from
-    DevBuf &sa = w->d_sa[w->sa_next];
-    PSS_HIP(hipSetDevice(w->device));
-    PSS_TRY(ctx->slot[W_TEXT].reserve(n + 64));
-    PSS_TRY(sa.reserve(n * 4));
-    {
-        Phase ph("dump: upload+build");
-        PSS_HIP(hipMemcpyAsync(ctx->slot[W_TEXT].p, w->buf, n, hipMemcpyHostToDevice, ctx->stream));
-        PSS_TRY(sa_build_device(ctx, ctx->slot[W_TEXT].p, sa.p, (int32_t)n, 0, nullptr));
+    std::unique_lock<std::mutex> lk(w->mu);
+    // the SA buffer this chunk builds into was last used by chunk k - 2 G: its record must be out
+    w->cv.wait(lk, [&] { return w->next_seq - w->written < 2 * G; });
+    PSS_TRY(w_report(w));
+    WJob job;
+    job.seq = w->next_seq++;
+    job.text = w->buf;
+    job.text_alloc = w->alloc;
+    job.n = w->len;
+    job.state = WJob::QUEUED;
+    w->jobs.push_back(job);
+    // go on filling a buffer that a written job gave back (or a fresh one, allocated on demand)
+    w->buf = nullptr;
+    w->alloc = 0;
+    if (!w->free_text.empty()) {
+        w->buf = w->free_text.back().first;
+        w->alloc = w->free_text.back().second;
+        w->free_text.pop_back();
     }
-    PSS_TRY(io_start(w));
-    PSS_TRY(io_wait(w));                      // previous record done: its text buffer is free again
-    WriterIo *io = w->io;
-    {
-        std::lock_guard<std::mutex> lk(io->mu);
-        // hand the filled text buffer to the job, continue filling the other one
-        uint8_t *done_text = io->text;
-        const size_t done_alloc = io->text_alloc;
-        io->text = w->buf;
-        io->text_alloc = w->alloc;
-        io->n = n;
-        io->d_sa = sa.p;
-        io->have_job = true;
-        io->busy = true;
-        w->buf = done_text ? done_text : w->spare;
-        w->alloc = done_text ? done_alloc : w->spare_alloc;
-        w->spare = nullptr;
-        w->spare_alloc = 0;
-        io->cv.notify_all();
-    }
-    w->sa_next ^= 1;
     w->len = 0;
+    w->cv.notify_all();
     return PSS_OK;
 }
 
 }  // namespace
 
-extern "C" int pss_writer_open_format(const char *path, int64_t max_chunk_len, int32_t device, int32_t format_version,
-                                      pss_writer **out)
+extern "C" int pss_writer_open_multi(const char *path, int64_t max_chunk_len, const int32_t *devices, int32_t n_devices,
+                                     int32_t format_version, pss_writer **out)
 {
     return guarded([&]() -> int {
-        if (!path || !out || (format_version != 1 && format_version != 2)) {
-            set_error("pss_writer_open: bad arguments (format_version must be 1 or 2)");
+        if (!path || !out || (format_version != 1 && format_version != 2) || !devices || n_devices < 1 || n_devices > 64) {
+            set_error("pss_writer_open: bad arguments (format_version must be 1 or 2, 1..64 devices)");
             return PSS_EINVAL;
         }
+        for (int i = 0; i < n_devices; ++i)
+            if (devices[i] < 0) {
+                set_error("pss_writer_open: device %d out of range", devices[i]);
+                return PSS_EINVAL;
+            }
         if (format_version == 2 && max_chunk_len > (int64_t)INT32_MAX) {
             set_error("max_chunk_len %lld: a chunk holds at most 2^31 - 1 bytes (32-bit suffix array)", (long long)max_chunk_len);
             return PSS_EINVAL;
@@ -483,11 +558,18 @@ extern "C" int pss_writer_open_format(const char *path, int64_t max_chunk_len, i
         pss_writer *w = new pss_writer();
         w->fp = fp;
         w->limit = max_chunk_len < 0 ? (size_t)512 * 1024 * 1024 : (size_t)max_chunk_len;   // lib.rs:57
-        w->device = device;
+        w->devs.resize((size_t)n_devices);
+        for (int i = 0; i < n_devices; ++i) w->devs[(size_t)i].device = devices[i];
         w->version = format_version;
         *out = w;
         return PSS_OK;
     });
+}
+
+extern "C" int pss_writer_open_format(const char *path, int64_t max_chunk_len, int32_t device, int32_t format_version,
+                                      pss_writer **out)
+{
+    return pss_writer_open_multi(path, max_chunk_len, &device, 1, format_version, out);
 }
 
 extern "C" int pss_writer_open(const char *path, int64_t max_chunk_len, int32_t device, pss_writer **out)
@@ -619,16 +701,16 @@ extern "C" int pss_writer_close(pss_writer *w)
         if (w->len) rc = w_dump(w);   // Drop -> finalize, lib.rs:138-144
         const int rc2 = io_wait(w);
         if (rc == PSS_OK) rc = rc2;
-        if (w->io) {
-            if (w->io->text != w->buf) free(w->io->text);
-            io_stop(w);
-        }
+        const int e = errno;
+        const std::string msg = rc != PSS_OK ? last_error() : std::string();
+        pipe_stop(w);
         errno = 0;
         if (fclose(w->fp) != 0 && rc == PSS_OK) rc = io_error("close");
+        else if (rc != PSS_OK) {
+            set_error("%s", msg.c_str());
+            errno = e;
+        }
         free(w->buf);
-        free(w->spare);
-        (void)hipSetDevice(w->device);
-        for (auto &b : w->d_sa) b.release();
         delete w;
         return rc;
     });
@@ -851,7 +933,10 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
         fseeko(fp, 0, SEEK_SET);
         DeviceCtx *ctx;
         PSS_TRY(get_ctx(device, &ctx));
-        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+        // The device context (staging buffers, streams) is shared with every other handle on the device: it is
+        // held chunk by chunk, around the uploads only, so searches of other readers and Writer builds
+        // interleave with a long load instead of waiting for the whole file.
+        std::unique_lock<std::recursive_mutex> lk(ctx->mu, std::defer_lock);
         pss_reader *r = new pss_reader();
         r->device = device;
         r->ctx = ctx;
@@ -881,6 +966,7 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
         };
         const char *kTrunc = "failed to fill whole buffer (truncated index file)";
         while (bytes_read < flen) {   // lib.rs:174
+            if (lk.owns_lock()) lk.unlock();
             uint64_t dlen64 = 0, slen = 0;
             if (!get_len(&dlen64)) { set_error("%s", kTrunc); rc = PSS_EFORMAT; break; }
             if (dlen64 > (uint64_t)INT32_MAX || bytes_read + 2 * hl + dlen64 > flen) {
@@ -896,6 +982,7 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
             ChunkDesc cd{};
             pss_reader::Mem cm;
             if (mine && dlen) {
+                lk.lock();
                 rc = reader_alloc_chunk(r, dlen, &cd, &cm);
                 if (rc) break;
                 r->chunks.push_back(cd);
@@ -930,6 +1017,7 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
             bytes_read += 2 * hl + (uint64_t)dlen + sa_bytes_file;   // lib.rs:184
             ++index;
         }
+        if (!lk.owns_lock()) lk.lock();
         if (rc == PSS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {
             set_error("key samples: %s", hipGetErrorString(hipGetLastError()));
             rc = PSS_EDEVICE;

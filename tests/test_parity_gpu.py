@@ -488,3 +488,73 @@ def test_container_format_2(tmp_path, oracle):
         pysubstringsearch.Writer(str(tmp_path / 'bad.idx'), 1 << 31, format_version=2)
     with pytest.raises(ValueError):
         pysubstringsearch.Writer(str(tmp_path / 'bad.idx'), format_version=3)
+
+
+@pytest.mark.parametrize('devices', [[0, 0], [0, 0, 0, 0, 0]])
+def test_multi_device_writer_is_byte_identical(tmp_path, oracle, devices):
+    """Writer(devices=[...]): chunk k is built on devices[k % G], several chunks in flight, records in
+    chunk order -- the file must equal the single-device file and the oracle's (src/lib.rs:105-124),
+    byte for byte.  One GPU here, so the list names it several times ("virtual devices"): same
+    pipeline, same ordering logic, G builder threads."""
+    from tests.util import gen_corpus
+    src = tmp_path / 'c.txt'
+    raw = gen_corpus(1, 3 << 20).tobytes()
+    src.write_bytes(raw)
+    rng = random.Random(3)
+    single, multi, orc = str(tmp_path / 's.idx'), str(tmp_path / 'm.idx'), str(tmp_path / 'o.idx')
+    for limit in (1 << 18, 300000, 1 << 20):
+        def fill(w):
+            w.add_entry('first')
+            w.add_entries_from_file_lines(str(src))      # 3 MiB -> 3..12 chunks
+            for i in range(50):
+                w.add_entry('tail entry %d' % i)
+                if i in (7, 8, 30):
+                    w.dump_data()                          # explicit chunk boundaries, incl. back-to-back
+            w.add_entry('')
+            w.dump_data()                                  # a one-byte chunk in the middle of the pipeline
+            w.add_entry('last')
+        w = pysubstringsearch.Writer(single, limit)
+        fill(w)
+        w.close()
+        w = pysubstringsearch.Writer(multi, limit, devices=devices)
+        fill(w)
+        w.finalize()
+        w.add_entry('after finalize')                      # the pipeline keeps going after a finalize
+        w.close()
+        w = pysubstringsearch.Writer(single + '2', limit)
+        fill(w)
+        w.finalize()
+        w.add_entry('after finalize')
+        w.close()
+        assert open(multi, 'rb').read() == open(single + '2', 'rb').read(), (limit, devices)
+        oracle.use_reference_sa(True if oracle.have_reference() else False)
+        ow = oracle.OracleWriter(orc, limit)
+        fill(ow)
+        ow.close()
+        oracle.use_reference_sa(False)
+        assert open(single, 'rb').read() == open(orc, 'rb').read(), limit
+    with pysubstringsearch.Reader(multi) as r:
+        assert r.num_chunks >= 4 and r.search('after finalize') == ['after finalize']
+    with pytest.raises(ValueError):
+        pysubstringsearch.Writer(multi, devices=[])
+    with pytest.raises(ValueError):
+        pysubstringsearch.Writer(multi, device=0, devices=[0])
+
+
+def test_writer_failure_is_sticky(tmp_path):
+    """A record that cannot be written (here: /dev/full) fails every later dump / finalize / close, and
+    nothing is appended after the broken record."""
+    if not os.path.exists('/dev/full'):
+        pytest.skip('no /dev/full')
+    w = pysubstringsearch.Writer('/dev/full', 64)
+    for i in range(40):
+        try:
+            w.add_entry('entry %03d of the failing writer' % i)
+        except OSError:
+            break
+    with pytest.raises(OSError):
+        w.finalize()
+    with pytest.raises(OSError):
+        w.finalize()                                       # reported again, not swallowed after the first time
+    with pytest.raises(OSError):
+        w.close()
