@@ -87,6 +87,16 @@ typedef struct pss_sa_stats {
     double fs_ms[9];
     uint64_t fs_launches[9];
     uint64_t fs_elems[9];
+    /* initial sort taken by the hybrid MSD path (two global 10-bit partition passes over 8-byte
+     * [key | index] elements, then every joint bucket sorted in LDS): 1 when it ran */
+    uint64_t msd;
+    uint64_t msd_buckets;      /* non-empty joint (20-bit) buckets; filled whenever the path was tried */
+    uint64_t msd_max_bucket;   /* largest of them (the path declines above 4096) */
+    uint64_t msd_tiles;        /* local-sort workgroups */
+    double msd_ms_g1;          /* profile mode: partition scatter from the text (1 B in, 8 B out per suffix) */
+    double msd_ms_g2;          /* ... second partition scatter (8 B in, 8 B out) */
+    double msd_ms_local;       /* ... local sort (8 B in, 4 B out, sequential) */
+    uint64_t msd_slow_tiles;   /* tiles with crowded bins that took the general local-sort kernel */
 } pss_sa_stats;
 
 /*

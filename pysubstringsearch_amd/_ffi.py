@@ -40,6 +40,14 @@ class SaStats(ctypes.Structure):
         ('fs_ms', ctypes.c_double * 9),
         ('fs_launches', ctypes.c_uint64 * 9),
         ('fs_elems', ctypes.c_uint64 * 9),
+        ('msd', ctypes.c_uint64),
+        ('msd_buckets', ctypes.c_uint64),
+        ('msd_max_bucket', ctypes.c_uint64),
+        ('msd_tiles', ctypes.c_uint64),
+        ('msd_ms_g1', ctypes.c_double),
+        ('msd_ms_g2', ctypes.c_double),
+        ('msd_ms_local', ctypes.c_double),
+        ('msd_slow_tiles', ctypes.c_uint64),
     ]
 
     def as_dict(self):

@@ -1,0 +1,29 @@
+// msd_sort.h -- initial suffix sort as a hybrid MSD radix sort (see msd_sort.hip).
+#pragma once
+#include "common.h"
+#include "radix_sort.h"
+
+namespace pss {
+
+struct MsdStats {
+    uint32_t buckets = 0;      // non-empty joint (20-bit) buckets
+    uint32_t max_bucket = 0;   // largest of them
+    uint32_t tiles = 0;        // local-sort workgroups
+    uint32_t slow_tiles = 0;   // of them, tiles the counting kernel handed to the general (ballot LSD) kernel
+    double ms_g1 = 0, ms_g2 = 0, ms_local = 0;   // profile mode: the two partition scatters and the local sort
+};
+
+// Bytes of workspace msd_suffix_sort needs besides the two 8 n-byte element buffers.
+size_t msd_workspace_bytes(uint32_t n);
+// Largest key width (bits of packed key >> drop) the 8-byte elements can carry for n suffixes.
+int msd_max_key_bits(uint32_t n);
+
+// Same contract as suffix_sort_flags: sa_out[i] = index of the i-th smallest suffix by the low key_bits
+// of (packed text key >> text->drop), bit 31 = "same key as my predecessor".  The order among equal
+// keys is unspecified (suffix_sort_flags leaves them by index; nothing downstream relies on that).
+// *accepted = false (and sa_out untouched) when some joint bucket exceeds what a workgroup sorts in
+// LDS: the caller then uses suffix_sort_flags.  h_small: >= 32 bytes of pinned host memory.
+int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bits, uint64_t *A[2], uint32_t *sa_out,
+                    void *work, uint32_t *h_small, bool profile, MsdStats *stats, bool *accepted);
+
+}  // namespace pss

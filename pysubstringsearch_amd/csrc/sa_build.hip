@@ -36,6 +36,7 @@
 // flags are ballot masks, head positions come from msb(mask), compaction
 // offsets from v_mbcnt.
 #include "prims.h"
+#include "msd_sort.h"
 #include "radix_sort.h"
 #include "sa_build.h"
 #include "scan.h"
@@ -901,12 +902,17 @@ __global__ __launch_bounds__(256) void sample_keys_kernel(const u8 *codes, u32 n
     vals[t] = t;
 }
 
-__global__ __launch_bounds__(256) void sample_ties_kernel(const u64 *keys, u32 S, u32 *tied /* [8]: W = 8, 16, .. 64 */)
+// tied[8]: sample members whose 48th successor still shares their top 20 key bits -- a joint bucket of the
+// MSD path (msd_sort.hip) with >= 49 of the S sample members holds about 49 n / S suffixes, far beyond
+// what a workgroup sorts in LDS: any such member rules that path out before it starts.
+constexpr u32 kMsdScreenRun = 48;
+__global__ __launch_bounds__(256) void sample_ties_kernel(const u64 *keys, u32 S, u32 *tied /* [8]: W = 8, 16, .. 64; [8] screen */)
 {
     __shared__ u32 s_c[8];
     if (threadIdx.x < 8) s_c[threadIdx.x] = 0;
     __syncthreads();
     u32 c[8] = {};
+    u32 crowded = 0;
     for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < S; t += gridDim.x * blockDim.x) {
         const u64 k = keys[t];
         const u64 dp = t > 0 ? (keys[t - 1] ^ k) : ~0ull, dn = t + 1 < S ? (keys[t + 1] ^ k) : ~0ull;
@@ -914,7 +920,9 @@ __global__ __launch_bounds__(256) void sample_ties_kernel(const u64 *keys, u32 S
         const int lz = max(dp ? __builtin_clzll(dp) : 64, dn ? __builtin_clzll(dn) : 64);
 #pragma unroll
         for (int w = 0; w < 8; ++w) c[w] += lz >= 8 * (w + 1) ? 1u : 0u;
+        if (t + kMsdScreenRun < S && ((keys[t + kMsdScreenRun] ^ k) >> 44) == 0) ++crowded;
     }
+    if (crowded) atomicAdd(&tied[8], crowded);
 #pragma unroll
     for (int w = 0; w < 8; ++w)
         if (c[w]) atomicAdd(&s_c[w], c[w]);
@@ -974,6 +982,7 @@ struct Knobs {
     bool no_flags = false;      // PSS_NO_TIES_PASS  plain 8-byte-key passes + key comparison in the rerank
     int mode = -1;              // PSS_MODE       dense / sparse / text tie resolution (-1 = choose)
     int text_rounds_max = 5;    // PSS_TEXT_ROUNDS
+    int msd = -1;               // PSS_MSD        0: never the MSD initial sort, 1: whenever the key fits, unset: screened
     bool timing = false;        // PSS_TIMING     per-round trace on stderr
     static Knobs read()
     {
@@ -988,6 +997,7 @@ struct Knobs {
             else if (!strcmp(e, "text")) k.mode = 2;
         }
         if (const char *e = getenv("PSS_TEXT_ROUNDS")) k.text_rounds_max = atoi(e);
+        if (const char *e = getenv("PSS_MSD")) k.msd = atoi(e);
         k.timing = getenv("PSS_TIMING") != nullptr;
         return k;
     }
@@ -1007,12 +1017,12 @@ struct BuildTimer {
 // that leave <= 2 % of the suffixes tied, else the full kmax symbols.  K / V are free scratch.
 static int size_initial_key(DeviceCtx *ctx, const u8 *codes, u32 n, int b, int kmax, int plus_one, u64 *K[2], u32 *V[2],
                             void *work, u32 *d_tied, u32 *h_small, bool profile, SortStats *ss, int *key_chars,
-                            int *key_drop)
+                            int *key_drop, bool *msd_screen_ok)
 {
     hipStream_t s = ctx->stream;
     const u32 S = 1u << 21;
     const int bits_max = kmax * b, pmax = (bits_max + 7) / 8;
-    PSS_HIP(hipMemsetAsync(d_tied, 0, 32, s));
+    PSS_HIP(hipMemsetAsync(d_tied, 0, 64, s));
     hipLaunchKernelGGL(sample_keys_kernel, dim3(S / 256), dim3(256), 0, s, codes, n, S, b, kmax, plus_one, K[0], V[0]);
     u32 mask = 0;
     for (int p = 0; p < 8; ++p)
@@ -1023,8 +1033,9 @@ static int size_initial_key(DeviceCtx *ctx, const u8 *codes, u32 n, int b, int k
     ss->launches = launches;   // not passes of the suffix sort (their profile figures stay in: same kernel, same stream)
     ss->elems = elems;
     hipLaunchKernelGGL(sample_ties_kernel, dim3(256), dim3(256), 0, s, K[sd], S, d_tied);
-    PSS_HIP(hipMemcpyAsync(h_small, d_tied, 32, hipMemcpyDeviceToHost, s));
+    PSS_HIP(hipMemcpyAsync(h_small, d_tied, 64, hipMemcpyDeviceToHost, s));
     PSS_HIP(hipStreamSynchronize(s));
+    *msd_screen_ok = h_small[8] == 0;
     *key_chars = kmax;
     *key_drop = 0;
     for (int p = 2; p < pmax; ++p) {
@@ -1066,7 +1077,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     PSS_TRY(ctx->slot[S_V0].reserve((size_t)n * 4));
     PSS_TRY(ctx->slot[S_V1].reserve((size_t)n * 4));
     PSS_TRY(ctx->slot[S_ISA].reserve((size_t)n * 4 + 64));
-    PSS_TRY(ctx->slot[S_P0].reserve((size_t)n * 4));
+    PSS_TRY(ctx->slot[S_P0].reserve(std::max((size_t)n * 4, msd_workspace_bytes(n))));   // also the tables of the MSD sort
     PSS_TRY(ctx->slot[S_P1].reserve((size_t)n * 4));
     PSS_TRY(ctx->slot[S_GRP].reserve((size_t)n * 4));
     const size_t sort_ws = radix_sort_workspace_bytes();
@@ -1127,10 +1138,12 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     // ---- 1. initial sort on the first key_chars symbols ----
     SortStats ss;
     int key_drop = 0;
+    bool msd_screen_ok = false, sampled = false;
     if (n >= (1u << 24) && !forced_chars && knobs.key_chars == 0 && !knobs.no_sample) {
         PSS_TRY(size_initial_key(ctx, codes, n, b, kmax, plus_one, K, V, work, d_counters + 16, h_small, profile, &ss,
-                                 &key_chars, &key_drop));
+                                 &key_chars, &key_drop, &msd_screen_ok));
         st.key_chars = (u32)key_chars;
+        sampled = true;
     }
     if (knobs.key_drop >= 0 && knobs.key_drop < b && key_chars > 1) key_drop = knobs.key_drop;
     TextKeys tk{codes, b, key_chars, plus_one, key_drop};
@@ -1149,7 +1162,44 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     // the last pass writes only the suffix indices with bit 31 = "tied with my predecessor", and
     // the rerank reads 4-byte flagged values instead of comparing 8-byte keys.
     const bool ties = passes0 >= 2 && !knobs.no_flags;
-    if (ties) PSS_TRY(suffix_sort_flags(ctx, K, V, n, key_bits0, &tk, work, &cur, profile, &ss));
+    // Hybrid MSD sort (msd_sort.hip): two global partition passes over 8-byte elements, then every joint
+    // bucket sorted in LDS.  Taken when the key the sizing asked for (<= 48 bits) is covered by what an
+    // element can carry, and the sorted sample shows no crowded 20-bit prefix; the exact bucket check
+    // inside can still decline, then the LSD passes run as before.
+    bool msd_done = false;
+    if (ties && knobs.msd != 0) {
+        int kb = std::min(msd_max_key_bits(n), 42);
+        const int kc = std::min(kb / b, kmax);                   // whole symbols only
+        kb = kc * b;
+        const bool fits = kc >= 1 && kb >= 21 && !plus_one;
+        const bool auto_ok = sampled && msd_screen_ok && key_bits0 <= 48 && kb + 8 >= key_bits0;
+        if (fits && (knobs.msd == 1 || (knobs.msd < 0 && auto_ok))) {
+            TextKeys mk{codes, b, kc, plus_one, 0};
+            MsdStats ms;
+            bool accepted = false;
+            PSS_TRY(msd_suffix_sort(ctx, &mk, n, kb, K, SA, ctx->slot[S_P0].p, h_small, profile, &ms, &accepted));
+            st.msd_buckets = ms.buckets;
+            st.msd_max_bucket = ms.max_bucket;
+            if (accepted) {
+                msd_done = true;
+                key_chars = kc;
+                key_drop = 0;
+                st.key_chars = (u32)kc;
+                st.key_bits = (u64)kb;
+                st.msd = 1;
+                st.msd_tiles = ms.tiles;
+                st.msd_slow_tiles = ms.slow_tiles;
+                st.msd_ms_g1 = ms.ms_g1;
+                st.msd_ms_g2 = ms.ms_g2;
+                st.msd_ms_local = ms.ms_local;
+                cur = final_buf;                                 // V[final_buf] is the caller's SA buffer
+                ss.launches = 3;
+                ss.elems = 3ull * n;
+            }
+        }
+    }
+    if (msd_done) {
+    } else if (ties) PSS_TRY(suffix_sort_flags(ctx, K, V, n, key_bits0, &tk, work, &cur, profile, &ss));
     else PSS_TRY(radix_sort_pairs(ctx, K, V, n, key_bits0, 0xffffffffu, &tk, 0, work, &cur, profile, &ss));
     st.initial_passes = (u32)ss.launches;
     const bool sa_in_place = (cur == final_buf);

@@ -160,3 +160,82 @@ def test_radix_sort_pairs_stable(n, bits):
     assert (dk.cpu().numpy().view(np.uint64) == keys[order]).all()
     if n > 8192:                                             # the one-tile bitonic path is not stable by design
         assert (dv.cpu().numpy().view(np.uint32) == vals[order]).all()
+
+
+# ---- hybrid MSD initial sort (msd_sort.hip) ----
+
+def _sa_device(host, stats=None):
+    import ctypes
+    import torch
+    from pysubstringsearch_amd import _ffi
+    n = host.size
+    dT = torch.from_numpy(host).cuda()
+    dSA = torch.empty(n, dtype=torch.int32, device='cuda')
+    st = _ffi.SaStats()
+    _ffi.check(_ffi.lib.pss_sa_build_device(dT.data_ptr(), dSA.data_ptr(), n, 0, 0, ctypes.byref(st)))
+    if stats is not None:
+        stats.update(st.as_dict())
+    return dSA.cpu().numpy()
+
+
+@pytest.mark.parametrize('slow_local', [False, True])
+def test_msd_initial_sort_forced_matches_libsais(oracle, monkeypatch, slow_local):
+    """PSS_MSD=1 takes the hybrid MSD initial sort (two 10-bit partition passes over 8-byte elements +
+    LDS-resident local sort) whenever the key fits; sizes around the tile (8192) and range boundaries,
+    alphabets from 2 symbols to all 256 byte values, with and without the general local-sort kernel.
+    The suffix array is unique, so every path must reproduce libsais' bytes."""
+    monkeypatch.setenv('PSS_MSD', '1')
+    if slow_local:
+        monkeypatch.setenv('PSS_MSD_SLOW_LOCAL', '1')
+    rng = np.random.default_rng(7)
+    took = 0
+    for n in (2, 3, 17, 100, 4095, 4097, 8191, 8192, 8193, 20000, 70001, 131072, 131073, 300000, (1 << 20) + 5, (1 << 21) + 77):
+        for alpha in (2, 3, 4, 16, 39, 100, 256):
+            if n > 300000 and alpha not in (4, 39, 256):
+                continue
+            t = rng.integers(0, alpha, n).astype(np.uint8)
+            if alpha < 200:
+                t += 40
+            if rng.random() < 0.4:
+                t[rng.integers(0, n, max(1, n // 50))] = 10
+            st = {}
+            sa = _sa_device(t, st)
+            took += int(st['msd'])
+            assert np.array_equal(sa, oracle.sa(t)), (n, alpha, st['msd'])
+    assert took > 40        # the path really ran (it declines only when a key or a bucket does not fit)
+
+
+def test_msd_crowded_bins_and_oversized_buckets(oracle, monkeypatch):
+    """Inputs the fast local kernel must hand over or the whole path must decline: thousands of equal
+    lines (every joint bucket one crowded bin: the general local kernel takes those tiles), and a text
+    whose 20-bit prefixes are so skewed that a bucket exceeds a tile (the LSD passes run instead)."""
+    monkeypatch.setenv('PSS_MSD', '1')
+    rng = np.random.default_rng(11)
+    line = bytes(rng.integers(97, 123, 200).astype(np.uint8)) + b'\n'
+    t = np.frombuffer(line * 3000, dtype=np.uint8).copy()              # 3000 copies: buckets of <= 3000 equal keys
+    st = {}
+    sa = _sa_device(t, st)
+    assert np.array_equal(sa, oracle.sa(t))
+    assert st['msd'] == 1 and st['msd_slow_tiles'] > 0
+    mix = np.concatenate([rng.integers(97, 123, 1 << 20).astype(np.uint8), np.full(1 << 18, 97, np.uint8),
+                          rng.integers(97, 123, 1 << 18).astype(np.uint8)])
+    st = {}
+    sa = _sa_device(mix, st)
+    assert np.array_equal(sa, oracle.sa(mix))
+    assert st['msd'] == 0 and st['msd_max_bucket'] > 4096               # declined after the exact bucket count
+
+
+def test_msd_is_chosen_for_high_entropy_text_only(oracle):
+    """Without the switch the sorted key sample decides: the `lines` corpus (uniform symbols) takes the
+    MSD path at 2^24, natural-text-like `words` (crowded prefixes) keeps the LSD passes."""
+    from tests.util import gen_corpus
+    st = {}
+    t = gen_corpus(0, 1 << 24)
+    sa = _sa_device(t, st)
+    assert st['msd'] == 1 and st['msd_max_bucket'] <= 4096 and st['msd_slow_tiles'] == 0
+    assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(t).tobytes()).hexdigest()
+    st = {}
+    t = gen_corpus(1, 1 << 24)
+    sa = _sa_device(t, st)
+    assert st['msd'] == 0
+    assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(t).tobytes()).hexdigest()
