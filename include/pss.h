@@ -91,7 +91,7 @@ typedef struct pss_sa_stats {
      * [key | index] elements, then every joint bucket sorted in LDS): 1 when it ran */
     uint64_t msd;
     uint64_t msd_buckets;      /* non-empty joint (20-bit) buckets; filled whenever the path was tried */
-    uint64_t msd_max_bucket;   /* largest of them (the path declines above 4096) */
+    uint64_t msd_max_bucket;   /* largest of them (the path declines above 4088) */
     uint64_t msd_tiles;        /* local-sort workgroups */
     double msd_ms_g1;          /* profile mode: partition scatter from the text (1 B in, 8 B out per suffix) */
     double msd_ms_g2;          /* ... second partition scatter (8 B in, 8 B out) */

@@ -13,6 +13,16 @@ struct MsdStats {
     double ms_g1 = 0, ms_g2 = 0, ms_local = 0;   // profile mode: the two partition scatters and the local sort
 };
 
+// Optional fusion of the first rerank: instead of flagging ties in bit 31 of sa_out (left clean), the
+// local sort emits the active list itself -- for every suffix that is tied with a neighbour its SA slot,
+// its index and 1 + the slot of its group's head, in slot order -- which is exactly what rr_apply_tied
+// would compute from the flags with two more passes over the 4 n-byte array.
+struct MsdActive {
+    uint32_t *pos, *idx, *grp;               // the list (capacity n each)
+    uint32_t *st_pos, *st_idx;               // staging of the same size (per-tile blocks before they are lined up)
+    uint32_t count = 0;                      // out: entries in the list
+};
+
 // Bytes of workspace msd_suffix_sort needs besides the two 8 n-byte element buffers.
 size_t msd_workspace_bytes(uint32_t n);
 // Largest key width (bits of packed key >> drop) the 8-byte elements can carry for n suffixes.
@@ -24,6 +34,6 @@ int msd_max_key_bits(uint32_t n);
 // *accepted = false (and sa_out untouched) when some joint bucket exceeds what a workgroup sorts in
 // LDS: the caller then uses suffix_sort_flags.  h_small: >= 32 bytes of pinned host memory.
 int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bits, uint64_t *A[2], uint32_t *sa_out,
-                    void *work, uint32_t *h_small, bool profile, MsdStats *stats, bool *accepted);
+                    void *work, uint32_t *h_small, bool profile, MsdStats *stats, bool *accepted, MsdActive *active = nullptr);
 
 }  // namespace pss

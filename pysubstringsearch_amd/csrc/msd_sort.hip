@@ -47,7 +47,8 @@ constexpr int MSD_WAVES = MSD_BLOCK / kWave;
 constexpr int MSD_IPT = 16;
 constexpr u32 MSD_TILE = MSD_BLOCK * MSD_IPT;        // 8192 elements
 constexpr u32 MSD_CAPH = 4096;                       // buckets whose start falls into one window of this size share a tile
-constexpr u32 MSD_MAX_BUCKET = 4096;                 // => a tile holds < CAPH + MAX_BUCKET = 8192 elements
+constexpr u32 MSD_MAX_BUCKET = 4088;                 // => a tile holds <= CAPH - 1 + MAX_BUCKET = 8183 elements (the last eight
+                                                     //    slots of the LDS tile carry the fast kernel's scalars)
 constexpr u32 MSD_TILE_BUCKETS = 1024;               // and at most this many buckets (10 bits of the LDS sort key)
 constexpr u32 MSD_G1_RANGES = 1024;
 constexpr u32 MSD_G2_RANGE = 16 * MSD_TILE;          // elements per G2 range (a piece of one G1 bucket)
@@ -299,6 +300,119 @@ __global__ __launch_bounds__(256) void msd_tiles_kernel(const u32 *cstart, u32 n
     }
 }
 
+struct MsdTile {
+    u32 e0, count, k0, nb;      // first element, elements, first compacted bucket, buckets
+};
+
+// ---- output of a sorted tile ------------------------------------------------------------------------
+
+// Where the still-tied suffixes go when the caller wants the active list of the first rerank straight
+// from the local sort (instead of re-reading 4 n bytes of flagged suffix array twice).  Ties are rare on
+// the texts this path takes (a handful per tile), so the sorting workgroup only drops a record per tied
+// element -- SA slot and suffix, bit 31 of the suffix word = "tied with my predecessor" -- into the
+// tile's block of the staging arrays, in whatever order the lanes get there (one LDS atomic each; the
+// block starts at the tile's own first SA slot: no allocation, no overlap).  msd_gather_kernel then
+// orders every block by slot with a bitmap, derives the group heads and packs the blocks in tile order.
+struct MsdEmit {
+    u32 *st_pos, *st_idx;            // staging (capacity n each)
+    u32 *blk_cnt;                    // [tiles] records of every tile
+};
+
+// exch[0 .. count) is the sorted tile (position p <-> thread p % 512, row p / 512).  Writes the suffix
+// indices to sa_out[e0 ..]; without `em` bit 31 marks "same key as my predecessor" (the contract of
+// suffix_sort_flags), with it the array is written clean and a record goes out for every element that
+// is tied with a neighbour (it or its successor carries the flag; a tile starts at a bucket boundary,
+// so groups never cross tiles).  s_count: one zeroed word of LDS; the caller's next barrier publishes it.
+__device__ __forceinline__ void msd_emit_tile(const u64 *exch, u32 count, u32 e0, int idx_bits, u32 *sa_out, const MsdEmit *em,
+                                              u32 *s_count)
+{
+    const u32 tid = threadIdx.x, lane = tid & 63u;
+    const u32 imask = (u32)((1ull << idx_bits) - 1ull);
+    const u32 rows = (count + MSD_BLOCK - 1) / MSD_BLOCK;
+#pragma unroll 1
+    for (u32 r = 0; r < rows; ++r) {
+        const u32 p = r * MSD_BLOCK + tid;
+        const bool valid = p < count;
+        u64 x = 0;
+        bool tie = false;
+        if (valid) {
+            x = exch[p];
+            tie = p > 0 && (exch[p - 1] >> idx_bits) == (x >> idx_bits);
+            sa_out[e0 + p] = ((u32)x & imask) | ((tie && em == nullptr) ? 0x80000000u : 0u);
+        }
+        if (em != nullptr) {
+            const u64 tm = __ballot(tie);
+            // my successor's flag: the next lane's, or (lane 63) one more look into LDS
+            const bool tie_next = lane < 63 ? ((tm >> (lane + 1)) & 1ull) != 0
+                                            : (p + 1 < count && (exch[p + 1] >> idx_bits) == (x >> idx_bits));
+            if (valid && (tie || tie_next)) {
+                const u32 slot = e0 + atomicAdd(s_count, 1u);
+                em->st_pos[slot] = e0 + p;
+                em->st_idx[slot] = ((u32)x & imask) | (tie ? 0x80000000u : 0u);
+            }
+        }
+    }
+}
+
+struct InBlkCnt {
+    const u32 *c;
+    __device__ u64 operator()(u64 t) const { return c[t]; }
+};
+
+// One wavefront per tile: the tile's records (unordered) -> the active list of the first rerank in slot
+// order: (SA slot, suffix, 1 + SA slot of the group's head).  A bitmap of the tile's occupied slots ranks
+// a record by the bits below its slot; a second bitmap of the untied ones (group heads -- the head of a
+// tied element is itself active, so it has a record) gives its head as the nearest set bit at or below.
+// O(records) whatever the tile looks like.
+constexpr u32 GA_WORDS = MSD_TILE / 32;      // 256 words per bitmap
+__global__ __launch_bounds__(256) void msd_gather_kernel(const MsdTile *tiles, const u32 *blk_cnt, const u64 *dst_off, u32 nt,
+                                                           const u32 *st_pos, const u32 *st_idx, u32 *pos, u32 *idx, u32 *grp)
+{
+    __shared__ u32 s_occ[4][GA_WORDS], s_head[4][GA_WORDS], s_pre[4][GA_WORDS];
+    const u32 w = wave_id(), lane = lane_id();
+    const u32 t = blockIdx.x * 4 + w;
+    if (t >= nt) return;
+    const u32 c = blk_cnt[t];
+    if (c == 0) return;
+    const u32 e0 = tiles[t].e0;
+    const u64 d = dst_off[t];
+    u32 *occ = s_occ[w], *head = s_head[w], *pre = s_pre[w];
+    for (u32 i = lane; i < GA_WORDS; i += kWave) occ[i] = head[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (u32 i = lane; i < c; i += kWave) {
+        const u32 q = st_pos[e0 + i] - e0;
+        atomicOr(&occ[q >> 5], 1u << (q & 31u));
+        if (!(st_idx[e0 + i] >> 31)) atomicOr(&head[q >> 5], 1u << (q & 31u));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {   // exclusive prefix of the popcounts: four consecutive words per lane
+        const u32 c0 = __popc(occ[4 * lane]), c1 = __popc(occ[4 * lane + 1]), c2 = __popc(occ[4 * lane + 2]),
+                  c3 = __popc(occ[4 * lane + 3]);
+        const u32 ex = wave_incl_sum(c0 + c1 + c2 + c3) - (c0 + c1 + c2 + c3);
+        pre[4 * lane] = ex;
+        pre[4 * lane + 1] = ex + c0;
+        pre[4 * lane + 2] = ex + c0 + c1;
+        pre[4 * lane + 3] = ex + c0 + c1 + c2;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (u32 i = lane; i < c; i += kWave) {
+        const u32 ps = st_pos[e0 + i], q = ps - e0;
+        const u32 below = (q & 31u) ? (occ[q >> 5] & ((1u << (q & 31u)) - 1u)) : 0u;
+        const u32 rank = pre[q >> 5] + __popc(below);
+        // nearest head at or below q (exists: the first element of a group is never flagged)
+        u32 wi = q >> 5;
+        u32 m = head[wi] & ((q & 31u) == 31u ? ~0u : ((2u << (q & 31u)) - 1u));
+        while (m == 0 && wi > 0) m = head[--wi];
+        const u32 hq = wi * 32 + (31u - (u32)__builtin_clz(m | 1u));
+        pos[d + rank] = ps;
+        idx[d + rank] = st_idx[e0 + i] & 0x7fffffffu;
+        grp[d + rank] = e0 + hq + 1;
+    }
+}
+
 // ---- local sort --------------------------------------------------------------------------------
 
 // One workgroup per tile: <= 8192 elements of <= 1024 consecutive joint buckets.  Sort key in LDS:
@@ -307,8 +421,9 @@ __global__ __launch_bounds__(256) void msd_tiles_kernel(const u32 *cstart, u32 n
 // This is the general (slower) form: it takes whatever the fast kernel below hands back.
 __global__ __launch_bounds__(MSD_BLOCK) void msd_local_sort_kernel(const u64 *in, const u32 *cstart, const u32 *tile_first,
                                                                      u32 ne, u32 n, int rem_bits, int idx_bits, u32 *sa_out,
-                                                                     const u32 *tile_list)
+                                                                     const u32 *tile_list, int fused, MsdEmit em_val)
 {
+    const MsdEmit *em = fused ? &em_val : nullptr;
     __shared__ __attribute__((aligned(16))) u64 exch[MSD_TILE];
     __shared__ u32 wave_hist[MSD_WAVES][256];
     __shared__ u32 s_bstart[MSD_TILE_BUCKETS + 1];
@@ -406,17 +521,11 @@ __global__ __launch_bounds__(MSD_BLOCK) void msd_local_sort_kernel(const u64 *in
         for (int r = 0; r < MSD_IPT; ++r) exch[wave * (kWave * MSD_IPT) + r * kWave + lane] = key[r];
         __syncthreads();
     }
-    // sequential output; bit 31 = same (bucket, key) as my predecessor
-    const u32 imask = (u32)((1ull << idx_bits) - 1ull);
-#pragma unroll
-    for (int k = 0; k < MSD_IPT; ++k) {
-        const u32 p = k * MSD_BLOCK + tid;
-        if (p < count) {
-            const u64 e = exch[p];
-            const bool tie = p > 0 && (exch[p - 1] >> idx_bits) == (e >> idx_bits);
-            sa_out[e0 + p] = ((u32)e & imask) | (tie ? 0x80000000u : 0u);
-        }
-    }
+    if (tid == 0) scr[0] = 0;
+    __syncthreads();
+    msd_emit_tile(exch, count, e0, idx_bits, sa_out, em, &scr[0]);
+    __syncthreads();
+    if (em && tid == 0) em->blk_cnt[t] = scr[0];
 }
 
 
@@ -430,117 +539,181 @@ constexpr int LS_BIN_BITS = 11;
 constexpr u32 LS_BINS = 1u << LS_BIN_BITS;
 constexpr u32 LS_KMAX = 64;
 
-__global__ __launch_bounds__(MSD_BLOCK) void msd_local_fast_kernel(const u64 *in, const u32 *cstart, const u32 *tile_first,
-                                                                     u32 ne, u32 n, int rem_bits, int idx_bits, u32 *sa_out,
-                                                                     u32 *fail_list, u32 *fail_count)
+__global__ __launch_bounds__(256) void msd_tile_desc_kernel(const u32 *cstart, const u32 *tile_first, u32 nt, u32 ne, u32 n,
+                                                              MsdTile *tiles)
 {
-    __shared__ __attribute__((aligned(16))) u64 exch[MSD_TILE];
-    __shared__ u32 hist[LS_BINS + 4];
-    __shared__ u32 s_bstart[MSD_TILE_BUCKETS + 1];
-    __shared__ u32 scr[MSD_WAVES + 1];
-    __shared__ u32 s_fail;
-    const u32 tid = threadIdx.x;
-    const u32 t = blockIdx.x;
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
     const u32 k0 = tile_first[t], k1 = tile_first[t + 1];
-    const u32 nb = k1 - k0;
-    const u32 e0 = cstart[k0];
-    const u32 e1 = k1 < ne ? cstart[k1] : n;
-    const u32 count = e1 - e0;
-    for (u32 i = tid; i <= nb; i += MSD_BLOCK) s_bstart[i] = (k0 + i < ne) ? cstart[k0 + i] : n;
-    for (u32 i = tid; i < LS_BINS + 4; i += MSD_BLOCK) hist[i] = 0;
-    if (tid == 0) s_fail = 0;
-    __syncthreads();
-    int seg_bits = 0;
-    while ((1u << seg_bits) < nb) ++seg_bits;
-    const int sort_bits = rem_bits + seg_bits;
-    const int bin_shift = idx_bits + (sort_bits > LS_BIN_BITS ? sort_bits - LS_BIN_BITS : 0);
+    const u32 e0 = cstart[k0], e1 = k1 < ne ? cstart[k1] : n;
+    tiles[t] = MsdTile{e0, e1 - e0, k0, k1 - k0};
+}
+
+// Workgroup barrier that waits for this wave's LDS traffic only: global loads issued before it (the
+// prefetch of the next tile) stay in flight across it.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// A tile lives ~3 us, and what it needs first -- its descriptor, then the starts of its buckets and its
+// elements -- are dependent trips to HBM of ~1 us each: one workgroup per tile leaves the CU waiting for
+// memory most of the time.  The workgroups therefore persist (two per CU) and walk over the tiles with the
+// loads one tile ahead: descriptor two tiles ahead, bucket starts and elements of the next tile issued as
+// soon as the registers of the current one are free, landing while the current tile is being sorted.
+__global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 *in, const u32 *cstart, const MsdTile *tiles,
+                                                                     u32 nt, int rem_bits, int idx_bits, u32 *sa_out,
+                                                                     u32 *fail_list, u32 *fail_count, int fused, MsdEmit em_val)
+{
+    const MsdEmit *em = fused ? &em_val : nullptr;
+    // 80 KiB of LDS to the byte: two workgroups per CU
+    __shared__ __attribute__((aligned(16))) u64 exch[MSD_TILE];
+    __shared__ u32 hist[LS_BINS], hist2[LS_BINS];
+    u32 *const s_bstart = hist2;      // the bucket starts are read before the scan first writes hist2
+    u32 *const scr = reinterpret_cast<u32 *>(&exch[MSD_TILE - 8]);      // a tile never reaches these slots (MSD_MAX_BUCKET)
+    u32 &s_fail = scr[MSD_WAVES + 2];
+    const u32 tid = threadIdx.x;
+    const u32 stride = gridDim.x;
+    u32 t = blockIdx.x;
+    if (t >= nt) return;
     const u64 low_mask = (1ull << (rem_bits + idx_bits)) - 1ull;
-    const u32 rows = (count + MSD_BLOCK - 1) / MSD_BLOCK;          // uniform over the workgroup
-    u64 e[MSD_IPT];
-    u32 rk[MSD_IPT];
+    constexpr int BS_PER = (MSD_TILE_BUCKETS + MSD_BLOCK) / MSD_BLOCK;      // bucket starts per thread (3)
+
+    MsdTile cur = tiles[t];
+    MsdTile nxt = t + stride < nt ? tiles[t + stride] : MsdTile{0, 0, 0, 0};
+    u64 pe[MSD_IPT];          // prefetched raw elements of the tile about to be sorted
+    u32 pb[BS_PER];           // prefetched bucket starts (entries tid, tid + 512, ...)
+    auto prefetch = [&](const MsdTile &d) {
 #pragma unroll
-    for (int r = 0; r < MSD_IPT; ++r) {
-        if ((u32)r < rows) {
+        for (int j = 0; j < BS_PER; ++j) {
+            const u32 i = j * MSD_BLOCK + tid;
+            pb[j] = i < d.nb ? cstart[d.k0 + i] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < MSD_IPT; ++r) {
             const u32 p = r * MSD_BLOCK + tid;
+            pe[r] = p < d.count ? in[d.e0 + p] : 0ull;
+        }
+    };
+    prefetch(cur);
+    for (;;) {
+        const u32 count = cur.count, nb = cur.nb, e0 = cur.e0;
+#pragma unroll
+        for (int j = 0; j < BS_PER; ++j) {
+            const u32 i = j * MSD_BLOCK + tid;
+            if (i < nb) s_bstart[i] = pb[j];
+        }
+        for (u32 i = tid; i < LS_BINS; i += MSD_BLOCK) hist[i] = 0;
+        if (tid == 0) {
+            s_fail = 0;
+            scr[MSD_WAVES + 3] = 0;        // records this tile has emitted
+        }
+        lds_barrier();
+        int seg_bits = 0;
+        while ((1u << seg_bits) < nb) ++seg_bits;
+        const int sort_bits = rem_bits + seg_bits;
+        const int bin_shift = idx_bits + (sort_bits > LS_BIN_BITS ? sort_bits - LS_BIN_BITS : 0);
+        const u32 rows = (count + MSD_BLOCK - 1) / MSD_BLOCK;          // uniform over the workgroup
+        u64 e[MSD_IPT];
+#pragma unroll
+        for (int r = 0; r < MSD_IPT; ++r) {
             e[r] = ~0ull;
+            if ((u32)r < rows) {
+                const u32 p = r * MSD_BLOCK + tid;
+                if (p < count) {
+                    // bucket of position e0 + p: the last start <= it (bucket 0 starts at e0)
+                    u32 lo = 0, hi = nb;
+                    const u32 at = e0 + p;
+                    while (hi - lo > 1) {
+                        const u32 mid = (lo + hi) >> 1;
+                        if (s_bstart[mid] <= at) lo = mid; else hi = mid;
+                    }
+                    e[r] = ((u64)lo << (rem_bits + idx_bits)) | (pe[r] & low_mask);
+                    atomicAdd(&hist[(u32)(e[r] >> bin_shift)], 1u);          // count now; the slot is taken after the scan
+                }
+            }
+        }
+        // the raw elements are consumed: their registers take the next tile while this one is sorted
+        const bool more = t + stride < nt;
+        if (more) prefetch(nxt);
+        lds_barrier();
+        {
+            // exclusive scan over the 2048 bins in place, four adjacent bins per thread
+            const u32 c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+            const u32 sum = c0 + c1 + c2 + c3;
+            const u32 incl = wave_incl_sum(sum);
+            if (lane_id() == kWave - 1) scr[wave_id()] = incl;
+            lds_barrier();
+            u32 ex = incl - sum;
+            for (int w = 0; w < wave_id(); ++w) ex += scr[w];
+            hist[4 * tid] = hist2[4 * tid] = ex;
+            hist[4 * tid + 1] = hist2[4 * tid + 1] = ex + c0;
+            hist[4 * tid + 2] = hist2[4 * tid + 2] = ex + c0 + c1;
+            hist[4 * tid + 3] = hist2[4 * tid + 3] = ex + c0 + c1 + c2;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < MSD_IPT; ++r) {
+            if ((u32)r < rows) {
+                const u32 p = r * MSD_BLOCK + tid;
+                // (a second returning atomic on the bin's running start hands out the slot: one more LDS atomic per
+                // element, sixteen fewer registers held across the prefetch)
+                if (p < count) exch[atomicAdd(&hist2[(u32)(e[r] >> bin_shift)], 1u)] = e[r];
+            }
+        }
+        lds_barrier();
+        // place inside the bin = number of smaller elements there (thread <-> position: neighbours share the bin)
+        u32 rk[MSD_IPT];
+#pragma unroll
+        for (int r = 0; r < MSD_IPT; ++r) {
             rk[r] = 0;
-            if (p < count) {
-                const u64 x = in[e0 + p];
-                u32 lo = 0, hi = nb;
-                const u32 at = e0 + p;
-                while (hi - lo > 1) {
-                    const u32 mid = (lo + hi) >> 1;
-                    if (s_bstart[mid] <= at) lo = mid; else hi = mid;
+            if ((u32)r < rows) {
+                const u32 p = r * MSD_BLOCK + tid;
+                if (p < count) {
+                    const u64 x = exch[p];
+                    const u32 bin = (u32)(x >> bin_shift);
+                    const u32 s0 = hist[bin], s1 = bin + 1 < LS_BINS ? hist[bin + 1] : count;
+                    u32 smaller = 0;
+                    if (s1 - s0 > LS_KMAX) {
+                        s_fail = 1;
+                    } else {
+                        // four independent LDS reads per step (a read past the bin is masked out)
+                        for (u32 q = s0; q < s1; q += 4) {
+                            const u64 y0 = exch[q], y1 = exch[min(q + 1, MSD_TILE - 1)], y2 = exch[min(q + 2, MSD_TILE - 1)],
+                                      y3 = exch[min(q + 3, MSD_TILE - 1)];
+                            smaller += (y0 < x ? 1u : 0u) + ((q + 1 < s1 && y1 < x) ? 1u : 0u) +
+                                       ((q + 2 < s1 && y2 < x) ? 1u : 0u) + ((q + 3 < s1 && y3 < x) ? 1u : 0u);
+                        }
+                    }
+                    e[r] = x;
+                    rk[r] = s0 + smaller;
                 }
-                e[r] = ((u64)lo << (rem_bits + idx_bits)) | (x & low_mask);
-                rk[r] = atomicAdd(&hist[(u32)(e[r] >> bin_shift)], 1u);
             }
         }
-    }
-    __syncthreads();
-    {
-        // exclusive scan over the 2048 bins in place, four adjacent bins per thread
-        const u32 c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
-        const u32 ex = block_excl_sum<MSD_WAVES>(c0 + c1 + c2 + c3, scr, nullptr);
-        hist[4 * tid] = ex;
-        hist[4 * tid + 1] = ex + c0;
-        hist[4 * tid + 2] = ex + c0 + c1;
-        hist[4 * tid + 3] = ex + c0 + c1 + c2;
-        if (tid == 0) hist[LS_BINS] = count;
-    }
-    __syncthreads();
+        lds_barrier();
+        const bool failed = s_fail != 0;
+        if (failed) {
+            if (tid == 0) fail_list[atomicAdd(fail_count, 1u)] = t;
+        } else {
 #pragma unroll
-    for (int r = 0; r < MSD_IPT; ++r) {
-        if ((u32)r < rows) {
-            const u32 p = r * MSD_BLOCK + tid;
-            if (p < count) exch[hist[(u32)(e[r] >> bin_shift)] + rk[r]] = e[r];
-        }
-    }
-    __syncthreads();
-    // place inside the bin = number of smaller elements there (thread <-> position: neighbours share the bin)
-#pragma unroll
-    for (int r = 0; r < MSD_IPT; ++r) {
-        if ((u32)r < rows) {
-            const u32 p = r * MSD_BLOCK + tid;
-            if (p < count) {
-                const u64 x = exch[p];
-                const u32 bin = (u32)(x >> bin_shift);
-                const u32 s0 = hist[bin], s1 = hist[bin + 1];
-                u32 smaller = 0;
-                if (s1 - s0 > LS_KMAX) {
-                    s_fail = 1;
-                } else {
-                    for (u32 q = s0; q < s1; ++q) smaller += exch[q] < x ? 1u : 0u;
+            for (int r = 0; r < MSD_IPT; ++r) {
+                if ((u32)r < rows) {
+                    const u32 p = r * MSD_BLOCK + tid;
+                    if (p < count) exch[rk[r]] = e[r];
                 }
-                e[r] = x;
-                rk[r] = s0 + smaller;
             }
         }
-    }
-    __syncthreads();
-    if (s_fail) {
-        if (tid == 0) fail_list[atomicAdd(fail_count, 1u)] = t;
-        return;
-    }
-#pragma unroll
-    for (int r = 0; r < MSD_IPT; ++r) {
-        if ((u32)r < rows) {
-            const u32 p = r * MSD_BLOCK + tid;
-            if (p < count) exch[rk[r]] = e[r];
+        lds_barrier();
+        if (!failed) msd_emit_tile(exch, count, e0, idx_bits, sa_out, em, &scr[MSD_WAVES + 3]);
+        if (em) {
+            lds_barrier();
+            if (tid == 0 && !failed) em->blk_cnt[t] = scr[MSD_WAVES + 3];
         }
-    }
-    __syncthreads();
-    const u32 imask = (u32)((1ull << idx_bits) - 1ull);
-#pragma unroll
-    for (int r = 0; r < MSD_IPT; ++r) {
-        if ((u32)r < rows) {
-            const u32 p = r * MSD_BLOCK + tid;
-            if (p < count) {
-                const u64 x = exch[p];
-                const bool tie = p > 0 && (exch[p - 1] >> idx_bits) == (x >> idx_bits);
-                sa_out[e0 + p] = ((u32)x & imask) | (tie ? 0x80000000u : 0u);
-            }
-        }
+        if (!more) break;
+        t += stride;
+        cur = nxt;
+        nxt = t + stride < nt ? tiles[t + stride] : MsdTile{0, 0, 0, 0};
+        lds_barrier();          // the output has read exch / s_fail: the next tile may overwrite them
     }
 }
 
@@ -557,6 +730,7 @@ size_t msd_workspace_bytes(uint32_t n)
            + (nbk + 8) * 8                            // scan output (ranks)
            + (nbk + 8) * 4                            // compacted starts
            + ((size_t)n / MSD_CAPH + nbk / MSD_TILE_BUCKETS + 32) * 8   // tile_first, then the tiles left to the general kernel
+           + ((size_t)n / MSD_CAPH + nbk / MSD_TILE_BUCKETS + 32) * 16  // blocks of active records per tile + their final offsets
            + (SC_MAX_BLOCKS + 8) * 8 + 4096;
 }
 
@@ -568,7 +742,7 @@ int msd_max_key_bits(uint32_t n)
 }
 
 int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bits, uint64_t *A[2], uint32_t *sa_out,
-                    void *work, uint32_t *h_small, bool profile, MsdStats *stats, bool *accepted)
+                    void *work, uint32_t *h_small, bool profile, MsdStats *stats, bool *accepted, MsdActive *active)
 {
     *accepted = false;
     hipStream_t s = ctx->stream;
@@ -593,6 +767,8 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     u32 *cstart = reinterpret_cast<u32 *>(carve((nbk + 8) * 4));
     const size_t max_tiles = (size_t)n / MSD_CAPH + nbk / MSD_TILE_BUCKETS + 8;
     u32 *tile_first = reinterpret_cast<u32 *>(carve((max_tiles + 16) * 8));
+    u32 *blk_cnt = reinterpret_cast<u32 *>(carve((max_tiles + 8) * 4));
+    u64 *dst_off = reinterpret_cast<u64 *>(carve((max_tiles + 8) * 8));
     u64 *partial = reinterpret_cast<u64 *>(carve((SC_MAX_BLOCKS + 8) * 8));
     u64 *d_total = partial + SC_MAX_BLOCKS;
 
@@ -673,23 +849,39 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     PSS_HIP(hipStreamSynchronize(s));
     const u32 nt = h_small[0];
     PSS_TRY(mark());
-    // counters[4] = tiles the fast kernel declined; their numbers go behind the tile table
+    // counters[4] = tiles the fast kernel declined (their numbers go behind the tile table), [5] = active records
     u32 *fail_list = tile_first + nt + 8;
+    MsdEmit em{};
+    const int fused = active != nullptr;
+    if (fused) em = MsdEmit{active->st_pos, active->st_idx, blk_cnt};
+    const int rem_bits = key_bits - 2 * MSD_D;
+    MsdTile *tiles_all = reinterpret_cast<MsdTile *>(ranks);          // the scan output is consumed: reuse it
+    hipLaunchKernelGGL(msd_tile_desc_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, cstart, tile_first, nt, ne, n, tiles_all);
     if (getenv("PSS_MSD_SLOW_LOCAL")) {
-        hipLaunchKernelGGL(msd_local_sort_kernel, dim3(nt), dim3(MSD_BLOCK), 0, s, A[1], cstart, tile_first, ne, n,
-                           key_bits - 2 * MSD_D, ib, sa_out, (const u32 *)nullptr);
+        hipLaunchKernelGGL(msd_local_sort_kernel, dim3(nt), dim3(MSD_BLOCK), 0, s, A[1], cstart, tile_first, ne, n, rem_bits, ib,
+                           sa_out, (const u32 *)nullptr, fused, em);
     } else {
-        hipLaunchKernelGGL(msd_local_fast_kernel, dim3(nt), dim3(MSD_BLOCK), 0, s, A[1], cstart, tile_first, ne, n,
-                           key_bits - 2 * MSD_D, ib, sa_out, fail_list, counters + 4);
+        MsdTile *tiles = tiles_all;
+        const u32 grid = std::min<u32>(nt, 2u * (u32)ctx->num_cus);
+        hipLaunchKernelGGL(msd_local_fast_kernel, dim3(grid), dim3(MSD_BLOCK), 0, s, A[1], cstart, tiles, nt, rem_bits, ib, sa_out,
+                           fail_list, counters + 4, fused, em);
         PSS_HIP(hipMemcpyAsync(h_small, counters + 4, 4, hipMemcpyDeviceToHost, s));
         PSS_HIP(hipStreamSynchronize(s));
         const u32 nfail = h_small[0];
         if (stats) stats->slow_tiles = nfail;
         if (nfail)
             hipLaunchKernelGGL(msd_local_sort_kernel, dim3(nfail), dim3(MSD_BLOCK), 0, s, A[1], cstart, tile_first, ne, n,
-                               key_bits - 2 * MSD_D, ib, sa_out, (const u32 *)fail_list);
+                               rem_bits, ib, sa_out, (const u32 *)fail_list, fused, em);
     }
     PSS_TRY(mark());
+    if (fused) {
+        PSS_TRY(device_excl_scan(ctx, InBlkCnt{blk_cnt}, nt, partial, d_total, dst_off));
+        hipLaunchKernelGGL(msd_gather_kernel, dim3((nt + 3) / 4), dim3(256), 0, s, (const MsdTile *)tiles_all, blk_cnt, dst_off, nt,
+                           active->st_pos, active->st_idx, active->pos, active->idx, active->grp);
+        PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
+        PSS_HIP(hipStreamSynchronize(s));
+        active->count = h_small[0];
+    }
     PSS_HIP(hipGetLastError());
     if (stats) stats->tiles = nt;
     if (profile && nev >= 6) {

@@ -983,6 +983,7 @@ struct Knobs {
     int mode = -1;              // PSS_MODE       dense / sparse / text tie resolution (-1 = choose)
     int text_rounds_max = 5;    // PSS_TEXT_ROUNDS
     int msd = -1;               // PSS_MSD        0: never the MSD initial sort, 1: whenever the key fits, unset: screened
+    bool no_msd_fuse = false;   // PSS_MSD_NO_FUSE  MSD sort flags ties in the suffix array; the rerank kernels read them
     bool timing = false;        // PSS_TIMING     per-round trace on stderr
     static Knobs read()
     {
@@ -998,6 +999,7 @@ struct Knobs {
         }
         if (const char *e = getenv("PSS_TEXT_ROUNDS")) k.text_rounds_max = atoi(e);
         if (const char *e = getenv("PSS_MSD")) k.msd = atoi(e);
+        k.no_msd_fuse = getenv("PSS_MSD_NO_FUSE") != nullptr;
         k.timing = getenv("PSS_TIMING") != nullptr;
         return k;
     }
@@ -1166,7 +1168,8 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     // bucket sorted in LDS.  Taken when the key the sizing asked for (<= 48 bits) is covered by what an
     // element can carry, and the sorted sample shows no crowded 20-bit prefix; the exact bucket check
     // inside can still decline, then the LSD passes run as before.
-    bool msd_done = false;
+    bool msd_done = false, msd_fused = false;
+    u32 msd_active = 0;
     if (ties && knobs.msd != 0) {
         int kb = std::min(msd_max_key_bits(n), 42);
         const int kc = std::min(kb / b, kmax);                   // whole symbols only
@@ -1177,7 +1180,20 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
             TextKeys mk{codes, b, kc, plus_one, 0};
             MsdStats ms;
             bool accepted = false;
-            PSS_TRY(msd_suffix_sort(ctx, &mk, n, kb, K, SA, ctx->slot[S_P0].p, h_small, profile, &ms, &accepted));
+            // The local sort hands over the active list of the first rerank (SA slot, suffix, group rank of every
+            // suffix tied with a neighbour) in the buffers round 0 would fill: P[1], the free value buffer, G[1].
+            // Staging: the first element buffer (free once the second partition pass has read it).
+            PSS_TRY(ctx->slot[S_GRP2].reserve((size_t)n * 4));
+            MsdActive act;
+            act.pos = ctx->slot[S_P1].as<u32>();
+            act.idx = (final_buf == 0) ? V[1] : V[0];
+            act.grp = ctx->slot[S_GRP2].as<u32>();
+            act.st_pos = reinterpret_cast<u32 *>(K[0]);
+            act.st_idx = reinterpret_cast<u32 *>(K[0]) + n;
+            PSS_TRY(msd_suffix_sort(ctx, &mk, n, kb, K, SA, ctx->slot[S_P0].p, h_small, profile, &ms, &accepted,
+                                    knobs.no_msd_fuse ? nullptr : &act));
+            msd_fused = accepted && !knobs.no_msd_fuse;
+            msd_active = act.count;
             st.msd_buckets = ms.buckets;
             st.msd_max_bucket = ms.max_bucket;
             if (accepted) {
@@ -1246,7 +1262,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         ra.keys = Kr[cur];
         ra.idx = V[cur];
         ra.SA = (round == 0 && sa_in_place) ? nullptr : SA;      // round 0: the sort already wrote SA
-        ra.tied_sa = (round == 0 && ties) ? V[cur] : nullptr;
+        ra.tied_sa = (round == 0 && ties && !msd_fused) ? V[cur] : nullptr;
         ra.pos = identity_pos ? nullptr : P[pcur];
         ra.grp = (round > 0 && !keyed_grp) ? G[gcur] : nullptr;   // group-local rounds: keys do not carry the group
         ra.pos_out = P[pcur ^ 1];
@@ -1256,12 +1272,15 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
             G[1] = ctx->slot[S_GRP2].as<u32>();
         }
         ra.grp_out = G[gcur ^ 1];
-        if (ra.tied_sa) hipLaunchKernelGGL(rr_reduce_tied_kernel, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
-        else hipLaunchKernelGGL(rr_reduce_kernel, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
-        hipLaunchKernelGGL(rr_scan_kernel, dim3(1), dim3(1024), 0, s, d_agg_head, d_agg_cnt, ra.num_ranges, d_counters);
-        PSS_HIP(hipMemcpyAsync(h_small, d_counters, 4, hipMemcpyDeviceToHost, s));
-        PSS_HIP(hipStreamSynchronize(s));
-        const u32 m_next = h_small[0];
+        const bool fused0 = round == 0 && msd_fused;     // the MSD local sort already produced this round's active list
+        if (!fused0) {
+            if (ra.tied_sa) hipLaunchKernelGGL(rr_reduce_tied_kernel, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
+            else hipLaunchKernelGGL(rr_reduce_kernel, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
+            hipLaunchKernelGGL(rr_scan_kernel, dim3(1), dim3(1024), 0, s, d_agg_head, d_agg_cnt, ra.num_ranges, d_counters);
+            PSS_HIP(hipMemcpyAsync(h_small, d_counters, 4, hipMemcpyDeviceToHost, s));
+            PSS_HIP(hipStreamSynchronize(s));
+        }
+        const u32 m_next = fused0 ? msd_active : h_small[0];
         if (round == 0) {
             // few ties: sparse (hash + key search); otherwise extend the ties from the text first
             mode = ((u64)m_next * 1024 <= (u64)n) ? M_SPARSE : M_TEXT;
@@ -1271,7 +1290,12 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
             if (mode == M_TEXT && text_rounds_max <= 0) mode = M_DENSE;
             was_text = mode == M_TEXT;
         }
-        if (mode == M_DENSE) hipLaunchKernelGGL(rr_apply_kernel<MODE_ISA>, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
+        if (fused0) {
+            if (mode == M_DENSE && m_next) {      // rank rounds from the start: they need the inverse suffix array
+                hipLaunchKernelGGL(isa_from_sa_kernel, dim3(grid_all), dim3(256), 0, s, SA, n, ISA);
+                hipLaunchKernelGGL(isa_active_kernel, dim3(grid_all), dim3(256), 0, s, ra.idx_out, ra.grp_out, m_next, ISA);
+            }
+        } else if (mode == M_DENSE) hipLaunchKernelGGL(rr_apply_kernel<MODE_ISA>, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
         else if (mode == M_SPARSE && round > 0) hipLaunchKernelGGL(rr_apply_kernel<MODE_HT>, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
         else if (ra.tied_sa && ra.SA == nullptr && ra.pos == nullptr)
             hipLaunchKernelGGL(rr_apply_tied_kernel, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);

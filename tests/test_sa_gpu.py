@@ -1,5 +1,6 @@
 """GPU parity: pss_sa_build (HIP, through the C ABI) == the oracle's suffix
 array, bit for bit (libsais from oracle/_ref when built, else the restatement)."""
+import hashlib
 import random
 
 import numpy as np
@@ -222,7 +223,7 @@ def test_msd_crowded_bins_and_oversized_buckets(oracle, monkeypatch):
     st = {}
     sa = _sa_device(mix, st)
     assert np.array_equal(sa, oracle.sa(mix))
-    assert st['msd'] == 0 and st['msd_max_bucket'] > 4096               # declined after the exact bucket count
+    assert st['msd'] == 0 and st['msd_max_bucket'] > 4088               # declined after the exact bucket count
 
 
 def test_msd_is_chosen_for_high_entropy_text_only(oracle):
@@ -232,7 +233,7 @@ def test_msd_is_chosen_for_high_entropy_text_only(oracle):
     st = {}
     t = gen_corpus(0, 1 << 24)
     sa = _sa_device(t, st)
-    assert st['msd'] == 1 and st['msd_max_bucket'] <= 4096 and st['msd_slow_tiles'] == 0
+    assert st['msd'] == 1 and st['msd_max_bucket'] <= 4088 and st['msd_slow_tiles'] == 0
     assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(t).tobytes()).hexdigest()
     st = {}
     t = gen_corpus(1, 1 << 24)

@@ -14,7 +14,11 @@ def build(host):
 os.environ['PSS_MSD']='1'
 rng=np.random.default_rng(0)
 bad=0
-for trial in range(60):
+for trial in range(90):
+    for k in ('PSS_MSD_NO_FUSE','PSS_MODE','PSS_MSD_SLOW_LOCAL'): os.environ.pop(k,None)
+    if trial % 3 == 1: os.environ['PSS_MSD_NO_FUSE']='1'
+    if trial % 5 == 2: os.environ['PSS_MODE']=['dense','sparse','text'][trial % 3]
+    if trial % 7 == 3: os.environ['PSS_MSD_SLOW_LOCAL']='1' 
     n=int(rng.choice([2,3,17,100,4097,8192,8193,20000,70001,300000,1<<20,(1<<21)+77]))
     alpha=int(rng.choice([1,2,3,4,16,39,100,255]))
     t=rng.integers(0,alpha,n).astype(np.uint8)+ (0 if alpha>200 else 40)
@@ -24,6 +28,14 @@ for trial in range(60):
     ok=np.array_equal(sa,ref)
     print(trial,n,alpha,'msd',st['msd'],'maxb',st['msd_max_bucket'],'buckets',st['msd_buckets'],'tiles',st['msd_tiles'],'rounds',st['rounds'],'OK' if ok else 'FAIL',flush=True)
     bad+= (not ok)
+for k in ('PSS_MSD_NO_FUSE','PSS_MODE','PSS_MSD_SLOW_LOCAL'): os.environ.pop(k,None)
+# duplicates: big tied groups inside buckets (general local kernel + long groups in the emit)
+line=bytes(rng.integers(97,123,200).astype(np.uint8))+b'\n'
+for mode in (None,'dense'):
+    if mode: os.environ['PSS_MODE']=mode
+    t=np.frombuffer(line*3000,dtype=np.uint8).copy(); sa,st=build(t); ok=np.array_equal(sa,O.sa(t)); bad+=(not ok)
+    print('dups',mode,'msd',st['msd'],'slow',st['msd_slow_tiles'],'rounds',st['rounds'],'OK' if ok else 'FAIL')
+os.environ.pop('PSS_MODE',None)
 for kind in (0,1,2,3):
     n=1<<22
     t=np.empty(n,np.uint8); lib.pss_gen_corpus(kind,t.ctypes.data,n,0)
