@@ -144,7 +144,43 @@ __global__ __launch_bounds__(MSD_BLOCK) void msd_hist_kernel(MsdArgs a)
             if (msd_valid<FROM_TEXT>(base, valid, k, a.n)) atomicAdd(&hist[dig[k]], 1u);
     }
     __syncthreads();
-    for (u32 i = tid; i < MSD_BINS; i += MSD_BLOCK) a.T[(size_t)r * MSD_BINS + i] = hist[i];
+    // G1: digit-major (one row per digit: its offsets kernel scans rows); G2: range-major (one row per range)
+    for (u32 i = tid; i < MSD_BINS; i += MSD_BLOCK) {
+        if (FROM_TEXT) a.T[(size_t)i * a.num_ranges1 + r] = hist[i];
+        else a.T[(size_t)r * MSD_BINS + i] = hist[i];
+    }
+}
+
+// G1 offsets, step 1: one workgroup per digit turns its row of per-range counts into exclusive prefixes
+// and leaves the digit's total; step 2 (one workgroup) scans the totals into the bucket starts J1.
+__global__ __launch_bounds__(256) void msd_offsets1_kernel(u32 *T, u32 num_ranges, u32 *totals)
+{
+    __shared__ u32 scr[256 / kWave + 1];
+    const u32 d = blockIdx.x, tid = threadIdx.x;
+    u32 *row = T + (size_t)d * num_ranges;
+    u32 v[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32 r = tid * 4 + j;
+        v[j] = r < num_ranges ? row[r] : 0u;
+        sum += v[j];
+    }
+    u32 total = 0;
+    u32 run = block_excl_sum<256 / kWave>(sum, scr, &total);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32 r = tid * 4 + j;
+        if (r < num_ranges) row[r] = run;
+        run += v[j];
+    }
+    if (tid == 0) totals[d] = total;
+}
+__global__ __launch_bounds__(MSD_BINS) void msd_offsets1b_kernel(const u32 *totals, u32 *J1, u32 n)
+{
+    __shared__ u32 scr[MSD_BINS / kWave + 1];
+    const u32 d = threadIdx.x;
+    J1[d] = block_excl_sum<MSD_BINS / kWave>(totals[d], scr, nullptr);
+    if (d == 0) J1[MSD_BINS] = n;
 }
 
 // One workgroup per segment (G1: the whole input; G2: one G1 bucket), thread = digit:
@@ -209,7 +245,7 @@ __global__ __launch_bounds__(MSD_BLOCK) void msd_scatter_kernel(MsdArgs a)
     }
     for (u32 i = tid; i < MSD_BINS; i += MSD_BLOCK) {
         hist[i] = 0;
-        s_off[i] = a.T[(size_t)r * MSD_BINS + i];
+        s_off[i] = FROM_TEXT ? a.T[(size_t)i * a.num_ranges1 + r] + a.J1[i] : a.T[(size_t)r * MSD_BINS + i];
     }
     __syncthreads();
     const int shift2 = a.idx_bits + a.key_bits - 2 * MSD_D;
@@ -815,8 +851,9 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     // ---- G1: text -> A[0] by the top 10 key bits ----
     a.out = A[0];
     hipLaunchKernelGGL(msd_hist_kernel<true>, dim3(a.num_ranges1), dim3(MSD_BLOCK), 0, s, a);
-    hipLaunchKernelGGL(msd_offsets_kernel, dim3(1), dim3(MSD_BINS), 0, s, T, (const u32 *)nullptr, (const u32 *)nullptr, J1,
-                       a.num_ranges1, n, 1u);
+    static_assert(MSD_G1_RANGES <= 1024, "msd_offsets1_kernel takes four ranges per thread");
+    hipLaunchKernelGGL(msd_offsets1_kernel, dim3(MSD_BINS), dim3(256), 0, s, T, a.num_ranges1, seg_first);   // totals: scratch
+    hipLaunchKernelGGL(msd_offsets1b_kernel, dim3(1), dim3(MSD_BINS), 0, s, (const u32 *)seg_first, J1, n);
     PSS_TRY(mark());
     hipLaunchKernelGGL(msd_scatter_kernel<true>, dim3(a.num_ranges1), dim3(MSD_BLOCK), 0, s, a);
     PSS_TRY(mark());
