@@ -565,14 +565,15 @@ __global__ __launch_bounds__(MSD_BLOCK) void msd_local_sort_kernel(const u64 *in
 }
 
 
-// The fast form.  One counting pass on the top 11 bits of (bucket, key) with returning LDS atomics (no
+// The fast form.  One counting pass on the top 12 bits of (bucket, key) with returning LDS atomics (no
 // order to preserve: the whole element, index included, is the sort key, so the result is a total order
 // anyway) leaves bins of a handful of elements; every element then finds its place inside its bin by
 // counting the smaller ones -- neighbouring lanes sit in the same bin, so those LDS reads are broadcasts.
 // A tile with a bin above LS_KMAX elements (many equal or nearly equal keys) is handed to the general
 // kernel instead.
-constexpr int LS_BIN_BITS = 11;
-constexpr u32 LS_BINS = 1u << LS_BIN_BITS;
+constexpr int LS_BIN_BITS = 12;
+constexpr u32 LS_BINS = 1u << LS_BIN_BITS;          // 16-bit counters, two per LDS word (a tile has < 8192 elements)
+constexpr u32 LS_WORDS = LS_BINS / 2;
 constexpr u32 LS_KMAX = 64;
 
 __global__ __launch_bounds__(256) void msd_tile_desc_kernel(const u32 *cstart, const u32 *tile_first, u32 nt, u32 ne, u32 n,
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
     const MsdEmit *em = fused ? &em_val : nullptr;
     // 80 KiB of LDS to the byte: two workgroups per CU
     __shared__ __attribute__((aligned(16))) u64 exch[MSD_TILE];
-    __shared__ u32 hist[LS_BINS], hist2[LS_BINS];
+    __shared__ u32 hist[LS_WORDS], hist2[LS_WORDS];      // counts, then bin starts (hist) / running slots (hist2), packed
     u32 *const s_bstart = hist2;      // the bucket starts are read before the scan first writes hist2
     u32 *const scr = reinterpret_cast<u32 *>(&exch[MSD_TILE - 8]);      // a tile never reaches these slots (MSD_MAX_BUCKET)
     u32 &s_fail = scr[MSD_WAVES + 2];
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
             const u32 i = j * MSD_BLOCK + tid;
             if (i < nb) s_bstart[i] = pb[j];
         }
-        for (u32 i = tid; i < LS_BINS; i += MSD_BLOCK) hist[i] = 0;
+        for (u32 i = tid; i < LS_WORDS; i += MSD_BLOCK) hist[i] = 0;
         if (tid == 0) {
             s_fail = 0;
             scr[MSD_WAVES + 3] = 0;        // records this tile has emitted
@@ -665,7 +666,8 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
                         if (s_bstart[mid] <= at) lo = mid; else hi = mid;
                     }
                     e[r] = ((u64)lo << (rem_bits + idx_bits)) | (pe[r] & low_mask);
-                    atomicAdd(&hist[(u32)(e[r] >> bin_shift)], 1u);          // count now; the slot is taken after the scan
+                    const u32 bin = (u32)(e[r] >> bin_shift);
+                    atomicAdd(&hist[bin >> 1], 1u << (16u * (bin & 1u)));    // count now; the slot is taken after the scan
                 }
             }
         }
@@ -674,18 +676,27 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
         if (more) prefetch(nxt);
         lds_barrier();
         {
-            // exclusive scan over the 2048 bins in place, four adjacent bins per thread
-            const u32 c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
-            const u32 sum = c0 + c1 + c2 + c3;
+            // exclusive scan over the 4096 bins in place: four adjacent words = eight bins per thread
+            u32 c[8];
+            u32 sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32 wv = hist[4 * tid + j];
+                c[2 * j] = wv & 0xffffu;
+                c[2 * j + 1] = wv >> 16;
+                sum += c[2 * j] + c[2 * j + 1];
+            }
             const u32 incl = wave_incl_sum(sum);
             if (lane_id() == kWave - 1) scr[wave_id()] = incl;
             lds_barrier();
             u32 ex = incl - sum;
             for (int w = 0; w < wave_id(); ++w) ex += scr[w];
-            hist[4 * tid] = hist2[4 * tid] = ex;
-            hist[4 * tid + 1] = hist2[4 * tid + 1] = ex + c0;
-            hist[4 * tid + 2] = hist2[4 * tid + 2] = ex + c0 + c1;
-            hist[4 * tid + 3] = hist2[4 * tid + 3] = ex + c0 + c1 + c2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32 lo = ex, hi = ex + c[2 * j];
+                hist[4 * tid + j] = hist2[4 * tid + j] = lo | (hi << 16);
+                ex = hi + c[2 * j + 1];
+            }
         }
         lds_barrier();
 #pragma unroll
@@ -694,7 +705,10 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
                 const u32 p = r * MSD_BLOCK + tid;
                 // (a second returning atomic on the bin's running start hands out the slot: one more LDS atomic per
                 // element, sixteen fewer registers held across the prefetch)
-                if (p < count) exch[atomicAdd(&hist2[(u32)(e[r] >> bin_shift)], 1u)] = e[r];
+                if (p < count) {
+                    const u32 bin = (u32)(e[r] >> bin_shift), sh = 16u * (bin & 1u);
+                    exch[(atomicAdd(&hist2[bin >> 1], 1u << sh) >> sh) & 0xffffu] = e[r];
+                }
             }
         }
         lds_barrier();
@@ -708,7 +722,8 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
                 if (p < count) {
                     const u64 x = exch[p];
                     const u32 bin = (u32)(x >> bin_shift);
-                    const u32 s0 = hist[bin], s1 = bin + 1 < LS_BINS ? hist[bin + 1] : count;
+                    const u32 s0 = (hist[bin >> 1] >> (16u * (bin & 1u))) & 0xffffu;
+                    const u32 s1 = bin + 1 < LS_BINS ? ((hist[(bin + 1) >> 1] >> (16u * ((bin + 1) & 1u))) & 0xffffu) : count;
                     u32 smaller = 0;
                     if (s1 - s0 > LS_KMAX) {
                         s_fail = 1;
