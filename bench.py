@@ -390,6 +390,12 @@ def run_chunk(args, D):
                               prof['fs_elems'][idx], bpe))
         if prof['pairs_launches']:
             cands.append((prof['ms_pairs'], 'rs_scatter_kernel<false>', prof['pairs_launches'], prof['pairs_elems'], 24))
+        if prof['msd']:
+            # hybrid MSD initial sort (msd_sort.hip): partition from the text (1 B in, 8 B out per suffix), partition of
+            # the 8-byte elements (8 in, 8 out), LDS-resident local sort (8 in, 4 out)
+            cands.append((prof['msd_ms_g1'], 'msd_scatter_kernel<true>', 1, n, 9))
+            cands.append((prof['msd_ms_g2'], 'msd_scatter_kernel<false>', 1, n, 16))
+            cands.append((prof['msd_ms_local'], 'msd_local_fast_kernel', 1, n, 12))
         roof = None
         if cands:
             ms_sum, kname, launches, elems, bpe = max(cands)
@@ -422,6 +428,10 @@ def run_chunk(args, D):
             kin = kout
         a_sort += 32 * max(0, sa_stats['sort_elems'] - passes0 * n)     # (u64, u32) pair passes of the rounds
         a_model = 3 * n + 8 * n + a_sort + 80 * sa_stats['sum_active']
+        if sa_stats['msd']:
+            # MSD initial sort: (1 hist + 1 + 8) + (8 hist + 8 + 8) + (8 + 4) bytes per suffix; the first rerank is fused
+            # into the local sort (no pass over the flagged array)
+            a_model = 3 * n + 46 * n + 80 * sa_stats['sum_active']
         measured = None
         pmcb = os.path.join(ROOT, 'profiles', 'pmc_build_traffic.json')
         if os.path.exists(pmcb) and args.corpus == 'lines' and args.logn == 29:
@@ -462,7 +472,12 @@ def run_chunk(args, D):
             'entries_per_batch': last.get('entries'),
             'search_stats': last.get('search_stats'),
             'sa_stats': {k: sa_stats[k] for k in ('sigma', 'code_bits', 'key_chars', 'initial_passes', 'rounds',
-                                                  'round_passes', 'sum_active', 'sort_launches', 'mode', 'key_bits', 'ms_total')},
+                                                  'round_passes', 'sum_active', 'sort_launches', 'mode', 'key_bits', 'ms_total',
+                                                  'msd', 'msd_buckets', 'msd_max_bucket', 'msd_tiles', 'msd_slow_tiles')},
+            'initial_sort': 'hybrid MSD (2 partition passes over 8-byte [key|index] elements + LDS local sort)' if sa_stats['msd']
+                            else 'LSD passes with shrinking keys',
+            'kernel_ms': ({'msd_scatter_kernel<true>': round(prof['msd_ms_g1'], 3), 'msd_scatter_kernel<false>': round(prof['msd_ms_g2'], 3),
+                           'msd_local_fast_kernel': round(prof['msd_ms_local'], 3)} if prof['msd'] else None),
             'roofline': roof,
             'build_roofline': build_roof,
             'cpu_baseline': cpu,

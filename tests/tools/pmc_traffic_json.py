@@ -1,0 +1,44 @@
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE CSVs (separate runs, tests/tools/pmc_traffic.sh) -> profiles/pmc_traffic.json and
+profiles/pmc_build_traffic.json: HBM bytes per launch of every kernel of ONE default build of the lines 2^29 chunk.
+bytes = FETCH_SIZE_KB * 1024 * 2 (gfx950 correction, /opt/skills/guides/MI355X_MICROARCH.md "HBM") + WRITE_SIZE_KB * 1024.
+
+    python tests/tools/pmc_traffic_json.py <pmc dir with g*/pmc_counter_collection.csv> <builds in the run> <out dir>
+"""
+import csv, glob, json, sys
+from collections import defaultdict
+root, builds, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+agg = defaultdict(lambda: defaultdict(list))
+for f in sorted(glob.glob(f'{root}/g*/*counter_collection.csv')):
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE'):
+            agg[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
+ALGO = {   # algorithmic bytes per element of the kernels of the initial sort
+    'msd_scatter_kernel<true>': 9, 'msd_scatter_kernel<false>': 16, 'msd_local_fast_kernel': 12,
+    'msd_hist_kernel<true>': 1, 'msd_hist_kernel<false>': 8,
+    'fs_scatter_kernel<0, 4>': 9, 'fs_scatter_kernel<4, 4>': 16, 'fs_scatter_kernel<4, 0>': 12,
+}
+n = 1 << 29
+kernels, total = {}, 0.0
+for name, cs in agg.items():
+    short = name.replace('void ', '').replace('pss::', '').split('(')[0]
+    fk, wk = cs.get('FETCH_SIZE', []), cs.get('WRITE_SIZE', [])
+    launches = max(len(fk), len(wk)) / builds
+    f_b = sum(fk) / builds * 1024 * 2
+    w_b = sum(wk) / builds * 1024
+    total += f_b + w_b
+    per = (f_b + w_b) / max(launches, 1)
+    e = {'launches_per_build': launches, 'FETCH_SIZE_KB_per_launch': round(sum(fk) / max(len(fk), 1), 1),
+         'WRITE_SIZE_KB_per_launch': round(sum(wk) / max(len(wk), 1), 1), 'bytes_per_launch': int(per)}
+    if short in ALGO:
+        e['algorithmic_bytes_per_launch'] = ALGO[short] * n
+        e['ratio'] = round(per / (ALGO[short] * n), 3)
+    kernels[short] = e
+src = ('tests/tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) around default-config '
+       'pss_sa_build_device calls on the lines corpus, n = 2^29')
+corr = 'bytes = FETCH_SIZE_KB * 1024 * 2 (gfx950 counts 64 B per 128-B request) + WRITE_SIZE_KB * 1024'
+big = {k: v for k, v in kernels.items() if v['bytes_per_launch'] * v['launches_per_build'] > 50e6}
+json.dump({'source': src, 'correction': corr, 'kernels': big}, open(f'{out}/pmc_traffic.json', 'w'), indent=1)
+json.dump({'source': src, 'correction': corr, 'total_bytes': int(total), 'bytes_per_suffix': round(total / n, 1),
+           'by_kernel': {k: int(v['bytes_per_launch'] * v['launches_per_build']) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['bytes_per_launch'] * kv[1]['launches_per_build'])[:16]}},
+          open(f'{out}/pmc_build_traffic.json', 'w'), indent=1)
+print(json.dumps({k: v.get('ratio') for k, v in big.items()}))
