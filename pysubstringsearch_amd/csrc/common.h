@@ -78,7 +78,8 @@ struct DeviceCtx {
     int num_cus = 256;
     static constexpr int kSlots = 32;
     DevBuf slot[kSlots];
-    static constexpr size_t kPinnedBytes = (size_t)192 << 10;   // 64 KiB of counters / small tables + 128 KiB of result bytes
+    static constexpr size_t kPinnedBytes = (size_t)640 << 10;   // 64 KiB of counters / small tables / query staging, 64 KiB of
+                                                                // result bytes, 512 KiB of entry records (search.hip, SM_OFF_*)
     void *pinned = nullptr;   // small pinned host scratch for D2H of counters
     size_t pinned_cap = 0;
     void *pinned_dev = nullptr;          // the same memory as the device sees it (zero-copy reads / writes)

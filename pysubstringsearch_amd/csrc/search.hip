@@ -686,12 +686,12 @@ __global__ __launch_bounds__(256) void hit_lines_kernel(const ChunkDesc *chunks,
 // multi-kernel path runs instead.
 constexpr u32 SM_MAX_VQ = 1024;
 constexpr u32 SM_MAX_HITS = 1024;
-constexpr u32 SM_ENT_CAP = 4096;
+constexpr u32 SM_ENT_CAP = 65536;
 #ifndef PSS_SM_BYTE_PREFIX
 #define PSS_SM_BYTE_PREFIX 65536
 #endif
 constexpr u32 SM_BYTE_PREFIX = PSS_SM_BYTE_PREFIX;   // result bytes that also go to pinned host memory
-constexpr u32 SM_BYTE_CAP = 2u << 20;
+constexpr u32 SM_BYTE_CAP = 8u << 20;
 constexpr u32 SM_MAX_PLEN = 256;       // longest query the path takes (kept in LDS)
 
 struct SmallHeader {   // device memory; all zero between launches (the last wave to finish resets it)
@@ -705,12 +705,13 @@ struct SmallEntry {
 };
 // layout of the pinned scratch (DeviceCtx::pinned) on this path
 constexpr size_t SM_OFF_FLAGS = 0;                                              // u32 overflow
-constexpr size_t SM_OFF_REC = 64;
-constexpr size_t SM_OFF_ENT = SM_OFF_REC + SM_MAX_VQ * sizeof(SmallRecord);
-constexpr size_t SM_OFF_QUERY = 49152;                                          // query bytes, then offsets at + 8192
-constexpr size_t SM_OFF_BYTES = 65536;
-static_assert(SM_OFF_ENT + SM_ENT_CAP * sizeof(SmallEntry) <= SM_OFF_QUERY, "entry table must fit below the query staging");
-static_assert(SM_OFF_BYTES + SM_BYTE_PREFIX <= DeviceCtx::kPinnedBytes, "result prefix must fit the pinned scratch");
+constexpr size_t SM_OFF_REC = 64;                                               // 2048 records (one per pair, or per (pair, sub-block))
+constexpr size_t SM_OFF_QUERY = 32768;                                          // query bytes, then offsets at + 8192
+constexpr size_t SM_OFF_BYTES = 65536;                                          // first SM_BYTE_PREFIX result bytes
+constexpr size_t SM_OFF_ENT = SM_OFF_BYTES + SM_BYTE_PREFIX;                    // entry table
+static_assert(SM_OFF_REC + 2048 * sizeof(SmallRecord) <= SM_OFF_QUERY && SM_MAX_VQ <= 2048, "records must fit below the query staging");
+static_assert(SM_OFF_QUERY + 16384 <= SM_OFF_BYTES, "query staging must fit below the result prefix");
+static_assert(SM_OFF_ENT + SM_ENT_CAP * sizeof(SmallEntry) <= DeviceCtx::kPinnedBytes, "entry table must fit the pinned scratch");
 
 __device__ __forceinline__ void small_pair(const ChunkDesc &ch, const u8 *pat, u32 plen, u32 vq, SmallHeader *hdr,
                                            u32 *h_overflow, SmallRecord *rec, SmallEntry *ent, u8 *bytes, u8 *hbytes,
@@ -814,19 +815,27 @@ __global__ __launch_bounds__(256) void search_small_kernel(const ChunkDesc *chun
 // suffix-array order of the kept hits.
 constexpr u32 SM_BLOCK = 1024;
 constexpr u32 SM_BLOCK_MAX_VQ = 64;
-constexpr u32 SM_BLOCK_MAX_HITS = 4096;
+constexpr u32 SM_BLOCK_MAX_HITS = 1024;
+// ... and up to SM_SPREAD workgroups per pair: workgroup k of a pair takes hits [1024 k, 1024 (k + 1)) of its
+// interval -- one hit per thread, one round of dependent loads -- and every workgroup finds the interval
+// itself (a few microseconds, no hand-over), so a single query with up to 32 768 hits per chunk stays on
+// this one-kernel path instead of falling back to the multi-kernel pipeline.  The record of (pair, k)
+// holds its entries; read in (pair, k) order they are in suffix-array order.
+constexpr u32 SM_SPREAD = 32;
+constexpr u32 SM_MAX_REC = SM_BLOCK_MAX_VQ * SM_SPREAD;          // 2048 records
 
 __global__ __launch_bounds__(SM_BLOCK) void search_block_kernel(const ChunkDesc *chunks, u32 nc, const u8 *qbytes,
                                                                   const u64 *qoff, u32 nvq, SmallHeader *hdr,
                                                                   u32 *h_overflow, SmallRecord *rec, SmallEntry *ent,
-                                                                  u8 *bytes, u8 *hbytes)
+                                                                  u8 *bytes, u8 *hbytes, u32 spread)
 {
     __shared__ u32 s_ls[SM_BLOCK_MAX_HITS];
     __shared__ u32 s_ll[SM_BLOCK_MAX_HITS];
     __shared__ __attribute__((aligned(8))) u8 s_pat[SM_MAX_PLEN + 32];
     __shared__ u32 s_L, s_cnt, s_e0, s_b0;
     __shared__ u32 s_we[SM_BLOCK / kWave], s_wb[SM_BLOCK / kWave];
-    const u32 vq = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+    const u32 vq = blockIdx.x / spread, sub = blockIdx.x % spread;
+    const u32 tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const u32 q = vq / nc, c = vq % nc;
     const ChunkDesc ch = chunks[c];
     const u64 o0 = qoff[q];
@@ -852,11 +861,16 @@ __global__ __launch_bounds__(SM_BLOCK) void search_block_kernel(const ChunkDesc 
         }
     }
     __syncthreads();
-    const u32 L = s_L, cnt = s_cnt;
-    if (cnt == 0) {
-        if (tid == 0) rec[vq] = SmallRecord{0, 0};
-    } else if (cnt > SM_BLOCK_MAX_HITS) {
+    const u32 total = s_cnt;
+    const u32 first = sub * SM_BLOCK_MAX_HITS;                 // this workgroup's slice of the interval
+    const u32 L = s_L + first;
+    const u32 cnt = total > first ? min(total - first, SM_BLOCK_MAX_HITS) : 0u;
+    const u32 ri = blockIdx.x;                                  // record of (pair, sub-block)
+    static_assert(SM_MAX_REC <= 2048, "one record per (pair, sub-block)");
+    if (total > spread * SM_BLOCK_MAX_HITS) {
         if (tid == 0) *h_overflow = 1;
+    } else if (cnt == 0) {
+        if (tid == 0) rec[ri] = SmallRecord{0, 0};
     } else {
         // pass 1: entry bounds of every hit, one hit per thread and round
         for (u32 j = tid; j < cnt; j += SM_BLOCK) {
@@ -899,7 +913,7 @@ __global__ __launch_bounds__(SM_BLOCK) void search_block_kernel(const ChunkDesc 
             s_e0 = e0;
             s_b0 = b0;
             if (e0 + n_ent > SM_ENT_CAP || b0 + n_bytes > SM_BYTE_CAP) *h_overflow = 1;
-            else rec[vq] = SmallRecord{e0, n_ent};
+            else rec[ri] = SmallRecord{e0, n_ent};
         }
         __syncthreads();
         const u32 e0 = s_e0, b0 = s_b0;
@@ -915,7 +929,7 @@ __global__ __launch_bounds__(SM_BLOCK) void search_block_kernel(const ChunkDesc 
             }
         }
     }
-    if (tid == 0 && atomicAdd(&hdr->done, 1u) == nvq - 1) {
+    if (tid == 0 && atomicAdd(&hdr->done, 1u) == nvq * spread - 1) {
         hdr->ent_cursor = 0;
         hdr->byte_cursor = 0;
         hdr->done = 0;
@@ -1069,9 +1083,15 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
         u32 *v_flags = reinterpret_cast<u32 *>(v_arena + SM_OFF_FLAGS);
         SmallRecord *v_rec = reinterpret_cast<SmallRecord *>(v_arena + SM_OFF_REC);
         SmallEntry *v_ent = reinterpret_cast<SmallEntry *>(v_arena + SM_OFF_ENT);
-        if (nvq <= SM_BLOCK_MAX_VQ && !knobs.no_block_path)
-            hipLaunchKernelGGL(search_block_kernel, dim3((u32)nvq), dim3(SM_BLOCK), 0, s, d_chunks, nc, v_q, v_qoff,
-                               (u32)nvq, d_hdr, v_flags, v_rec, v_ent, d_bytes, v_arena + SM_OFF_BYTES);
+        const bool block_path = nvq <= SM_BLOCK_MAX_VQ && !knobs.no_block_path;
+        // workgroups per pair: as many as keep the launch at <= 64 workgroups (every one of them searches the
+        // interval first; on 15 chunks 32 per pair cost a miss 7 us, 4 per pair nothing measurable)
+        u32 spread = 1;
+        if (block_path)
+            while (spread < SM_SPREAD && nvq * spread * 2 <= 64) spread *= 2;
+        if (block_path)
+            hipLaunchKernelGGL(search_block_kernel, dim3((u32)nvq * spread), dim3(SM_BLOCK), 0, s, d_chunks, nc, v_q, v_qoff,
+                               (u32)nvq, d_hdr, v_flags, v_rec, v_ent, d_bytes, v_arena + SM_OFF_BYTES, spread);
         else
             hipLaunchKernelGGL(search_small_kernel, dim3((u32)((nvq + waves_per_block - 1) / waves_per_block)), dim3(256),
                                0, s, d_chunks, nc, v_q, v_qoff, (u32)nvq, d_hdr, v_flags, v_rec, v_ent, d_bytes,
@@ -1082,24 +1102,31 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
             const SmallRecord *h_rec = reinterpret_cast<const SmallRecord *>(h_arena + SM_OFF_REC);
             const SmallEntry *h_ent = reinterpret_cast<const SmallEntry *>(h_arena + SM_OFF_ENT);
             u64 E = 0, B = 0;
-            for (u64 vq = 0; vq < nvq; ++vq) {
-                const SmallRecord r = h_rec[vq];
+            for (u64 ri = 0; ri < nvq * spread; ++ri) {
+                const SmallRecord r = h_rec[ri];
                 E += r.ent_count;
                 for (u32 k = 0; k < r.ent_count; ++k) B += h_ent[r.ent_start + k].len;
             }
             std::vector<u8> h_more;
             const u8 *h_bytes = h_arena + SM_OFF_BYTES;
             if (B > SM_BYTE_PREFIX) {
-                h_more.resize(B);
-                PSS_HIP(hipMemcpyAsync(h_more.data(), d_bytes, B, hipMemcpyDeviceToHost, s));
+                // the rest comes from the device arena with one copy: through the pinned staging when it fits
+                u8 *dst = nullptr;
+                if (B <= DeviceCtx::kStageR && !knobs.no_search_stage && ctx->ensure_search_stage() == PSS_OK) {
+                    dst = static_cast<u8 *>(ctx->search_stage) + DeviceCtx::kStageQ;
+                } else {
+                    h_more.resize(B);
+                    dst = h_more.data();
+                }
+                PSS_HIP(hipMemcpyAsync(dst, d_bytes, B, hipMemcpyDeviceToHost, s));
                 PSS_HIP(hipStreamSynchronize(s));
-                h_bytes = h_more.data();
+                h_bytes = dst;
             }
             PSS_TRY(alloc_result(res, E, B, false));
             u64 e_out = 0, b_out = 0;
-            for (u64 vq = 0; vq < nvq; ++vq) {               // pairs in (query, chunk) order
-                const SmallRecord r = h_rec[vq];
-                res->qcount[vq / nc] += r.ent_count;
+            for (u64 ri = 0; ri < nvq * spread; ++ri) {       // pairs in (query, chunk) order, sub-blocks in interval order
+                const SmallRecord r = h_rec[ri];
+                res->qcount[(ri / spread) / nc] += r.ent_count;
                 for (u32 k = 0; k < r.ent_count; ++k) {
                     const SmallEntry en = h_ent[r.ent_start + k];
                     res->offsets[e_out++] = b_out;
