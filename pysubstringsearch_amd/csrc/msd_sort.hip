@@ -134,14 +134,39 @@ __global__ __launch_bounds__(MSD_BLOCK) void msd_hist_kernel(MsdArgs a)
     for (u32 i = tid; i < MSD_BINS; i += MSD_BLOCK) hist[i] = 0;
     __syncthreads();
     const int shift2 = a.idx_bits + a.key_bits - 2 * MSD_D;
-    for (u32 base = e0; base < e1; base += MSD_TILE) {
-        const u32 valid = min(MSD_TILE, e1 - base);
-        u64 elem[MSD_IPT];
-        u32 dig[MSD_IPT];
-        msd_load_tile<FROM_TEXT>(a, base, valid, elem, dig, shift2);
+    if (FROM_TEXT) {
+        // the digit is the top 10 bits of the key: the first m = ceil(10 / b) symbols are all it takes -- a 32-bit
+        // sliding window instead of the 64-bit keys of text_keys16 (0.41 -> 0.16 ms at n = 2^29)
+        const int b = a.code_bits;
+        const int m = (MSD_D + b - 1) / b;
+        const u32 wmask = (m * b >= 32) ? ~0u : ((1u << (m * b)) - 1u);
+        const int down = m * b - MSD_D;
+        for (u32 base = e0; base < e1; base += MSD_TILE) {
+            const u32 i0 = base + tid * MSD_IPT;
+            if (i0 >= e1) continue;
+            const uint4 *p = reinterpret_cast<const uint4 *>(a.codes + i0);
+            const uint4 lo = p[0], hi = p[1];
+            const u64 q[4] = {(u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
+                              (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32)};
+            auto sym = [&](u32 j) -> u32 { return (u32)(q[j >> 3] >> ((j & 7u) * 8u)) & 0xffu; };   // codes are 0 past the text
+            u32 win = 0;
+            for (int t = 0; t < m; ++t) win = (win << b) | sym((u32)t);
 #pragma unroll
-        for (int k = 0; k < MSD_IPT; ++k)
-            if (msd_valid<FROM_TEXT>(base, valid, k, a.n)) atomicAdd(&hist[dig[k]], 1u);
+            for (int r = 0; r < MSD_IPT; ++r) {
+                if (r > 0) win = ((win << b) | sym((u32)(m - 1 + r))) & wmask;
+                if (i0 + r < e1) atomicAdd(&hist[win >> down], 1u);
+            }
+        }
+    } else {
+        for (u32 base = e0; base < e1; base += MSD_TILE) {
+            const u32 valid = min(MSD_TILE, e1 - base);
+            u64 elem[MSD_IPT];
+            u32 dig[MSD_IPT];
+            msd_load_tile<FROM_TEXT>(a, base, valid, elem, dig, shift2);
+#pragma unroll
+            for (int k = 0; k < MSD_IPT; ++k)
+                if (msd_valid<FROM_TEXT>(base, valid, k, a.n)) atomicAdd(&hist[dig[k]], 1u);
+        }
     }
     __syncthreads();
     // G1: digit-major (one row per digit: its offsets kernel scans rows); G2: range-major (one row per range)
