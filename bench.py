@@ -371,8 +371,16 @@ def run_chunk(args, D):
             best = wst.ms_total if best is None else min(best, wst.ms_total)
         wd = wst.as_dict()
         w_ok, w_how = verify_sa(dSA, w_host, 'words', 0, load_big_goldens(), want_sha=False)
+        w_traffic = None
+        wp = os.path.join(ROOT, 'profiles', 'pmc_build_traffic_words.json')
+        if os.path.exists(wp) and args.logn == 29:
+            try:
+                w_traffic = json.load(open(wp)).get('total_bytes')
+            except Exception:
+                w_traffic = None
         secondary = {'corpus': 'words', 'chunk_bytes': n, 'build_ms': round(best, 3),
                      'index_build_gbs': round(n / best / 1e6, 4), 'verified': w_ok, 'verified_by': w_how,
+                     'traffic': w_traffic, 'traffic_gbs': None if not w_traffic else round(w_traffic / best / 1e6, 1),
                      'sa_stats': {k: wd[k] for k in ('key_chars', 'initial_passes', 'rounds', 'text_rounds', 'round_passes',
                                                      'sum_active', 'big_elems', 'mode')}}
         del w_dT

@@ -14,9 +14,13 @@ src = os.path.join(d, 'corpus.txt'); idx = os.path.join(d, 'out.idx')
 with open(src, 'wb') as f:
     for c in range(chunks):
         buf = np.empty(n, dtype=np.uint8); _ffi.lib.pss_gen_corpus(0, buf.ctypes.data, n, c); f.write(buf.tobytes())
-for rep in range(2):
+import json
+rows = []
+devs_list = [None, [0, 0]] if len(sys.argv) > 3 else [None]     # third argument: also the two-lane (virtual device) pipeline
+for rep in range(2 * len(devs_list)):
+    devs = devs_list[rep // 2]
     t0 = time.perf_counter()
-    w = pysubstringsearch.Writer(idx, n)
+    w = pysubstringsearch.Writer(idx, n) if devs is None else pysubstringsearch.Writer(idx, n, devices=devs)
     w.add_entries_from_file_lines(src)
     w.finalize(); w.close()
     t1 = time.perf_counter()
@@ -27,5 +31,8 @@ for rep in range(2):
     sz = os.path.getsize(idx)
     print(f'rep {rep}: write {n*chunks/ (t1-t0)/1e9:.3f} GB/s text ({t1-t0:.2f}s, idx {sz/1e9:.2f} GB -> {sz/(t1-t0)/1e9:.2f} GB/s file) | '
           f'reader open {sz/(t2-t1)/1e9:.2f} GB/s ({t2-t1:.2f}s) chunks={r.num_chunks} | first search {1e3*(t3-t2):.2f} ms hits={len(got)}')
+    rows.append({'devices': devs, 'text_gbs': round(n * chunks / (t1 - t0) / 1e9, 3), 'file_gbs': round(sz / (t1 - t0) / 1e9, 2),
+                 'reader_open_gbs': round(sz / (t2 - t1) / 1e9, 2), 'chunks': r.num_chunks})
     r.close()
+print(json.dumps({'chunk_bytes': n, 'chunks': chunks, 'tmp': d, 'runs': rows}))
 os.remove(src); os.remove(idx); os.rmdir(d)
