@@ -558,3 +558,50 @@ def test_writer_failure_is_sticky(tmp_path):
         w.finalize()                                       # reported again, not swallowed after the first time
     with pytest.raises(OSError):
         w.close()
+
+
+def test_sharded_reader_over_rccl_single_rank(tmp_path, oracle):
+    """The device-resident gather on the real backend: torch.distributed with backend "nccl" (= RCCL) and
+    the one GPU of the box as a world of one rank -- device tensors over the engine's workspace
+    (Reader.search_batch_device), the size exchange as an RCCL collective, the download through pinned
+    memory and the C merge.  (More than one rank needs more than one GPU: covered with gloo elsewhere.)"""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from pysubstringsearch_amd import dist as pdist
+    from tests.util import gen_corpus
+    src = tmp_path / 'c.txt'
+    src.write_bytes(gen_corpus(1, 1 << 19).tobytes())
+    p = str(tmp_path / 'c.idx')
+    w = pysubstringsearch.Writer(p, 1 << 17)
+    w.add_entries_from_file_lines(str(src))
+    w.close()
+    text = src.read_bytes()
+    rng = np.random.default_rng(21)
+    qs = [b'', b'zzzzzz', b'\n']
+    while len(qs) < 3000:
+        s = int(rng.integers(0, len(text) - 20))
+        qs.append(text[s:s + int(rng.integers(2, 12))])
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+    try:
+        sr = pdist.ShardedReader(p)
+        blob, offsets, counts = sr.search_multiple_packed(qs)
+        dr = sr.local.search_batch_device(qs[:100])
+        assert dr.data.is_cuda and dr.starts.is_cuda and dr.counts.is_cuda and dr.data.numel() == dr.num_bytes
+        ents, total = sr.search_multiple_bytes(qs[:500])
+        sr.local.close()
+    finally:
+        dist.destroy_process_group()
+    o = oracle.OracleReader(p)
+    oe, oc = o.search_multiple_bytes(qs)
+    assert counts.tolist() == oc.tolist()
+    data = bytes(blob)
+    got = [data[int(offsets[i]):int(offsets[i + 1])] for i in range(len(offsets) - 1)]
+    assert sorted(got) == sorted(oe)
+    oe5, oc5 = o.search_multiple_bytes(qs[:500])
+    assert total.tolist() == oc5.tolist() and sorted(ents) == sorted(oe5)
