@@ -73,7 +73,8 @@ def build(path, entries, limit, W):
     return open(path, 'rb').read()
 
 
-KNOBS = ('PSS_MODE', 'PSS_KEY_CHARS', 'PSS_KEY_DROP', 'PSS_TEXT_ROUNDS', 'PSS_NO_TIES_PASS', 'PSS_NO_SMALL_PATH')
+KNOBS = ('PSS_MODE', 'PSS_KEY_CHARS', 'PSS_KEY_DROP', 'PSS_TEXT_ROUNDS', 'PSS_NO_TIES_PASS', 'PSS_NO_SMALL_PATH', 'PSS_MSD',
+         'PSS_MSD_NO_FUSE', 'PSS_MSD_SLOW_LOCAL', 'PSS_NO_PINNED_RESULTS')
 
 
 def random_knobs(rng):
@@ -96,6 +97,14 @@ def random_knobs(rng):
         os.environ['PSS_NO_TIES_PASS'] = '1'
     if rng.random() < 0.5:
         os.environ['PSS_NO_SMALL_PATH'] = '1'
+    if rng.random() < 0.6:
+        os.environ['PSS_MSD'] = rng.choice(['0', '1', '1'])      # hybrid MSD initial sort forced on / off
+        if rng.random() < 0.3:
+            os.environ['PSS_MSD_NO_FUSE'] = '1'
+        if rng.random() < 0.3:
+            os.environ['PSS_MSD_SLOW_LOCAL'] = '1'
+    if rng.random() < 0.3:
+        os.environ['PSS_NO_PINNED_RESULTS'] = '1'
     _ffi.lib.pss_reload_env()
 
 
