@@ -738,6 +738,16 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_small_sort_kernel(u64 *keys, u32 
     }
 }
 
+// profiling events of one sort call: destroyed on every exit path
+struct EventSet {
+    hipEvent_t ev[2 * 16] = {};
+    int created = 0;
+    ~EventSet()
+    {
+        for (int i = 0; i < created; ++i) (void)hipEventDestroy(ev[i]);
+    }
+};
+
 size_t radix_sort_workspace_bytes()
 {
     // digit table + 16 totals rows + the (has, first_z, last_z) tables and zeros[] of the fs passes
@@ -771,9 +781,11 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
     u32 *totals_base = table + (size_t)256 * RS_MAX_RANGES;
     PSS_HIP(hipMemsetAsync(totals_base, 0, 256 * 4 * 16, ctx->stream));
 
-    hipEvent_t ev[2 * 16];
+    EventSet evs;
+    hipEvent_t *ev = evs.ev;
     int ev_kind[16];   // 0 = text pass, 1 = (key, value) pass
-    int nev = 0, nev_created = 0;
+    int nev = 0;
+    int &nev_created = evs.created;
     if (profile) {   // created up front: a hipEventCreate between launch and record would idle the GPU
         for (; nev_created < 32; ++nev_created) PSS_HIP(hipEventCreate(&ev[nev_created]));
     }
@@ -839,7 +851,6 @@ int radix_sort_pairs(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint3
             }
         }
     }
-    for (int i = 0; i < nev_created; ++i) (void)hipEventDestroy(ev[i]);
     if (executed == 0 && text != nullptr) {
         set_error("radix_sort_pairs: text source needs at least one pass");
         return PSS_EINVAL;
@@ -870,9 +881,11 @@ int suffix_sort_flags(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint
     u32 *zeros = has + (size_t)256 * RS_MAX_RANGES;
     PSS_HIP(hipMemsetAsync(totals_base, 0, 256 * 4 * 16, ctx->stream));
 
-    hipEvent_t ev[2 * 16];
+    EventSet evs;
+    hipEvent_t *ev = evs.ev;
     int ev_idx[16];
-    int nev = 0, nev_created = 0;
+    int nev = 0;
+    int &nev_created = evs.created;
     if (profile) {
         for (; nev_created < 2 * passes && nev_created < 32; ++nev_created) PSS_HIP(hipEventCreate(&ev[nev_created]));
     }
@@ -951,7 +964,6 @@ int suffix_sort_flags(DeviceCtx *ctx, uint64_t *keys[2], uint32_t *vals[2], uint
             }
         }
     }
-    for (int i = 0; i < nev_created; ++i) (void)hipEventDestroy(ev[i]);
     *dst = cur;
     return PSS_OK;
 }
