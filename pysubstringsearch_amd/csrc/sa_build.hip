@@ -905,6 +905,9 @@ __global__ __launch_bounds__(256) void sample_keys_kernel(const u8 *codes, u32 n
 // tied[8]: sample members whose 48th successor still shares their top 20 key bits -- a joint bucket of the
 // MSD path (msd_sort.hip) with >= 49 of the S sample members holds about 49 n / S suffixes, far beyond
 // what a workgroup sorts in LDS: any such member rules that path out before it starts.
+// tied[9]: distinct 20-bit prefixes in the sample; n / distinct estimates the average non-empty bucket
+// (exact when there are far fewer buckets than sample members), and a path whose AVERAGE bucket is close
+// to the tile limit will not pass the exact check either (`lines` at n = 2^30: 6 000 per bucket).
 constexpr u32 kMsdScreenRun = 48;
 __global__ __launch_bounds__(256) void sample_ties_kernel(const u64 *keys, u32 S, u32 *tied /* [8]: W = 8, 16, .. 64; [8] screen */)
 {
@@ -912,7 +915,7 @@ __global__ __launch_bounds__(256) void sample_ties_kernel(const u64 *keys, u32 S
     if (threadIdx.x < 8) s_c[threadIdx.x] = 0;
     __syncthreads();
     u32 c[8] = {};
-    u32 crowded = 0;
+    u32 crowded = 0, distinct = 0;
     for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < S; t += gridDim.x * blockDim.x) {
         const u64 k = keys[t];
         const u64 dp = t > 0 ? (keys[t - 1] ^ k) : ~0ull, dn = t + 1 < S ? (keys[t + 1] ^ k) : ~0ull;
@@ -921,8 +924,10 @@ __global__ __launch_bounds__(256) void sample_ties_kernel(const u64 *keys, u32 S
 #pragma unroll
         for (int w = 0; w < 8; ++w) c[w] += lz >= 8 * (w + 1) ? 1u : 0u;
         if (t + kMsdScreenRun < S && ((keys[t + kMsdScreenRun] ^ k) >> 44) == 0) ++crowded;
+        if (t == 0 || (dp >> 44) != 0) ++distinct;          // first sample member of its 20-bit prefix
     }
     if (crowded) atomicAdd(&tied[8], crowded);
+    if (distinct) atomicAdd(&tied[9], distinct);
 #pragma unroll
     for (int w = 0; w < 8; ++w)
         if (c[w]) atomicAdd(&s_c[w], c[w]);
@@ -1037,7 +1042,7 @@ static int size_initial_key(DeviceCtx *ctx, const u8 *codes, u32 n, int b, int k
     hipLaunchKernelGGL(sample_ties_kernel, dim3(256), dim3(256), 0, s, K[sd], S, d_tied);
     PSS_HIP(hipMemcpyAsync(h_small, d_tied, 64, hipMemcpyDeviceToHost, s));
     PSS_HIP(hipStreamSynchronize(s));
-    *msd_screen_ok = h_small[8] == 0;
+    *msd_screen_ok = h_small[8] == 0 && h_small[9] != 0 && (double)n / (double)h_small[9] <= 3400.0;
     *key_chars = kmax;
     *key_drop = 0;
     for (int p = 2; p < pmax; ++p) {

@@ -10,7 +10,7 @@ host = np.empty(n, dtype=np.uint8); _ffi.lib.pss_gen_corpus(kind, host.ctypes.da
 dT = torch.from_numpy(host).cuda(); dSA = torch.empty(n, dtype=torch.int32, device='cuda')
 st = _ffi.SaStats()
 t0 = time.time(); _ffi.check(_ffi.lib.pss_sa_build_device(dT.data_ptr(), dSA.data_ptr(), n, 0, 0, ctypes.byref(st))); t1 = time.time()
-print(f'n={n} build {1e3*(t1-t0):.1f} ms  {n/(t1-t0)/1e9:.2f} GB/s', {k: getattr(st, k) for k in ('key_chars', 'initial_passes', 'rounds', 'round_passes', 'sum_active', 'mode', 'text_rounds', 'big_elems')})
+print(f'n={n} build {1e3*(t1-t0):.1f} ms  {n/(t1-t0)/1e9:.2f} GB/s', {k: getattr(st, k) for k in ('key_chars', 'initial_passes', 'rounds', 'round_passes', 'sum_active', 'mode', 'text_rounds', 'big_elems', 'msd', 'msd_max_bucket', 'msd_buckets')})
 sa = dSA.to(torch.int64)
 cnt = torch.zeros(n, dtype=torch.int8, device='cuda'); cnt[sa] = 1
 assert int(cnt.sum().item()) == n and int(sa.min()) == 0 and int(sa.max()) == n - 1, 'not a permutation'
