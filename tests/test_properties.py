@@ -39,6 +39,23 @@ def brute_search(entries, pattern: str):
     return out
 
 
+def chunks_of(entries, cap):
+    """Writer::add_entry's flush rule (src/lib.rs:96-100), restated in Python: an entry that does not fit
+    (len + entry + 1 > capacity) starts a new chunk.  (Entries here are far below the capacity, so the Vec
+    growth corner does not arise.)"""
+    chunks, cur, size = [], [], 0
+    for e in entries:
+        need = len(e.encode()) + 1
+        if size + need > cap and cur:
+            chunks.append(cur)
+            cur, size = [], 0
+        cur.append(e)
+        size += need
+    if cur:
+        chunks.append(cur)
+    return chunks
+
+
 entry = st.text(alphabet=st.sampled_from('ab é'), min_size=0, max_size=12)
 
 
@@ -51,9 +68,11 @@ def test_oracle_search_matches_brute_force(oracle, tmp_path_factory, entries, pa
         w.add_entry(e)
     w.close()
     r = oracle.OracleReader(p)
-    # chunking (limit 64) must not matter as long as the pattern does not span a chunk boundary
-    if '\n' not in pattern:
-        assert sorted(r.search(pattern)) == sorted(brute_search(entries, pattern))
+    # every chunk is searched on its own (src/lib.rs:207): a hit -- also one that runs across newlines, or
+    # starts on an entry's terminating newline -- must lie inside one chunk's text
+    want = [e for ch in chunks_of(entries, 64) for e in brute_search(ch, pattern)]
+    assert r.num_chunks == len(chunks_of(entries, 64))
+    assert sorted(r.search(pattern)) == sorted(want)
     r.close()
 
 
