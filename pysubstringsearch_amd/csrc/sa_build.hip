@@ -807,6 +807,181 @@ __global__ __launch_bounds__(256) void group_sort_kernel(const u64 *key, const u
     }
 }
 
+// ---- middle tier: groups of up to MID_CAP members sorted by one workgroup in LDS -----------------
+// group_sort ranks groups of <= GS_CAP members by direct counting (O(size) LDS reads per member) and hands
+// everything larger to two chained global radix sorts (key, then group): a dozen passes of 24 B per member.
+// On natural text a third of the tied suffixes sit in groups of a few hundred to a few thousand members
+// (`words` round 1: 120 M of 366 M), far too many for that price and far too few per group to need it.
+// mid_collect finds the extent of every flagged group (group ranks never decrease along the list: a binary
+// search from the head); mid_sort sorts one group per workgroup with the counting scheme of the MSD local
+// sort (msd_sort.hip): one pass of LDS atomics over the top 12 key bits, then every member counts the smaller
+// ones of its bin, ties by list position (stable, like group_sort).  A group with a crowded bin (many equal
+// keys) stays flagged and takes the chained sorts as before.  Sorted groups are un-flagged and taken out of
+// the per-window counts big_compact works from.
+constexpr u32 MID_CAP = 4096;
+constexpr int MID_BLOCK = 512;
+constexpr int MID_IPT = MID_CAP / MID_BLOCK;
+constexpr int MID_WAVES = MID_BLOCK / kWave;
+constexpr u32 MID_BINS = 4096, MID_WORDS = MID_BINS / 2;      // 16-bit counters, two per LDS word
+#ifndef PSS_MID_KMAX
+#define PSS_MID_KMAX 512
+#endif
+constexpr u32 MID_KMAX = PSS_MID_KMAX;
+
+struct MidGroup {
+    u32 start, size;
+};
+
+__global__ __launch_bounds__(256) void mid_collect_kernel(const u8 *big, const u32 *grp, u32 m, MidGroup *list, u32 *count)
+{
+    for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x) {
+        if (!big[j]) continue;
+        const u32 g = grp[j];
+        if (j > 0 && grp[j - 1] == g) continue;                  // not a head
+        // first index behind the group, looked for in (j, j + MID_CAP]
+        const u32 limit = min(m, j + MID_CAP + 1);
+        u32 lo = j + 1, hi = limit;
+        while (lo < hi) {
+            const u32 mid = lo + ((hi - lo) >> 1);
+            if (grp[mid] == g) lo = mid + 1; else hi = mid;
+        }
+        const u32 size = lo - j;
+        if (size <= MID_CAP && size >= 2) list[atomicAdd(count, 1u)] = MidGroup{j, size};
+    }
+}
+
+__global__ __launch_bounds__(MID_BLOCK) void mid_sort_kernel(const u64 *key, const u32 *idx, const MidGroup *list, const u32 *count,
+                                                               int key_bits, u64 *okey, u32 *oidx, u8 *big, u32 *blk_big,
+                                                               u32 *blk_heads)
+{
+    __shared__ u64 s_key[MID_CAP];
+    __shared__ u16 s_perm[MID_CAP];                    // slot (bin order) -> member
+    __shared__ u32 hist[MID_WORDS], hist2[MID_WORDS];
+    __shared__ u32 scr[MID_WAVES + 1];
+    __shared__ u32 s_fail;
+    __shared__ u64 s_diff;
+    const u32 tid = threadIdx.x;
+    const u32 total = *count;
+    (void)key_bits;
+    for (u32 gi = blockIdx.x; gi < total; gi += gridDim.x) {
+        const u32 gs = list[gi].start, size = list[gi].size;
+        const u32 rows = (size + MID_BLOCK - 1) / MID_BLOCK;
+        for (u32 i = tid; i < MID_WORDS; i += MID_BLOCK) hist[i] = 0;
+        if (tid == 0) {
+            s_fail = 0;
+            s_diff = 0;
+        }
+        __syncthreads();
+        u64 k[MID_IPT];
+        const u64 k_first = key[gs];
+        u64 diff = 0;
+#pragma unroll
+        for (int r = 0; r < MID_IPT; ++r) {
+            k[r] = 0;
+            const u32 p = r * MID_BLOCK + tid;
+            if ((u32)r < rows && p < size) {
+                k[r] = key[gs + p];
+                s_key[p] = k[r];
+                diff |= k[r] ^ k_first;
+            }
+        }
+        // The members of a group often share the next symbols too (the rest of a word): bin on the 12 bits right
+        // below the keys' common prefix, not on the top 12 bits of the key.
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor(diff, o);
+        if ((tid & 63u) == 0 && diff) atomicOr(reinterpret_cast<unsigned long long *>(&s_diff), (unsigned long long)diff);
+        __syncthreads();
+        const u64 dall = s_diff;
+        const int top = dall ? 64 - __builtin_clzll(dall) : 0;          // bits [0, top) vary
+        const int shift = top > 12 ? top - 12 : 0;
+#pragma unroll
+        for (int r = 0; r < MID_IPT; ++r) {
+            const u32 p = r * MID_BLOCK + tid;
+            if ((u32)r < rows && p < size) {
+                const u32 bin = (u32)(k[r] >> shift) & (MID_BINS - 1u);
+                atomicAdd(&hist[bin >> 1], 1u << (16u * (bin & 1u)));
+            }
+        }
+        __syncthreads();
+        {
+            u32 c[8];
+            u32 sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32 wv = hist[4 * tid + j];
+                c[2 * j] = wv & 0xffffu;
+                c[2 * j + 1] = wv >> 16;
+                sum += c[2 * j] + c[2 * j + 1];
+            }
+            u32 ex = block_excl_sum<MID_WAVES>(sum, scr, nullptr);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32 lo = ex, hi = ex + c[2 * j];
+                hist[4 * tid + j] = hist2[4 * tid + j] = lo | (hi << 16);
+                ex = hi + c[2 * j + 1];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < MID_IPT; ++r) {
+            const u32 p = r * MID_BLOCK + tid;
+            if ((u32)r < rows && p < size) {
+                const u32 bin = (u32)(k[r] >> shift) & (MID_BINS - 1u), sh = 16u * (bin & 1u);
+                s_perm[(atomicAdd(&hist2[bin >> 1], 1u << sh) >> sh) & 0xffffu] = (u16)p;
+            }
+        }
+        __syncthreads();
+        // thread <-> slot: neighbouring lanes sit in the same bin; rank = smaller members of the bin (ties by list position)
+        u32 fin[MID_IPT], who[MID_IPT];
+#pragma unroll
+        for (int r = 0; r < MID_IPT; ++r) {
+            fin[r] = who[r] = 0;
+            const u32 q0 = r * MID_BLOCK + tid;
+            if ((u32)r < rows && q0 < size) {
+                const u32 i = s_perm[q0];
+                const u64 x = s_key[i];
+                const u32 bin = (u32)(x >> shift) & (MID_BINS - 1u);
+                const u32 s0 = (hist[bin >> 1] >> (16u * (bin & 1u))) & 0xffffu;
+                const u32 s1 = bin + 1 < MID_BINS ? ((hist[(bin + 1) >> 1] >> (16u * ((bin + 1) & 1u))) & 0xffffu) : size;
+                u32 smaller = 0;
+                if (s1 - s0 > MID_KMAX) {
+                    s_fail = 1;
+                } else {
+                    for (u32 q = s0; q < s1; ++q) {
+                        const u32 j = s_perm[q];
+                        const u64 y = s_key[j];
+                        smaller += (y < x || (y == x && j < i)) ? 1u : 0u;
+                    }
+                }
+                fin[r] = s0 + smaller;
+                who[r] = i;
+                k[r] = x;
+            }
+        }
+        __syncthreads();
+        if (!s_fail) {
+#pragma unroll
+            for (int r = 0; r < MID_IPT; ++r) {
+                const u32 q0 = r * MID_BLOCK + tid;
+                if ((u32)r < rows && q0 < size) {
+                    okey[gs + fin[r]] = k[r];
+                    oidx[gs + fin[r]] = idx[gs + who[r]];
+                    big[gs + q0] = 0;
+                }
+            }
+            if (tid == 0) {
+                // the group leaves the per-window tallies of flagged members / flagged heads
+                atomicSub(&blk_heads[gs / GS_T], 1u);
+                for (u32 w = gs / GS_T; w * GS_T < gs + size; ++w) {
+                    const u32 a = max(gs, w * (u32)GS_T), b = min(gs + size, (w + 1) * (u32)GS_T);
+                    atomicSub(&blk_big[w], b - a);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Ordered compaction of the flagged elements of window b: their list index
 // bt[], text key and dense group number (0-based ordinal of the big group).
 __global__ __launch_bounds__(256) void big_compact_kernel(const u8 *big, const u32 *grp, const u64 *key, u32 m,
@@ -989,6 +1164,7 @@ struct Knobs {
     int text_rounds_max = 5;    // PSS_TEXT_ROUNDS
     int msd = -1;               // PSS_MSD        0: never the MSD initial sort, 1: whenever the key fits, unset: screened
     bool no_msd_fuse = false;   // PSS_MSD_NO_FUSE  MSD sort flags ties in the suffix array; the rerank kernels read them
+    bool no_mid_tier = false;   // PSS_NO_MID_TIER  groups above 512 members all take the chained radix sorts
     bool timing = false;        // PSS_TIMING     per-round trace on stderr
     static Knobs read()
     {
@@ -1005,6 +1181,7 @@ struct Knobs {
         if (const char *e = getenv("PSS_TEXT_ROUNDS")) k.text_rounds_max = atoi(e);
         if (const char *e = getenv("PSS_MSD")) k.msd = atoi(e);
         k.no_msd_fuse = getenv("PSS_MSD_NO_FUSE") != nullptr;
+        k.no_mid_tier = getenv("PSS_NO_MID_TIER") != nullptr;
         k.timing = getenv("PSS_TIMING") != nullptr;
         return k;
     }
@@ -1332,7 +1509,8 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         auto local_round = [&](bool use_text, bool *bail) -> int {
             *bail = false;
             const u32 nblk = (m + GS_T - 1) / GS_T;
-            PSS_TRY(ctx->slot[S_SCR].reserve((size_t)m + (size_t)nblk * 24 + (SC_MAX_BLOCKS + 8) * 8 + 4096));
+            PSS_TRY(ctx->slot[S_SCR].reserve((size_t)m + (size_t)nblk * 24 + (SC_MAX_BLOCKS + 8) * 8 + 4096 +
+                                             ((size_t)m / 2 + 16) * sizeof(MidGroup) + 256));
             u8 *scr = ctx->slot[S_SCR].as<u8>();
             size_t o = 0;
             auto carve = [&](size_t bytes) { u8 *p = scr + o; o = round_up(o + bytes, 64); return p; };
@@ -1350,6 +1528,17 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
                 hipLaunchKernelGGL(rank_keys_kernel, dim3(grid), dim3(256), 0, s, V[src], m, n, h32, ISA, K[src]);
             hipLaunchKernelGGL(group_sort_kernel, dim3(nblk), dim3(256), 0, s, K[src], V[src], G[gcur], m, K[src ^ 1],
                                V[src ^ 1], d_big, d_blk_big, d_blk_heads);
+            if (!knobs.no_mid_tier) {
+                // groups of up to MID_CAP members: one workgroup each, in LDS (no host round trip: the list and its
+                // length stay on the device, the workgroups persist and walk over it)
+                MidGroup *d_mid = reinterpret_cast<MidGroup *>(carve(((size_t)m / 2 + 16) * sizeof(MidGroup)));
+                u32 *d_mid_count = reinterpret_cast<u32 *>(carve(64));
+                PSS_HIP(hipMemsetAsync(d_mid_count, 0, 4, s));
+                hipLaunchKernelGGL(mid_collect_kernel, dim3(grid), dim3(256), 0, s, d_big, G[gcur], m, d_mid, d_mid_count);
+                hipLaunchKernelGGL(mid_sort_kernel, dim3((u32)ctx->num_cus * 4), dim3(MID_BLOCK), 0, s, K[src], V[src], d_mid,
+                                   (const u32 *)d_mid_count, use_text ? kt * b : rank_bits, K[src ^ 1], V[src ^ 1], d_big, d_blk_big,
+                                   d_blk_heads);
+            }
             PSS_TRY(device_excl_scan(ctx, InU32{d_blk_big}, nblk, d_partial, d_total, d_off_big));
             PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
             PSS_HIP(hipStreamSynchronize(s));

@@ -74,7 +74,7 @@ def build(path, entries, limit, W):
 
 
 KNOBS = ('PSS_MODE', 'PSS_KEY_CHARS', 'PSS_KEY_DROP', 'PSS_TEXT_ROUNDS', 'PSS_NO_TIES_PASS', 'PSS_NO_SMALL_PATH', 'PSS_MSD',
-         'PSS_MSD_NO_FUSE', 'PSS_MSD_SLOW_LOCAL', 'PSS_NO_PINNED_RESULTS')
+         'PSS_MSD_NO_FUSE', 'PSS_MSD_SLOW_LOCAL', 'PSS_NO_PINNED_RESULTS', 'PSS_NO_MID_TIER')
 
 
 def random_knobs(rng):
@@ -105,6 +105,8 @@ def random_knobs(rng):
             os.environ['PSS_MSD_SLOW_LOCAL'] = '1'
     if rng.random() < 0.3:
         os.environ['PSS_NO_PINNED_RESULTS'] = '1'
+    if rng.random() < 0.3:
+        os.environ['PSS_NO_MID_TIER'] = '1'
     _ffi.lib.pss_reload_env()
 
 
