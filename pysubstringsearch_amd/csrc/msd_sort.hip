@@ -960,6 +960,7 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
         const u32 grid = std::min<u32>(nt, 2u * (u32)ctx->num_cus);
         hipLaunchKernelGGL(msd_local_fast_kernel, dim3(grid), dim3(MSD_BLOCK), 0, s, A[1], cstart, tiles, nt, rem_bits, ib, sa_out,
                            fail_list, counters + 4, fused, em);
+        PSS_TRY(mark());            // (profile mode) the events bracket this launch alone
         PSS_HIP(hipMemcpyAsync(h_small, counters + 4, 4, hipMemcpyDeviceToHost, s));
         PSS_HIP(hipStreamSynchronize(s));
         const u32 nfail = h_small[0];
@@ -968,7 +969,7 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
             hipLaunchKernelGGL(msd_local_sort_kernel, dim3(nfail), dim3(MSD_BLOCK), 0, s, A[1], cstart, tile_first, ne, n,
                                rem_bits, ib, sa_out, (const u32 *)fail_list, fused, em);
     }
-    PSS_TRY(mark());
+    if (getenv("PSS_MSD_SLOW_LOCAL")) PSS_TRY(mark());
     if (fused) {
         PSS_TRY(device_excl_scan(ctx, InBlkCnt{blk_cnt}, nt, partial, d_total, dst_off));
         hipLaunchKernelGGL(msd_gather_kernel, dim3((nt + 3) / 4), dim3(256), 0, s, (const MsdTile *)tiles_all, blk_cnt, dst_off, nt,
