@@ -97,6 +97,15 @@ typedef struct pss_sa_stats {
     double msd_ms_g2;          /* ... second partition scatter (8 B in, 8 B out) */
     double msd_ms_local;       /* ... local sort (8 B in, 4 B out, sequential) */
     uint64_t msd_slow_tiles;   /* tiles with crowded bins that took the general local-sort kernel */
+    /* run-length path (texts made of long runs of equal bytes): the run heads are sorted as a string of one
+     * symbol per run, the other suffixes by one short radix sort.  `rounds` etc. then describe the sort of
+     * the reduced string. */
+    uint64_t runs;             /* maximal runs of equal bytes in the text (always filled) */
+    uint64_t rle;              /* 1 when the path ran */
+    uint64_t rle_id_bits;      /* key bits of the expansion sort */
+    double rle_ms_table;       /* profile mode: run table and symbols */
+    double rle_ms_reduced;     /* ... suffix sort of the reduced string */
+    double rle_ms_expand;      /* ... expansion and its radix sort */
 } pss_sa_stats;
 
 /*

@@ -48,6 +48,12 @@ class SaStats(ctypes.Structure):
         ('msd_ms_g2', ctypes.c_double),
         ('msd_ms_local', ctypes.c_double),
         ('msd_slow_tiles', ctypes.c_uint64),
+        ('runs', ctypes.c_uint64),
+        ('rle', ctypes.c_uint64),
+        ('rle_id_bits', ctypes.c_uint64),
+        ('rle_ms_table', ctypes.c_double),
+        ('rle_ms_reduced', ctypes.c_double),
+        ('rle_ms_expand', ctypes.c_double),
     ]
 
     def as_dict(self):

@@ -250,10 +250,10 @@ __global__ __launch_bounds__(MSD_BINS) void msd_ranges_kernel(const u32 *J1, Msd
 }
 
 template <bool FROM_TEXT>
-__global__ __launch_bounds__(MSD_BLOCK) void msd_scatter_kernel(MsdArgs a)
+__global__ __launch_bounds__(MSD_BLOCK, 4) void msd_scatter_kernel(MsdArgs a)
 {
+    // (79.9 KB of LDS: both instantiations fit twice into a CU)
     __shared__ __attribute__((aligned(16))) u64 exch[MSD_TILE];
-    __shared__ u16 exd[FROM_TEXT ? MSD_TILE : 1];      // G1 strips the digit from the element: kept beside it
     __shared__ u32 hist[MSD_BINS], s_delta[MSD_BINS], s_off[MSD_BINS];
     __shared__ u16 s_start[MSD_BINS];                 // 16-bit (a tile has 8192 slots): the G2 kernel then fits twice into a CU's LDS
     __shared__ u32 scr[MSD_WAVES + 1];
@@ -304,8 +304,10 @@ __global__ __launch_bounds__(MSD_BLOCK) void msd_scatter_kernel(MsdArgs a)
         for (int k = 0; k < MSD_IPT; ++k) {
             if (msd_valid<FROM_TEXT>(base, valid, k, a.n)) {
                 const u32 lp = (u32)s_start[dig[k]] + rank[k];
-                exch[lp] = elem[k];
-                if (FROM_TEXT) exd[lp] = (u16)dig[k];
+                // G1's element no longer holds its digit, and the output loop needs it: through LDS it travels as
+                // [key rest | digit | position in the tile] (13 bits instead of the suffix index, which is base + position)
+                if (FROM_TEXT) exch[lp] = ((elem[k] >> a.idx_bits) << 23) | ((u64)dig[k] << 13) | (u64)(tid * MSD_IPT + k);
+                else exch[lp] = elem[k];
             }
         }
         __syncthreads();                                    // (C) tile in bin order
@@ -313,8 +315,14 @@ __global__ __launch_bounds__(MSD_BLOCK) void msd_scatter_kernel(MsdArgs a)
         for (int k = 0; k < MSD_IPT; ++k) {
             const u32 p = k * MSD_BLOCK + tid;
             if (p < valid) {
-                const u64 e = exch[p];
-                const u32 d = FROM_TEXT ? (u32)exd[p] : ((u32)(e >> shift2) & (MSD_BINS - 1u));
+                u64 e = exch[p];
+                u32 d;
+                if (FROM_TEXT) {
+                    d = (u32)(e >> 13) & (MSD_BINS - 1u);
+                    e = ((e >> 23) << a.idx_bits) | (u64)(base + ((u32)e & (MSD_TILE - 1u)));
+                } else {
+                    d = (u32)(e >> shift2) & (MSD_BINS - 1u);
+                }
                 a.out[s_delta[d] + p] = e;
             }
         }

@@ -37,6 +37,7 @@
 // offsets from v_mbcnt.
 #include "prims.h"
 #include "msd_sort.h"
+#include "rle_build.h"
 #include "radix_sort.h"
 #include "sa_build.h"
 #include "scan.h"
@@ -51,13 +52,16 @@ namespace pss {
 // present[c] = 1 for every byte value that occurs (exact); counts[c] += its
 // occurrences inside a 1/16 sample of the 16-byte vectors (for the entropy
 // estimate that sizes the initial key).
-__global__ __launch_bounds__(256) void sa_symbols_kernel(const u8 *T, u32 n, u32 *present, u32 *counts)
+// *runs += maximal runs of equal bytes (positions whose byte differs from the one before, and position 0):
+// texts made of long runs take the run-length path (rle_build.hip).
+__global__ __launch_bounds__(256) void sa_symbols_kernel(const u8 *T, u32 n, u32 *present, u32 *counts, u32 *runs)
 {
     __shared__ u32 seen[256];
     __shared__ u32 cnt[256];
     const u32 tid = threadIdx.x;
     seen[tid] = 0;
     cnt[tid] = 0;
+    u32 nruns = 0;
     __syncthreads();
     const u32 nvec = n / 16;
     const uint4 *Tv = reinterpret_cast<const uint4 *>(T);
@@ -67,14 +71,19 @@ __global__ __launch_bounds__(256) void sa_symbols_kernel(const u8 *T, u32 n, u32
             const uint4 v = Tv[i];
             const u32 w[4] = {v.x, v.y, v.z, v.w};
             const bool sample = (i & 15u) == 0;
+            u32 prev = i ? (u32)T[i * 16 - 1] : (~v.x & 0xffu);
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 4; ++k) {
+                const u32 diff = w[k] ^ ((w[k] << 8) | prev);       // byte j: T[j] ^ T[j - 1]
+                prev = w[k] >> 24;
+                nruns += (u32)__popc((((diff & 0x7f7f7f7fu) + 0x7f7f7f7fu) | diff) & 0x80808080u);
 #pragma unroll
                 for (int s = 0; s < 32; s += 8) {
                     const u32 c = (w[k] >> s) & 0xffu;
                     if (!seen[c]) seen[c] = 1;
                     if (sample) atomicAdd(&cnt[c], 1u);
                 }
+            }
         }
     }
     const u32 tail0 = aligned ? nvec * 16 : 0;
@@ -82,10 +91,14 @@ __global__ __launch_bounds__(256) void sa_symbols_kernel(const u8 *T, u32 n, u32
         const u32 c = T[i];
         if (!seen[c]) seen[c] = 1;
         atomicAdd(&cnt[c], 1u);
+        if (i == 0 || (u32)T[i - 1] != c) ++nruns;
     }
     __syncthreads();
     if (seen[tid]) present[tid] = 1;
     if (cnt[tid]) atomicAdd(&counts[tid], cnt[tid]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nruns += __shfl_xor(nruns, o);
+    if (lane_id() == 0 && nruns) atomicAdd(runs, nruns);
 }
 
 // codes[i] = lut[T[i]] for i < n, 0 for n <= i < n_pad (n_pad % 16 == 0).
@@ -1165,6 +1178,7 @@ struct Knobs {
     int msd = -1;               // PSS_MSD        0: never the MSD initial sort, 1: whenever the key fits, unset: screened
     bool no_msd_fuse = false;   // PSS_MSD_NO_FUSE  MSD sort flags ties in the suffix array; the rerank kernels read them
     bool no_mid_tier = false;   // PSS_NO_MID_TIER  groups above 512 members all take the chained radix sorts
+    int rle = -1;               // PSS_RLE        0: never the run-length path, 1: always, unset: when runs average >= 8 bytes
     bool timing = false;        // PSS_TIMING     per-round trace on stderr
     static Knobs read()
     {
@@ -1182,6 +1196,7 @@ struct Knobs {
         if (const char *e = getenv("PSS_MSD")) k.msd = atoi(e);
         k.no_msd_fuse = getenv("PSS_MSD_NO_FUSE") != nullptr;
         k.no_mid_tier = getenv("PSS_NO_MID_TIER") != nullptr;
+        if (const char *e = getenv("PSS_RLE")) k.rle = atoi(e);
         k.timing = getenv("PSS_TIMING") != nullptr;
         return k;
     }
@@ -1233,176 +1248,60 @@ static int size_initial_key(DeviceCtx *ctx, const u8 *codes, u32 n, int b, int k
     return PSS_OK;
 }
 
-int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, uint32_t flags, pss_sa_stats *stats)
+// Everything after the initial sort: rerank + compaction of the tied suffixes, then rounds until no
+// ties are left.  Its own function since round 2: the run-length path (rle_build below) sorts the
+// suffixes of an INTEGER string (one symbol per run of the text) with the same rounds -- there is no
+// text to pack keys from then (codes == nullptr): rank rounds only, starting from h0 = 1.
+struct RoundsIO {
+    u32 n;
+    u32 *SA;
+    u64 *K[2];
+    u32 *V[2];
+    u32 *ISA;
+    u32 *P[2];
+    u32 *GRP;
+    const u8 *codes;            // recoded text (nullptr: rank rounds only)
+    int b, plus_one, key_chars, key_drop;
+    u64 h0;                     // symbols every group of the initial sort is known to share
+    int cur;                    // K[cur] / V[cur]: sorted keys / suffixes of the initial sort
+    int final_buf;              // V[final_buf] was redirected to SA for the initial sort (-1: not)
+    u32 *v_scratch;             // ... and this is the buffer it stands for
+    bool ties;                  // V[cur] carries tie flags in bit 31 (no keys)
+    bool msd_fused;             // the MSD sort already produced the first active list
+    u32 msd_active;
+    u8 *work;
+    u32 *d_agg_head, *d_agg_cnt;
+    u64 *d_red;
+    u32 *d_counters;
+    u32 *h_small;
+    bool profile;
+};
+
+static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortStats &ss, pss_sa_stats &st)
 {
-    pss_sa_stats st;
-    memset(&st, 0, sizeof st);
-    if (n_in < 0 || (n_in > 0 && (d_T == nullptr || d_SA == nullptr))) {
-        set_error("pss_sa_build: bad arguments");
-        return PSS_EINVAL;
-    }
-    const u32 n = (u32)n_in;
-    const bool profile = flags & 1u;
-    const Knobs knobs = Knobs::read();
     hipStream_t s = ctx->stream;
-    if (n < 2) {
-        if (n == 1) PSS_HIP(hipMemsetAsync(d_SA, 0, 4, s));
-        PSS_HIP(hipStreamSynchronize(s));
-        if (stats) *stats = st;
-        return PSS_OK;
-    }
-    const u8 *T = static_cast<const u8 *>(d_T);
-    u32 *SA = static_cast<u32 *>(d_SA);
-
-    const size_t n_pad = round_up((size_t)n, 16) + 64;
-    PSS_TRY(ctx->slot[S_CODES].reserve(n_pad));
-    PSS_TRY(ctx->slot[S_K0].reserve((size_t)n * 8));
-    PSS_TRY(ctx->slot[S_K1].reserve((size_t)n * 8));
-    PSS_TRY(ctx->slot[S_V0].reserve((size_t)n * 4));
-    PSS_TRY(ctx->slot[S_V1].reserve((size_t)n * 4));
-    PSS_TRY(ctx->slot[S_ISA].reserve((size_t)n * 4 + 64));
-    PSS_TRY(ctx->slot[S_P0].reserve(std::max((size_t)n * 4, msd_workspace_bytes(n))));   // also the tables of the MSD sort
-    PSS_TRY(ctx->slot[S_P1].reserve((size_t)n * 4));
-    PSS_TRY(ctx->slot[S_GRP].reserve((size_t)n * 4));
-    const size_t sort_ws = radix_sort_workspace_bytes();
-    PSS_TRY(ctx->slot[S_WORK].reserve(sort_ws + 65536));
-    u8 *work = ctx->slot[S_WORK].as<u8>();
-    u8 *small = work + sort_ws;                       // 64 KiB of small device state
-    u32 *d_present = reinterpret_cast<u32 *>(small);              // [256] presence, [256] sampled counts
-    u8 *d_lut = small + 2048;                                     // [256]
-    u32 *d_agg_head = reinterpret_cast<u32 *>(small + 4096);      // [1024]
-    u32 *d_agg_cnt = reinterpret_cast<u32 *>(small + 8192);       // [1024]
-    u64 *d_red = reinterpret_cast<u64 *>(small + 12288);          // [2]
-    u32 *d_counters = reinterpret_cast<u32 *>(small + 12288 + 64);
-
-    u8 *codes = ctx->slot[S_CODES].as<u8>();
-    u64 *K[2] = {ctx->slot[S_K0].as<u64>(), ctx->slot[S_K1].as<u64>()};
-    u32 *V[2] = {ctx->slot[S_V0].as<u32>(), ctx->slot[S_V1].as<u32>()};
-    u32 *ISA = ctx->slot[S_ISA].as<u32>();
-    u32 *P[2] = {ctx->slot[S_P0].as<u32>(), ctx->slot[S_P1].as<u32>()};
-    u32 *GRP = ctx->slot[S_GRP].as<u32>();
-    u32 *h_small = static_cast<u32 *>(ctx->pinned);
-
-    BuildTimer timer;
-    PSS_HIP(hipEventCreate(&timer.ev0));
-    PSS_HIP(hipEventCreate(&timer.ev1));
-    PSS_HIP(hipEventRecord(timer.ev0, s));
-
-    // ---- 0. alphabet ----
+    const u32 n = io.n;
+    u32 *SA = io.SA;
+    u64 *K[2] = {io.K[0], io.K[1]};
+    u32 *V[2] = {io.V[0], io.V[1]};
+    u32 *ISA = io.ISA;
+    u32 *P[2] = {io.P[0], io.P[1]};
+    u32 *GRP = io.GRP;
+    const u8 *codes = io.codes;
+    const bool rank_only = codes == nullptr;
+    const int b = io.b, plus_one = io.plus_one, key_chars = io.key_chars;
+    const bool profile = io.profile;
+    u8 *work = io.work;
+    u32 *d_agg_head = io.d_agg_head, *d_agg_cnt = io.d_agg_cnt, *d_counters = io.d_counters, *h_small = io.h_small;
+    u64 *d_red = io.d_red;
     const int grid_stream = ctx->num_cus * 8;
-    PSS_HIP(hipMemsetAsync(d_present, 0, 2048, s));
-    hipLaunchKernelGGL(sa_symbols_kernel, dim3(grid_stream), dim3(256), 0, s, T, n, d_present, d_present + 256);
-    PSS_HIP(hipMemcpyAsync(h_small, d_present, 2048, hipMemcpyDeviceToHost, s));
-    PSS_HIP(hipStreamSynchronize(s));
-    u8 lut[256];
-    u32 sigma = 0;
-    for (int c = 0; c < 256; ++c) lut[c] = h_small[c] ? (u8)(++sigma) : 0;   // codes 1..sigma
-    int b = 1;
-    while ((1u << b) <= sigma) ++b;               // codes 0..sigma need b bits
-    int plus_one = 0;
-    if (sigma == 256) {
-        // 257 code points do not fit a byte: keep the raw bytes and let the key
-        // packer add 1 to every in-text symbol (9-bit codes, 0 = past the end).
-        b = 9;
-        plus_one = 1;
-        for (int c = 0; c < 256; ++c) lut[c] = (u8)c;
-    }
-    int kmax = 64 / b;
-    if (kmax > 16) kmax = 16;
-    int key_chars = choose_key_chars(h_small + 256, n, b, kmax);
-    const bool forced_chars = knobs.key_chars >= 1 && knobs.key_chars <= kmax;
-    if (forced_chars) key_chars = knobs.key_chars;
-    st.sigma = sigma;
-    st.code_bits = (u32)b;
-    st.key_chars = (u32)key_chars;
-    memcpy(h_small + 1024, lut, 256);
-    PSS_HIP(hipMemcpyAsync(d_lut, h_small + 1024, 256, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(sa_recode_kernel, dim3(grid_stream), dim3(256), 0, s, T, n, (u32)n_pad, d_lut, codes);
+    int cur = io.cur;
+    const int final_buf = io.final_buf;
+    u32 *const v_scratch = io.v_scratch;
+    const bool ties = io.ties, msd_fused = io.msd_fused;
+    const u32 msd_active = io.msd_active;
+    const bool sa_in_place = (final_buf >= 0 && cur == final_buf);
 
-    // ---- 1. initial sort on the first key_chars symbols ----
-    SortStats ss;
-    int key_drop = 0;
-    bool msd_screen_ok = false, sampled = false;
-    if (n >= (1u << 24) && !forced_chars && knobs.key_chars == 0 && !knobs.no_sample) {
-        PSS_TRY(size_initial_key(ctx, codes, n, b, kmax, plus_one, K, V, work, d_counters + 16, h_small, profile, &ss,
-                                 &key_chars, &key_drop, &msd_screen_ok));
-        st.key_chars = (u32)key_chars;
-        sampled = true;
-    }
-    if (knobs.key_drop >= 0 && knobs.key_drop < b && key_chars > 1) key_drop = knobs.key_drop;
-    TextKeys tk{codes, b, key_chars, plus_one, key_drop};
-    const int key_bits0 = key_chars * b - key_drop;
-    st.key_bits = (u64)key_bits0;
-    // The sorted suffix indices of the initial sort ARE the suffix array (ties are reordered
-    // later, inside their slots): let the pass that finishes the sort write straight into the
-    // caller's SA buffer.  The text pass writes buffer 0 and the passes alternate, so the
-    // buffer that receives the last pass is known up front.
-    const int passes0 = (key_bits0 + 7) / 8;
-    const int final_buf = (passes0 - 1) & 1;
-    u32 *const v_scratch = V[final_buf];
-    V[final_buf] = SA;
-    int cur = 0;
-    // With >= 2 passes the sort carries tie flags instead of consumed digits (radix_sort.hip, fs_*):
-    // the last pass writes only the suffix indices with bit 31 = "tied with my predecessor", and
-    // the rerank reads 4-byte flagged values instead of comparing 8-byte keys.
-    const bool ties = passes0 >= 2 && !knobs.no_flags;
-    // Hybrid MSD sort (msd_sort.hip): two global partition passes over 8-byte elements, then every joint
-    // bucket sorted in LDS.  Taken when the key the sizing asked for (<= 48 bits) is covered by what an
-    // element can carry, and the sorted sample shows no crowded 20-bit prefix; the exact bucket check
-    // inside can still decline, then the LSD passes run as before.
-    bool msd_done = false, msd_fused = false;
-    u32 msd_active = 0;
-    if (ties && knobs.msd != 0) {
-        int kb = std::min(msd_max_key_bits(n), 42);
-        const int kc = std::min(kb / b, kmax);                   // whole symbols only
-        kb = kc * b;
-        const bool fits = kc >= 1 && kb >= 21 && !plus_one;
-        const bool auto_ok = sampled && msd_screen_ok && key_bits0 <= 48 && kb + 8 >= key_bits0;
-        if (fits && (knobs.msd == 1 || (knobs.msd < 0 && auto_ok))) {
-            TextKeys mk{codes, b, kc, plus_one, 0};
-            MsdStats ms;
-            bool accepted = false;
-            // The local sort hands over the active list of the first rerank (SA slot, suffix, group rank of every
-            // suffix tied with a neighbour) in the buffers round 0 would fill: P[1], the free value buffer, G[1].
-            // Staging: the first element buffer (free once the second partition pass has read it).
-            PSS_TRY(ctx->slot[S_GRP2].reserve((size_t)n * 4));
-            MsdActive act;
-            act.pos = ctx->slot[S_P1].as<u32>();
-            act.idx = (final_buf == 0) ? V[1] : V[0];
-            act.grp = ctx->slot[S_GRP2].as<u32>();
-            act.st_pos = reinterpret_cast<u32 *>(K[0]);
-            act.st_idx = reinterpret_cast<u32 *>(K[0]) + n;
-            PSS_TRY(msd_suffix_sort(ctx, &mk, n, kb, K, SA, ctx->slot[S_P0].p, h_small, profile, &ms, &accepted,
-                                    knobs.no_msd_fuse ? nullptr : &act));
-            msd_fused = accepted && !knobs.no_msd_fuse;
-            msd_active = act.count;
-            st.msd_buckets = ms.buckets;
-            st.msd_max_bucket = ms.max_bucket;
-            if (accepted) {
-                msd_done = true;
-                key_chars = kc;
-                key_drop = 0;
-                st.key_chars = (u32)kc;
-                st.key_bits = (u64)kb;
-                st.msd = 1;
-                st.msd_tiles = ms.tiles;
-                st.msd_slow_tiles = ms.slow_tiles;
-                st.msd_ms_g1 = ms.ms_g1;
-                st.msd_ms_g2 = ms.ms_g2;
-                st.msd_ms_local = ms.ms_local;
-                cur = final_buf;                                 // V[final_buf] is the caller's SA buffer
-                ss.launches = 3;
-                ss.elems = 3ull * n;
-            }
-        }
-    }
-    if (msd_done) {
-    } else if (ties) PSS_TRY(suffix_sort_flags(ctx, K, V, n, key_bits0, &tk, work, &cur, profile, &ss));
-    else PSS_TRY(radix_sort_pairs(ctx, K, V, n, key_bits0, 0xffffffffu, &tk, 0, work, &cur, profile, &ss));
-    st.initial_passes = (u32)ss.launches;
-    const bool sa_in_place = (cur == final_buf);
-
-    // ---- 2. rerank + compaction, 3. doubling rounds ----
     int rank_bits = 1;
     while ((1ull << rank_bits) <= (u64)n) ++rank_bits;      // ranks 0..n
     RerankArgs ra;
@@ -1433,7 +1332,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     const int k0buf = cur;       // K[k0buf] = sorted initial keys (kept intact in sparse mode)
     u64 *SK[2] = {nullptr, nullptr};   // sparse mode: small ping-pong key buffers
     u64 **Kr = K;
-    u64 h = (u64)(key_drop ? key_chars - 1 : key_chars);   // symbols every group is known to share
+    u64 h = io.h0;               // symbols every group is known to share
     const u32 grid_all = (u32)grid_stream;
     for (int round = 0;; ++round) {
         if (round > 96) {
@@ -1470,6 +1369,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
             if (mode == M_SPARSE && (u64)m_next * 16 > (u64)n) mode = M_TEXT;   // hash table must fit the ISA buffer
             if (m_next == 0) mode = M_SPARSE;                                   // nothing left: no ISA at all
             if (mode == M_TEXT && text_rounds_max <= 0) mode = M_DENSE;
+            if (rank_only && m_next) mode = M_DENSE;                            // no text to pack keys from
             was_text = mode == M_TEXT;
         }
         if (fused0) {
@@ -1483,7 +1383,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
             hipLaunchKernelGGL(rr_apply_tied_kernel, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
         else hipLaunchKernelGGL(rr_apply_kernel<MODE_NONE>, dim3(ra.num_ranges), dim3(RR_BLOCK), 0, s, ra);
         PSS_HIP(hipGetLastError());
-        if (round == 0) V[final_buf] = v_scratch;                 // later rounds must not scribble over SA
+        if (round == 0 && final_buf >= 0) V[final_buf] = v_scratch;   // later rounds must not scribble over SA
         if (m_next == 0) break;
         if (h >= (u64)n) {
             set_error("sa_build: %u suffixes unresolved at h=%llu >= n (internal error)", m_next,
@@ -1687,6 +1587,270 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         ss.pairs_elems += rs.pairs_elems;
         h *= 2;
     }
+    st.mode = was_text ? (mode == M_TEXT ? 2u : 3u) : (u64)mode;
+    return PSS_OK;
+}
+
+// Suffix array of an INTEGER string of m symbols (rle_build.hip: one symbol per run of the text).  K[cur] / V[cur]:
+// the (symbol key, index) pairs sorted by key; both buffer pairs hold m elements and are scratch afterwards.
+// The end of the string is smaller than every symbol.  SA_out: m entries.  st: rounds / passes are added.
+int suffix_rounds_integer(DeviceCtx *ctx, uint32_t m, uint64_t *K[2], uint32_t *V[2], int cur, uint32_t *SA_out,
+                          pss_sa_stats *st)
+{
+    const Knobs knobs = Knobs::read();
+    PSS_TRY(ctx->slot[S_ISA].reserve((size_t)m * 4 + 64));
+    PSS_TRY(ctx->slot[S_P0].reserve((size_t)m * 4));
+    PSS_TRY(ctx->slot[S_P1].reserve((size_t)m * 4));
+    PSS_TRY(ctx->slot[S_GRP].reserve((size_t)m * 4));
+    const size_t sort_ws = radix_sort_workspace_bytes();
+    PSS_TRY(ctx->slot[S_WORK].reserve(sort_ws + 65536));
+    u8 *work = ctx->slot[S_WORK].as<u8>();
+    u8 *small = work + sort_ws;                       // the same 64 KiB of small device state as in sa_build_device
+    RoundsIO io;
+    io.n = m;
+    io.SA = SA_out;
+    io.K[0] = K[0]; io.K[1] = K[1];
+    io.V[0] = V[0]; io.V[1] = V[1];
+    io.ISA = ctx->slot[S_ISA].as<u32>();
+    io.P[0] = ctx->slot[S_P0].as<u32>(); io.P[1] = ctx->slot[S_P1].as<u32>();
+    io.GRP = ctx->slot[S_GRP].as<u32>();
+    io.codes = nullptr;
+    io.b = 8; io.plus_one = 0; io.key_chars = 1; io.key_drop = 0;
+    io.h0 = 1;
+    io.cur = cur;
+    io.final_buf = -1;
+    io.v_scratch = nullptr;
+    io.ties = false;
+    io.msd_fused = false;
+    io.msd_active = 0;
+    io.work = work;
+    io.d_agg_head = reinterpret_cast<u32 *>(small + 4096);
+    io.d_agg_cnt = reinterpret_cast<u32 *>(small + 8192);
+    io.d_red = reinterpret_cast<u64 *>(small + 12288);
+    io.d_counters = reinterpret_cast<u32 *>(small + 12288 + 64);
+    io.h_small = static_cast<u32 *>(ctx->pinned);
+    io.profile = false;
+    SortStats ss;
+    pss_sa_stats local;
+    memset(&local, 0, sizeof local);
+    PSS_TRY(refine_rounds(ctx, knobs, io, ss, st ? *st : local));
+    return PSS_OK;
+}
+
+int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, uint32_t flags, pss_sa_stats *stats)
+{
+    pss_sa_stats st;
+    memset(&st, 0, sizeof st);
+    if (n_in < 0 || (n_in > 0 && (d_T == nullptr || d_SA == nullptr))) {
+        set_error("pss_sa_build: bad arguments");
+        return PSS_EINVAL;
+    }
+    const u32 n = (u32)n_in;
+    const bool profile = flags & 1u;
+    const Knobs knobs = Knobs::read();
+    hipStream_t s = ctx->stream;
+    if (n < 2) {
+        if (n == 1) PSS_HIP(hipMemsetAsync(d_SA, 0, 4, s));
+        PSS_HIP(hipStreamSynchronize(s));
+        if (stats) *stats = st;
+        return PSS_OK;
+    }
+    const u8 *T = static_cast<const u8 *>(d_T);
+    u32 *SA = static_cast<u32 *>(d_SA);
+
+    const size_t n_pad = round_up((size_t)n, 16) + 64;
+    PSS_TRY(ctx->slot[S_CODES].reserve(n_pad));
+    PSS_TRY(ctx->slot[S_K0].reserve((size_t)n * 8));
+    PSS_TRY(ctx->slot[S_K1].reserve((size_t)n * 8));
+    PSS_TRY(ctx->slot[S_V0].reserve((size_t)n * 4));
+    PSS_TRY(ctx->slot[S_V1].reserve((size_t)n * 4));
+    PSS_TRY(ctx->slot[S_ISA].reserve((size_t)n * 4 + 64));
+    PSS_TRY(ctx->slot[S_P0].reserve(std::max((size_t)n * 4, msd_workspace_bytes(n))));   // also the tables of the MSD sort
+    PSS_TRY(ctx->slot[S_P1].reserve((size_t)n * 4));
+    PSS_TRY(ctx->slot[S_GRP].reserve((size_t)n * 4));
+    const size_t sort_ws = radix_sort_workspace_bytes();
+    PSS_TRY(ctx->slot[S_WORK].reserve(sort_ws + 65536));
+    u8 *work = ctx->slot[S_WORK].as<u8>();
+    u8 *small = work + sort_ws;                       // 64 KiB of small device state
+    u32 *d_present = reinterpret_cast<u32 *>(small);              // [256] presence, [256] sampled counts
+    u8 *d_lut = small + 2048;                                     // [256]
+    u32 *d_agg_head = reinterpret_cast<u32 *>(small + 4096);      // [1024]
+    u32 *d_agg_cnt = reinterpret_cast<u32 *>(small + 8192);       // [1024]
+    u64 *d_red = reinterpret_cast<u64 *>(small + 12288);          // [2]
+    u32 *d_counters = reinterpret_cast<u32 *>(small + 12288 + 64);
+
+    u8 *codes = ctx->slot[S_CODES].as<u8>();
+    u64 *K[2] = {ctx->slot[S_K0].as<u64>(), ctx->slot[S_K1].as<u64>()};
+    u32 *V[2] = {ctx->slot[S_V0].as<u32>(), ctx->slot[S_V1].as<u32>()};
+    u32 *ISA = ctx->slot[S_ISA].as<u32>();
+    u32 *P[2] = {ctx->slot[S_P0].as<u32>(), ctx->slot[S_P1].as<u32>()};
+    u32 *GRP = ctx->slot[S_GRP].as<u32>();
+    u32 *h_small = static_cast<u32 *>(ctx->pinned);
+
+    BuildTimer timer;
+    PSS_HIP(hipEventCreate(&timer.ev0));
+    PSS_HIP(hipEventCreate(&timer.ev1));
+    PSS_HIP(hipEventRecord(timer.ev0, s));
+
+    // ---- 0. alphabet ----
+    const int grid_stream = ctx->num_cus * 8;
+    u32 *d_runs = d_counters + 40;
+    PSS_HIP(hipMemsetAsync(d_present, 0, 2048, s));
+    PSS_HIP(hipMemsetAsync(d_runs, 0, 4, s));
+    hipLaunchKernelGGL(sa_symbols_kernel, dim3(grid_stream), dim3(256), 0, s, T, n, d_present, d_present + 256, d_runs);
+    PSS_HIP(hipMemcpyAsync(h_small, d_present, 2048, hipMemcpyDeviceToHost, s));
+    PSS_HIP(hipMemcpyAsync(h_small + 512, d_runs, 4, hipMemcpyDeviceToHost, s));
+    PSS_HIP(hipStreamSynchronize(s));
+    // Long runs of equal bytes (every suffix inside a run is tied with its neighbours for as long as the run
+    // lasts: the worst case of prefix doubling): sort the run heads as a string of one symbol per run, then
+    // every other suffix falls into place with one short radix sort (rle_build.hip).
+    const u32 text_runs = h_small[512];
+    st.runs = text_runs;
+    if (knobs.rle == 1 || (knobs.rle < 0 && n >= 4096 && (u64)text_runs * 8 <= (u64)n)) {
+        RleStats rls;
+        PSS_TRY(rle_suffix_array(ctx, T, n, text_runs, SA, profile, &rls, &st));
+        st.rle = 1;
+        st.rle_id_bits = rls.id_bits;
+        st.rle_ms_table = rls.ms_table;
+        st.rle_ms_reduced = rls.ms_reduced;
+        st.rle_ms_expand = rls.ms_expand;
+        for (int c = 0; c < 256; ++c) st.sigma += h_small[c] ? 1u : 0u;
+        PSS_HIP(hipEventRecord(timer.ev1, s));
+        PSS_HIP(hipStreamSynchronize(s));
+        float ms = 0.f;
+        PSS_HIP(hipEventElapsedTime(&ms, timer.ev0, timer.ev1));
+        st.ms_total = ms;
+        if (stats) *stats = st;
+        return PSS_OK;
+    }
+    u8 lut[256];
+    u32 sigma = 0;
+    for (int c = 0; c < 256; ++c) lut[c] = h_small[c] ? (u8)(++sigma) : 0;   // codes 1..sigma
+    int b = 1;
+    while ((1u << b) <= sigma) ++b;               // codes 0..sigma need b bits
+    int plus_one = 0;
+    if (sigma == 256) {
+        // 257 code points do not fit a byte: keep the raw bytes and let the key
+        // packer add 1 to every in-text symbol (9-bit codes, 0 = past the end).
+        b = 9;
+        plus_one = 1;
+        for (int c = 0; c < 256; ++c) lut[c] = (u8)c;
+    }
+    int kmax = 64 / b;
+    if (kmax > 16) kmax = 16;
+    int key_chars = choose_key_chars(h_small + 256, n, b, kmax);
+    const bool forced_chars = knobs.key_chars >= 1 && knobs.key_chars <= kmax;
+    if (forced_chars) key_chars = knobs.key_chars;
+    st.sigma = sigma;
+    st.code_bits = (u32)b;
+    st.key_chars = (u32)key_chars;
+    memcpy(h_small + 1024, lut, 256);
+    PSS_HIP(hipMemcpyAsync(d_lut, h_small + 1024, 256, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(sa_recode_kernel, dim3(grid_stream), dim3(256), 0, s, T, n, (u32)n_pad, d_lut, codes);
+
+    // ---- 1. initial sort on the first key_chars symbols ----
+    SortStats ss;
+    int key_drop = 0;
+    bool msd_screen_ok = false, sampled = false;
+    if (n >= (1u << 24) && !forced_chars && knobs.key_chars == 0 && !knobs.no_sample) {
+        PSS_TRY(size_initial_key(ctx, codes, n, b, kmax, plus_one, K, V, work, d_counters + 16, h_small, profile, &ss,
+                                 &key_chars, &key_drop, &msd_screen_ok));
+        st.key_chars = (u32)key_chars;
+        sampled = true;
+    }
+    if (knobs.key_drop >= 0 && knobs.key_drop < b && key_chars > 1) key_drop = knobs.key_drop;
+    TextKeys tk{codes, b, key_chars, plus_one, key_drop};
+    const int key_bits0 = key_chars * b - key_drop;
+    st.key_bits = (u64)key_bits0;
+    // The sorted suffix indices of the initial sort ARE the suffix array (ties are reordered
+    // later, inside their slots): let the pass that finishes the sort write straight into the
+    // caller's SA buffer.  The text pass writes buffer 0 and the passes alternate, so the
+    // buffer that receives the last pass is known up front.
+    const int passes0 = (key_bits0 + 7) / 8;
+    const int final_buf = (passes0 - 1) & 1;
+    u32 *const v_scratch = V[final_buf];
+    V[final_buf] = SA;
+    int cur = 0;
+    // With >= 2 passes the sort carries tie flags instead of consumed digits (radix_sort.hip, fs_*):
+    // the last pass writes only the suffix indices with bit 31 = "tied with my predecessor", and
+    // the rerank reads 4-byte flagged values instead of comparing 8-byte keys.
+    const bool ties = passes0 >= 2 && !knobs.no_flags;
+    // Hybrid MSD sort (msd_sort.hip): two global partition passes over 8-byte elements, then every joint
+    // bucket sorted in LDS.  Taken when the key the sizing asked for (<= 48 bits) is covered by what an
+    // element can carry, and the sorted sample shows no crowded 20-bit prefix; the exact bucket check
+    // inside can still decline, then the LSD passes run as before.
+    bool msd_done = false, msd_fused = false;
+    u32 msd_active = 0;
+    if (ties && knobs.msd != 0) {
+        int kb = std::min(msd_max_key_bits(n), 42);
+        const int kc = std::min(kb / b, kmax);                   // whole symbols only
+        kb = kc * b;
+        const bool fits = kc >= 1 && kb >= 21 && !plus_one;
+        const bool auto_ok = sampled && msd_screen_ok && key_bits0 <= 48 && kb + 8 >= key_bits0;
+        if (fits && (knobs.msd == 1 || (knobs.msd < 0 && auto_ok))) {
+            TextKeys mk{codes, b, kc, plus_one, 0};
+            MsdStats ms;
+            bool accepted = false;
+            // The local sort hands over the active list of the first rerank (SA slot, suffix, group rank of every
+            // suffix tied with a neighbour) in the buffers round 0 would fill: P[1], the free value buffer, G[1].
+            // Staging: the first element buffer (free once the second partition pass has read it).
+            PSS_TRY(ctx->slot[S_GRP2].reserve((size_t)n * 4));
+            MsdActive act;
+            act.pos = ctx->slot[S_P1].as<u32>();
+            act.idx = (final_buf == 0) ? V[1] : V[0];
+            act.grp = ctx->slot[S_GRP2].as<u32>();
+            act.st_pos = reinterpret_cast<u32 *>(K[0]);
+            act.st_idx = reinterpret_cast<u32 *>(K[0]) + n;
+            PSS_TRY(msd_suffix_sort(ctx, &mk, n, kb, K, SA, ctx->slot[S_P0].p, h_small, profile, &ms, &accepted,
+                                    knobs.no_msd_fuse ? nullptr : &act));
+            msd_fused = accepted && !knobs.no_msd_fuse;
+            msd_active = act.count;
+            st.msd_buckets = ms.buckets;
+            st.msd_max_bucket = ms.max_bucket;
+            if (accepted) {
+                msd_done = true;
+                key_chars = kc;
+                key_drop = 0;
+                st.key_chars = (u32)kc;
+                st.key_bits = (u64)kb;
+                st.msd = 1;
+                st.msd_tiles = ms.tiles;
+                st.msd_slow_tiles = ms.slow_tiles;
+                st.msd_ms_g1 = ms.ms_g1;
+                st.msd_ms_g2 = ms.ms_g2;
+                st.msd_ms_local = ms.ms_local;
+                cur = final_buf;                                 // V[final_buf] is the caller's SA buffer
+                ss.launches = 3;
+                ss.elems = 3ull * n;
+            }
+        }
+    }
+    if (msd_done) {
+    } else if (ties) PSS_TRY(suffix_sort_flags(ctx, K, V, n, key_bits0, &tk, work, &cur, profile, &ss));
+    else PSS_TRY(radix_sort_pairs(ctx, K, V, n, key_bits0, 0xffffffffu, &tk, 0, work, &cur, profile, &ss));
+    st.initial_passes = (u32)ss.launches;
+    // ---- 2. rerank + compaction, 3. doubling rounds ----
+    RoundsIO io;
+    io.n = n;
+    io.SA = SA;
+    io.K[0] = K[0]; io.K[1] = K[1];
+    io.V[0] = V[0]; io.V[1] = V[1];
+    io.ISA = ISA;
+    io.P[0] = P[0]; io.P[1] = P[1];
+    io.GRP = GRP;
+    io.codes = codes;
+    io.b = b; io.plus_one = plus_one; io.key_chars = key_chars; io.key_drop = key_drop;
+    io.h0 = (u64)(key_drop ? key_chars - 1 : key_chars);
+    io.cur = cur;
+    io.final_buf = final_buf;
+    io.v_scratch = v_scratch;
+    io.ties = ties;
+    io.msd_fused = msd_fused;
+    io.msd_active = msd_active;
+    io.work = work;
+    io.d_agg_head = d_agg_head; io.d_agg_cnt = d_agg_cnt; io.d_red = d_red; io.d_counters = d_counters; io.h_small = h_small;
+    io.profile = profile;
+    PSS_TRY(refine_rounds(ctx, knobs, io, ss, st));
     PSS_HIP(hipEventRecord(timer.ev1, s));
     PSS_HIP(hipStreamSynchronize(s));
     float ms = 0.f;
@@ -1705,7 +1869,6 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         st.fs_launches[i] = ss.fs_launches[i];
         st.fs_elems[i] = ss.fs_elems[i];
     }
-    st.mode = was_text ? (mode == M_TEXT ? 2u : 3u) : (u64)mode;
     if (stats) *stats = st;
     return PSS_OK;
 }

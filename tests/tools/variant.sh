@@ -7,7 +7,7 @@ root=$(cd "$(dirname "$0")/../.." && pwd)
 src=$root/pysubstringsearch_amd/csrc
 obj=$root/variants/obj_$name
 mkdir -p $obj
-for f in radix_sort msd_sort sa_build search; do
+for f in radix_sort msd_sort rle_build sa_build search; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -x hip -c $src/$f.hip -o $obj/$f.o &
 done
 for f in common capi corpus; do
