@@ -385,6 +385,36 @@ def run_chunk(args, D):
                                                      'sum_active', 'big_elems', 'mode')}}
         del w_dT
 
+    # configs[4]: the adversarial corpora (long runs of equal bytes; period 4096), outside the timed region,
+    # N = 1 only: the run-length path (rle_build.hip), and once the prefix-doubling path it replaces
+    adversarial = None
+    if world == 1 and args.corpus == 'lines' and not os.environ.get('PSS_BENCH_NO_SECONDARY'):
+        adversarial = []
+        for kind in ('runs', 'periodic'):
+            a_host = np.empty(n, dtype=np.uint8)
+            _ffi.check(lib.pss_gen_corpus(KINDS[kind], a_host.ctypes.data, n, 0))
+            a_dT = torch.from_numpy(a_host).cuda()
+            ast = _ffi.SaStats()
+            best = None
+            for _ in range(3):
+                _ffi.check(lib.pss_sa_build_device(a_dT.data_ptr(), dSA.data_ptr(), n, dev, 0, ctypes.byref(ast)))
+                best = ast.ms_total if best is None else min(best, ast.ms_total)
+            ad = ast.as_dict()
+            a_ok, a_how = verify_sa(dSA, a_host, kind, 0, load_big_goldens(), want_sha=False)
+            os.environ['PSS_RLE'] = '0'
+            try:
+                _ffi.check(lib.pss_sa_build_device(a_dT.data_ptr(), dSA.data_ptr(), n, dev, 0, ctypes.byref(ast)))
+            finally:
+                del os.environ['PSS_RLE']
+            d_ok, _ = verify_sa(dSA, a_host, kind, 0, load_big_goldens(), want_sha=False)
+            adversarial.append({'corpus': kind, 'chunk_bytes': n, 'build_ms': round(best, 3),
+                                'index_build_gbs': round(n / best / 1e6, 3), 'verified': a_ok, 'verified_by': a_how,
+                                'run_length_path': bool(ad['rle']), 'runs': ad['runs'], 'reduced_rounds': ad['rounds'],
+                                'expansion_key_bits': ad['rle_id_bits'],
+                                'prefix_doubling_ms': round(ast.ms_total, 1), 'prefix_doubling_rounds': ast.rounds,
+                                'prefix_doubling_verified': d_ok})
+            del a_dT
+
     if rank == 0:
         # dominant kernel = the scatter instantiation with the largest summed duration in the profiled
         # build: the passes of the initial sort are fs_scatter_kernel<KIN, KOUT> (key plane bytes in /
@@ -490,6 +520,7 @@ def run_chunk(args, D):
             'build_roofline': build_roof,
             'cpu_baseline': cpu,
             'secondary': secondary,
+            'adversarial': adversarial,
         }
         print(json.dumps(out))
     reader.close()

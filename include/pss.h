@@ -101,7 +101,8 @@ typedef struct pss_sa_stats {
      * symbol per run, the other suffixes by one short radix sort.  `rounds` etc. then describe the sort of
      * the reduced string. */
     uint64_t runs;             /* maximal runs of equal bytes in the text (always filled) */
-    uint64_t rle;              /* 1 when the path ran */
+    uint64_t rle;              /* 0: not taken; 1: taken, expansion by a stable radix sort; 2: taken, expansion by the
+                                  matrix walk (no sort) */
     uint64_t rle_id_bits;      /* key bits of the expansion sort */
     double rle_ms_table;       /* profile mode: run table and symbols */
     double rle_ms_reduced;     /* ... suffix sort of the reduced string */

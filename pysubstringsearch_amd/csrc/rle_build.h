@@ -6,6 +6,7 @@ namespace pss {
 
 struct RleStats {
     uint32_t runs = 0;          // maximal runs of equal bytes
+    bool columns = false;       // expansion by the matrix walk (no radix sort)
     uint32_t id_bits = 0;       // bits of the (class, remaining length) key of the expansion sort
     double ms_table = 0, ms_reduced = 0, ms_expand = 0;   // profile mode
 };

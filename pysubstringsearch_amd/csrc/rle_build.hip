@@ -27,6 +27,14 @@
 //     ...; the last run, whose successor is the end of the text, goes first) and a STABLE radix sort by
 //     id(x) alone -- 13 bits for `periodic`, 15 for `runs`: two passes -- leaves the suffix array.
 //
+//     When the table fits (below), the radix sort is not needed either: the expansion is a matrix walk.  Put the
+//     runs in generation order into columns and the ids into rows: entry (id, t) exists iff run t covers
+//     that id, i.e. lo_t <= id < hi_t (a run covers one id per remaining length), and the suffix array is the
+//     row-major walk over the existing entries.  Blocks of 64 columns (one wave): a ballot gives the entries
+//     of a row inside a block, popcounts give the table count[block][id]; its column-wise exclusive sums plus
+//     the row starts are where every (block, row) segment begins, and the second walk stores
+//     SA[start + lanes below me] = position -- contiguous segments, no sort, no keys (col_* kernels).
+//
 // Every step is exact for every text (a text without runs reduces to itself and pays for it: the
 // caller takes this path when runs average >= 8 bytes).  HBM-bound integer work, no MFMA.
 #include "rle_build.h"
@@ -225,6 +233,106 @@ __global__ __launch_bounds__(RL_BLOCK) void rle_expand_kernel(const u32 *SAr, co
     }
 }
 
+
+// ---- expansion as a matrix walk (see the header) ----------------------------------------------------
+
+constexpr u32 CB = 64;           // runs per block = lanes of a wave
+constexpr u32 CSEG = 64;         // blocks per segment of the column scan
+
+// Per run in generation order: the ids it covers, [lo, hi), and how the position follows from the id:
+// type 0: id = base + r - 1  ->  x = e - r = (e - 1 + base) - id;   type 1: id = top - r  ->  x = (e - top) + id.
+__global__ __launch_bounds__(RL_BLOCK) void col_prep_kernel(const u32 *SAr, const u32 *j0p, const u32 *start, const u32 *sbase, u32 S,
+                                                            u32 *lo, u32 *hi, u32 *c0)
+{
+    const u32 j0 = *j0p;
+    for (u32 t = blockIdx.x * RL_BLOCK + threadIdx.x; t < S; t += gridDim.x * RL_BLOCK) {
+        const u32 k = rle_ord(SAr, j0, S, t);
+        const u32 s0 = start[k], e = start[k + 1], sb = sbase[k], L = e - s0;
+        if (sb >> 31) {
+            const u32 top = sb & 0x7fffffffu;
+            lo[t] = top - L;
+            hi[t] = top | 0x80000000u;          // bit 31: x = c0 + id
+            c0[t] = e - top;
+        } else {
+            lo[t] = sb;
+            hi[t] = sb + L;                     // x = c0 - id
+            c0[t] = e - 1u + sb;
+        }
+    }
+}
+
+// wave (b, c): block b of 64 runs, chunk c of 64 ids.  count[b][id] = runs of the block that cover id.
+__global__ __launch_bounds__(256) void col_count_kernel(const u32 *lo, const u32 *hi, u32 S, u32 idpad, u32 nchunks, u32 nwaves,
+                                                        u32 *table)
+{
+    const u32 w = blockIdx.x * 4u + (u32)wave_id(), lane = (u32)lane_id();
+    if (w >= nwaves) return;
+    const u32 c = w % nchunks, b = w / nchunks;
+    const u32 t = b * CB + lane;
+    const u32 mylo = t < S ? lo[t] : 0xffffffffu, myhi = t < S ? (hi[t] & 0x7fffffffu) : 0u;
+    const u32 id0 = c * 64u;
+    if (__ballot(mylo < id0 + 64u && myhi > id0) == 0ull) return;         // the table was zeroed
+    u32 mine = 0;
+#pragma unroll 8
+    for (u32 j = 0; j < 64u; ++j) {
+        const u32 id = id0 + j;
+        const u32 cnt = (u32)__popcll(__ballot(mylo <= id && id < myhi));
+        if (lane == j) mine = cnt;
+    }
+    table[(size_t)b * idpad + id0 + lane] = mine;
+}
+
+// exclusive sums down the columns, two levels: inside segments of CSEG blocks, then over the segments
+__global__ __launch_bounds__(256) void col_scan1_kernel(u32 *table, u32 idpad, u32 NB, u32 *segtot)
+{
+    const u32 id = blockIdx.x * 256u + threadIdx.x, seg = blockIdx.y;
+    if (id >= idpad) return;
+    const u32 b0 = seg * CSEG, b1 = min(NB, b0 + CSEG);
+    u32 run = 0;
+    for (u32 b = b0; b < b1; ++b) {
+        const u32 v = table[(size_t)b * idpad + id];
+        table[(size_t)b * idpad + id] = run;
+        run += v;
+    }
+    segtot[(size_t)seg * idpad + id] = run;
+}
+__global__ __launch_bounds__(256) void col_scan2_kernel(u32 *segtot, u32 idpad, u32 nseg, u32 *tot)
+{
+    const u32 id = blockIdx.x * 256u + threadIdx.x;
+    if (id >= idpad) return;
+    u32 run = 0;
+    for (u32 seg = 0; seg < nseg; ++seg) {
+        const u32 v = segtot[(size_t)seg * idpad + id];
+        segtot[(size_t)seg * idpad + id] = run;
+        run += v;
+    }
+    tot[id] = run;
+}
+
+__global__ __launch_bounds__(256) void col_scatter_kernel(const u32 *lo, const u32 *hi, const u32 *c0, u32 S, u32 idpad, u32 nchunks,
+                                                          u32 nwaves, const u32 *table, const u32 *segtot, const u64 *idoff, u32 *SA)
+{
+    const u32 w = blockIdx.x * 4u + (u32)wave_id(), lane = (u32)lane_id();
+    if (w >= nwaves) return;
+    const u32 c = w % nchunks, b = w / nchunks;
+    const u32 t = b * CB + lane;
+    const u32 mylo = t < S ? lo[t] : 0xffffffffu, hraw = t < S ? hi[t] : 0u, myc0 = t < S ? c0[t] : 0u;
+    const u32 myhi = hraw & 0x7fffffffu;
+    const bool plus = (hraw >> 31) != 0u;
+    const u32 id0 = c * 64u;
+    if (__ballot(mylo < id0 + 64u && myhi > id0) == 0ull) return;
+    const u32 offs = table[(size_t)b * idpad + id0 + lane] + segtot[(size_t)(b / CSEG) * idpad + id0 + lane] + (u32)idoff[id0 + lane];
+#pragma unroll 4
+    for (u32 j = 0; j < 64u; ++j) {
+        const u32 id = id0 + j;
+        const bool act = mylo <= id && id < myhi;
+        const u64 m = __ballot(act);
+        if (m == 0ull) continue;
+        const u32 o = (u32)__builtin_amdgcn_readlane((int)offs, (int)j);
+        if (act) SA[o + mbcnt(m)] = plus ? myc0 + id : myc0 - id;
+    }
+}
+
 struct RleEvents {
     hipEvent_t ev[4] = {};
     int created = 0;
@@ -299,30 +407,58 @@ int rle_suffix_array(DeviceCtx *ctx, const uint8_t *T, uint32_t n, uint32_t S, u
 
     // 3. expansion
     hipLaunchKernelGGL(rle_j0_kernel, dim3(grid_runs), dim3(RL_BLOCK), 0, s, d_sar, S, d_j0);
-    PSS_TRY(device_excl_scan(ctx, InOrdLen{d_sar, d_start, d_j0, S}, S, d_part, d_total, d_off));
     PSS_HIP(hipMemcpyAsync(h_small, d_cbase + 512, 4, hipMemcpyDeviceToHost, s));
     PSS_HIP(hipStreamSynchronize(s));
     const u32 num_ids = h_small[0];
     int id_bits = 1;
     while ((1ull << id_bits) < (u64)num_ids) ++id_bits;
-    const bool small = n <= 4096u;                      // single-workgroup sort: whole 64-bit key, ties by value
-    const int passes = (id_bits + 7) / 8;
-    const int final_buf = small ? 0 : (passes & 1);     // pass p reads buffer p & 1 (starting from 0) and writes the other
-    u32 *const v_scratch = V[final_buf];
-    V[final_buf] = SA;
-    const u32 chunks = (n + EX_IPT - 1) / EX_IPT;
-    const u32 grid_ex = (u32)std::min<u64>((u64)grid_stream * 4, ((u64)chunks + RL_BLOCK - 1) / RL_BLOCK);
-    hipLaunchKernelGGL(rle_expand_kernel, dim3(grid_ex), dim3(RL_BLOCK), 0, s, d_sar, d_j0, d_start, d_sbase, d_off, S, n, K[0],
-                       V[0], small ? 1 : 0);
-    PSS_HIP(hipGetLastError());
-    int dst = 0;
     SortStats fs;
-    PSS_TRY(radix_sort_pairs(ctx, K, V, n, small ? 64 : id_bits, small ? 0xffu : ((1u << passes) - 1u), nullptr, 0, work, &dst,
-                             profile, &fs));
-    if (V[dst] != SA) PSS_HIP(hipMemcpyAsync(SA, V[dst], (size_t)n * 4, hipMemcpyDeviceToDevice, s));
-    V[final_buf] = v_scratch;
+    const u32 NB = (S + CB - 1) / CB, idpad = (u32)round_up((size_t)num_ids, 64), nchunks = idpad / 64u;
+    const u32 nseg = (NB + CSEG - 1) / CSEG;
+    // (the bounds keep the table inside the first key buffer and everything else inside the second)
+    const bool columns = !getenv("PSS_RLE_SORT") && n >= 4096u && (u64)S * 4 <= (u64)n && (u64)idpad * 4 <= (u64)n &&
+                         (u64)NB * idpad * 4 <= (u64)n * 8 && (u64)NB * nchunks < (1ull << 31);
+    if (columns) {
+        // matrix walk: table in the first key buffer, everything else in the second
+        u32 *table = reinterpret_cast<u32 *>(K[0]);
+        u8 *q = reinterpret_cast<u8 *>(K[1]);
+        size_t qo = 0;
+        auto qcarve = [&](size_t bytes) { u8 *p = q + qo; qo = round_up(qo + bytes, 256); return p; };
+        u32 *segtot = reinterpret_cast<u32 *>(qcarve((size_t)nseg * idpad * 4));
+        u32 *tot = reinterpret_cast<u32 *>(qcarve((size_t)idpad * 4));
+        u64 *idoff = reinterpret_cast<u64 *>(qcarve(((size_t)idpad + 1) * 8));
+        u32 *lo = reinterpret_cast<u32 *>(qcarve((size_t)S * 4)), *hi = reinterpret_cast<u32 *>(qcarve((size_t)S * 4));
+        u32 *c0 = reinterpret_cast<u32 *>(qcarve((size_t)S * 4));
+        const u32 nwaves = NB * nchunks;
+        PSS_HIP(hipMemsetAsync(table, 0, (size_t)NB * idpad * 4, s));
+        hipLaunchKernelGGL(col_prep_kernel, dim3(grid_runs), dim3(RL_BLOCK), 0, s, d_sar, d_j0, d_start, d_sbase, S, lo, hi, c0);
+        hipLaunchKernelGGL(col_count_kernel, dim3((nwaves + 3) / 4), dim3(256), 0, s, lo, hi, S, idpad, nchunks, nwaves, table);
+        hipLaunchKernelGGL(col_scan1_kernel, dim3((idpad + 255) / 256, nseg), dim3(256), 0, s, table, idpad, NB, segtot);
+        hipLaunchKernelGGL(col_scan2_kernel, dim3((idpad + 255) / 256), dim3(256), 0, s, segtot, idpad, nseg, tot);
+        PSS_TRY(device_excl_scan(ctx, InU32{tot}, idpad, d_part, d_total, idoff));
+        hipLaunchKernelGGL(col_scatter_kernel, dim3((nwaves + 3) / 4), dim3(256), 0, s, lo, hi, c0, S, idpad, nchunks, nwaves, table,
+                           segtot, idoff, SA);
+        PSS_HIP(hipGetLastError());
+    } else {
+        PSS_TRY(device_excl_scan(ctx, InOrdLen{d_sar, d_start, d_j0, S}, S, d_part, d_total, d_off));
+        const bool small = n <= 4096u;                      // single-workgroup sort: whole 64-bit key, ties by value
+        const int passes = (id_bits + 7) / 8;
+        const int final_buf = small ? 0 : (passes & 1);     // pass p reads buffer p & 1 (starting from 0) and writes the other
+        u32 *const v_scratch = V[final_buf];
+        V[final_buf] = SA;
+        const u32 chunks = (n + EX_IPT - 1) / EX_IPT;
+        const u32 grid_ex = (u32)std::min<u64>((u64)grid_stream * 4, ((u64)chunks + RL_BLOCK - 1) / RL_BLOCK);
+        hipLaunchKernelGGL(rle_expand_kernel, dim3(grid_ex), dim3(RL_BLOCK), 0, s, d_sar, d_j0, d_start, d_sbase, d_off, S, n, K[0],
+                           V[0], small ? 1 : 0);
+        PSS_HIP(hipGetLastError());
+        int dst = 0;
+        PSS_TRY(radix_sort_pairs(ctx, K, V, n, small ? 64 : id_bits, small ? 0xffu : ((1u << passes) - 1u), nullptr, 0, work, &dst,
+                                 profile, &fs));
+        if (V[dst] != SA) PSS_HIP(hipMemcpyAsync(SA, V[dst], (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        V[final_buf] = v_scratch;
+    }
     mark(3);
-    if (st) {
+    if (st && !columns) {
         st->sort_launches += fs.launches;
         st->sort_elems += fs.elems;
         st->ms_sort += fs.ms;
@@ -333,6 +469,7 @@ int rle_suffix_array(DeviceCtx *ctx, const uint8_t *T, uint32_t n, uint32_t S, u
     if (rs) {
         rs->runs = S;
         rs->id_bits = (u32)id_bits;
+        rs->columns = columns;
         if (profile) {
             PSS_HIP(hipStreamSynchronize(s));
             float ms = 0.f;

@@ -1709,7 +1709,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     if (knobs.rle == 1 || (knobs.rle < 0 && n >= 4096 && (u64)text_runs * 8 <= (u64)n)) {
         RleStats rls;
         PSS_TRY(rle_suffix_array(ctx, T, n, text_runs, SA, profile, &rls, &st));
-        st.rle = 1;
+        st.rle = rls.columns ? 2 : 1;
         st.rle_id_bits = rls.id_bits;
         st.rle_ms_table = rls.ms_table;
         st.rle_ms_reduced = rls.ms_reduced;

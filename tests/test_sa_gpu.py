@@ -240,3 +240,86 @@ def test_msd_is_chosen_for_high_entropy_text_only(oracle):
     sa = _sa_device(t, st)
     assert st['msd'] == 0
     assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(t).tobytes()).hexdigest()
+
+
+# ---- run-length path (rle_build.hip) ----
+
+def _runs_text(rng, n, alpha, maxrun, base=40):
+    out = np.empty(n + maxrun, np.uint8)
+    o = 0
+    while o < n:
+        length = int(rng.integers(1, maxrun + 1))
+        out[o:o + length] = base + int(rng.integers(0, alpha))
+        o += length
+    return out[:n].copy()
+
+
+@pytest.mark.parametrize('expansion', ['columns', 'sort'])
+def test_rle_path_forced_matches_libsais(oracle, monkeypatch, expansion):
+    """PSS_RLE=1 sends EVERY text through the run-length path (run table -> one symbol per run -> suffix
+    sort of the reduced string by rank rounds -> stable radix sort of all suffixes by (class, remaining
+    run length)): texts without runs, one single run, runs of every length around the tile and sort
+    thresholds, periodic texts (the reduced string is periodic too), byte values 0 and 255, and the
+    end-of-text cases (last run of either type).  The expansion is the matrix walk where its table fits
+    (stats rle == 2) and the stable radix sort otherwise or with PSS_RLE_SORT.  The result must be
+    libsais' bytes."""
+    monkeypatch.setenv('PSS_RLE', '1')
+    if expansion == 'sort':
+        monkeypatch.setenv('PSS_RLE_SORT', '1')
+    walked = 0
+    rng = np.random.default_rng(5)
+    cases = []
+    for n in (2, 3, 5, 17, 100, 4095, 4096, 4097, 8192, 20000, 70001, 300000):
+        cases.append(rng.integers(0, 3, n).astype(np.uint8) + 97)                      # hardly any runs
+        cases.append(np.full(n, 97, np.uint8))                                         # one run
+        cases.append(_runs_text(rng, n, 2, 9))
+        cases.append(_runs_text(rng, n, 3, 5000))
+        t = np.full(n, 97, np.uint8)
+        t[15::16] = 10                                                                 # periodic, period 16
+        cases.append(t)
+        t = _runs_text(rng, n, 200, 40, base=0)
+        t[-1] = 255
+        cases.append(t)
+        unit = _runs_text(rng, 50, 2, 20)
+        cases.append(np.tile(unit, n // 50 + 1)[:n].copy())                            # a periodic pattern of runs
+        t = _runs_text(rng, n, 2, 300)
+        t[-1] = 10                                                                     # the reference's texts end in a newline
+        cases.append(t)
+    cases.append(_runs_text(rng, (1 << 21) + 77, 2, 8192))
+    for t in cases:
+        st = {}
+        sa = _sa_device(t, st)
+        assert st['rle'] in (1, 2)
+        walked += st['rle'] == 2
+        assert np.array_equal(sa, oracle.sa(t)), (t.size, st['runs'])
+    assert (walked > 20) if expansion == 'columns' else (walked == 0)
+
+
+def test_rle_path_is_chosen_for_long_runs_only(oracle, monkeypatch):
+    """Without the switch: runs averaging >= 8 bytes take the path (`runs`, `periodic`, a zero-padded
+    binary-like text), anything else (lines, words, short runs) keeps the key sort + rounds; PSS_RLE=0
+    turns it off and the doubling rounds give the same bytes."""
+    from tests.util import gen_corpus
+    for kind, want in ((0, 0), (1, 0), (2, 1), (3, 1)):
+        st = {}
+        t = gen_corpus(kind, 1 << 22)
+        sa = _sa_device(t, st)
+        assert (st['rle'] > 0) == bool(want), kind
+        assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(t).tobytes()).hexdigest()
+    rng = np.random.default_rng(9)
+    t = rng.integers(1, 256, 1 << 20).astype(np.uint8)
+    for o in rng.integers(0, t.size - 30000, 10):
+        t[o:o + int(rng.integers(1000, 20000))] = 0                                    # zero padding inside random bytes
+    st = {}
+    sa = _sa_device(t, st)
+    assert st['rle'] == 0 and st['runs'] * 8 > t.size                                 # runs are long but few: not worth it
+    assert np.array_equal(sa, oracle.sa(t))
+    t = _runs_text(rng, 1 << 20, 4, 64)
+    st = {}
+    sa = _sa_device(t, st)
+    assert st['rle'] == 2
+    assert np.array_equal(sa, oracle.sa(t))
+    monkeypatch.setenv('PSS_RLE', '0')
+    st = {}
+    sa0 = _sa_device(t, st)
+    assert st['rle'] == 0 and np.array_equal(sa0, sa)

@@ -30,6 +30,8 @@ trials = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 for trial in range(trials):
     os.environ['PSS_RLE'] = '1' if trial % 4 else ''
     if not os.environ['PSS_RLE']: os.environ.pop('PSS_RLE')
+    os.environ.pop('PSS_RLE_SORT', None)
+    if trial % 5 == 4: os.environ['PSS_RLE_SORT'] = '1'
     n = int(rng.choice([2, 3, 5, 17, 100, 4095, 4096, 4097, 8192, 20000, 70001, 300000, 1 << 20, (1 << 21) + 77]))
     kind = trial % 6
     if kind == 0: t = rng.integers(0, int(rng.choice([1, 2, 3, 255])), n).astype(np.uint8)          # no long runs at all (alphabet 1: one run)
@@ -48,7 +50,7 @@ for trial in range(trials):
     print(trial, 'n', n, 'kind', kind, 'rle', st['rle'], 'runs', st['runs'], 'idbits', st['rle_id_bits'], 'rounds', st['rounds'],
           'OK' if ok else 'FAIL', flush=True)
     bad += (not ok)
-os.environ.pop('PSS_RLE', None)
+os.environ.pop('PSS_RLE', None); os.environ.pop('PSS_RLE_SORT', None)
 print('BAD', bad)
 if len(sys.argv) > 3: sys.exit(bad)
 import bench
@@ -58,9 +60,10 @@ for kind, name in ((2, 'runs'), (3, 'periodic')):
     t = np.empty(n, np.uint8); lib.pss_gen_corpus(kind, t.ctypes.data, n, 0)
     dT = torch.from_numpy(t).cuda(); dSA = torch.empty(n, dtype=torch.int32, device='cuda'); st = _ffi.SaStats()
     g = gold[(name, 0, n)]
-    for env, flags in ((None, 0), (None, 0), (None, 1), ('0', 0)):
-        if env is None: os.environ.pop('PSS_RLE', None)
-        else: os.environ['PSS_RLE'] = env
+    for env, flags in ((None, 0), (None, 0), (None, 1), ('sort', 0), ('sort', 1), ('0', 0)):
+        os.environ.pop('PSS_RLE', None); os.environ.pop('PSS_RLE_SORT', None)
+        if env == 'sort': os.environ['PSS_RLE_SORT'] = '1'
+        elif env is not None: os.environ['PSS_RLE'] = env
         _ffi.check(lib.pss_sa_build_device(dT.data_ptr(), dSA.data_ptr(), n, 0, flags, ctypes.byref(st)))
         d = st.as_dict()
         print(name, 'PSS_RLE', env, 'flags', flags, 'ms', round(d['ms_total'], 2), 'rle', d['rle'], 'runs', d['runs'], 'idbits', d['rle_id_bits'],
