@@ -403,7 +403,10 @@ def run_chunk(args, D):
             a_ok, a_how = verify_sa(dSA, a_host, kind, 0, load_big_goldens(), want_sha=False)
             os.environ['PSS_RLE'] = '0'
             try:
-                _ffi.check(lib.pss_sa_build_device(a_dT.data_ptr(), dSA.data_ptr(), n, dev, 0, ctypes.byref(ast)))
+                pd_ms = None
+                for _ in range(2):         # the first build grows the workspace of the rank rounds (allocation inside the events)
+                    _ffi.check(lib.pss_sa_build_device(a_dT.data_ptr(), dSA.data_ptr(), n, dev, 0, ctypes.byref(ast)))
+                    pd_ms = ast.ms_total if pd_ms is None else min(pd_ms, ast.ms_total)
             finally:
                 del os.environ['PSS_RLE']
             d_ok, _ = verify_sa(dSA, a_host, kind, 0, load_big_goldens(), want_sha=False)
@@ -411,7 +414,7 @@ def run_chunk(args, D):
                                 'index_build_gbs': round(n / best / 1e6, 3), 'verified': a_ok, 'verified_by': a_how,
                                 'run_length_path': bool(ad['rle']), 'runs': ad['runs'], 'reduced_rounds': ad['rounds'],
                                 'expansion_key_bits': ad['rle_id_bits'],
-                                'prefix_doubling_ms': round(ast.ms_total, 1), 'prefix_doubling_rounds': ast.rounds,
+                                'prefix_doubling_ms': round(pd_ms, 1), 'prefix_doubling_rounds': ast.rounds,
                                 'prefix_doubling_verified': d_ok})
             del a_dT
 

@@ -271,13 +271,18 @@ __global__ __launch_bounds__(256) void col_count_kernel(const u32 *lo, const u32
     const u32 t = b * CB + lane;
     const u32 mylo = t < S ? lo[t] : 0xffffffffu, myhi = t < S ? (hi[t] & 0x7fffffffu) : 0u;
     const u32 id0 = c * 64u;
-    if (__ballot(mylo < id0 + 64u && myhi > id0) == 0ull) return;         // the table was zeroed
+    const bool touch = mylo < id0 + 64u && myhi > id0, full = mylo <= id0 && myhi >= id0 + 64u;
+    if (__ballot(touch) == 0ull) return;                                  // the table was zeroed
     u32 mine = 0;
+    if (__ballot(touch && !full) == 0ull) {
+        mine = (u32)__popcll(__ballot(full));                             // no run starts or ends inside the chunk: one count for all 64 ids
+    } else {
 #pragma unroll 8
-    for (u32 j = 0; j < 64u; ++j) {
-        const u32 id = id0 + j;
-        const u32 cnt = (u32)__popcll(__ballot(mylo <= id && id < myhi));
-        if (lane == j) mine = cnt;
+        for (u32 j = 0; j < 64u; ++j) {
+            const u32 id = id0 + j;
+            const u32 cnt = (u32)__popcll(__ballot(mylo <= id && id < myhi));
+            if (lane == j) mine = cnt;
+        }
     }
     table[(size_t)b * idpad + id0 + lane] = mine;
 }
@@ -320,8 +325,22 @@ __global__ __launch_bounds__(256) void col_scatter_kernel(const u32 *lo, const u
     const u32 myhi = hraw & 0x7fffffffu;
     const bool plus = (hraw >> 31) != 0u;
     const u32 id0 = c * 64u;
-    if (__ballot(mylo < id0 + 64u && myhi > id0) == 0ull) return;
+    const bool touch = mylo < id0 + 64u && myhi > id0, full = mylo <= id0 && myhi >= id0 + 64u;
+    if (__ballot(touch) == 0ull) return;
     const u32 offs = table[(size_t)b * idpad + id0 + lane] + segtot[(size_t)(b / CSEG) * idpad + id0 + lane] + (u32)idoff[id0 + lane];
+    if (__ballot(touch && !full) == 0ull) {
+        // the same runs cover all 64 ids of the chunk: one ballot, 64 stores per covering lane
+        const u32 rank = mbcnt(__ballot(full));
+        u32 x = plus ? myc0 + id0 : myc0 - id0;
+        const u32 step = plus ? 1u : 0xffffffffu;
+#pragma unroll 8
+        for (u32 j = 0; j < 64u; ++j) {
+            const u32 o = (u32)__builtin_amdgcn_readlane((int)offs, (int)j);      // (every lane takes part in the readlane)
+            if (full) SA[o + rank] = x;
+            x += step;
+        }
+        return;
+    }
 #pragma unroll 4
     for (u32 j = 0; j < 64u; ++j) {
         const u32 id = id0 + j;

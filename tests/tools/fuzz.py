@@ -74,7 +74,7 @@ def build(path, entries, limit, W):
 
 
 KNOBS = ('PSS_MODE', 'PSS_KEY_CHARS', 'PSS_KEY_DROP', 'PSS_TEXT_ROUNDS', 'PSS_NO_TIES_PASS', 'PSS_NO_SMALL_PATH', 'PSS_MSD',
-         'PSS_MSD_NO_FUSE', 'PSS_MSD_SLOW_LOCAL', 'PSS_NO_PINNED_RESULTS', 'PSS_NO_MID_TIER')
+         'PSS_MSD_NO_FUSE', 'PSS_MSD_SLOW_LOCAL', 'PSS_NO_PINNED_RESULTS', 'PSS_NO_MID_TIER', 'PSS_RLE', 'PSS_RLE_SORT')
 
 
 def random_knobs(rng):
@@ -107,6 +107,10 @@ def random_knobs(rng):
         os.environ['PSS_NO_PINNED_RESULTS'] = '1'
     if rng.random() < 0.3:
         os.environ['PSS_NO_MID_TIER'] = '1'
+    if rng.random() < 0.5:
+        os.environ['PSS_RLE'] = rng.choice(['0', '1', '1'])      # run-length path forced on / off
+        if rng.random() < 0.4:
+            os.environ['PSS_RLE_SORT'] = '1'                     # ... with the radix-sort expansion
     _ffi.lib.pss_reload_env()
 
 
