@@ -71,7 +71,9 @@ __global__ __launch_bounds__(256) void sa_symbols_kernel(const u8 *T, u32 n, u32
             const uint4 v = Tv[i];
             const u32 w[4] = {v.x, v.y, v.z, v.w};
             const bool sample = (i & 15u) == 0;
-            u32 prev = i ? (u32)T[i * 16 - 1] : (~v.x & 0xffu);
+            // byte before the vector: the neighbouring lane holds it (lane k - 1 reads vector i - 1), lane 0 loads it
+            u32 prev = __shfl_up(v.w >> 24, 1);
+            if (lane_id() == 0) prev = i ? (u32)T[i * 16 - 1] : (~v.x & 0xffu);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const u32 diff = w[k] ^ ((w[k] << 8) | prev);       // byte j: T[j] ^ T[j - 1]
