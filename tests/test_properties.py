@@ -107,3 +107,43 @@ def test_gpu_container_and_search_match_oracle(oracle, tmp_path_factory, entries
         for s in patterns:
             assert sorted(r.search(s)) == sorted(o.search(s))
     o.close()
+
+
+# ---- the argument behind the run-length path (pysubstringsearch_amd/csrc/rle_build.hip), on the CPU ----
+
+def rle_suffix_array(t: bytes):
+    """Suffix array by way of the run-length reduced string, exactly as rle_build.hip derives it (its
+    header comment): (1) maximal runs; (2) one symbol per run, meta = (byte, type, type ? -L : L) with
+    type = (next byte > byte), the end of the text counting as a byte below all; the run heads are ordered
+    like the suffixes of the meta string (sorted here by brute force); (3) every suffix gets the key
+    (byte, type, type ? -r : r) with r = bytes left in its run, and equal keys are ordered by the rank of
+    the next run head -- realised, as on the GPU, by generating the suffixes in that order and sorting
+    STABLY by the key alone."""
+    n = len(t)
+    starts = [i for i in range(n) if i == 0 or t[i] != t[i - 1]] + [n]
+    S = len(starts) - 1
+    meta = []
+    for k in range(S):
+        c, L = t[starts[k]], starts[k + 1] - starts[k]
+        typ = 1 if starts[k + 1] < n and t[starts[k + 1]] > c else 0
+        meta.append((c, typ, -L if typ else L))
+    sar = sorted(range(S), key=lambda k: meta[k:])                 # suffix array of the reduced string
+    order = [S - 1] + [k - 1 for k in sar if k > 0]                # runs by the rank of their successor's head
+    gen = []
+    for k in order:
+        c, typ, _ = meta[k]
+        for x in range(starts[k], starts[k + 1]):
+            r = starts[k + 1] - x
+            gen.append(((c, typ, -r if typ else r), x))
+    gen.sort(key=lambda kv: kv[0])                                 # stable
+    return [x for _, x in gen]
+
+
+run_text = st.lists(st.tuples(st.sampled_from([0, 10, 97, 98, 255]), st.integers(1, 9)), min_size=1, max_size=40).map(
+    lambda runs: b''.join(bytes([c]) * length for c, length in runs))
+
+
+@settings(max_examples=300, deadline=None)
+@given(st.one_of(run_text, small_alphabet_bytes.filter(lambda b: len(b) > 0)))
+def test_run_length_reduction_gives_the_suffix_array(t):
+    assert rle_suffix_array(t) == brute_sa(t)

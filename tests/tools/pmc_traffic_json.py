@@ -2,11 +2,14 @@
 profiles/pmc_build_traffic.json: HBM bytes per launch of every kernel of ONE default build of the lines 2^29 chunk.
 bytes = FETCH_SIZE_KB * 1024 * 2 (gfx950 correction, /opt/skills/guides/MI355X_MICROARCH.md "HBM") + WRITE_SIZE_KB * 1024.
 
-    python tests/tools/pmc_traffic_json.py <pmc dir with g*/pmc_counter_collection.csv> <builds in the run> <out dir>
+    python tests/tools/pmc_traffic_json.py <pmc dir with g*/pmc_counter_collection.csv> <builds in the run> <out dir> [corpus]
+
+With a corpus other than lines only <out dir>/pmc_build_traffic_<corpus>.json is written.
 """
 import csv, glob, json, sys
 from collections import defaultdict
 root, builds, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+corpus = sys.argv[4] if len(sys.argv) > 4 else 'lines'
 agg = defaultdict(lambda: defaultdict(list))
 for f in sorted(glob.glob(f'{root}/g*/*counter_collection.csv')):
     for r in csv.DictReader(open(f)):
@@ -34,11 +37,12 @@ for name, cs in agg.items():
         e['ratio'] = round(per / (ALGO[short] * n), 3)
     kernels[short] = e
 src = ('tests/tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) around default-config '
-       'pss_sa_build_device calls on the lines corpus, n = 2^29')
+       f'pss_sa_build_device calls on the {corpus} corpus, n = 2^29')
 corr = 'bytes = FETCH_SIZE_KB * 1024 * 2 (gfx950 counts 64 B per 128-B request) + WRITE_SIZE_KB * 1024'
 big = {k: v for k, v in kernels.items() if v['bytes_per_launch'] * v['launches_per_build'] > 50e6}
-json.dump({'source': src, 'correction': corr, 'kernels': big}, open(f'{out}/pmc_traffic.json', 'w'), indent=1)
+if corpus == 'lines':
+    json.dump({'source': src, 'correction': corr, 'kernels': big}, open(f'{out}/pmc_traffic.json', 'w'), indent=1)
 json.dump({'source': src, 'correction': corr, 'total_bytes': int(total), 'bytes_per_suffix': round(total / n, 1),
            'by_kernel': {k: int(v['bytes_per_launch'] * v['launches_per_build']) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['bytes_per_launch'] * kv[1]['launches_per_build'])[:16]}},
-          open(f'{out}/pmc_build_traffic.json', 'w'), indent=1)
+          open(f'{out}/pmc_build_traffic.json' if corpus == 'lines' else f'{out}/pmc_build_traffic_{corpus}.json', 'w'), indent=1)
 print(json.dumps({k: v.get('ratio') for k, v in big.items()}))
