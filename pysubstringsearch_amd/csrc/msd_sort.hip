@@ -142,11 +142,22 @@ __global__ __launch_bounds__(MSD_BLOCK) void msd_hist_kernel(MsdArgs a)
         const int m = (MSD_D + b - 1) / b;
         const u32 wmask = (m * b >= 32) ? ~0u : ((1u << (m * b)) - 1u);
         const int down = m * b - MSD_D;
+        // (the next tile's 32 bytes are loaded before this tile's atomics: two trips to HBM in flight per thread)
+        uint4 nlo = make_uint4(0, 0, 0, 0), nhi = nlo;
+        if (e0 + tid * MSD_IPT < e1) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(a.codes + e0 + tid * MSD_IPT);
+            nlo = p[0];
+            nhi = p[1];
+        }
         for (u32 base = e0; base < e1; base += MSD_TILE) {
             const u32 i0 = base + tid * MSD_IPT;
+            const uint4 lo = nlo, hi = nhi;
+            if ((u64)i0 + MSD_TILE < e1) {
+                const uint4 *p = reinterpret_cast<const uint4 *>(a.codes + i0 + MSD_TILE);
+                nlo = p[0];
+                nhi = p[1];
+            }
             if (i0 >= e1) continue;
-            const uint4 *p = reinterpret_cast<const uint4 *>(a.codes + i0);
-            const uint4 lo = p[0], hi = p[1];
             const u64 q[4] = {(u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
                               (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32)};
             auto sym = [&](u32 j) -> u32 { return (u32)(q[j >> 3] >> ((j & 7u) * 8u)) & 0xffu; };   // codes are 0 past the text
@@ -703,21 +714,6 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
         const int bin_shift = idx_bits + (sort_bits > LS_BIN_BITS ? sort_bits - LS_BIN_BITS : 0);
         const u32 rows = (count + MSD_BLOCK - 1) / MSD_BLOCK;          // uniform over the workgroup
         u64 e[MSD_IPT];
-#pragma unroll
-        for (int r = 0; r < MSD_IPT; ++r) {
-            e[r] = ~0ull;
-            if ((u32)r < rows) {
-                const u32 p = r * MSD_BLOCK + tid;
-                if (p < count) {
-                    // bucket of position e0 + p: the last start <= it (bucket 0 starts at e0)
-                    u32 lo = 0, hi = nb;
-                    const u32 at = e0 + p;
-                    while (hi - lo > 1) {
-                        const u32 mid = (lo + hi) >> 1;
-                        if (s_bstart[mid] <= at) lo = mid; else hi = mid;
-                    }
-                    e[r] = ((u64)lo << (rem_bits + idx_bits)) | (pe[r] & low_mask);
-                    const u32 bin = (u32)(e[r] >> bin_shift);
                     atomicAdd(&hist[bin >> 1], 1u << (16u * (bin & 1u)));    // count now; the slot is taken after the scan
                 }
             }
