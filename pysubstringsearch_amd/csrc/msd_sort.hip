@@ -714,6 +714,21 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
         const int bin_shift = idx_bits + (sort_bits > LS_BIN_BITS ? sort_bits - LS_BIN_BITS : 0);
         const u32 rows = (count + MSD_BLOCK - 1) / MSD_BLOCK;          // uniform over the workgroup
         u64 e[MSD_IPT];
+#pragma unroll
+        for (int r = 0; r < MSD_IPT; ++r) {
+            e[r] = ~0ull;
+            if ((u32)r < rows) {
+                const u32 p = r * MSD_BLOCK + tid;
+                if (p < count) {
+                    // bucket of position e0 + p: the last start <= it (bucket 0 starts at e0)
+                    u32 lo = 0, hi = nb;
+                    const u32 at = e0 + p;
+                    while (hi - lo > 1) {
+                        const u32 mid = (lo + hi) >> 1;
+                        if (s_bstart[mid] <= at) lo = mid; else hi = mid;
+                    }
+                    e[r] = ((u64)lo << (rem_bits + idx_bits)) | (pe[r] & low_mask);
+                    const u32 bin = (u32)(e[r] >> bin_shift);
                     atomicAdd(&hist[bin >> 1], 1u << (16u * (bin & 1u)));    // count now; the slot is taken after the scan
                 }
             }
