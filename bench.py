@@ -23,6 +23,11 @@
 
     N > 1: one process per GPU (torch.distributed, RCCL); chunk r lives on rank r, no
     collective on the build path, results of every rank are gathered to rank 0.
+    `python3 bench.py --gpus N` starts the N ranks itself (fresh child processes, one per GPU,
+    before anything touches a GPU); under torchrun (WORLD_SIZE set) it is one of the ranks.
+
+    The same line carries BASELINE configs[2] / [3] under "corpus15" (the leg below with at most
+    3 steps; --no-corpus15 skips it): queries/s on the 7.5 GB corpus next to the CPU path.
 
 --config corpus15 (BASELINE.json configs[2] / [3], strong scaling)
     The 7.5 GB corpus: 15 `lines` chunks of 512 MiB, chunk c on rank c mod N (built there,
@@ -92,7 +97,7 @@ def sa_poly64_numpy(sa: np.ndarray) -> int:
     return acc
 
 
-def verify_sa(d_sa, host_text: np.ndarray, kind: str, chunk_index: int, goldens, want_sha: bool):
+def verify_sa(d_sa, host_text: np.ndarray, kind: str, chunk_index: int, goldens, want_sha: bool, host_sa=None):
     """Is the device suffix array libsais' (the reference's) suffix array of this chunk?
     Returns (verified, how): True / False when it could be decided, None when no known answer exists
     for this input and it is too large to run libsais on the spot."""
@@ -102,7 +107,8 @@ def verify_sa(d_sa, host_text: np.ndarray, kind: str, chunk_index: int, goldens,
         ok = sa_poly64_torch(d_sa) == g['sa_poly64']
         how = 'positional checksum vs libsais golden (tests/golden/sa_big.json)'
         if ok and want_sha:
-            ok = hashlib.sha256(d_sa.cpu().numpy().astype('<i4', copy=False)).hexdigest() == g['sa_sha256']
+            sa_np = host_sa if host_sa is not None else d_sa.cpu().numpy()
+            ok = hashlib.sha256(sa_np.astype('<i4', copy=False)).hexdigest() == g['sa_sha256']
             how = 'sha256 of the int32 array + positional checksum vs libsais golden (tests/golden/sa_big.json)'
         return bool(ok), how
     if n <= (1 << 25):
@@ -280,6 +286,15 @@ class Dist:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         bad, unknown = t.tolist()
         return False if bad else (None if unknown else True)
+
+    def gather_floats(self, value: float):
+        """[value of rank 0, value of rank 1, ...] on every rank."""
+        if self.world == 1:
+            return [float(value)]
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device='cuda' if self.backend == 'nccl' else 'cpu')
+        out = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [float(x.item()) for x in out]
 
     def finish(self):
         if self.world > 1:

@@ -50,7 +50,8 @@ constexpr u32 MSD_WIN = 6144;                        // buckets whose start fall
 constexpr u32 MSD_TILE_CAP = 8183;                   // ... unless that is more than a tile holds: then the window's last bucket goes alone
 constexpr u32 MSD_MAX_BUCKET = 4088;                 // a bucket must fit a tile on its own (the last eight slots of the LDS tile
                                                      // carry the fast kernel's scalars: MSD_TILE_CAP)
-constexpr u32 MSD_TILE_BUCKETS = 1024;               // and at most this many buckets (10 bits of the LDS sort key)
+constexpr int MSD_TAG_BITS = MSD_D + 1;              // an element entering the local sort carries the low 11 bits of its joint bucket number ...
+constexpr u32 MSD_TAG_SPAN = 1u << MSD_TAG_BITS;     // ... so a tile never crosses a multiple of 2048 buckets: inside it the tags only grow
 constexpr u32 MSD_G1_RANGES = 1024;
 constexpr u32 MSD_G2_RANGE = 16 * MSD_TILE;          // elements per G2 range (a piece of one G1 bucket)
 
@@ -74,6 +75,7 @@ struct MsdArgs {
     MsdRange *ranges2;   // G2 range descriptors
     u32 *seg_first;      // [1025] first G2 range of every G1 bucket
     u32 *counters;       // [0] number of G2 ranges, [1] largest joint bucket, [2] non-empty buckets, [3] tiles
+    const u64 *dense;    // G2 scatter: [2^20] number of every joint bucket among the non-empty ones
     const u64 *in;
     u64 *out;
 };
@@ -270,6 +272,7 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_scatter_kernel(MsdArgs a)
     __shared__ u32 scr[MSD_WAVES + 1];
     const u32 tid = threadIdx.x, r = blockIdx.x;
     u32 e0, e1;
+    u32 tag0 = 0, tag1 = 0;      // G2: what the elements of bins 2 tid, 2 tid + 1 are tagged with
     if (FROM_TEXT) {
         if (r >= a.num_ranges1) return;
         e0 = r * a.tiles_per_range1 * MSD_TILE;
@@ -279,13 +282,24 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_scatter_kernel(MsdArgs a)
         if (r >= a.counters[0]) return;
         e0 = a.ranges2[r].start;
         e1 = a.ranges2[r].end;
+        // The element leaves G2 as [ tag | remaining key bits | index ], tag = low 11 bits of its joint bucket's number
+        // among the non-empty buckets (known before this pass: the plan runs on G2's histogram): the local sort
+        // reads the bucket of an element from the element (msd_local_*: no table of bucket starts, no search).
+        // The tag of a bin rides in the high half of its counter word -- the returning atomic of the ranking brings it
+        // along for nothing, the output loop reads it with the bin's offset.
+        const u64 *dn = a.dense + (size_t)a.ranges2[r].seg * MSD_BINS;
+        tag0 = ((u32)dn[2 * tid] & (MSD_TAG_SPAN - 1u)) << 16;
+        tag1 = ((u32)dn[2 * tid + 1] & (MSD_TAG_SPAN - 1u)) << 16;
+        hist[2 * tid] = tag0;
+        hist[2 * tid + 1] = tag1;
     }
     for (u32 i = tid; i < MSD_BINS; i += MSD_BLOCK) {
-        hist[i] = 0;
+        if (FROM_TEXT) hist[i] = 0;
         s_off[i] = FROM_TEXT ? a.T[(size_t)i * a.num_ranges1 + r] + a.J1[i] : a.T[(size_t)r * MSD_BINS + i];
     }
     __syncthreads();
     const int shift2 = a.idx_bits + a.key_bits - 2 * MSD_D;
+    const u64 low_mask2 = (1ull << shift2) - 1ull;
     for (u32 base = e0; base < e1; base += MSD_TILE) {
         const u32 valid = min(MSD_TILE, e1 - base);
         u64 elem[MSD_IPT];
@@ -294,11 +308,11 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_scatter_kernel(MsdArgs a)
         msd_load_tile<FROM_TEXT>(a, base, valid, elem, dig, shift2);
 #pragma unroll
         for (int k = 0; k < MSD_IPT; ++k)
-            rank[k] = msd_valid<FROM_TEXT>(base, valid, k, a.n) ? atomicAdd(&hist[dig[k]], 1u) : 0u;
+            rank[k] = msd_valid<FROM_TEXT>(base, valid, k, a.n) ? (atomicAdd(&hist[dig[k]], 1u) & 0xffffu) : 0u;
         __syncthreads();                                    // (A) counts complete; previous tile fully written out
         {
             // exclusive scan over the 1024 bins, two adjacent bins per thread
-            const u32 c0 = hist[2 * tid], c1 = hist[2 * tid + 1];
+            const u32 c0 = hist[2 * tid] & 0xffffu, c1 = hist[2 * tid + 1] & 0xffffu;
             const u32 ex = block_excl_sum<MSD_WAVES>(c0 + c1, scr, nullptr);
             s_start[2 * tid] = (u16)ex;
             s_start[2 * tid + 1] = (u16)(ex + c0);
@@ -307,8 +321,8 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_scatter_kernel(MsdArgs a)
             s_delta[2 * tid + 1] = o1 - (ex + c0);
             s_off[2 * tid] = o0 + c0;
             s_off[2 * tid + 1] = o1 + c1;
-            hist[2 * tid] = 0;
-            hist[2 * tid + 1] = 0;
+            hist[2 * tid] = tag0;
+            hist[2 * tid + 1] = tag1;
         }
         __syncthreads();                                    // (B) bin starts published
 #pragma unroll
@@ -333,6 +347,7 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_scatter_kernel(MsdArgs a)
                     e = ((e >> 23) << a.idx_bits) | (u64)(base + ((u32)e & (MSD_TILE - 1u)));
                 } else {
                     d = (u32)(e >> shift2) & (MSD_BINS - 1u);
+                    e = (e & low_mask2) | ((u64)(hist[d] >> 16) << shift2);
                 }
                 a.out[s_delta[d] + p] = e;
             }
@@ -364,12 +379,12 @@ __global__ __launch_bounds__(256) void msd_compact_kernel(const u32 *J, u32 nb, 
 
 // Tiles: the (non-empty) buckets that start inside one MSD_WIN window form a tile (< MSD_WIN + MSD_MAX_BUCKET
 // elements); when that exceeds MSD_TILE_CAP the window's last bucket becomes a tile of its own (what is left
-// ends before the window does: < MSD_WIN).  At most MSD_TILE_BUCKETS buckets per tile.  Every decision looks at
+// ends before the window does: < MSD_WIN).  A tile stays inside one aligned block of MSD_TAG_SPAN buckets.  Every decision looks at
 // one window only, so all of them are taken in parallel -- and tiles come out at ~5 500 elements on `lines`
 // instead of the 4 096 of a plain "one tile per 4096-slot window" rule (a fifth fewer tiles).
 __device__ __forceinline__ bool msd_tile_head(const u32 *cstart, u32 ne, u32 n, u32 k)
 {
-    if (k == 0 || (k % MSD_TILE_BUCKETS) == 0) return true;
+    if ((k & (MSD_TAG_SPAN - 1u)) == 0) return true;
     const u32 w = cstart[k] / MSD_WIN;
     if (cstart[k - 1] / MSD_WIN != w) return true;                       // first bucket of its window
     if (k + 1 < ne && cstart[k + 1] / MSD_WIN == w) return false;        // neither first nor last
@@ -399,7 +414,7 @@ __global__ __launch_bounds__(256) void msd_tiles_kernel(const u32 *cstart, u32 n
 }
 
 struct MsdTile {
-    u32 e0, count, k0, nb;      // first element, elements, first compacted bucket, buckets
+    u32 e0, count, tag0, nb;      // first element, elements, tag of the first bucket, buckets
 };
 
 // ---- output of a sorted tile ------------------------------------------------------------------------
@@ -517,46 +532,29 @@ __global__ __launch_bounds__(256) void msd_gather_kernel(const MsdTile *tiles, c
 // [ bucket number inside the tile | remaining key bits | suffix index ] -- stable 8-bit LSD passes
 // over the bucket and key bits (the index bits ride along), wave-ballot ranking as in radix_sort.hip.
 // This is the general (slower) form: it takes whatever the fast kernel below hands back.
-__global__ __launch_bounds__(MSD_BLOCK) void msd_local_sort_kernel(const u64 *in, const u32 *cstart, const u32 *tile_first,
-                                                                     u32 ne, u32 n, int rem_bits, int idx_bits, u32 *sa_out,
-                                                                     const u32 *tile_list, int fused, MsdEmit em_val)
+__global__ __launch_bounds__(MSD_BLOCK) void msd_local_sort_kernel(const u64 *in, const MsdTile *tiles, int rem_bits, int idx_bits,
+                                                                     u32 *sa_out, const u32 *tile_list, int fused, MsdEmit em_val)
 {
     const MsdEmit *em = fused ? &em_val : nullptr;
     __shared__ __attribute__((aligned(16))) u64 exch[MSD_TILE];
     __shared__ u32 wave_hist[MSD_WAVES][256];
-    __shared__ u32 s_bstart[MSD_TILE_BUCKETS + 1];
     __shared__ u32 scr[MSD_WAVES + 1];
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const u32 t = tile_list ? tile_list[blockIdx.x] : blockIdx.x;
-    const u32 k0 = tile_first[t], k1 = tile_first[t + 1];
-    const u32 nb = k1 - k0;
-    const u32 e0 = cstart[k0];
-    const u32 e1 = k1 < ne ? cstart[k1] : n;
-    const u32 count = e1 - e0;
-    for (u32 i = tid; i <= nb; i += MSD_BLOCK) s_bstart[i] = (k0 + i < ne) ? cstart[k0 + i] : n;
+    const MsdTile td = tiles[t];
+    const u32 e0 = td.e0, count = td.count;
     for (u32 i = tid; i < MSD_WAVES * 256; i += MSD_BLOCK) (&wave_hist[0][0])[i] = 0;
     __syncthreads();
     int seg_bits = 0;
-    while ((1u << seg_bits) < nb) ++seg_bits;
-    const u64 low_mask = (1ull << (rem_bits + idx_bits)) - 1ull;
+    while ((1u << seg_bits) < td.nb) ++seg_bits;
+    const u64 tag_base = (u64)td.tag0 << (rem_bits + idx_bits);
     // element r of this thread sits at tile position wave * 1024 + r * 64 + lane (order = position)
     u64 key[MSD_IPT];
 #pragma unroll
     for (int r = 0; r < MSD_IPT; ++r) {
         const u32 p = wave * (kWave * MSD_IPT) + r * kWave + lane;
-        if (p < count) {
-            const u64 e = in[e0 + p];
-            // bucket of position e0 + p: last start <= it
-            u32 lo = 0, hi = nb;
-            const u32 at = e0 + p;
-            while (hi - lo > 1) {
-                const u32 mid = (lo + hi) >> 1;
-                if (s_bstart[mid] <= at) lo = mid; else hi = mid;
-            }
-            key[r] = ((u64)lo << (rem_bits + idx_bits)) | (e & low_mask);
-        } else {
-            key[r] = ~0ull;                                   // padding
-        }
+        // [bucket inside the tile | remaining key bits | index] (G2 tagged the element with its bucket's number); ~0: padding
+        key[r] = p < count ? in[e0 + p] - tag_base : ~0ull;
     }
     const int sort_bits = rem_bits + seg_bits;
     for (int shift = idx_bits; shift < idx_bits + sort_bits; shift += 8) {
@@ -637,6 +635,14 @@ constexpr int LS_BIN_BITS = 12;
 constexpr u32 LS_BINS = 1u << LS_BIN_BITS;          // 16-bit counters, two per LDS word (a tile has < 8192 elements)
 constexpr u32 LS_WORDS = LS_BINS / 2;
 constexpr u32 LS_KMAX = 64;
+#ifndef PSS_LS_GROUP
+#define PSS_LS_GROUP 1
+#endif
+constexpr int LS_GROUP = PSS_LS_GROUP;              // rows ranked / written out together: their LDS reads are issued back to back
+#ifndef PSS_LS_WINDOW
+#define PSS_LS_WINDOW 8
+#endif
+constexpr int LS_WINDOW = PSS_LS_WINDOW;                        // members of its bin every element reads unconditionally (bins average 1.3)
 
 __global__ __launch_bounds__(256) void msd_tile_desc_kernel(const u32 *cstart, const u32 *tile_first, u32 nt, u32 ne, u32 n,
                                                               MsdTile *tiles)
@@ -645,11 +651,14 @@ __global__ __launch_bounds__(256) void msd_tile_desc_kernel(const u32 *cstart, c
     if (t >= nt) return;
     const u32 k0 = tile_first[t], k1 = tile_first[t + 1];
     const u32 e0 = cstart[k0], e1 = k1 < ne ? cstart[k1] : n;
-    tiles[t] = MsdTile{e0, e1 - e0, k0, k1 - k0};
+    tiles[t] = MsdTile{e0, e1 - e0, k0 & (MSD_TAG_SPAN - 1u), k1 - k0};
 }
 
 // Workgroup barrier that waits for this wave's LDS traffic only: global loads issued before it (the
 // prefetch of the next tile) stay in flight across it.
+// Pins a loaded value: the load that produced it cannot be sunk into a later branch.
+__device__ __forceinline__ void keep_load(u64 &v) { asm volatile("" : "+v"(v)); }
+
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -660,34 +669,27 @@ __device__ __forceinline__ void lds_barrier()
 // memory most of the time.  The workgroups therefore persist (two per CU) and walk over the tiles with the
 // loads one tile ahead: descriptor two tiles ahead, bucket starts and elements of the next tile issued as
 // soon as the registers of the current one are free, landing while the current tile is being sorted.
-__global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 *in, const u32 *cstart, const MsdTile *tiles,
-                                                                     u32 nt, int rem_bits, int idx_bits, u32 *sa_out,
-                                                                     u32 *fail_list, u32 *fail_count, int fused, MsdEmit em_val)
+__global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 *in, const MsdTile *tiles, u32 nt, int rem_bits,
+                                                                     int idx_bits, u32 *sa_out, u32 *fail_list, u32 *fail_count,
+                                                                     int fused, MsdEmit em_val)
 {
     const MsdEmit *em = fused ? &em_val : nullptr;
-    // 80 KiB of LDS to the byte: two workgroups per CU
-    __shared__ __attribute__((aligned(16))) u64 exch[MSD_TILE];
-    __shared__ u32 hist[LS_WORDS], hist2[LS_WORDS];      // counts, then bin starts (hist) / running slots (hist2), packed
-    u32 *const s_bstart = hist2;      // the bucket starts are read before the scan first writes hist2
+    // 80 KiB of LDS to the byte: two workgroups per CU.  One array: the tile, then the counters -- the ranking below reads
+    // up to LS_WINDOW - 1 elements past the tile's last slot (masked out afterwards), and those reads must stay inside it.
+    __shared__ __attribute__((aligned(16))) u64 lds_all[MSD_TILE + LS_WORDS];
+    u64 *const exch = lds_all;
+    u32 *const hist = reinterpret_cast<u32 *>(lds_all + MSD_TILE);      // counts, then bin starts (hist) / running slots (hist2), packed
+    u32 *const hist2 = hist + LS_WORDS;
     u32 *const scr = reinterpret_cast<u32 *>(&exch[MSD_TILE - 8]);      // a tile never reaches these slots (MSD_MAX_BUCKET)
     u32 &s_fail = scr[MSD_WAVES + 2];
     const u32 tid = threadIdx.x;
     const u32 stride = gridDim.x;
     u32 t = blockIdx.x;
     if (t >= nt) return;
-    const u64 low_mask = (1ull << (rem_bits + idx_bits)) - 1ull;
-    constexpr int BS_PER = (MSD_TILE_BUCKETS + MSD_BLOCK) / MSD_BLOCK;      // bucket starts per thread (3)
-
     MsdTile cur = tiles[t];
     MsdTile nxt = t + stride < nt ? tiles[t + stride] : MsdTile{0, 0, 0, 0};
     u64 pe[MSD_IPT];          // prefetched raw elements of the tile about to be sorted
-    u32 pb[BS_PER];           // prefetched bucket starts (entries tid, tid + 512, ...)
     auto prefetch = [&](const MsdTile &d) {
-#pragma unroll
-        for (int j = 0; j < BS_PER; ++j) {
-            const u32 i = j * MSD_BLOCK + tid;
-            pb[j] = i < d.nb ? cstart[d.k0 + i] : 0u;
-        }
 #pragma unroll
         for (int r = 0; r < MSD_IPT; ++r) {
             const u32 p = r * MSD_BLOCK + tid;
@@ -696,23 +698,19 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
     };
     prefetch(cur);
     for (;;) {
-        const u32 count = cur.count, nb = cur.nb, e0 = cur.e0;
-#pragma unroll
-        for (int j = 0; j < BS_PER; ++j) {
-            const u32 i = j * MSD_BLOCK + tid;
-            if (i < nb) s_bstart[i] = pb[j];
-        }
+        const u32 count = cur.count, e0 = cur.e0;
         for (u32 i = tid; i < LS_WORDS; i += MSD_BLOCK) hist[i] = 0;
         if (tid == 0) {
             s_fail = 0;
             scr[MSD_WAVES + 3] = 0;        // records this tile has emitted
         }
         lds_barrier();
+        const u32 rows = (count + MSD_BLOCK - 1) / MSD_BLOCK;          // uniform over the workgroup
         int seg_bits = 0;
-        while ((1u << seg_bits) < nb) ++seg_bits;
+        while ((1u << seg_bits) < cur.nb) ++seg_bits;
+        const u64 tag_base = (u64)cur.tag0 << (rem_bits + idx_bits);
         const int sort_bits = rem_bits + seg_bits;
         const int bin_shift = idx_bits + (sort_bits > LS_BIN_BITS ? sort_bits - LS_BIN_BITS : 0);
-        const u32 rows = (count + MSD_BLOCK - 1) / MSD_BLOCK;          // uniform over the workgroup
         u64 e[MSD_IPT];
 #pragma unroll
         for (int r = 0; r < MSD_IPT; ++r) {
@@ -720,14 +718,8 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
             if ((u32)r < rows) {
                 const u32 p = r * MSD_BLOCK + tid;
                 if (p < count) {
-                    // bucket of position e0 + p: the last start <= it (bucket 0 starts at e0)
-                    u32 lo = 0, hi = nb;
-                    const u32 at = e0 + p;
-                    while (hi - lo > 1) {
-                        const u32 mid = (lo + hi) >> 1;
-                        if (s_bstart[mid] <= at) lo = mid; else hi = mid;
-                    }
-                    e[r] = ((u64)lo << (rem_bits + idx_bits)) | (pe[r] & low_mask);
+                    // the element carries its bucket (G2 put it there): [bucket inside the tile | remaining key bits | index]
+                    e[r] = pe[r] - tag_base;
                     const u32 bin = (u32)(e[r] >> bin_shift);
                     atomicAdd(&hist[bin >> 1], 1u << (16u * (bin & 1u)));    // count now; the slot is taken after the scan
                 }
@@ -774,33 +766,60 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
             }
         }
         lds_barrier();
-        // place inside the bin = number of smaller elements there (thread <-> position: neighbours share the bin)
+        // Place inside the bin = number of smaller elements there (thread <-> position: neighbours share the bin, their
+        // reads are broadcasts).  The kernel is bound by the latency of dependent LDS reads, not by their number: every
+        // element reads a fixed window of LS_WINDOW members of its bin (no loop, no branch -- a read past the bin is
+        // masked out), LS_GROUP rows at a time with all their reads in flight; a longer bin (rare: bins average 1.3
+        // elements) finishes in a loop.
+        const u16 *const starts16 = reinterpret_cast<const u16 *>(hist);      // starts16[bin] = first slot of the bin
         u32 rk[MSD_IPT];
 #pragma unroll
-        for (int r = 0; r < MSD_IPT; ++r) {
-            rk[r] = 0;
-            if ((u32)r < rows) {
-                const u32 p = r * MSD_BLOCK + tid;
-                if (p < count) {
-                    const u64 x = exch[p];
-                    const u32 bin = (u32)(x >> bin_shift);
-                    const u32 s0 = (hist[bin >> 1] >> (16u * (bin & 1u))) & 0xffffu;
-                    const u32 s1 = bin + 1 < LS_BINS ? ((hist[(bin + 1) >> 1] >> (16u * ((bin + 1) & 1u))) & 0xffffu) : count;
-                    u32 smaller = 0;
-                    if (s1 - s0 > LS_KMAX) {
-                        s_fail = 1;
-                    } else {
-                        // four independent LDS reads per step (a read past the bin is masked out)
-                        for (u32 q = s0; q < s1; q += 4) {
-                            const u64 y0 = exch[q], y1 = exch[min(q + 1, MSD_TILE - 1)], y2 = exch[min(q + 2, MSD_TILE - 1)],
-                                      y3 = exch[min(q + 3, MSD_TILE - 1)];
-                            smaller += (y0 < x ? 1u : 0u) + ((q + 1 < s1 && y1 < x) ? 1u : 0u) +
-                                       ((q + 2 < s1 && y2 < x) ? 1u : 0u) + ((q + 3 < s1 && y3 < x) ? 1u : 0u);
+        for (int g = 0; g < MSD_IPT; g += LS_GROUP) {
+            if ((u32)g < rows) {
+                u64 x[LS_GROUP];
+                u32 s0[LS_GROUP], len[LS_GROUP], sm[LS_GROUP];
+#pragma unroll
+                for (int j = 0; j < LS_GROUP; ++j) x[j] = exch[(g + j) * MSD_BLOCK + tid];
+#pragma unroll
+                for (int j = 0; j < LS_GROUP; ++j) {
+                    const u32 p = (g + j) * MSD_BLOCK + tid;
+                    const u32 bin = (u32)(x[j] >> bin_shift) & (LS_BINS - 1u);      // (a slot past the tile holds anything)
+                    s0[j] = starts16[bin];
+                    const u32 nx = starts16[min(bin + 1u, LS_BINS - 1u)];
+                    const u32 s1 = bin + 1u < LS_BINS ? nx : count;
+                    len[j] = p < count ? s1 - s0[j] : 0u;
+                }
+                u64 y[LS_GROUP][LS_WINDOW];
+#pragma unroll
+                for (int j = 0; j < LS_GROUP; ++j) {
+#pragma unroll
+                    for (int k = 0; k < LS_WINDOW; ++k) y[j][k] = exch[s0[j] + k];
+                }
+#pragma unroll
+                for (int j = 0; j < LS_GROUP; ++j) {
+                    u32 c = 0;
+#pragma unroll
+                    for (int k = 0; k < LS_WINDOW; ++k) {
+                        keep_load(y[j][k]);      // (or the compiler makes every read conditional on k < len: a branch and a wait per read)
+                        c += ((u32)k < len[j] ? 1u : 0u) & (y[j][k] < x[j] ? 1u : 0u);
+                    }
+                    sm[j] = c;
+                }
+#pragma unroll
+                for (int j = 0; j < LS_GROUP; ++j) {
+                    if (len[j] > (u32)LS_WINDOW) {
+                        if (len[j] > LS_KMAX) {
+                            s_fail = 1;
+                        } else {
+                            for (u32 q = s0[j] + LS_WINDOW; q < s0[j] + len[j]; ++q) sm[j] += exch[q] < x[j] ? 1u : 0u;
                         }
                     }
-                    e[r] = x;
-                    rk[r] = s0 + smaller;
+                    e[g + j] = x[j];
+                    rk[g + j] = s0[j] + sm[j];
                 }
+            } else {
+#pragma unroll
+                for (int j = 0; j < LS_GROUP; ++j) rk[g + j] = 0;
             }
         }
         lds_barrier();
@@ -817,7 +836,49 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
             }
         }
         lds_barrier();
-        if (!failed) msd_emit_tile(exch, count, e0, idx_bits, sa_out, em, &scr[MSD_WAVES + 3]);
+        if (!failed) {
+            // Output (msd_emit_tile with the loads of LS_GROUP rows in flight): suffix indices to sa_out[e0 ..]; a record for
+            // every element tied with a neighbour when the first rerank is fused, else bit 31 = "same key as my predecessor".
+            const u32 imask = (u32)((1ull << idx_bits) - 1ull);
+            u32 *const s_count = &scr[MSD_WAVES + 3];
+#pragma unroll
+            for (int g = 0; g < MSD_IPT; g += LS_GROUP) {
+                if ((u32)g < rows) {
+                    u64 cur[LS_GROUP], prv[LS_GROUP], nxt[LS_GROUP];
+#pragma unroll
+                    for (int j = 0; j < LS_GROUP; ++j) {
+                        const u32 p = (g + j) * MSD_BLOCK + tid;
+                        cur[j] = exch[p];
+                        prv[j] = exch[p ? p - 1 : 0];
+                        nxt[j] = exch[p + 1];                                   // (position 8191 + 1 is the first counter word)
+                    }
+#pragma unroll
+                    for (int j = 0; j < LS_GROUP; ++j) {
+                        keep_load(cur[j]);
+                        keep_load(prv[j]);
+                        keep_load(nxt[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < LS_GROUP; ++j) {
+                        const u32 p = (g + j) * MSD_BLOCK + tid;
+                        if (p < count) {
+                            const u64 kx = cur[j] >> idx_bits;
+                            const bool tie = p > 0 && (prv[j] >> idx_bits) == kx;
+                            const u32 sfx = (u32)cur[j] & imask;
+                            sa_out[e0 + p] = sfx | ((tie && em == nullptr) ? 0x80000000u : 0u);
+                            if (em != nullptr) {
+                                const bool tie_next = p + 1 < count && (nxt[j] >> idx_bits) == kx;
+                                if (tie || tie_next) {
+                                    const u32 slot = e0 + atomicAdd(s_count, 1u);
+                                    em->st_pos[slot] = e0 + p;
+                                    em->st_idx[slot] = sfx | (tie ? 0x80000000u : 0u);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
         if (em) {
             lds_barrier();
             if (tid == 0 && !failed) em->blk_cnt[t] = scr[MSD_WAVES + 3];
@@ -832,6 +893,13 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
 
 // ---- host --------------------------------------------------------------------------------------
 
+// Upper bound on the tiles of the plan: at most two per MSD_WIN window (msd_tile_head) plus one per aligned block
+// of MSD_TAG_SPAN joint buckets.
+static size_t msd_max_tiles(uint32_t n)
+{
+    return (size_t)n / (MSD_WIN / 2) + ((size_t)MSD_BINS * MSD_BINS) / MSD_TAG_SPAN + 8;
+}
+
 size_t msd_workspace_bytes(uint32_t n)
 {
     const size_t max_ranges2 = (size_t)n / MSD_G2_RANGE + MSD_BINS + 8;
@@ -842,16 +910,17 @@ size_t msd_workspace_bytes(uint32_t n)
            + max_ranges2 * sizeof(MsdRange) + (MSD_BINS + 8) * 4 + 64   // ranges, seg_first, counters
            + (nbk + 8) * 8                            // scan output (ranks)
            + (nbk + 8) * 4                            // compacted starts
-           + ((size_t)n / (MSD_WIN / 2) + nbk / MSD_TILE_BUCKETS + 32) * 8   // tile_first, then the tiles left to the general kernel
-           + ((size_t)n / (MSD_WIN / 2) + nbk / MSD_TILE_BUCKETS + 32) * 16  // blocks of active records per tile + their final offsets
-           + (SC_MAX_BLOCKS + 8) * 8 + 4096;
+           + (msd_max_tiles(n) + 32) * 8              // tile_first, then the tiles left to the general kernel
+           + (msd_max_tiles(n) + 32) * 16             // blocks of active records per tile + their final offsets
+           + (msd_max_tiles(n) + 32) * sizeof(MsdTile)
+           + (SC_MAX_BLOCKS + 8) * 8 + 8192;
 }
 
 int msd_max_key_bits(uint32_t n)
 {
     int ib = 1;
     while ((1ull << ib) < (u64)n) ++ib;
-    return 64 + MSD_D - ib;      // [K - 10 key bits | ib index bits] must fit 64 bits after G1
+    return 64 + MSD_D - MSD_TAG_BITS - ib + MSD_D;      // [11-bit bucket tag | K - 20 key bits | ib index bits] must fit 64 bits after G2
 }
 
 int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bits, uint64_t *A[2], uint32_t *sa_out,
@@ -861,7 +930,7 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     hipStream_t s = ctx->stream;
     int ib = 1;
     while ((1ull << ib) < (u64)n) ++ib;
-    if (key_bits < 2 * MSD_D + 1 || key_bits > 64 + MSD_D - ib || n < 2) {
+    if (key_bits < 2 * MSD_D + 1 || key_bits > msd_max_key_bits(n) || n < 2) {
         set_error("msd_suffix_sort: key of %d bits does not fit (n = %u)", key_bits, n);
         return PSS_EINVAL;
     }
@@ -878,7 +947,8 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     u32 *counters = reinterpret_cast<u32 *>(carve(64));
     u64 *ranks = reinterpret_cast<u64 *>(carve((nbk + 8) * 8));
     u32 *cstart = reinterpret_cast<u32 *>(carve((nbk + 8) * 4));
-    const size_t max_tiles = (size_t)n / (MSD_WIN / 2) + nbk / MSD_TILE_BUCKETS + 8;      // at most two tiles per window
+    const size_t max_tiles = msd_max_tiles(n);
+    MsdTile *tiles_all = reinterpret_cast<MsdTile *>(carve((max_tiles + 16) * sizeof(MsdTile)));
     u32 *tile_first = reinterpret_cast<u32 *>(carve((max_tiles + 16) * 8));
     u32 *blk_cnt = reinterpret_cast<u32 *>(carve((max_tiles + 8) * 4));
     u64 *dst_off = reinterpret_cast<u64 *>(carve((max_tiles + 8) * 8));
@@ -938,6 +1008,7 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     hipLaunchKernelGGL(msd_ranges_kernel, dim3(1), dim3(MSD_BINS), 0, s, J1, ranges2, seg_first, counters);
     a.in = A[0];
     a.out = A[1];
+    a.dense = ranks;
     hipLaunchKernelGGL(msd_hist_kernel<false>, dim3((u32)max_ranges2), dim3(MSD_BLOCK), 0, s, a);
     hipLaunchKernelGGL(msd_offsets_kernel, dim3(MSD_BINS), dim3(MSD_BINS), 0, s, T, (const u32 *)seg_first, (const u32 *)J1, J,
                        0u, n, MSD_BINS);
@@ -962,6 +1033,10 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
     PSS_HIP(hipStreamSynchronize(s));
     const u32 nt = h_small[0];
+    if ((size_t)nt > max_tiles) {       // cannot happen (msd_max_tiles is an upper bound of the plan): never run past the tables
+        set_error("msd_suffix_sort: %u tiles planned, tables hold %zu (internal error)", nt, max_tiles);
+        return PSS_EDEVICE;
+    }
     PSS_TRY(mark());
     // counters[4] = tiles the fast kernel declined (their numbers go behind the tile table), [5] = active records
     u32 *fail_list = tile_first + nt + 8;
@@ -969,24 +1044,23 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     const int fused = active != nullptr;
     if (fused) em = MsdEmit{active->st_pos, active->st_idx, blk_cnt};
     const int rem_bits = key_bits - 2 * MSD_D;
-    MsdTile *tiles_all = reinterpret_cast<MsdTile *>(ranks);          // the scan output is consumed: reuse it
     hipLaunchKernelGGL(msd_tile_desc_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, cstart, tile_first, nt, ne, n, tiles_all);
     if (getenv("PSS_MSD_SLOW_LOCAL")) {
-        hipLaunchKernelGGL(msd_local_sort_kernel, dim3(nt), dim3(MSD_BLOCK), 0, s, A[1], cstart, tile_first, ne, n, rem_bits, ib,
+        hipLaunchKernelGGL(msd_local_sort_kernel, dim3(nt), dim3(MSD_BLOCK), 0, s, A[1], (const MsdTile *)tiles_all, rem_bits, ib,
                            sa_out, (const u32 *)nullptr, fused, em);
     } else {
         MsdTile *tiles = tiles_all;
         const u32 grid = std::min<u32>(nt, 2u * (u32)ctx->num_cus);
-        hipLaunchKernelGGL(msd_local_fast_kernel, dim3(grid), dim3(MSD_BLOCK), 0, s, A[1], cstart, tiles, nt, rem_bits, ib, sa_out,
-                           fail_list, counters + 4, fused, em);
+        hipLaunchKernelGGL(msd_local_fast_kernel, dim3(grid), dim3(MSD_BLOCK), 0, s, A[1], (const MsdTile *)tiles, nt, rem_bits, ib,
+                           sa_out, fail_list, counters + 4, fused, em);
         PSS_TRY(mark());            // (profile mode) the events bracket this launch alone
         PSS_HIP(hipMemcpyAsync(h_small, counters + 4, 4, hipMemcpyDeviceToHost, s));
         PSS_HIP(hipStreamSynchronize(s));
         const u32 nfail = h_small[0];
         if (stats) stats->slow_tiles = nfail;
         if (nfail)
-            hipLaunchKernelGGL(msd_local_sort_kernel, dim3(nfail), dim3(MSD_BLOCK), 0, s, A[1], cstart, tile_first, ne, n,
-                               rem_bits, ib, sa_out, (const u32 *)fail_list, fused, em);
+            hipLaunchKernelGGL(msd_local_sort_kernel, dim3(nfail), dim3(MSD_BLOCK), 0, s, A[1], (const MsdTile *)tiles_all, rem_bits,
+                               ib, sa_out, (const u32 *)fail_list, fused, em);
     }
     if (getenv("PSS_MSD_SLOW_LOCAL")) PSS_TRY(mark());
     if (fused) {
