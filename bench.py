@@ -365,8 +365,34 @@ def run_chunk(args, D):
     build_s, search_s, total_s = D.max_over_ranks([build_s, search_s, total_s])
 
     # the suffix array the last timed step left in dSA: is it the reference's?
-    verified, how = verify_sa(dSA, host, args.corpus, rank, load_big_goldens(), want_sha=(world == 1))
+    host_sa = dSA.cpu().numpy() if world == 1 else None
+    verified, how = verify_sa(dSA, host, args.corpus, rank, load_big_goldens(), want_sha=(world == 1), host_sa=host_sa)
     verified = D.all_true(verified)
+
+    # ... and are the results of the query leg the reference's?  A sample of the batch (sampled and random queries alike)
+    # through the oracle's restatement of Reader::search (src/lib.rs:209-278) over the same text and the suffix array
+    # just verified, compared per query as multisets (the reference's tests use assertCountEqual, tests:32-37).
+    verified_search = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        pick = list(range(0, len(queries), max(1, len(queries) // 200)))
+        qs = [queries[i] for i in pick]
+        got, got_counts = reader.search_batch_raw(qs)
+        o = O.OracleReader.from_arrays([host], [host_sa])
+        exp, exp_counts = o.search_multiple_bytes(qs)
+        o.close()
+        ok, pos_g, pos_e = list(got_counts) == [int(c) for c in exp_counts], 0, 0
+        for cg, ce in zip(got_counts, exp_counts):
+            if not ok:
+                break
+            ok = sorted(got[pos_g:pos_g + cg]) == sorted(exp[pos_e:pos_e + int(ce)])
+            pos_g += cg
+            pos_e += int(ce)
+        verified_search = {'ok': bool(ok), 'queries': len(qs), 'entries': int(sum(got_counts)),
+                           'by': 'oracle Reader::search restatement on the same text + verified suffix array, per-query multisets'}
+        if not ok:
+            verified = False
+    del host_sa
 
     # roofline of the dominant kernel: one extra build in profile mode (HIP events
     # on the engine's own stream around every radix-pass launch), outside the timed region
@@ -467,6 +493,9 @@ def run_chunk(args, D):
                     traffic = None
             roof = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                    'traffic_source': None if traffic is None else
+                    'profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this workload '
+                    '(FETCH x 2 on gfx950), committed with the code -- a constant of the build, not measured in this run',
                     'kernel': kname, 'launches_per_build': launches, 'algorithmic_bytes_per_element': bpe,
                     'ms_per_launch': round(ms_per_launch, 4), 'algorithmic_bytes_per_launch': int(bytes_per_launch)}
         # whole-build roofline: A_min = read T once + write SA once; A_model = what this
@@ -502,6 +531,7 @@ def run_chunk(args, D):
                       'effective_gbs_a_min': round(5 * n / build_ms / 1e6, 1),
                       'achieved': round(a_model / build_ms / 1e6, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                       'frac': round(a_model / build_ms / 1e6 / HBM_PEAK_GBS, 4), 'traffic': measured,
+                      'traffic_source': None if measured is None else 'profiles/pmc_build_traffic.json (committed PMC runs, not measured in this run)',
                       'passes': sa_stats['initial_passes'], 'rounds': sa_stats['rounds'], 'sum_active': sa_stats['sum_active']}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -515,7 +545,7 @@ def run_chunk(args, D):
             'ms_per_step': round(total_s / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'u64', 'data': 'synthetic',
-            'verified': verified, 'verified_by': how,
+            'verified': verified, 'verified_by': how, 'verified_search': verified_search,
             'config': {
                 'workload': f'configs[1]: one {n >> 20} MiB synthetic `{args.corpus}` chunk per GPU, suffix-array build + '
                             f'{len(queries)} {args.qlen}-byte queries (50% sampled from the text) in one batch',
@@ -540,15 +570,19 @@ def run_chunk(args, D):
             'secondary': secondary,
             'adversarial': adversarial,
         }
-        print(json.dumps(out))
+    else:
+        out = None
     reader.close()
-    return 1 if verified is False else 0
+    del dT, dSA
+    return (1 if verified is False else 0), out
 
 
 # ----------------------------------------------------------------------------- configs[2] / [3] --
 
-def run_corpus(args, D):
+def run_corpus(args, D, steps=None, warmup=None):
     import torch
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     from pysubstringsearch_amd import Reader, _ffi
     from pysubstringsearch_amd import dist as pdist
     lib = _ffi.lib
@@ -612,12 +646,12 @@ def run_corpus(args, D):
             keep.append(reader.search_multiple_bytes_as_str(queries))
             last['entries'] = len(keep[-1])
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     keep.clear()
     D.sync_all()
     t_begin = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     D.sync_all()
     total_s = time.perf_counter() - t_begin
@@ -625,10 +659,11 @@ def run_corpus(args, D):
     stats = reader.last_stats()
     D.sync_all()
     t_p = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step(packed=True)
     D.sync_all()
     packed_s = time.perf_counter() - t_p
+    per_rank_build_ms = [round(x * 1e3, 2) for x in D.gather_floats(build_s)]
     total_s, packed_s, build_s = D.max_over_ranks([total_s, packed_s, build_s])
 
     lat = None
@@ -642,7 +677,7 @@ def run_corpus(args, D):
         lat = {'median': round(ts[len(ts) // 2] * 1e6, 1), 'p90': round(ts[int(len(ts) * 0.9)] * 1e6, 1),
                'queries_per_sec': round(len(ts) / sum(ts), 1)}
 
-    rc = 0
+    rc, out = 0, None
     if rank == 0:
         cpu = None
         if keep_host:
@@ -655,17 +690,19 @@ def run_corpus(args, D):
         # A_query = chunks touched x 7.4 KB (58 dependent probes x 128 B) + 132 B per hit
         a_query = len(mine) * len(queries) * 7424 + stats['hits'] * 132
         ms_dev = stats['ms_device']
-        roof = {'bound': 'hbm', 'achieved': round(a_query / ms_dev / 1e6, 1) if ms_dev else None, 'peak': HBM_PEAK_GBS,
-                'unit': 'GB/s', 'frac': round(a_query / ms_dev / 1e6 / HBM_PEAK_GBS, 4) if ms_dev else None, 'traffic': None,
+        # No fraction of the HBM peak is claimed for the search: SURVEY's 58-probe model is not what this implementation
+        # moves (key samples + 64-ary steps), and its traffic has not been measured with PMC counters.
+        roof = {'bound': 'hbm', 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None, 'traffic': None,
                 'kernel': 'search pipeline of one batch on rank 0 (interval search, entry recovery, emit)',
                 'ms_device': round(ms_dev, 3), 'ms_interval': round(stats['ms_interval'], 3),
-                'algorithmic_bytes': int(a_query),
-                'note': 'latency / transaction bound by construction (SURVEY 8(d)): graded on queries/s against the CPU path'}
-        qps = len(queries) * args.steps / total_s
+                'survey_model_bytes': int(a_query),
+                'note': 'latency / transaction bound by construction (SURVEY 8(d)): graded on queries/s against the CPU path; '
+                        'no roofline fraction claimed (bytes of the SURVEY model are not the bytes this search moves)'}
+        qps = len(queries) * steps / total_s
         out = {
             'metric': METRIC, 'value': None if verified is False else round(qps, 1), 'unit': 'queries/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(total_s / args.steps * 1e3, 3),
+            'n_gpus': world, 'steps': steps, 'warmup': warmup,
+            'ms_per_step': round(total_s / steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
             'verified': verified, 'verified_by': how + ('; per-query entry counts of a sample equal to the CPU oracle' if cpu else ''),
             'config': {
@@ -678,9 +715,10 @@ def run_corpus(args, D):
                              f'fullest rank: best-case speed-up {chunks / max(len([c for c in range(chunks) if c % world == r]) for r in range(world)):.2f}x',
             },
             'entries_per_batch': last.get('entries'), 'hits_per_query': round(hits_q, 2),
-            'packed_queries_per_sec': round(len(queries) * args.steps / packed_s, 1),
+            'packed_queries_per_sec': round(len(queries) * steps / packed_s, 1),
             'single_query_us': lat,
             'index_build_gbs': round(chunks * n / build_s / 1e9, 3),
+            'per_rank_build_ms': per_rank_build_ms,
             'search_stats': stats,
             'roofline': roof, 'cpu_baseline': cpu,
         }
@@ -688,7 +726,7 @@ def run_corpus(args, D):
             # The CPU figures above stop at the packed result, like the packed API here.  The reference hands
             # Python a list[str] (pyo3, src/lib.rs:284-286): creating those str objects costs the same on
             # either side, so the list-level CPU figure adds the per-entry cost measured on the GPU path.
-            list_s_per_entry = max(total_s - packed_s, 0.0) / args.steps / max(last.get('entries') or 1, 1)
+            list_s_per_entry = max(total_s - packed_s, 0.0) / steps / max(last.get('entries') or 1, 1)
             ns = min(len(queries), args.cpu_sample_queries)
             e_sample = cpu['entries_per_query'] * ns
             cpu['list_level_queries_per_sec'] = round(ns / (ns / cpu['value'] + e_sample * list_s_per_entry), 1)
@@ -701,9 +739,52 @@ def run_corpus(args, D):
                 out['gpu_over_cpu']['list_api_vs_reference_access_path'] = round(qps / dl, 2)
                 out['gpu_over_cpu']['packed_api_vs_reference_access_path'] = round(
                     out['packed_queries_per_sec'] / cpu['disk_queries_per_sec'], 2)
-        print(json.dumps(out))
         rc = 1 if verified is False else 0
     reader.close()
+    return rc, out
+
+
+def launch_ranks(n: int) -> int:
+    """`python3 bench.py --gpus N` without a launcher: this process never touches a GPU; it starts N fresh copies of
+    itself, one per GPU, with the torch.distributed environment of a one-node job (rendezvous on 127.0.0.1), lets
+    rank 0's stdout through (the one JSON line) and returns the worst exit code.  A rank that dies takes the others
+    with it (they would wait in a collective forever)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+
+    def forward():
+        # rank 0's stdout: the JSON line goes to ours, anything else a library printed there (gloo's connection
+        # banner ...) to stderr -- the driver reads ONE line from this process
+        for line in procs[0].stdout:
+            (sys.stdout if line.startswith('{') else sys.stderr).write(line)
+            sys.stdout.flush()
+
+    import threading
+    fw = threading.Thread(target=forward, daemon=True)
+    fw.start()
+    rc, live = 0, set(range(n))
+    while live:
+        time.sleep(0.2)
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                rc = rc or code
+                for q in live:      # exactly the processes started above
+                    procs[q].terminate()
+    fw.join(timeout=10)
     return rc
 
 
@@ -724,9 +805,32 @@ def main():
     ap.add_argument('--cpu-sample-queries', type=int, default=5000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-disk-baseline', action='store_true')
+    ap.add_argument('--no-corpus15', action='store_true', help='chunk config: skip the configs[2]/[3] leg of the line')
+    ap.add_argument('--corpus15-queries', type=int, default=100000)
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus))      # nothing has touched a GPU yet (torch is not even imported)
     D = Dist(args)
-    rc = run_chunk(args, D) if args.config == 'chunk' else run_corpus(args, D)
+    if args.config == 'chunk':
+        rc, out = run_chunk(args, D)
+        if not args.no_corpus15:
+            # BASELINE configs[2] / [3] in the same line: the 7.5 GB corpus (chunk c on rank c mod N), one batch of 100 000
+            # queries of 4..32 bytes, at most 3 timed steps; the CPU path (one thread per chunk; RAM and the reference's
+            # lseek + read probes) beside it at N = 1
+            import torch
+            torch.cuda.empty_cache()
+            q0, args.queries = args.queries, args.corpus15_queries
+            rc2, out2 = run_corpus(args, D, steps=min(args.steps, 3), warmup=min(args.warmup, 1))
+            args.queries = q0
+            rc = rc or rc2
+            if out is not None and out2 is not None:
+                out['corpus15'] = {k: out2[k] for k in out2 if k not in ('metric', 'higher_is_better', 'vs_baseline', 'data')}
+                if out2['value'] is None:
+                    out['value'] = None
+    else:
+        rc, out = run_corpus(args, D)
+    if out is not None:
+        print(json.dumps(out), flush=True)
     D.finish()
     sys.exit(rc)
 

@@ -99,7 +99,13 @@ class Writer:
         rc = _lib.pss_writer_open_multi(
             path, -1 if max_chunk_len is None else max_chunk_len, arr, len(devs), format_version, ctypes.byref(self._h))
         _ffi.check(rc, index_file_path)
-        self.writer = self   # the reference wrapper exposes `.writer` (__init__.py:12)
+
+    @property
+    def writer(self) -> 'Writer':
+        """The reference wrapper exposes `.writer` (the native object, __init__.py:12).  A property, not an attribute
+        holding `self`: that would make every handle a reference cycle, and `del w` would flush the last chunk only
+        when the cyclic collector gets round to it -- the reference's Drop flushes at once (src/lib.rs:138-144)."""
+        return self
 
     def _handle(self):
         if not self._h:
@@ -176,8 +182,7 @@ class _DevicePtr:
 
 
 class DeviceResult(typing.NamedTuple):
-    """Packed result of one batch left in HBM (torch tensors over the engine's workspace: valid until
-    the next search or build on that device -- consume or clone them first)."""
+    """Packed result of one batch left in HBM (torch tensors owned by the caller)."""
     data: typing.Any      # torch uint8 [num_bytes]
     starts: typing.Any    # torch int64 [num_entries]: start of every entry in data
     counts: typing.Any    # torch int64 [num_queries]
@@ -199,13 +204,17 @@ class Reader:
         rc = _lib.pss_reader_open(
             path, _default_device() if device is None else device, shard[0], shard[1], ctypes.byref(self._h))
         _ffi.check(rc, index_file_path)
-        self.reader = self   # the reference wrapper exposes `.reader` (__init__.py:49)
+
+    @property
+    def reader(self) -> 'Reader':
+        """The reference wrapper exposes `.reader` (__init__.py:49); a property for the reason given at Writer.writer
+        (a dropped Reader gives its HBM back at once)."""
+        return self
 
     @classmethod
     def _from_handle(cls, handle) -> 'Reader':
         r = cls.__new__(cls)
         r._h = handle
-        r.reader = r
         return r
 
     def _handle(self):
@@ -319,8 +328,13 @@ class Reader:
                 return torch.empty(0, dtype=dtype, device=dev)
             return torch.as_tensor(_DevicePtr(ptr, nbytes), device=dev).view(dtype)
 
-        return DeviceResult(wrap(dr.d_bytes, dr.num_bytes, torch.uint8), wrap(dr.d_offsets, dr.num_entries * 8, torch.int64),
-                            wrap(dr.d_counts, nq * 8, torch.int64), int(dr.num_bytes))
+        # The three ranges are slots of the device's shared workspace: another handle or thread on the device may
+        # reuse them as soon as the call has returned.  Own them before anyone else gets in (device-to-device, a few
+        # microseconds for the sizes a batch produces).
+        out = DeviceResult(wrap(dr.d_bytes, dr.num_bytes, torch.uint8).clone(), wrap(dr.d_offsets, dr.num_entries * 8, torch.int64).clone(),
+                           wrap(dr.d_counts, nq * 8, torch.int64).clone(), int(dr.num_bytes))
+        torch.cuda.current_stream(dev).synchronize()
+        return out
 
     def search_multiple_bytes_as_str(self, patterns: typing.Sequence[bytes]) -> typing.List[str]:
         """``search_multiple`` for queries that are already UTF-8 bytes."""

@@ -805,7 +805,7 @@ int reader_alloc_chunk(pss_reader *r, uint32_t n, ChunkDesc *out, pss_reader::Me
         out->skeys = samples ? reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(m.sa) + sa_bytes) : nullptr;
     } else {
         // tier 2: suffix array in pinned host memory, samples in HBM
-        e = hipHostMalloc(&m.sa, sa_bytes, hipHostMallocDefault);
+        e = hipHostMalloc(&m.sa, sa_bytes, hipHostMallocPortable);
         if (e == hipSuccess && sk_bytes) e = hipMalloc(&m.skeys, sk_bytes);
         if (e != hipSuccess) {
             (void)hipGetLastError();
@@ -1199,7 +1199,18 @@ extern "C" int pss_merge_packed(uint32_t world, uint64_t nq, const uint64_t *con
                 }
                 const uint64_t b0 = offsets[r][e0];
                 const uint64_t b1 = e1 < num_entries[r] ? offsets[r][e1] : num_bytes[r];
-                for (uint64_t e = e0; e < e1; ++e) out_offsets[e_out++] = b_out + (offsets[r][e] - b0);
+                if (b0 > b1 || b1 > num_bytes[r]) {      // offsets must grow and stay inside the rank's bytes
+                    set_error("pss_merge_packed: rank %u offsets are not monotonic or exceed its %llu bytes", r,
+                              (unsigned long long)num_bytes[r]);
+                    return PSS_EINVAL;
+                }
+                for (uint64_t e = e0; e < e1; ++e) {
+                    if (offsets[r][e] < b0 || offsets[r][e] > b1) {
+                        set_error("pss_merge_packed: rank %u offsets are not monotonic", r);
+                        return PSS_EINVAL;
+                    }
+                    out_offsets[e_out++] = b_out + (offsets[r][e] - b0);
+                }
                 if (b1 > b0) memcpy(out_bytes + b_out, bytes[r] + b0, (size_t)(b1 - b0));
                 b_out += b1 - b0;
                 cursor[r] = e1;

@@ -119,7 +119,7 @@ void *pinned_pool_alloc(size_t bytes, size_t *granted)
     }
     void *p = nullptr;
     const size_t want = round_up(bytes + bytes / 8, (size_t)2 << 20);   // headroom: the next batch is rarely the same size
-    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess) {      // the pool is shared by every device of the process
         (void)hipGetLastError();
         return nullptr;
     }

@@ -409,6 +409,10 @@ int rle_suffix_array(DeviceCtx *ctx, const uint8_t *T, uint32_t n, uint32_t S, u
     // 1. run table
     hipLaunchKernelGGL(rle_count_kernel, dim3(ntiles), dim3(RL_BLOCK), 0, s, T, n, d_bcnt);
     PSS_TRY(device_excl_scan(ctx, InU32{d_bcnt}, ntiles, d_part, d_total, d_boff));
+    // S (counted by sa_symbols_kernel) sizes every run table; the starts come from rle_count / rle_starts, a second
+    // implementation of the same definition.  Their totals are compared at the next host sync (below): a mismatch
+    // means one of the two kernels is wrong, and the tables would be too.
+    PSS_HIP(hipMemcpyAsync(h_small + 8, d_total, 8, hipMemcpyDeviceToHost, s));
     hipLaunchKernelGGL(rle_starts_kernel, dim3(ntiles), dim3(RL_BLOCK), 0, s, T, n, d_boff, d_start, S);
 
     // 2. reduced string: symbols, their sort, ties by rank rounds
@@ -428,6 +432,13 @@ int rle_suffix_array(DeviceCtx *ctx, const uint8_t *T, uint32_t n, uint32_t S, u
     hipLaunchKernelGGL(rle_j0_kernel, dim3(grid_runs), dim3(RL_BLOCK), 0, s, d_sar, S, d_j0);
     PSS_HIP(hipMemcpyAsync(h_small, d_cbase + 512, 4, hipMemcpyDeviceToHost, s));
     PSS_HIP(hipStreamSynchronize(s));
+    {
+        const u64 counted = (u64)h_small[8] | ((u64)h_small[9] << 32);
+        if (counted != (u64)S) {
+            set_error("rle_suffix_array: %llu run starts found, %u runs counted (internal error)", (unsigned long long)counted, S);
+            return PSS_EDEVICE;
+        }
+    }
     const u32 num_ids = h_small[0];
     int id_bits = 1;
     while ((1ull << id_bits) < (u64)num_ids) ++id_bits;

@@ -138,10 +138,8 @@ def gather_device(result, group=None, dst: int = 0):
     data, starts, counts = result.data, result.starts, result.counts
     if not on_device:
         data, starts, counts = data.cpu(), starts.cpu(), counts.cpu()
-    elif world > 1:
-        # the engine's workspace is not the caching allocator's memory and is reused by the next search:
-        # the collective works on copies (a device-to-device copy of this rank's share of the result)
-        data, starts, counts = data.clone(), starts.clone(), counts.clone()
+    # (Reader.search_batch_device hands out tensors it owns -- copies of the engine's workspace slots -- so the
+    # collective can use them as they are)
     dev = data.device
     nq = counts.numel()
     sizes = torch.tensor([starts.numel(), data.numel()], dtype=torch.int64, device=dev)

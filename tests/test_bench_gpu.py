@@ -31,7 +31,8 @@ def _last_json(out):
 
 def test_bench_single_gpu_contract():
     r = subprocess.run([sys.executable, 'bench.py', '--steps', '2', '--warmup', '1', '--logn', '22', '--queries', '500',
-                        '--cpu-sample-logn', '20'], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                        '--cpu-sample-logn', '20', '--chunks', '5', '--corpus15-queries', '3000', '--cpu-sample-queries', '300'],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
     for k in REQUIRED:
@@ -46,18 +47,48 @@ def test_bench_single_gpu_contract():
     assert cpu['cores'] == 1 and cpu['kind'] in ('reference', 'port') and cpu['value'] > 0 and cpu['sample']
     assert d['entries_per_batch'] == d['search_stats']['entries']
     assert d['verified'] is True and 'libsais' in d['verified_by']      # small n: libsais run on the spot
+    # the query leg of the line is checked too: a sample of the batch against the oracle, per query
+    vs = d['verified_search']
+    assert vs['ok'] is True and vs['queries'] >= 100 and vs['entries'] > 0
+    assert roof['traffic'] is None or roof['traffic_source']
+    # BASELINE configs[2] / [3] ride in the same line: queries/s on the multi-chunk corpus next to the CPU path
+    c = d['corpus15']
+    assert c['unit'] == 'queries/s' and c['value'] > 0 and c['scaling'] == 'strong' and c['verified'] is True
+    assert c['config']['chunks'] == 5 and c['packed_queries_per_sec'] > 0 and c['single_query_us']['median'] > 0
+    assert c['cpu_baseline']['value'] > 0 and c['cpu_baseline']['disk_queries_per_sec'] > 0
+    assert c['roofline']['frac'] is None and len(c['per_rank_build_ms']) == 1
 
 
-def test_bench_two_ranks_gloo_hook():
-    env = dict(os.environ, PSS_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--logn', '22',
-           '--queries', '500']
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    d = _last_json(r.stdout)
+def _check_two_ranks(d):
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0
     assert d['cpu_baseline'] is None and d['secondary'] is None     # rank 0, N = 1 only
     # rank 1 holds a different chunk (seed + 1): the sampled half of the queries comes from rank
     # 0's text, so the gathered batch has at least those hits
     assert d['entries_per_batch'] >= 250
+    c = d['corpus15']
+    assert c['n_gpus'] == 2 and c['value'] > 0 and c['verified'] is True and len(c['per_rank_build_ms']) == 2
+    assert '3 chunks on the fullest rank' in c['config']['imbalance']
+
+
+def test_bench_two_ranks_self_launch():
+    """`python bench.py --gpus 2` with no launcher in the command (the shape of the driver's command): bench.py starts
+    the two ranks itself, rank 0's JSON line is the only line on stdout."""
+    env = dict(os.environ, PSS_BENCH_BACKEND='gloo')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--logn', '22', '--queries', '500',
+           '--chunks', '5', '--corpus15-queries', '3000']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len([l for l in r.stdout.splitlines() if l.strip()]) == 1, r.stdout
+    _check_two_ranks(_last_json(r.stdout))
+
+
+def test_bench_two_ranks_under_torchrun():
+    env = dict(os.environ, PSS_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--logn', '22',
+           '--queries', '500', '--chunks', '5', '--corpus15-queries', '3000']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    _check_two_ranks(_last_json(r.stdout))

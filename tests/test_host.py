@@ -42,6 +42,26 @@ def test_api_signatures_match_reference(pss):
     assert list(inspect.signature(pss.Reader.search_multiple).parameters) == ['self', 'substrings']
 
 
+def test_handles_are_not_reference_cycles(pss, tmp_path):
+    """`.writer` / `.reader` exist like in the reference wrapper (__init__.py:12,49) but do not make the object refer to
+    itself: dropping the last reference runs __del__ at once (the reference's Drop, src/lib.rs:138-144), without
+    waiting for the cyclic collector."""
+    import gc
+    import weakref
+    gc.disable()
+    try:
+        p = str(tmp_path / 'c.idx')
+        w = pss.Writer(p)
+        assert w.writer is w
+        ref = weakref.ref(w)
+        del w
+        assert ref() is None           # freed by reference counting alone
+        assert os.path.getsize(p) == 0   # nothing was added: an empty, finalized file
+    finally:
+        gc.enable()
+    assert isinstance(pss.Reader.reader, property) and isinstance(pss.Writer.writer, property)
+
+
 def test_file_not_found(pss):
     # reference tests/test_pysubstringsearch.py:48-56
     with pytest.raises(FileNotFoundError):

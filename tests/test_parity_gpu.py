@@ -605,3 +605,29 @@ def test_sharded_reader_over_rccl_single_rank(tmp_path, oracle):
     assert sorted(got) == sorted(oe)
     oe5, oc5 = o.search_multiple_bytes(qs[:500])
     assert total.tolist() == oc5.tolist() and sorted(ents) == sorted(oe5)
+
+
+def test_dropped_writer_flushes_at_once(pss, oracle, tmp_path):
+    """`del writer` is the reference's Drop (src/lib.rs:138-144): the pending chunk is on disk when the statement
+    returns -- no gc.collect(), no close() -- and a dropped Reader releases its handle the same way."""
+    import gc
+    import weakref
+    gc.disable()
+    try:
+        p, q = str(tmp_path / 'g.idx'), str(tmp_path / 'o.idx')
+        w = pss.Writer(p)
+        ow = oracle.OracleWriter(q)
+        for e in ('ten', 'tenten', 'some short string'):
+            w.add_entry(e)
+            ow.add_entry(e)
+        ow.close()
+        del w
+        assert open(p, 'rb').read() == open(q, 'rb').read()
+        r = pss.Reader(p)
+        assert sorted(r.search('ten')) == ['ten', 'tenten']
+        ref = weakref.ref(r)
+        del r
+        assert ref() is None
+    finally:
+        gc.enable()
+

@@ -295,6 +295,28 @@ def test_rle_path_forced_matches_libsais(oracle, monkeypatch, expansion):
     assert (walked > 20) if expansion == 'columns' else (walked == 0)
 
 
+@pytest.mark.parametrize('rle', ['0', '1'])
+def test_unaligned_text_pointer(oracle, monkeypatch, rle):
+    """The text pointer handed to pss_sa_build_device need not be 16-byte aligned and n need not be a multiple of 16
+    (a chunk inside a larger device buffer): the run count of sa_symbols (shuffled 16-byte vectors) and the run
+    table of rle_count / rle_starts must agree -- the build compares them -- and the result is libsais'."""
+    import ctypes
+    import torch
+    from pysubstringsearch_amd import _ffi
+    monkeypatch.setenv('PSS_RLE', rle)
+    rng = np.random.default_rng(11)
+    for off, n in ((1, 100003), (3, 65537), (7, 4099), (8, 300001), (15, 1 << 20)):
+        t = _runs_text(rng, n, 3, 200) if rle == '1' else rng.integers(97, 101, n).astype(np.uint8)
+        t[-1] = 10
+        big = torch.zeros(n + 64, dtype=torch.uint8, device='cuda')
+        big[off:off + n] = torch.from_numpy(t).cuda()
+        dSA = torch.empty(n, dtype=torch.int32, device='cuda')
+        st = _ffi.SaStats()
+        _ffi.check(_ffi.lib.pss_sa_build_device(big.data_ptr() + off, dSA.data_ptr(), n, 0, 0, ctypes.byref(st)))
+        assert bool(st.rle) == (rle == '1')
+        assert np.array_equal(dSA.cpu().numpy(), oracle.sa(t)), (off, n)
+
+
 def test_rle_path_is_chosen_for_long_runs_only(oracle, monkeypatch):
     """Without the switch: runs averaging >= 8 bytes take the path (`runs`, `periodic`, a zero-padded
     binary-like text), anything else (lines, words, short runs) keeps the key sort + rounds; PSS_RLE=0
