@@ -107,6 +107,18 @@ typedef struct pss_sa_stats {
     double rle_ms_table;       /* profile mode: run table and symbols */
     double rle_ms_reduced;     /* ... suffix sort of the reduced string */
     double rle_ms_expand;      /* ... expansion and its radix sort */
+    /* initial sort taken by the sample sort over 16-byte [key | index] elements (natural text: texts the radix
+     * partition above cannot take because some 20-bit prefix holds far more suffixes than a tile): 1 when it ran */
+    uint64_t ss;
+    uint64_t ss_buckets;       /* non-empty joint buckets */
+    uint64_t ss_max_bucket;    /* largest of them (the path declines above 4088: a sampling accident) */
+    uint64_t ss_tiles;         /* local-sort workgroups */
+    uint64_t ss_samples;       /* sample members the splitters were taken from */
+    double ss_ms_sample;       /* profile mode: drawing and sorting the sample */
+    double ss_ms_g1;           /* ... first partition (digits from the text, scatter: 3 B in, 2 + 16 B out per suffix) */
+    double ss_ms_g2;           /* ... second partition (digits 16 in / 2 out, scatter 18 in / 16 out) */
+    double ss_ms_local;        /* ... local merge sort (16 B in, 4 B out) */
+    double ms_initial;         /* device time from the start of the build to the end of the initial sort (always filled) */
 } pss_sa_stats;
 
 /*

@@ -54,6 +54,16 @@ class SaStats(ctypes.Structure):
         ('rle_ms_table', ctypes.c_double),
         ('rle_ms_reduced', ctypes.c_double),
         ('rle_ms_expand', ctypes.c_double),
+        ('ss', ctypes.c_uint64),
+        ('ss_buckets', ctypes.c_uint64),
+        ('ss_max_bucket', ctypes.c_uint64),
+        ('ss_tiles', ctypes.c_uint64),
+        ('ss_samples', ctypes.c_uint64),
+        ('ss_ms_sample', ctypes.c_double),
+        ('ss_ms_g1', ctypes.c_double),
+        ('ss_ms_g2', ctypes.c_double),
+        ('ss_ms_local', ctypes.c_double),
+        ('ms_initial', ctypes.c_double),
     ]
 
     def as_dict(self):

@@ -36,4 +36,29 @@ int msd_max_key_bits(uint32_t n);
 int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bits, uint64_t *A[2], uint32_t *sa_out,
                     void *work, uint32_t *h_small, bool profile, MsdStats *stats, bool *accepted, MsdActive *active = nullptr);
 
+// ---- sample sort over 16-byte elements (ss_sort_impl.h): the initial sort of natural text ----
+
+struct SsStats {
+    uint32_t buckets = 0, max_bucket = 0, tiles = 0;
+    uint32_t b1 = 0, b2 = 0, samples = 0;
+    int key_chars = 0;
+    double ms_sample = 0, ms_g1 = 0, ms_g2 = 0, ms_local = 0;      // profile mode
+};
+struct SsBuffers {
+    void *A[2];            // 16 n bytes each: the element buffers of the two partition passes
+    uint16_t *digits;      // n + 64 entries
+    void *E0, *E;          // 16 S bytes each (S = ss_sample_count(n)): the sample, unsorted / sorted
+    uint64_t *K[2];        // >= S entries each: scratch of the sample's sort
+    uint32_t *V[2];
+    void *sort_work;       // radix_sort_workspace_bytes()
+};
+// Sample members drawn for n suffixes (0: the path does not take texts of this size).
+uint32_t ss_sample_count(uint32_t n);
+// Symbols of code_bits each that a 16-byte element carries next to the index of one of n suffixes.
+int ss_key_chars(uint32_t n, int code_bits);
+// Same contract as suffix_sort_flags / msd_suffix_sort without `active` (bit 31 of sa_out[i] = "same key as my
+// predecessor"); the key is the first ss_key_chars() symbols.  `work`: msd_workspace_bytes(n).
+int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, const SsBuffers &buf, uint32_t *sa_out, void *work,
+                   uint32_t *h_small, bool profile, SsStats *stats, bool *accepted, MsdActive *active);
+
 }  // namespace pss

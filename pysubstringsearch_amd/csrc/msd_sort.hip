@@ -34,6 +34,9 @@
 // HBM-bound integer work: no MFMA anywhere by design.
 #include "msd_sort.h"
 
+#include <algorithm>
+#include <vector>
+
 #include "prims.h"
 #include "scan.h"
 #include "text_keys.h"
@@ -382,34 +385,38 @@ __global__ __launch_bounds__(256) void msd_compact_kernel(const u32 *J, u32 nb, 
 // ends before the window does: < MSD_WIN).  A tile stays inside one aligned block of MSD_TAG_SPAN buckets.  Every decision looks at
 // one window only, so all of them are taken in parallel -- and tiles come out at ~5 500 elements on `lines`
 // instead of the 4 096 of a plain "one tile per 4096-slot window" rule (a fifth fewer tiles).
-__device__ __forceinline__ bool msd_tile_head(const u32 *cstart, u32 ne, u32 n, u32 k)
+struct TilePlan {
+    u32 win, cap;      // window of the rule above; elements a tile holds at most
+};
+__device__ __forceinline__ bool msd_tile_head(const u32 *cstart, u32 ne, u32 n, u32 k, TilePlan tp)
 {
     if ((k & (MSD_TAG_SPAN - 1u)) == 0) return true;
-    const u32 w = cstart[k] / MSD_WIN;
-    if (cstart[k - 1] / MSD_WIN != w) return true;                       // first bucket of its window
-    if (k + 1 < ne && cstart[k + 1] / MSD_WIN == w) return false;        // neither first nor last
+    const u32 w = cstart[k] / tp.win;
+    if (cstart[k - 1] / tp.win != w) return true;                        // first bucket of its window
+    if (k + 1 < ne && cstart[k + 1] / tp.win == w) return false;         // neither first nor last
     u32 lo = 0, hi = k;                                                  // first bucket of the window: start >= w * WIN
-    const u32 ws = w * MSD_WIN;
+    const u32 ws = w * tp.win;
     while (lo < hi) {
         const u32 mid = (lo + hi) >> 1;
         if (cstart[mid] < ws) lo = mid + 1; else hi = mid;
     }
     const u32 end = k + 1 < ne ? cstart[k + 1] : n;
-    return end - cstart[lo] > MSD_TILE_CAP;                              // the window does not fit: its last bucket goes alone
+    return end - cstart[lo] > tp.cap;                                    // the window does not fit: its last bucket goes alone
 }
 
 struct InTileHead {
     const u32 *cstart;
     u32 ne, n;
-    __device__ u64 operator()(u64 k) const { return msd_tile_head(cstart, ne, n, (u32)k) ? 1u : 0u; }
+    TilePlan tp;
+    __device__ u64 operator()(u64 k) const { return msd_tile_head(cstart, ne, n, (u32)k, tp) ? 1u : 0u; }
 };
 
 __global__ __launch_bounds__(256) void msd_tiles_kernel(const u32 *cstart, u32 ne, u32 n, const u64 *rank, const u64 *total,
-                                                          u32 *tile_first)
+                                                          u32 *tile_first, TilePlan tp)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) tile_first[*total] = ne;      // sentinel behind the last tile
     for (u32 k = blockIdx.x * blockDim.x + threadIdx.x; k < ne; k += gridDim.x * blockDim.x) {
-        if (msd_tile_head(cstart, ne, n, k)) tile_first[rank[k]] = k;
+        if (msd_tile_head(cstart, ne, n, k, tp)) tile_first[rank[k]] = k;
     }
 }
 
@@ -891,13 +898,15 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
     }
 }
 
+#include "ss_sort_impl.h"
+
 // ---- host --------------------------------------------------------------------------------------
 
 // Upper bound on the tiles of the plan: at most two per MSD_WIN window (msd_tile_head) plus one per aligned block
 // of MSD_TAG_SPAN joint buckets.
 static size_t msd_max_tiles(uint32_t n)
 {
-    return (size_t)n / (MSD_WIN / 2) + ((size_t)MSD_BINS * MSD_BINS) / MSD_TAG_SPAN + 8;
+    return (size_t)n / (SS_WIN / 2) + ((size_t)MSD_BINS * MSD_BINS) / MSD_TAG_SPAN + 8;      // (the smaller window of the two paths)
 }
 
 size_t msd_workspace_bytes(uint32_t n)
@@ -1028,8 +1037,9 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     PSS_TRY(mark());
     hipLaunchKernelGGL(msd_scatter_kernel<false>, dim3((u32)max_ranges2), dim3(MSD_BLOCK), 0, s, a);
     PSS_TRY(mark());
-    PSS_TRY(device_excl_scan(ctx, InTileHead{cstart, ne, n}, ne, partial, d_total, ranks));
-    hipLaunchKernelGGL(msd_tiles_kernel, dim3(1024), dim3(256), 0, s, cstart, ne, n, ranks, (const u64 *)d_total, tile_first);
+    const TilePlan tp{MSD_WIN, MSD_TILE_CAP};
+    PSS_TRY(device_excl_scan(ctx, InTileHead{cstart, ne, n, tp}, ne, partial, d_total, ranks));
+    hipLaunchKernelGGL(msd_tiles_kernel, dim3(1024), dim3(256), 0, s, cstart, ne, n, ranks, (const u64 *)d_total, tile_first, tp);
     PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
     PSS_HIP(hipStreamSynchronize(s));
     const u32 nt = h_small[0];
@@ -1082,6 +1092,212 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
         if (stats) stats->ms_g2 = ms;
         PSS_HIP(hipEventElapsedTime(&ms, ev[4], ev[5]));
         if (stats) stats->ms_local = ms;
+    }
+    *accepted = true;
+    return PSS_OK;
+}
+
+// ---- sample sort: host ---------------------------------------------------------------------------------------------
+
+struct SsGeometry {
+    u32 B1, B2, os, S;
+    int ib, kc;
+};
+static bool ss_geometry(uint32_t n, int b, SsGeometry *g)
+{
+    if (n < (1u << 16) || n > (1u << 30) || b < 1 || b > 9) return false;
+    int ib = 1;
+    while ((1ull << ib) < (u64)n) ++ib;
+    int kc = (128 - ib) / b;
+    if (kc > SS_MAX_CHARS) kc = SS_MAX_CHARS;
+    if (kc < 2) return false;
+    // joint buckets of ~512 elements (a tile holds 4088): B1 x B2 of them, both powers of two <= 1024
+    int lb = 4;
+    while (((u64)512 << lb) < (u64)n && lb < 20) ++lb;
+    const u32 B1 = 1u << ((lb + 1) / 2), B2 = 1u << (lb / 2);
+    // sample members per bucket: the bucket sizes follow a gamma distribution of that shape -- 4 puts a bucket of 512 on
+    // average beyond 4088 with probability 1e-10, an average of 1024 (n = 2^30) needs 8
+    const u32 os = ((u64)n > (u64)768 * B1 * B2) ? 8u : 4u;
+    g->B1 = B1;
+    g->B2 = B2;
+    g->os = os;
+    g->S = os * B1 * B2;
+    g->ib = ib;
+    g->kc = kc;
+    return (u64)g->S * 4 <= (u64)n;
+}
+uint32_t ss_sample_count(uint32_t n)
+{
+    SsGeometry g;
+    return ss_geometry(n, 8, &g) ? g.S : 0u;
+}
+int ss_key_chars(uint32_t n, int code_bits)
+{
+    SsGeometry g;
+    return ss_geometry(n, code_bits, &g) ? g.kc : 0;
+}
+
+int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, const SsBuffers &buf, uint32_t *sa_out, void *work,
+                   uint32_t *h_small, bool profile, SsStats *stats, bool *accepted, MsdActive *active)
+{
+    *accepted = false;
+    hipStream_t s = ctx->stream;
+    SsGeometry g;
+    if (!ss_geometry(n, text->code_bits, &g)) return PSS_OK;      // not this text
+    static_assert(SS_SBLOCK == (int)MSD_BINS, "one bin per thread in the scatter passes");
+    const size_t max_ranges2 = (size_t)n / MSD_G2_RANGE + MSD_BINS + 8;
+    const size_t nbk = (size_t)MSD_BINS * MSD_BINS;
+    u8 *w = static_cast<u8 *>(work);
+    size_t o = 0;
+    auto carve = [&](size_t bytes) { u8 *p = w + o; o = round_up(o + bytes, 256); return p; };
+    // (the same carving as msd_suffix_sort: msd_workspace_bytes covers it)
+    u32 *T = reinterpret_cast<u32 *>(carve(max_ranges2 * MSD_BINS * 4));
+    u32 *J1 = reinterpret_cast<u32 *>(carve((MSD_BINS + 8) * 4));
+    u32 *J = reinterpret_cast<u32 *>(carve((nbk + 8) * 4));
+    MsdRange *ranges2 = reinterpret_cast<MsdRange *>(carve(max_ranges2 * sizeof(MsdRange)));
+    u32 *seg_first = reinterpret_cast<u32 *>(carve((MSD_BINS + 8) * 4));
+    u32 *counters = reinterpret_cast<u32 *>(carve(64));
+    u64 *ranks = reinterpret_cast<u64 *>(carve((nbk + 8) * 8));
+    u32 *cstart = reinterpret_cast<u32 *>(carve((nbk + 8) * 4));
+    const size_t max_tiles = msd_max_tiles(n);
+    MsdTile *tiles_all = reinterpret_cast<MsdTile *>(carve((max_tiles + 16) * sizeof(MsdTile)));
+    u32 *tile_first = reinterpret_cast<u32 *>(carve((max_tiles + 16) * 8));
+    u32 *blk_cnt = reinterpret_cast<u32 *>(carve((max_tiles + 8) * 4));
+    u64 *dst_off = reinterpret_cast<u64 *>(carve((max_tiles + 8) * 8));
+    u64 *partial = reinterpret_cast<u64 *>(carve((SC_MAX_BLOCKS + 8) * 8));
+    u64 *d_total = partial + SC_MAX_BLOCKS;
+
+    hipEvent_t ev[8] = {};
+    int nev = 0;
+    struct EvGuard {
+        hipEvent_t *e;
+        int *n;
+        ~EvGuard()
+        {
+            for (int i = 0; i < *n; ++i) (void)hipEventDestroy(e[i]);
+        }
+    } guard{ev, &nev};
+    auto mark = [&]() -> int {
+        if (profile && nev < 8) {
+            PSS_HIP(hipEventCreate(&ev[nev]));
+            PSS_HIP(hipEventRecord(ev[nev], s));
+            ++nev;
+        }
+        return PSS_OK;
+    };
+
+    SsText tx{text->codes, n, text->code_bits, g.kc, text->plus_one, g.ib};
+    const u32 S = g.S;
+    E16 *E0 = static_cast<E16 *>(buf.E0), *E = static_cast<E16 *>(buf.E);
+    PSS_TRY(mark());                                                                       // [0]
+    // ---- the sample, sorted as 128-bit numbers ----
+    hipLaunchKernelGGL(ss_sample_kernel, dim3((S + 255) / 256), dim3(256), 0, s, tx, S, E0, buf.K[0], buf.V[0]);
+    if (S <= 8192) {
+        // (small texts, tests: the device sort's one-workgroup path is not stable, which the second of the chained sorts needs)
+        std::vector<E16> hs(S);
+        PSS_HIP(hipMemcpyAsync(hs.data(), E0, (size_t)S * 16, hipMemcpyDeviceToHost, s));
+        PSS_HIP(hipStreamSynchronize(s));
+        std::sort(hs.begin(), hs.end(), [](const E16 &x, const E16 &y) { return x.hi < y.hi || (x.hi == y.hi && x.lo < y.lo); });
+        PSS_HIP(hipMemcpyAsync(E, hs.data(), (size_t)S * 16, hipMemcpyHostToDevice, s));
+        PSS_HIP(hipStreamSynchronize(s));
+    } else {
+        u64 *K[2] = {buf.K[0], buf.K[1]};
+        u32 *V[2] = {buf.V[0], buf.V[1]};
+        SortStats ss1;
+        int d1 = 0, d2 = 0;
+        PSS_TRY(radix_sort_pairs(ctx, K, V, S, 64, 0xffu, nullptr, 0, buf.sort_work, &d1, false, &ss1));
+        hipLaunchKernelGGL(ss_gather_hi_kernel, dim3((S + 255) / 256), dim3(256), 0, s, E0, (const u32 *)V[d1], S, K[d1]);
+        const int hi_bits = std::max(1, g.kc * text->code_bits + g.ib - 64);
+        PSS_TRY(radix_sort_pairs(ctx, K, V, S, hi_bits, 0xffu, nullptr, d1, buf.sort_work, &d2, false, &ss1));
+        hipLaunchKernelGGL(ss_gather_elems_kernel, dim3((S + 255) / 256), dim3(256), 0, s, E0, (const u32 *)V[d2], S, E);
+    }
+    PSS_TRY(mark());                                                                       // [1]
+
+    SsArgs a;
+    memset(&a, 0, sizeof a);
+    a.text = tx;
+    a.sample = E;
+    a.B1 = g.B1;
+    a.B2 = g.B2;
+    a.spb = S / g.B1;
+    a.st2 = g.os;
+    const u32 num_tiles = (u32)(((u64)n + SS_DTILE1 - 1) / SS_DTILE1);
+    a.tiles_per_range1 = (num_tiles + MSD_G1_RANGES - 1) / MSD_G1_RANGES;
+    a.num_ranges1 = (num_tiles + a.tiles_per_range1 - 1) / a.tiles_per_range1;
+    a.T = T;
+    a.J1 = J1;
+    a.ranges2 = ranges2;
+    a.counters = counters;
+    a.digits = buf.digits;
+    PSS_HIP(hipMemsetAsync(counters, 0, 64, s));
+    // ---- G1: text -> A[0] by the first-level splitters ----
+    hipLaunchKernelGGL(ss_digits1_kernel, dim3(a.num_ranges1), dim3(SS_DBLOCK), 0, s, a);
+    hipLaunchKernelGGL(msd_offsets1_kernel, dim3(MSD_BINS), dim3(256), 0, s, T, a.num_ranges1, seg_first);
+    hipLaunchKernelGGL(msd_offsets1b_kernel, dim3(1), dim3(MSD_BINS), 0, s, (const u32 *)seg_first, J1, n);
+    a.out = static_cast<E16 *>(buf.A[0]);
+    hipLaunchKernelGGL(ss_scatter_kernel<true>, dim3(a.num_ranges1), dim3(SS_SBLOCK), 0, s, a);
+    PSS_TRY(mark());                                                                       // [2]
+    // ---- G2: A[0] -> A[1], every first-level bucket by its own splitters ----
+    hipLaunchKernelGGL(msd_ranges_kernel, dim3(1), dim3(MSD_BINS), 0, s, (const u32 *)J1, ranges2, seg_first, counters);
+    a.in = static_cast<const E16 *>(buf.A[0]);
+    a.out = static_cast<E16 *>(buf.A[1]);
+    hipLaunchKernelGGL(ss_digits2_kernel, dim3((u32)max_ranges2), dim3(SS_DBLOCK), 0, s, a);
+    hipLaunchKernelGGL(msd_offsets_kernel, dim3(MSD_BINS), dim3(MSD_BINS), 0, s, T, (const u32 *)seg_first, (const u32 *)J1, J,
+                       0u, n, MSD_BINS);
+    PSS_TRY(device_excl_scan(ctx, InNonEmpty{J}, nbk, partial, d_total, ranks));
+    hipLaunchKernelGGL(msd_compact_kernel, dim3(1024), dim3(256), 0, s, J, (u32)nbk, ranks, cstart, counters);
+    PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
+    PSS_HIP(hipMemcpyAsync(h_small + 2, counters, 16, hipMemcpyDeviceToHost, s));
+    PSS_HIP(hipStreamSynchronize(s));
+    const u32 ne = h_small[0];
+    const u32 maxb = h_small[3];
+    if (stats) {
+        stats->buckets = ne;
+        stats->max_bucket = maxb;
+        stats->b1 = g.B1;
+        stats->b2 = g.B2;
+        stats->samples = S;
+        stats->key_chars = g.kc;
+    }
+    if (maxb > SS_MAX_BUCKET) return PSS_OK;      // (a sampling accident, probability ~1e-10 per bucket: the caller falls back)
+    hipLaunchKernelGGL(ss_scatter_kernel<false>, dim3((u32)max_ranges2), dim3(SS_SBLOCK), 0, s, a);
+    PSS_TRY(mark());                                                                       // [3]
+    const TilePlan tp{SS_WIN, SS_TILE_CAP};
+    PSS_TRY(device_excl_scan(ctx, InTileHead{cstart, ne, n, tp}, ne, partial, d_total, ranks));
+    hipLaunchKernelGGL(msd_tiles_kernel, dim3(1024), dim3(256), 0, s, cstart, ne, n, ranks, (const u64 *)d_total, tile_first, tp);
+    PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
+    PSS_HIP(hipStreamSynchronize(s));
+    const u32 nt = h_small[0];
+    if ((size_t)nt > max_tiles) {
+        set_error("ss_suffix_sort: %u tiles planned, tables hold %zu (internal error)", nt, max_tiles);
+        return PSS_EDEVICE;
+    }
+    hipLaunchKernelGGL(msd_tile_desc_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, cstart, tile_first, nt, ne, n, tiles_all);
+    // Ties go out as flags (bit 31 = "same key as my predecessor", the contract of suffix_sort_flags), not as the records
+    // of the fused first rerank: groups of equal keys cross tile boundaries here, and the flag of a tile's first element
+    // takes a look at the tile before it (ss_boundary_kernel, once every tile is sorted).
+    (void)active;
+    (void)blk_cnt;
+    (void)dst_off;
+    MsdEmit em{};
+    PSS_TRY(mark());                                                                       // [4]
+    hipLaunchKernelGGL(ss_local_kernel, dim3(nt), dim3(SL_BLOCK), 0, s, (const E16 *)buf.A[1], (const MsdTile *)tiles_all, nt, g.ib,
+                       sa_out, 0, em);
+    PSS_TRY(mark());                                                                       // [5]
+    hipLaunchKernelGGL(ss_boundary_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, (const MsdTile *)tiles_all, nt, tx, sa_out);
+    PSS_HIP(hipGetLastError());
+    if (stats) stats->tiles = nt;
+    if (profile && nev >= 6 && stats) {
+        PSS_HIP(hipStreamSynchronize(s));
+        float ms = 0.f;
+        PSS_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
+        stats->ms_sample = ms;
+        PSS_HIP(hipEventElapsedTime(&ms, ev[1], ev[2]));
+        stats->ms_g1 = ms;
+        PSS_HIP(hipEventElapsedTime(&ms, ev[2], ev[3]));
+        stats->ms_g2 = ms;
+        PSS_HIP(hipEventElapsedTime(&ms, ev[4], ev[5]));
+        stats->ms_local = ms;
     }
     *accepted = true;
     return PSS_OK;

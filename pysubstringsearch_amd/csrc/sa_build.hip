@@ -1161,7 +1161,7 @@ static void rerank_geometry(u32 m, RerankArgs &a)
     a.num_ranges = (a.num_tiles + a.tiles_per_range - 1) / a.tiles_per_range;
 }
 
-enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK, S_GRP2 = 26, S_BIG = 27, S_SCR = 29 };
+enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK, S_SSA = 24, S_SSB = 25, S_GRP2 = 26, S_BIG = 27, S_SCR = 29 };
 
 // Initial key width.  Model the text as i.i.d. with per-symbol collision
 // probability c = sum p_i^2 (from the sampled counts): two suffixes agree on k
@@ -1203,6 +1203,8 @@ struct Knobs {
     int mode = -1;              // PSS_MODE       dense / sparse / text tie resolution (-1 = choose)
     int text_rounds_max = 5;    // PSS_TEXT_ROUNDS
     int msd = -1;               // PSS_MSD        0: never the MSD initial sort, 1: whenever the key fits, unset: screened
+    int ss = -1;                // PSS_SS         0: never the sample sort over 16-byte elements, 1: whenever the text has the size for it,
+                                //                unset: n >= 2^24 and the MSD sort did not take the text
     bool no_msd_fuse = false;   // PSS_MSD_NO_FUSE  MSD sort flags ties in the suffix array; the rerank kernels read them
     bool no_mid_tier = false;   // PSS_NO_MID_TIER  groups above 512 members all take the chained radix sorts
     int rle = -1;               // PSS_RLE        0: never the run-length path, 1: always, unset: when runs average >= 8 bytes
@@ -1221,6 +1223,7 @@ struct Knobs {
         }
         if (const char *e = getenv("PSS_TEXT_ROUNDS")) k.text_rounds_max = atoi(e);
         if (const char *e = getenv("PSS_MSD")) k.msd = atoi(e);
+        if (const char *e = getenv("PSS_SS")) k.ss = atoi(e);
         k.no_msd_fuse = getenv("PSS_MSD_NO_FUSE") != nullptr;
         k.no_mid_tier = getenv("PSS_NO_MID_TIER") != nullptr;
         if (const char *e = getenv("PSS_RLE")) k.rle = atoi(e);
@@ -1231,11 +1234,12 @@ struct Knobs {
 
 // start / stop events of one build, destroyed on every exit path
 struct BuildTimer {
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;
     ~BuildTimer()
     {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
+        if (ev_mid) (void)hipEventDestroy(ev_mid);
     }
 };
 
@@ -1296,6 +1300,7 @@ struct RoundsIO {
     bool ties;                  // V[cur] carries tie flags in bit 31 (no keys)
     bool msd_fused;             // the MSD sort already produced the first active list
     u32 msd_active;
+    bool no_sparse;             // the initial key does not fit 64 bits (sample sort): the sparse mode's key search cannot be used
     u8 *work;
     u32 *d_agg_head, *d_agg_cnt;
     u64 *d_red;
@@ -1394,6 +1399,7 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
             mode = ((u64)m_next * 1024 <= (u64)n) ? M_SPARSE : M_TEXT;
             if (knobs.mode >= 0) mode = (Mode)knobs.mode;
             if (mode == M_SPARSE && (u64)m_next * 16 > (u64)n) mode = M_TEXT;   // hash table must fit the ISA buffer
+            if (mode == M_SPARSE && io.no_sparse && m_next) mode = M_TEXT;
             if (m_next == 0) mode = M_SPARSE;                                   // nothing left: no ISA at all
             if (mode == M_TEXT && text_rounds_max <= 0) mode = M_DENSE;
             if (rank_only && m_next) mode = M_DENSE;                            // no text to pack keys from
@@ -1651,6 +1657,7 @@ int suffix_rounds_integer(DeviceCtx *ctx, uint32_t m, uint64_t *K[2], uint32_t *
     io.ties = false;
     io.msd_fused = false;
     io.msd_active = 0;
+    io.no_sparse = false;
     io.work = work;
     io.d_agg_head = reinterpret_cast<u32 *>(small + 4096);
     io.d_agg_cnt = reinterpret_cast<u32 *>(small + 8192);
@@ -1718,6 +1725,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     BuildTimer timer;
     PSS_HIP(hipEventCreate(&timer.ev0));
     PSS_HIP(hipEventCreate(&timer.ev1));
+    PSS_HIP(hipEventCreate(&timer.ev_mid));
     PSS_HIP(hipEventRecord(timer.ev0, s));
 
     // ---- 0. alphabet ----
@@ -1853,10 +1861,61 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
             }
         }
     }
+    // Natural text (some 20-bit prefix holds far more suffixes than a tile, and a 64-bit key leaves most suffixes tied
+    // anyway): sample sort over 16-byte [key | index] elements (ss_sort_impl.h) -- splitters from a sorted sample cut the
+    // text's own distribution into tile-sized buckets, the key is twice as long.
+    if (!msd_done && ties && knobs.ss != 0 && (knobs.ss == 1 || (n >= (1u << 24) && !forced_chars && knobs.key_chars == 0)) &&
+        ss_sample_count(n) != 0) {
+        const u32 S = ss_sample_count(n);
+        PSS_TRY(ctx->slot[S_SSA].reserve((size_t)n * 16 + 256));
+        PSS_TRY(ctx->slot[S_SSB].reserve((size_t)n * 16 + 256));
+        PSS_TRY(ctx->slot[S_GRP2].reserve((size_t)n * 4));
+        SsBuffers sb;
+        sb.A[0] = ctx->slot[S_SSA].p;
+        sb.A[1] = ctx->slot[S_SSB].p;
+        sb.digits = reinterpret_cast<uint16_t *>(ctx->slot[S_P1].p);      // 2 n + 128 bytes of the 4 n
+        sb.E0 = GRP;                                                       // 16 S <= 4 n bytes each
+        sb.E = ISA;
+        sb.K[0] = K[0]; sb.K[1] = K[1];
+        sb.V[0] = v_scratch; sb.V[1] = (final_buf == 0) ? V[1] : V[0];     // (never the caller's SA buffer)
+        sb.sort_work = work;
+        (void)S;
+        MsdActive act;
+        act.pos = ctx->slot[S_P1].as<u32>();
+        act.idx = (final_buf == 0) ? V[1] : V[0];
+        act.grp = ctx->slot[S_GRP2].as<u32>();
+        act.st_pos = reinterpret_cast<u32 *>(K[0]);
+        act.st_idx = reinterpret_cast<u32 *>(K[0]) + n;
+        TextKeys sk{codes, b, 0, plus_one, 0};
+        SsStats sst;
+        bool accepted = false;
+        PSS_TRY(ss_suffix_sort(ctx, &sk, n, sb, SA, ctx->slot[S_P0].p, h_small, profile, &sst, &accepted, &act));
+        st.ss_buckets = sst.buckets;
+        st.ss_max_bucket = sst.max_bucket;
+        st.ss_samples = sst.samples;
+        if (accepted) {
+            msd_done = true;
+            msd_fused = false;          // ties come back as flags in the suffix array (groups cross the tiles of this sort)
+            key_chars = sst.key_chars;
+            key_drop = 0;
+            st.key_chars = (u32)key_chars;
+            st.key_bits = (u64)key_chars * b;
+            st.ss = 1;
+            st.ss_tiles = sst.tiles;
+            st.ss_ms_sample = sst.ms_sample;
+            st.ss_ms_g1 = sst.ms_g1;
+            st.ss_ms_g2 = sst.ms_g2;
+            st.ss_ms_local = sst.ms_local;
+            cur = final_buf;
+            ss.launches = 4;
+            ss.elems = 4ull * n;
+        }
+    }
     if (msd_done) {
     } else if (ties) PSS_TRY(suffix_sort_flags(ctx, K, V, n, key_bits0, &tk, work, &cur, profile, &ss));
     else PSS_TRY(radix_sort_pairs(ctx, K, V, n, key_bits0, 0xffffffffu, &tk, 0, work, &cur, profile, &ss));
     st.initial_passes = (u32)ss.launches;
+    PSS_HIP(hipEventRecord(timer.ev_mid, s));
     // ---- 2. rerank + compaction, 3. doubling rounds ----
     RoundsIO io;
     io.n = n;
@@ -1875,6 +1934,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     io.ties = ties;
     io.msd_fused = msd_fused;
     io.msd_active = msd_active;
+    io.no_sparse = st.ss != 0;
     io.work = work;
     io.d_agg_head = d_agg_head; io.d_agg_cnt = d_agg_cnt; io.d_red = d_red; io.d_counters = d_counters; io.h_small = h_small;
     io.profile = profile;
@@ -1884,6 +1944,8 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     float ms = 0.f;
     PSS_HIP(hipEventElapsedTime(&ms, timer.ev0, timer.ev1));
     st.ms_total = ms;
+    PSS_HIP(hipEventElapsedTime(&ms, timer.ev0, timer.ev_mid));
+    st.ms_initial = ms;
     st.ms_sort = ss.ms;
     st.sort_launches = ss.launches;
     st.sort_elems = ss.elems;

@@ -1,0 +1,514 @@
+// ss_sort_impl.h -- initial suffix sort of natural text as a SAMPLE SORT over 16-byte elements, for gfx950.
+// Included by msd_sort.hip (it shares that file's partition tables, tile plan and tie gathering).
+//
+// The radix partition of msd_sort.hip needs every 20-bit key prefix to hold at most a tile of suffixes, which is a
+// property of high-entropy text.  Natural text fails it by three orders of magnitude ("the " alone), and a
+// 64-bit key (12 letters) leaves two thirds of its suffixes tied anyway: the LSD sort + text rounds that text
+// took before spent 29 + 41 ms on a 512 MiB chunk of the `words` corpus.  Two changes fix both ends:
+//
+//   * the element is 16 bytes, [ packed key | suffix index ] read as ONE 128-bit unsigned number: 99 key bits at
+//     n = 2^29 (19 five-bit symbols), and -- the index being part of the number -- no two elements are equal;
+//   * the partition is by SPLITTERS, not by digits: a sorted random sample of the elements (4 per final bucket) gives
+//     1023 first-level and 1023 x 1024 second-level splitters that cut the text's own distribution into 2^20 buckets
+//     of 512 +- 256 elements, whatever the text looks like (equal keys included: the index breaks the tie).
+//
+// Pipeline (n = 2^29: B1 = B2 = 1024, S = 2^22 samples):
+//   sample   S stratified random suffixes -> elements -> sorted (two chained stable 64-bit radix sorts)
+//   G1       text -> digits (binary search among the first-level splitters in LDS, 10 steps of 16 bytes; the digit
+//            of every suffix is kept, 2 bytes, so that the scatter pass need not search again) -> A0
+//   G2       A0 -> digits inside every first-level bucket (its 1023 splitters in LDS) -> A1; the scan of the counts is
+//            the table of joint bucket starts, as in msd_sort.hip
+//   local    tiles of consecutive buckets (<= 4096 elements, 64 KiB of LDS) sorted by a merge sort in LDS -- eight
+//            elements per thread sorted in registers, then nine rounds of pairwise merges, every thread finding its
+//            eight outputs with a merge-path search: comparison based, so no distribution can crowd a bin --
+//            and written out as suffix indices plus a record for every element tied with a neighbour (equal key
+//            bits), exactly what msd_local_fast_kernel emits; msd_gather_kernel lines the records up.
+//
+// HBM traffic per suffix: (1 + 2) + (1 + 2 + 16) + (16 + 2) + (16 + 2 + 16) + (16 + 4) = 94 bytes.
+
+constexpr int SS_MAX_CHARS = 32;                     // symbols packed into a key at most (byte window of the packers)
+constexpr u32 SS_TILE = 4096;                        // elements of one workgroup tile (64 KiB of LDS)
+constexpr int SS_SBLOCK = 1024;                      // scatter passes: one workgroup per CU (the tile fills most of its LDS)
+constexpr int SS_SIPT = SS_TILE / SS_SBLOCK;         // 4
+constexpr int SS_DBLOCK = 512;                       // digit passes
+constexpr u32 SS_DTILE1 = SS_DBLOCK * 16;            // G1 digits: 16 consecutive suffixes per thread
+constexpr u32 SS_WIN = 3072;                         // tile plan: see msd_tile_head
+constexpr u32 SS_TILE_CAP = 4088;
+constexpr u32 SS_MAX_BUCKET = 4088;
+
+struct __attribute__((aligned(16))) E16 {
+    u64 lo, hi;
+};
+__device__ __forceinline__ bool e16_lt(const E16 &a, const E16 &b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+__device__ __forceinline__ E16 e16_inf() { return E16{~0ull, ~0ull}; }
+// c ? a : b, word by word (a select of the aggregate goes through the stack)
+__device__ __forceinline__ E16 e16_sel(bool c, const E16 &a, const E16 &b) { return E16{c ? a.lo : b.lo, c ? a.hi : b.hi}; }
+__device__ __forceinline__ E16 e16_load(const E16 *p)
+{
+    const uint4 v = *reinterpret_cast<const uint4 *>(p);
+    return E16{(u64)v.x | ((u64)v.y << 32), (u64)v.z | ((u64)v.w << 32)};
+}
+__device__ __forceinline__ void e16_store(E16 *p, const E16 &e)
+{
+    *reinterpret_cast<uint4 *>(p) = make_uint4((u32)e.lo, (u32)(e.lo >> 32), (u32)e.hi, (u32)(e.hi >> 32));
+}
+// same key bits (everything above the index)?
+__device__ __forceinline__ bool e16_same_key(const E16 &a, const E16 &b, int ib)
+{
+    return a.hi == b.hi && ((a.lo ^ b.lo) >> ib) == 0;
+}
+
+struct SsText {
+    const u8 *codes;       // recoded text, zero padded for >= 64 bytes past n
+    u32 n;
+    int b, kc, plus_one;   // bits per symbol, symbols per key, raw bytes + 1 (sigma == 256)
+    int ib;                // index bits
+};
+
+// NE consecutive suffixes whose symbols start at byte 0 of the little-endian byte stream q (NQ words; byte j of the
+// stream = symbol j of the first suffix): element r = [ symbols r .. r + kc - 1 | idx0 + r ].
+template <int NE, int NQ>
+__device__ __forceinline__ void ss_pack(const u64 (&q)[NQ], u32 idx0, const SsText &t, E16 (&out)[NE])
+{
+    const int b = t.b, kc = t.kc;
+    auto sym = [&](int j) -> u32 { return (u32)(q[j >> 3] >> ((j & 7) * 8)) & 0xffu; };
+    u64 wlo = 0, whi = 0;      // the 128-bit key window
+#pragma unroll
+    for (int j = 0; j < SS_MAX_CHARS; ++j) {
+        if (j < kc) {
+            u32 c = sym(j);
+            if (t.plus_one) c = ((u64)idx0 + j < t.n) ? c + 1u : 0u;
+            whi = (whi << b) | (wlo >> (64 - b));
+            wlo = (wlo << b) | c;
+        }
+    }
+    const int kb = kc * b;
+    const u64 mlo = kb >= 64 ? ~0ull : ((1ull << kb) - 1ull);
+    const u64 mhi = kb > 64 ? ((1ull << (kb - 64)) - 1ull) : 0ull;
+    // the stream from byte kc on (kc is uniform): symbol kc + j is byte j of s
+    constexpr int NS = (NE + 6) / 8;      // words holding bytes 0 .. NE - 2
+    u64 s[NS > 0 ? NS : 1];
+    {
+        const int qs = kc >> 3, sh = (kc & 7) * 8;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            u64 a0 = 0, a1 = 0;
+#pragma unroll
+            for (int c = 0; c <= SS_MAX_CHARS / 8; ++c) {
+                if (c == qs) {
+                    a0 = (c + i < NQ) ? q[(c + i < NQ) ? c + i : 0] : 0ull;
+                    a1 = (c + i + 1 < NQ) ? q[(c + i + 1 < NQ) ? c + i + 1 : 0] : 0ull;
+                }
+            }
+            s[i] = sh ? (a0 >> sh) | (a1 << (64 - sh)) : a0;
+        }
+    }
+    const int ib = t.ib;
+#pragma unroll
+    for (int r = 0; r < NE; ++r) {
+        if (r > 0) {
+            const int j = r - 1;
+            u32 c = (u32)(s[j >> 3] >> ((j & 7) * 8)) & 0xffu;
+            if (t.plus_one) c = ((u64)idx0 + j + kc < t.n) ? c + 1u : 0u;
+            whi = ((whi << b) | (wlo >> (64 - b))) & mhi;
+            wlo = ((wlo << b) | c) & mlo;
+        }
+        out[r].hi = (whi << ib) | (wlo >> (64 - ib));
+        out[r].lo = (wlo << ib) | (u64)(idx0 + (u32)r);
+    }
+}
+
+// The byte stream of the text from (possibly unaligned) position pos on, NQ words of it, out of three aligned 16-byte
+// loads: q[0] starts at byte pos.  Needs (pos & 15) + 8 NQ <= 56 to be exact; words past that are zero-extended reads of
+// the padding and never used by the callers.
+template <int NQ>
+__device__ __forceinline__ void ss_stream_at(const u8 *codes, u32 pos, u64 (&q)[NQ])
+{
+    const uint4 *p = reinterpret_cast<const uint4 *>(codes + (pos & ~15u));
+    const uint4 v0 = p[0], v1 = p[1], v2 = p[2];
+    u64 w[8] = {(u64)v0.x | ((u64)v0.y << 32), (u64)v0.z | ((u64)v0.w << 32), (u64)v1.x | ((u64)v1.y << 32),
+                (u64)v1.z | ((u64)v1.w << 32), (u64)v2.x | ((u64)v2.y << 32), (u64)v2.z | ((u64)v2.w << 32), 0ull, 0ull};
+    const bool up = (pos & 8u) != 0;
+    const u32 sh = (pos & 7u) * 8u;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const u64 a0 = up ? w[i + 1 < 8 ? i + 1 : 7] : w[i < 8 ? i : 7];
+        const u64 a1 = up ? w[i + 2 < 8 ? i + 2 : 7] : w[i + 1 < 8 ? i + 1 : 7];
+        q[i] = sh ? (a0 >> sh) | (a1 << (64 - sh)) : a0;
+    }
+}
+
+// Number of splitters <= e among spl[0 .. B - 2] (B a power of two, the array sorted): the bucket of e.
+__device__ __forceinline__ u32 ss_bucket(const E16 *spl, u32 B, const E16 &e)
+{
+    u32 pos = 0;
+    for (u32 step = B >> 1; step; step >>= 1) {
+        const E16 s = spl[pos + step - 1];
+        pos += e16_lt(e, s) ? 0u : step;
+    }
+    return pos;
+}
+
+// ---- sample ---------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void ss_sample_kernel(SsText t, u32 S, E16 *E0, u64 *klo, u32 *vals)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+    const u32 stride = t.n / S;
+    u64 x = ((u64)i + 1) * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 29;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 32;
+    const u32 pos = i * stride + (u32)(x % stride);
+    u64 q[5];
+    ss_stream_at<5>(t.codes, pos, q);      // 40 bytes >= SS_MAX_CHARS
+    E16 e[1];
+    ss_pack<1, 5>(q, pos, t, e);
+    e16_store(&E0[i], e[0]);
+    klo[i] = e[0].lo;
+    vals[i] = i;
+}
+__global__ __launch_bounds__(256) void ss_gather_hi_kernel(const E16 *E0, const u32 *order, u32 S, u64 *khi)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < S) khi[i] = E0[order[i]].hi;
+}
+__global__ __launch_bounds__(256) void ss_gather_elems_kernel(const E16 *E0, const u32 *order, u32 S, E16 *E)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < S) e16_store(&E[i], e16_load(&E0[order[i]]));
+}
+
+// ---- digit passes ----------------------------------------------------------------------------------------------
+
+struct SsArgs {
+    SsText text;
+    const E16 *sample;     // the sorted sample
+    u32 B1, B2;            // buckets of the two levels (powers of two, <= 1024)
+    u32 spb, st2;          // sample members per first-level bucket; stride of the second-level splitters inside them
+    u32 tiles_per_range1, num_ranges1;      // G1 ranges, in tiles of SS_DTILE1 suffixes
+    u32 *T;
+    const u32 *J1;
+    const MsdRange *ranges2;
+    const u32 *counters;
+    u16 *digits;           // [n] digit of every element of the pass (by text position in G1, by position in A0 in G2)
+    const E16 *in;
+    E16 *out;
+};
+
+__global__ __launch_bounds__(SS_DBLOCK) void ss_digits1_kernel(SsArgs a)
+{
+    __shared__ E16 spl[MSD_BINS];
+    __shared__ u32 hist[MSD_BINS];
+    const u32 tid = threadIdx.x, r = blockIdx.x;
+    if (r >= a.num_ranges1) return;
+    for (u32 i = tid; i < MSD_BINS; i += SS_DBLOCK) {
+        hist[i] = 0;
+        spl[i] = e16_sel(i + 1 < a.B1, e16_load(&a.sample[(size_t)min(i + 1, a.B1 - 1) * a.spb]), e16_inf());
+    }
+    __syncthreads();
+    const u32 n = a.text.n;
+    const u64 e0 = (u64)r * a.tiles_per_range1 * SS_DTILE1;
+    const u64 e1 = min(e0 + (u64)a.tiles_per_range1 * SS_DTILE1, (u64)n);
+    for (u64 base = e0; base < e1; base += SS_DTILE1) {
+        const u32 i0 = (u32)base + tid * 16;
+        if (i0 >= n) continue;
+        u64 q[6];
+        {
+            const uint4 *p = reinterpret_cast<const uint4 *>(a.text.codes + i0);
+            const uint4 v0 = p[0], v1 = p[1], v2 = p[2];
+            q[0] = (u64)v0.x | ((u64)v0.y << 32); q[1] = (u64)v0.z | ((u64)v0.w << 32);
+            q[2] = (u64)v1.x | ((u64)v1.y << 32); q[3] = (u64)v1.z | ((u64)v1.w << 32);
+            q[4] = (u64)v2.x | ((u64)v2.y << 32); q[5] = (u64)v2.z | ((u64)v2.w << 32);
+        }
+        u32 dg[16];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {      // two halves of eight: sixteen 128-bit elements at once do not fit the registers
+            u64 qh[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) qh[i] = h ? (i + 1 < 6 ? q[i + 1] : 0ull) : q[i];
+            E16 e[8];
+            ss_pack<8, 6>(qh, i0 + 8 * h, a.text, e);
+            u32 pos[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pos[k] = 0;
+            for (u32 step = a.B1 >> 1; step; step >>= 1) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const E16 s = spl[pos[k] + step - 1];
+                    pos[k] += e16_lt(e[k], s) ? 0u : step;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                dg[8 * h + k] = pos[k];
+                if (i0 + 8 * h + k < n) atomicAdd(&hist[pos[k]], 1u);
+            }
+        }
+        uint4 d0, d1;
+        d0.x = dg[0] | (dg[1] << 16); d0.y = dg[2] | (dg[3] << 16); d0.z = dg[4] | (dg[5] << 16); d0.w = dg[6] | (dg[7] << 16);
+        d1.x = dg[8] | (dg[9] << 16); d1.y = dg[10] | (dg[11] << 16); d1.z = dg[12] | (dg[13] << 16); d1.w = dg[14] | (dg[15] << 16);
+        uint4 *dp = reinterpret_cast<uint4 *>(a.digits + i0);      // (the digit array is padded to a multiple of 16 entries)
+        dp[0] = d0;
+        dp[1] = d1;
+    }
+    __syncthreads();
+    for (u32 i = tid; i < MSD_BINS; i += SS_DBLOCK) a.T[(size_t)i * a.num_ranges1 + r] = hist[i];      // digit-major (msd_offsets1)
+}
+
+__global__ __launch_bounds__(SS_DBLOCK) void ss_digits2_kernel(SsArgs a)
+{
+    __shared__ E16 spl[MSD_BINS];
+    __shared__ u32 hist[MSD_BINS];
+    const u32 tid = threadIdx.x, r = blockIdx.x;
+    if (r >= a.counters[0]) return;
+    const u32 seg = a.ranges2[r].seg, e0 = a.ranges2[r].start, e1 = a.ranges2[r].end;
+    for (u32 i = tid; i < MSD_BINS; i += SS_DBLOCK) {
+        hist[i] = 0;
+        spl[i] = e16_sel(i + 1 < a.B2, e16_load(&a.sample[(size_t)seg * a.spb + (size_t)min(i + 1, a.B2 - 1) * a.st2]), e16_inf());
+    }
+    __syncthreads();
+    for (u32 base = e0; base < e1; base += SS_DBLOCK * 8) {
+        E16 e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const u32 p = base + k * SS_DBLOCK + tid;
+            e[k] = e16_sel(p < e1, e16_load(&a.in[min(p, e1 - 1)]), e16_inf());
+        }
+        u32 pos[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pos[k] = 0;
+        for (u32 step = a.B2 >> 1; step; step >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const E16 s = spl[pos[k] + step - 1];
+                pos[k] += e16_lt(e[k], s) ? 0u : step;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const u32 p = base + k * SS_DBLOCK + tid;
+            if (p < e1) {
+                a.digits[p] = (u16)pos[k];
+                atomicAdd(&hist[pos[k]], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (u32 i = tid; i < MSD_BINS; i += SS_DBLOCK) a.T[(size_t)r * MSD_BINS + i] = hist[i];      // range-major (msd_offsets)
+}
+
+// ---- scatter passes --------------------------------------------------------------------------------------------
+
+template <bool FROM_TEXT>
+__global__ __launch_bounds__(SS_SBLOCK) void ss_scatter_kernel(SsArgs a)
+{
+    __shared__ E16 exch[SS_TILE];
+    __shared__ u16 dstage[SS_TILE];
+    __shared__ u32 hist[MSD_BINS], s_delta[MSD_BINS], s_off[MSD_BINS];
+    __shared__ u16 s_start[MSD_BINS];
+    __shared__ u32 scr[SS_SBLOCK / kWave + 1];
+    const u32 tid = threadIdx.x, r = blockIdx.x;
+    u32 e0, e1;
+    if (FROM_TEXT) {
+        if (r >= a.num_ranges1) return;
+        const u64 s = (u64)r * a.tiles_per_range1 * SS_DTILE1;
+        if (s >= a.text.n) return;
+        e0 = (u32)s;
+        e1 = (u32)min(s + (u64)a.tiles_per_range1 * SS_DTILE1, (u64)a.text.n);
+    } else {
+        if (r >= a.counters[0]) return;
+        e0 = a.ranges2[r].start;
+        e1 = a.ranges2[r].end;
+    }
+    hist[tid] = 0;      // SS_SBLOCK == MSD_BINS
+    s_off[tid] = FROM_TEXT ? a.T[(size_t)tid * a.num_ranges1 + r] + a.J1[tid] : a.T[(size_t)r * MSD_BINS + tid];
+    __syncthreads();
+    for (u32 base = e0; base < e1; base += SS_TILE) {
+        const u32 valid = min(SS_TILE, e1 - base);
+        E16 e[SS_SIPT];
+        u32 dig[SS_SIPT], rank[SS_SIPT];
+        if (FROM_TEXT) {
+            // four consecutive suffixes per thread (base is a multiple of 16)
+            const u32 i0 = base + tid * SS_SIPT;
+            if (tid * SS_SIPT < valid) {
+                u64 q[5];
+                ss_stream_at<5>(a.text.codes, i0, q);
+                ss_pack<SS_SIPT, 5>(q, i0, a.text, e);
+                const u64 dd = *reinterpret_cast<const u64 *>(a.digits + i0);
+#pragma unroll
+                for (int k = 0; k < SS_SIPT; ++k) dig[k] = (u32)(dd >> (16 * k)) & 0xffffu;
+            }
+#pragma unroll
+            for (int k = 0; k < SS_SIPT; ++k) rank[k] = (tid * SS_SIPT + k < valid) ? atomicAdd(&hist[dig[k]], 1u) : 0u;
+        } else {
+#pragma unroll
+            for (int k = 0; k < SS_SIPT; ++k) {
+                const u32 p = k * SS_SBLOCK + tid;
+                if (p < valid) {
+                    e[k] = e16_load(&a.in[base + p]);
+                    dig[k] = a.digits[base + p];
+                    rank[k] = atomicAdd(&hist[dig[k]], 1u);
+                }
+            }
+        }
+        __syncthreads();                                    // (A) counts complete; previous tile fully written out
+        {
+            const u32 c = hist[tid];
+            const u32 ex = block_excl_sum<SS_SBLOCK / kWave>(c, scr, nullptr);
+            s_start[tid] = (u16)ex;
+            const u32 o = s_off[tid];
+            s_delta[tid] = o - ex;
+            s_off[tid] = o + c;
+            hist[tid] = 0;
+        }
+        __syncthreads();                                    // (B) bin starts published
+#pragma unroll
+        for (int k = 0; k < SS_SIPT; ++k) {
+            const bool ok = FROM_TEXT ? (tid * SS_SIPT + k < valid) : (k * SS_SBLOCK + tid < valid);
+            if (ok) {
+                const u32 lp = (u32)s_start[dig[k]] + rank[k];
+                e16_store(&exch[lp], e[k]);
+                dstage[lp] = (u16)dig[k];
+            }
+        }
+        __syncthreads();                                    // (C) tile in bin order
+#pragma unroll
+        for (int k = 0; k < SS_SIPT; ++k) {
+            const u32 p = k * SS_SBLOCK + tid;
+            if (p < valid) e16_store(&a.out[(size_t)s_delta[dstage[p]] + p], e16_load(&exch[p]));
+        }
+    }
+}
+
+// ---- local sort: merge sort of a tile in LDS ----------------------------------------------------------------------
+
+constexpr int SL_BLOCK = 512;
+constexpr int SL_IPT = SS_TILE / SL_BLOCK;      // 8
+
+// LDS slot of tile position p: eight consecutive positions (one thread's run of outputs) spread over eight 16-byte
+// columns, so that the threads' b128 accesses to "their" k-th element do not all land in the same banks.
+__device__ __forceinline__ u32 sl_slot(u32 p) { return p ^ (((p >> 3) ^ (p >> 6)) & 7u); }
+
+__device__ __forceinline__ void sl_cswap(E16 &a, E16 &b)
+{
+    const bool sw = e16_lt(b, a);
+    const E16 x = e16_sel(sw, b, a), y = e16_sel(sw, a, b);
+    a = x;
+    b = y;
+}
+
+__global__ __launch_bounds__(SL_BLOCK, 4) void ss_local_kernel(const E16 *in, const MsdTile *tiles, u32 nt, int ib, u32 *sa_out,
+                                                                int fused, MsdEmit em_val)
+{
+    const MsdEmit *em = fused ? &em_val : nullptr;
+    __shared__ E16 buf[SS_TILE];
+    __shared__ u32 s_count;
+    const u32 tid = threadIdx.x;
+    const u32 t = blockIdx.x;
+    if (t >= nt) return;
+    const u32 e0 = tiles[t].e0, count = tiles[t].count;
+    if (tid == 0) s_count = 0;
+    // coalesced load, positions past the tile = +infinity
+#pragma unroll
+    for (int k = 0; k < SL_IPT; ++k) {
+        const u32 p = k * SL_BLOCK + tid;
+        e16_store(&buf[sl_slot(p)], e16_sel(p < count, e16_load(&in[e0 + min(p, count - 1)]), e16_inf()));
+    }
+    __syncthreads();
+    E16 v[SL_IPT];
+    const u32 o0 = tid * SL_IPT;                 // this thread's run of eight positions
+#pragma unroll
+    for (int k = 0; k < SL_IPT; ++k) v[k] = e16_load(&buf[sl_slot(o0 + k)]);
+    // eight elements in registers: odd-even merge sort network (19 compare-exchanges)
+    sl_cswap(v[0], v[1]); sl_cswap(v[2], v[3]); sl_cswap(v[4], v[5]); sl_cswap(v[6], v[7]);
+    sl_cswap(v[0], v[2]); sl_cswap(v[1], v[3]); sl_cswap(v[4], v[6]); sl_cswap(v[5], v[7]);
+    sl_cswap(v[1], v[2]); sl_cswap(v[5], v[6]);
+    sl_cswap(v[0], v[4]); sl_cswap(v[1], v[5]); sl_cswap(v[2], v[6]); sl_cswap(v[3], v[7]);
+    sl_cswap(v[2], v[4]); sl_cswap(v[3], v[5]);
+    sl_cswap(v[1], v[2]); sl_cswap(v[3], v[4]); sl_cswap(v[5], v[6]);
+#pragma unroll
+    for (int k = 0; k < SL_IPT; ++k) e16_store(&buf[sl_slot(o0 + k)], v[k]);
+    __syncthreads();
+    // merge rounds: runs of L become runs of 2 L; thread -> outputs o0 .. o0 + 7 of its pair of runs (merge path)
+    for (u32 L = SL_IPT; L < SS_TILE; L <<= 1) {
+        const u32 pair0 = o0 & ~(2 * L - 1);             // first position of the pair of runs
+        const u32 d = o0 - pair0;                        // outputs of the pair before mine
+        const u32 A = pair0, B = pair0 + L;
+        // runs made of padding only need no work: everything from `count` on is +infinity already
+        const bool live = pair0 < count;
+        if (live) {
+            u32 lo = d > L ? d - L : 0, hi = d < L ? d : L;
+            while (lo < hi) {                            // smallest a with A[a] > B[d - 1 - a]
+                const u32 mid = (lo + hi) >> 1;
+                const E16 x = e16_load(&buf[sl_slot(A + mid)]), y = e16_load(&buf[sl_slot(B + d - 1 - mid)]);
+                if (e16_lt(x, y)) lo = mid + 1; else hi = mid;
+            }
+            u32 ai = lo, bi = d - lo;
+            E16 va = e16_sel(ai < L, e16_load(&buf[sl_slot(A + min(ai, L - 1))]), e16_inf());
+            E16 vb = e16_sel(bi < L, e16_load(&buf[sl_slot(B + min(bi, L - 1))]), e16_inf());
+#pragma unroll
+            for (int k = 0; k < SL_IPT; ++k) {
+                const bool ta = !e16_lt(vb, va);         // take from A (both +infinity: padding, either will do)
+                v[k] = e16_sel(ta, va, vb);
+                ai += ta ? 1u : 0u;
+                bi += ta ? 0u : 1u;
+                const u32 ni = ta ? ai : bi;
+                const E16 nx = e16_sel(ni < L, e16_load(&buf[sl_slot((ta ? A : B) + min(ni, L - 1))]), e16_inf());
+                va = e16_sel(ta, nx, va);
+                vb = e16_sel(ta, vb, nx);
+            }
+        }
+        __syncthreads();                                 // every read of this round is done
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < SL_IPT; ++k) e16_store(&buf[sl_slot(o0 + k)], v[k]);
+        }
+        __syncthreads();
+    }
+    // output: suffix indices, coalesced; a record for every element tied with a neighbour (same key bits) when the first
+    // rerank is fused, else bit 31 = "same key as my predecessor" (the contract of msd_emit_tile)
+    const u32 imask = (u32)((1ull << ib) - 1ull);
+#pragma unroll
+    for (int k = 0; k < SL_IPT; ++k) {
+        const u32 p = k * SL_BLOCK + tid;
+        if (p < count) {
+            const E16 x = e16_load(&buf[sl_slot(p)]);
+            const bool tie = p > 0 && e16_same_key(e16_load(&buf[sl_slot(p - 1)]), x, ib);
+            const u32 sfx = (u32)x.lo & imask;
+            sa_out[e0 + p] = sfx | ((tie && em == nullptr) ? 0x80000000u : 0u);
+            if (em != nullptr) {
+                const bool tie_next = p + 1 < count && e16_same_key(e16_load(&buf[sl_slot(p + 1)]), x, ib);
+                if (tie || tie_next) {
+                    const u32 slot = e0 + atomicAdd(&s_count, 1u);
+                    em->st_pos[slot] = e0 + p;
+                    em->st_idx[slot] = sfx | (tie ? 0x80000000u : 0u);
+                }
+            }
+        }
+    }
+    if (em) {
+        __syncthreads();
+        if (tid == 0) em->blk_cnt[t] = s_count;
+    }
+}
+
+// Equal keys may sit on both sides of a bucket boundary (the index is part of the number the splitters cut), hence of a
+// tile boundary, where the sorting workgroup cannot see its predecessor: one thread per tile compares the keys of the
+// last suffix of the tile before it and of its own first suffix (packed from the text again) and sets the flag.
+__global__ __launch_bounds__(256) void ss_boundary_kernel(const MsdTile *tiles, u32 nt, SsText t, u32 *sa)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 || i >= nt) return;
+    const u32 e0 = tiles[i].e0;
+    const u32 pa = sa[e0 - 1] & 0x7fffffffu, pc = sa[e0] & 0x7fffffffu;
+    u64 qa[5], qc[5];
+    ss_stream_at<5>(t.codes, pa, qa);
+    ss_stream_at<5>(t.codes, pc, qc);
+    E16 a[1], c[1];
+    ss_pack<1, 5>(qa, pa, t, a);
+    ss_pack<1, 5>(qc, pc, t, c);
+    if (e16_same_key(a[0], c[0], t.ib)) sa[e0] = pc | 0x80000000u;
+}
+
