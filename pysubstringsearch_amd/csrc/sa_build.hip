@@ -1161,7 +1161,7 @@ static void rerank_geometry(u32 m, RerankArgs &a)
     a.num_ranges = (a.num_tiles + a.tiles_per_range - 1) / a.tiles_per_range;
 }
 
-enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK, S_SSA = 24, S_SSB = 25, S_GRP2 = 26, S_BIG = 27, S_SCR = 29 };
+enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK, S_GRP2 = 26, S_BIG = 27, S_SCR = 29, S_SSA = 30, S_SSB = 31 };      // (10 .. 23, 28: search.hip; 24, 25: capi.cpp)
 
 // Initial key width.  Model the text as i.i.d. with per-symbol collision
 // probability c = sum p_i^2 (from the sampled counts): two suffixes agree on k

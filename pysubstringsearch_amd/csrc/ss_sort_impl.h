@@ -384,10 +384,14 @@ __global__ __launch_bounds__(SS_SBLOCK) void ss_scatter_kernel(SsArgs a)
 
 // ---- local sort: merge sort of a tile in LDS ----------------------------------------------------------------------
 
-constexpr int SL_BLOCK = 512;
-constexpr int SL_IPT = SS_TILE / SL_BLOCK;      // 8
+#ifndef PSS_SL_BLOCK
+#define PSS_SL_BLOCK 512
+#endif
+constexpr int SL_BLOCK = PSS_SL_BLOCK;          // threads of the sorting workgroup
+constexpr int SL_IPT = SS_TILE / SL_BLOCK;      // elements every thread merges per round (4 or 8)
+static_assert(SL_IPT == 4 || SL_IPT == 8, "the register sort below is written for 4 or 8 elements");
 
-// LDS slot of tile position p: eight consecutive positions (one thread's run of outputs) spread over eight 16-byte
+// LDS slot of tile position p: consecutive positions (one thread's run of outputs) spread over eight 16-byte
 // columns, so that the threads' b128 accesses to "their" k-th element do not all land in the same banks.
 __device__ __forceinline__ u32 sl_slot(u32 p) { return p ^ (((p >> 3) ^ (p >> 6)) & 7u); }
 
@@ -399,8 +403,8 @@ __device__ __forceinline__ void sl_cswap(E16 &a, E16 &b)
     b = y;
 }
 
-__global__ __launch_bounds__(SL_BLOCK, 4) void ss_local_kernel(const E16 *in, const MsdTile *tiles, u32 nt, int ib, u32 *sa_out,
-                                                                int fused, MsdEmit em_val)
+__global__ __launch_bounds__(SL_BLOCK, SL_BLOCK == 512 ? 4 : 8) void ss_local_kernel(const E16 *in, const MsdTile *tiles, u32 nt, int ib, u32 *sa_out,
+                                                             int fused, MsdEmit em_val)
 {
     const MsdEmit *em = fused ? &em_val : nullptr;
     __shared__ E16 buf[SS_TILE];
@@ -418,20 +422,26 @@ __global__ __launch_bounds__(SL_BLOCK, 4) void ss_local_kernel(const E16 *in, co
     }
     __syncthreads();
     E16 v[SL_IPT];
-    const u32 o0 = tid * SL_IPT;                 // this thread's run of eight positions
+    const u32 o0 = tid * SL_IPT;                 // this thread's run of positions
 #pragma unroll
     for (int k = 0; k < SL_IPT; ++k) v[k] = e16_load(&buf[sl_slot(o0 + k)]);
-    // eight elements in registers: odd-even merge sort network (19 compare-exchanges)
-    sl_cswap(v[0], v[1]); sl_cswap(v[2], v[3]); sl_cswap(v[4], v[5]); sl_cswap(v[6], v[7]);
-    sl_cswap(v[0], v[2]); sl_cswap(v[1], v[3]); sl_cswap(v[4], v[6]); sl_cswap(v[5], v[7]);
-    sl_cswap(v[1], v[2]); sl_cswap(v[5], v[6]);
-    sl_cswap(v[0], v[4]); sl_cswap(v[1], v[5]); sl_cswap(v[2], v[6]); sl_cswap(v[3], v[7]);
-    sl_cswap(v[2], v[4]); sl_cswap(v[3], v[5]);
-    sl_cswap(v[1], v[2]); sl_cswap(v[3], v[4]); sl_cswap(v[5], v[6]);
+    if (SL_IPT == 8) {
+        // eight elements in registers: odd-even merge sort network (19 compare-exchanges)
+        sl_cswap(v[0], v[1]); sl_cswap(v[2], v[3]); sl_cswap(v[4 % SL_IPT], v[5 % SL_IPT]); sl_cswap(v[6 % SL_IPT], v[7 % SL_IPT]);
+        sl_cswap(v[0], v[2]); sl_cswap(v[1], v[3]); sl_cswap(v[4 % SL_IPT], v[6 % SL_IPT]); sl_cswap(v[5 % SL_IPT], v[7 % SL_IPT]);
+        sl_cswap(v[1], v[2]); sl_cswap(v[5 % SL_IPT], v[6 % SL_IPT]);
+        sl_cswap(v[0], v[4 % SL_IPT]); sl_cswap(v[1], v[5 % SL_IPT]); sl_cswap(v[2], v[6 % SL_IPT]); sl_cswap(v[3], v[7 % SL_IPT]);
+        sl_cswap(v[2], v[4 % SL_IPT]); sl_cswap(v[3], v[5 % SL_IPT]);
+        sl_cswap(v[1], v[2]); sl_cswap(v[3], v[4 % SL_IPT]); sl_cswap(v[5 % SL_IPT], v[6 % SL_IPT]);
+    } else {
+        sl_cswap(v[0], v[1]); sl_cswap(v[2], v[3]);
+        sl_cswap(v[0], v[2]); sl_cswap(v[1], v[3]);
+        sl_cswap(v[1], v[2]);
+    }
 #pragma unroll
     for (int k = 0; k < SL_IPT; ++k) e16_store(&buf[sl_slot(o0 + k)], v[k]);
     __syncthreads();
-    // merge rounds: runs of L become runs of 2 L; thread -> outputs o0 .. o0 + 7 of its pair of runs (merge path)
+    // merge rounds: runs of L become runs of 2 L; thread -> outputs o0 .. o0 + SL_IPT - 1 of its pair of runs (merge path)
     for (u32 L = SL_IPT; L < SS_TILE; L <<= 1) {
         const u32 pair0 = o0 & ~(2 * L - 1);             // first position of the pair of runs
         const u32 d = o0 - pair0;                        // outputs of the pair before mine
@@ -439,8 +449,11 @@ __global__ __launch_bounds__(SL_BLOCK, 4) void ss_local_kernel(const E16 *in, co
         // runs made of padding only need no work: everything from `count` on is +infinity already
         const bool live = pair0 < count;
         if (live) {
+            // merge path: the smallest a in [lo, hi] with NOT A[a] < B[d - 1 - a].  (Measured: a 4-ary search -- three
+            // probes per step, half as many dependent steps -- is slower, 12.5 vs 11.0 ms at 2^29, and so are 1024 threads
+            // with four elements each, 15.2 ms: the kernel is bound by LDS traffic and bank conflicts, not by latency.)
             u32 lo = d > L ? d - L : 0, hi = d < L ? d : L;
-            while (lo < hi) {                            // smallest a with A[a] > B[d - 1 - a]
+            while (lo < hi) {
                 const u32 mid = (lo + hi) >> 1;
                 const E16 x = e16_load(&buf[sl_slot(A + mid)]), y = e16_load(&buf[sl_slot(B + d - 1 - mid)]);
                 if (e16_lt(x, y)) lo = mid + 1; else hi = mid;
@@ -454,10 +467,12 @@ __global__ __launch_bounds__(SL_BLOCK, 4) void ss_local_kernel(const E16 *in, co
                 v[k] = e16_sel(ta, va, vb);
                 ai += ta ? 1u : 0u;
                 bi += ta ? 0u : 1u;
-                const u32 ni = ta ? ai : bi;
-                const E16 nx = e16_sel(ni < L, e16_load(&buf[sl_slot((ta ? A : B) + min(ni, L - 1))]), e16_inf());
-                va = e16_sel(ta, nx, va);
-                vb = e16_sel(ta, vb, nx);
+                if (k + 1 < SL_IPT) {
+                    const u32 ni = ta ? ai : bi;
+                    const E16 nx = e16_sel(ni < L, e16_load(&buf[sl_slot((ta ? A : B) + min(ni, L - 1))]), e16_inf());
+                    va = e16_sel(ta, nx, va);
+                    vb = e16_sel(ta, vb, nx);
+                }
             }
         }
         __syncthreads();                                 // every read of this round is done

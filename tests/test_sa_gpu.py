@@ -242,6 +242,52 @@ def test_msd_is_chosen_for_high_entropy_text_only(oracle):
     assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(t).tobytes()).hexdigest()
 
 
+# ---- sample sort over 16-byte elements (ss_sort_impl.h) ----
+
+def test_sample_sort_forced_matches_libsais(oracle, monkeypatch):
+    """PSS_SS=1 sends every text of >= 2^16 bytes through the sample sort (splitters from a sorted sample, two partition
+    passes over 16-byte [key | index] elements, merge sort of every tile in LDS, ties as flags + the tile-boundary pass):
+    alphabets of 2 .. 256 symbols (keys of 11 .. 32 symbols), word-like repeats, long duplicated blocks (tie groups that
+    cross buckets and tiles), both bucket-count shapes (B1 = B2 and B1 = 2 B2), every tie-resolution mode afterwards."""
+    monkeypatch.setenv('PSS_SS', '1')
+    monkeypatch.setenv('PSS_MSD', '0')
+    rng = np.random.default_rng(3)
+    took = 0
+    for trial, n in enumerate((1 << 16, 70001, 100003, 300000, 1 << 20, (1 << 21) + 77, (1 << 22) + 5, 1 << 16, 200001, 1 << 19)):
+        alpha = (2, 3, 4, 16, 27, 39, 100, 255, 256, 27)[trial]
+        t = (rng.integers(0, alpha, n).astype(np.uint16) + (0 if alpha > 200 else 40)).astype(np.uint8)
+        if trial % 3 == 1:
+            words = [bytes(rng.integers(97, 97 + min(alpha, 26), int(rng.integers(2, 9))).astype(np.uint8)) for _ in range(50)]
+            t = np.frombuffer(b' '.join(words[int(i)] for i in rng.integers(0, 50, n // 4)), dtype=np.uint8)[:n].copy()
+        elif trial % 3 == 2:
+            blk = t[:5000].copy()
+            for o in rng.integers(0, n - 5000, 20):
+                t[o:o + 5000] = blk
+        t[-1] = 10
+        if trial % 4 == 3:
+            monkeypatch.setenv('PSS_MODE', ('dense', 'text')[trial % 2])
+        else:
+            monkeypatch.delenv('PSS_MODE', raising=False)
+        st = {}
+        sa = _sa_device(t, st)
+        took += st['ss']
+        assert st['ss'] == 1 and st['ss_max_bucket'] <= 4088, (trial, st['ss'], st['ss_max_bucket'])
+        assert np.array_equal(sa, oracle.sa(t)), (trial, n, alpha)
+    assert took == 10
+
+
+def test_sample_sort_is_chosen_for_natural_text(oracle):
+    """Without switches at n >= 2^24: `words` (some 20-bit prefix far beyond a tile) takes the sample sort, `lines` the
+    radix MSD sort; both give libsais' bytes."""
+    from tests.util import gen_corpus
+    for kind, want_ss, want_msd in ((1, 1, 0), (0, 0, 1)):
+        t = gen_corpus(kind, 1 << 24)
+        st = {}
+        sa = _sa_device(t, st)
+        assert (st['ss'], st['msd']) == (want_ss, want_msd), (kind, st['ss'], st['msd'])
+        assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(t).tobytes()).hexdigest()
+
+
 # ---- run-length path (rle_build.hip) ----
 
 def _runs_text(rng, n, alpha, maxrun, base=40):
