@@ -138,14 +138,18 @@ __device__ __forceinline__ void ss_stream_at(const u8 *codes, u32 pos, u64 (&q)[
     }
 }
 
-// Number of splitters <= e among spl[0 .. B - 2] (B a power of two, the array sorted): the bucket of e.
-__device__ __forceinline__ u32 ss_bucket(const E16 *spl, u32 B, const E16 &e)
+// The searches are bound by LDS bank conflicts (SQ_LDS_BANK_CONFLICT: 85 % of the LDS cycles -- every lane reads its own
+// random address of the table), and the price is per read instruction, not per byte (measured: one 8-byte read per step
+// instead of one 16-byte read, 4.1 -> 2.9 ms; two 8-byte reads per step, 7.9 ms).  So the first level searches the HIGH
+// WORDS of the splitters alone: order preserving, and the few splitters that share the element's high word (a run of
+// equal keys twelve symbols long) are settled by a walk over the full numbers.  Inside a first-level bucket high words
+// -- any 64-bit window -- collide all the time (the splitters of a long run of equal keys differ in their index bits
+// only): the second level reads the 16-byte numbers.
+// after the high-word search left `pos` = splitters whose high word is <= the element's: step back over the splitters
+// that share the high word but are larger as full numbers
+__device__ __forceinline__ u32 ss_settle(const u64 *win, const E16 *spl, u32 pos, u64 w, const E16 &e)
 {
-    u32 pos = 0;
-    for (u32 step = B >> 1; step; step >>= 1) {
-        const E16 s = spl[pos + step - 1];
-        pos += e16_lt(e, s) ? 0u : step;
-    }
+    while (pos > 0 && win[pos - 1] == w && e16_lt(e, spl[pos - 1])) --pos;
     return pos;
 }
 
@@ -200,12 +204,15 @@ struct SsArgs {
 __global__ __launch_bounds__(SS_DBLOCK) void ss_digits1_kernel(SsArgs a)
 {
     __shared__ E16 spl[MSD_BINS];
+    __shared__ u64 win[MSD_BINS];
     __shared__ u32 hist[MSD_BINS];
     const u32 tid = threadIdx.x, r = blockIdx.x;
     if (r >= a.num_ranges1) return;
     for (u32 i = tid; i < MSD_BINS; i += SS_DBLOCK) {
         hist[i] = 0;
-        spl[i] = e16_sel(i + 1 < a.B1, e16_load(&a.sample[(size_t)min(i + 1, a.B1 - 1) * a.spb]), e16_inf());
+        const E16 sp = e16_sel(i + 1 < a.B1, e16_load(&a.sample[(size_t)min(i + 1, a.B1 - 1) * a.spb]), e16_inf());
+        spl[i] = sp;
+        win[i] = sp.hi;
     }
     __syncthreads();
     const u32 n = a.text.n;
@@ -235,13 +242,11 @@ __global__ __launch_bounds__(SS_DBLOCK) void ss_digits1_kernel(SsArgs a)
             for (int k = 0; k < 8; ++k) pos[k] = 0;
             for (u32 step = a.B1 >> 1; step; step >>= 1) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const E16 s = spl[pos[k] + step - 1];
-                    pos[k] += e16_lt(e[k], s) ? 0u : step;
-                }
+                for (int k = 0; k < 8; ++k) pos[k] += e[k].hi < win[pos[k] + step - 1] ? 0u : step;
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
+                pos[k] = ss_settle(win, spl, pos[k], e[k].hi, e[k]);
                 dg[8 * h + k] = pos[k];
                 if (i0 + 8 * h + k < n) atomicAdd(&hist[pos[k]], 1u);
             }
@@ -282,8 +287,8 @@ __global__ __launch_bounds__(SS_DBLOCK) void ss_digits2_kernel(SsArgs a)
         for (u32 step = a.B2 >> 1; step; step >>= 1) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const E16 s = spl[pos[k] + step - 1];
-                pos[k] += e16_lt(e[k], s) ? 0u : step;
+                const E16 sp = spl[pos[k] + step - 1];
+                pos[k] += e16_lt(e[k], sp) ? 0u : step;
             }
         }
 #pragma unroll
@@ -449,9 +454,12 @@ __global__ __launch_bounds__(SL_BLOCK, SL_BLOCK == 512 ? 4 : 8) void ss_local_ke
         // runs made of padding only need no work: everything from `count` on is +infinity already
         const bool live = pair0 < count;
         if (live) {
-            // merge path: the smallest a in [lo, hi] with NOT A[a] < B[d - 1 - a].  (Measured: a 4-ary search -- three
-            // probes per step, half as many dependent steps -- is slower, 12.5 vs 11.0 ms at 2^29, and so are 1024 threads
-            // with four elements each, 15.2 ms: the kernel is bound by LDS traffic and bank conflicts, not by latency.)
+            // merge path: the smallest a in [lo, hi] with NOT A[a] < B[d - 1 - a].  The kernel is bound by VALU issue (128-bit
+            // compares and selects: ~450 instructions per thread and round) with the LDS busy half of the time; measured
+            // and left out, all at 2^29: a 4-ary search (three probes per step, half as many dependent steps), 12.5 vs
+            // 11.0 ms; 1024 threads with four elements each, 15.2 ms; merging only inside the bucket that straddles the
+            // border of two long runs (the buckets of a tile are in order already), 12.1 ms -- the skipped lanes save
+            // nothing while the rounds stay barrier-synchronised and the extra predicates cost in every round.
             u32 lo = d > L ? d - L : 0, hi = d < L ? d : L;
             while (lo < hi) {
                 const u32 mid = (lo + hi) >> 1;
