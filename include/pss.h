@@ -191,6 +191,18 @@ uint64_t pss_writer_chunk_limit(const pss_writer *w);
  * consult before the suffix array. */
 int pss_reader_open(const char *path, int32_t device, int32_t shard_index, int32_t shard_count,
                     pss_reader **out);
+/* The same over several devices in ONE process, no launcher, no torch (the reference fans a search over all chunks
+ * inside the process too: rayon, src/lib.rs:207, 280-284): chunk c of the file becomes resident on
+ * devices[c % n_devices]; every device answers a batch for its chunks on a thread of its own and the results are
+ * merged on the host (query-major, device-major inside a query).  The same ordinal may be listed more than once
+ * ("virtual devices": the parts then take turns on that GPU).  pss_reader_search_batch / count_batch / residency /
+ * evict / promote work on such a reader; the device-resident result and the chunk hand-off calls do not. */
+int pss_reader_open_multi(const char *path, const int32_t *devices, int32_t n_devices, pss_reader **out);
+/* Residency control: move the suffix array of resident chunk `index` (file order) out of HBM into
+ * pinned host memory, where the kernels read it over PCIe (evict), or back (promote; PSS_ENOMEM when HBM has no
+ * room).  Text and key samples stay in HBM.  No-ops when the chunk already is where it is asked to be. */
+int pss_reader_evict_chunk(pss_reader *r, uint64_t index);
+int pss_reader_promote_chunk(pss_reader *r, uint64_t index);
 /* An empty reader on `device`, to be filled with pss_reader_add_chunk_device
  * (Writer -> Reader hand-off through HBM, no file). */
 int pss_reader_create(int32_t device, pss_reader **out);

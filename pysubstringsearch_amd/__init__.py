@@ -197,12 +197,26 @@ class Reader:
         index_file_path: str,
         *,
         device: typing.Optional[int] = None,
+        devices: typing.Optional[typing.Sequence[int]] = None,
         shard: typing.Tuple[int, int] = (0, 1),
     ) -> None:
+        """``devices=[0, 1, ...]`` (extension) makes chunk c of the file resident on ``devices[c % len(devices)]`` and
+        answers every search on all of them at once, inside this process -- no launcher, no ``torch.distributed``: one
+        host thread per device, results merged on the host (the reference fans a search over its chunks with rayon,
+        src/lib.rs:207).  ``shard=(i, n)`` is the one-process-per-GPU form of the same split (``dist.ShardedReader``)."""
         self._h = ctypes.c_void_p()
         path = _path(index_file_path, 'index_file_path')
-        rc = _lib.pss_reader_open(
-            path, _default_device() if device is None else device, shard[0], shard[1], ctypes.byref(self._h))
+        if devices is not None:
+            if device is not None or tuple(shard) != (0, 1):
+                raise ValueError('pass devices, or device / shard')
+            devs = [int(d) for d in devices]
+            if not devs:
+                raise ValueError('devices must not be empty')
+            arr = (ctypes.c_int32 * len(devs))(*devs)
+            rc = _lib.pss_reader_open_multi(path, arr, len(devs), ctypes.byref(self._h))
+        else:
+            rc = _lib.pss_reader_open(
+                path, _default_device() if device is None else device, shard[0], shard[1], ctypes.byref(self._h))
         _ffi.check(rc, index_file_path)
 
     @property
@@ -233,6 +247,14 @@ class Reader:
         hbm, host, nhost = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
         _ffi.check(_lib.pss_reader_residency(self._handle(), ctypes.byref(hbm), ctypes.byref(host), ctypes.byref(nhost)))
         return {'hbm_bytes': hbm.value, 'host_bytes': host.value, 'host_chunks': nhost.value}
+
+    def evict(self, chunk: int) -> None:
+        """Extension: move the suffix array of resident chunk ``chunk`` out of HBM into pinned host
+        memory (searches keep working, the kernels read it over PCIe); ``promote`` brings it back."""
+        _ffi.check(_lib.pss_reader_evict_chunk(self._handle(), int(chunk)))
+
+    def promote(self, chunk: int) -> None:
+        _ffi.check(_lib.pss_reader_promote_chunk(self._handle(), int(chunk)))
 
     def _search_batch(self, patterns: typing.Sequence[bytes], as_str: bool):
         nq = len(patterns)

@@ -739,6 +739,29 @@ struct pss_reader {
     size_t d_descs_cap = 0;
     bool dirty = true;
     pss_search_stats last{};
+    // A reader over several devices (pss_reader_open_multi) is a front for one reader per device -- part k holds the
+    // chunks c with c % G == k on devices[k] -- each with a worker thread that answers the batch for its chunks; the
+    // calling thread takes part 0 itself and merges (reference: rayon fans one search over all chunks inside the
+    // process, src/lib.rs:207, 280-284).
+    struct Part;
+    std::vector<Part *> parts;
+    std::mutex multi_mu;                 // one batch at a time through the workers
+};
+
+struct pss_reader::Part {
+    pss_reader *reader = nullptr;        // plain single-device reader of this part's chunks
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    // mailbox: the caller fills the job and raises `pending`; the worker clears it when `rc` / `res` / `err` are set
+    bool pending = false, quit = false;
+    const uint8_t *qbytes = nullptr;
+    const uint64_t *qoffsets = nullptr;
+    uint32_t nq = 0;
+    int mode = 0;                        // SEARCH_FULL / SEARCH_COUNTS
+    int rc = 0;
+    HostResult res;
+    std::string err;
 };
 
 struct pss_result {
@@ -746,6 +769,8 @@ struct pss_result {
 };
 
 namespace {
+
+int reader_sync_descs(pss_reader *r);
 
 // HBM the reader may still take for suffix arrays: PSS_READER_HBM_BUDGET (bytes, over all chunks of
 // this reader; tests use it to force the host tier), else whatever hipMalloc grants while
@@ -842,9 +867,56 @@ int reader_sample_chunk(pss_reader *r, const ChunkDesc &c)
     return build_key_samples(r->ctx, c.text, c.sa, c.n, c.shift, const_cast<uint64_t *>(c.skeys));
 }
 
+void reader_free(pss_reader *r);
+
+void part_run(pss_reader::Part *p)      // the job in p's mailbox, on p's reader
+{
+    pss_reader *r = p->reader;
+    std::lock_guard<std::recursive_mutex> lk(r->ctx->mu);
+    p->res.release();
+    p->err.clear();
+    int rc = PSS_OK;
+    if (hipSetDevice(r->device) != hipSuccess) {
+        set_error("hipSetDevice(%d) failed", r->device);
+        rc = PSS_EDEVICE;
+    }
+    if (rc == PSS_OK) rc = reader_sync_descs(r);
+    if (rc == PSS_OK)
+        rc = search_batch_device(r->ctx, r->d_descs, (uint32_t)r->chunks.size(), p->qbytes, p->qoffsets, p->nq, &p->res, &r->last,
+                                 (SearchMode)p->mode);
+    if (rc != PSS_OK) p->err = last_error();
+    p->rc = rc;
+}
+
+void part_worker(pss_reader::Part *p)
+{
+    std::unique_lock<std::mutex> lk(p->mu);
+    for (;;) {
+        p->cv.wait(lk, [&] { return p->pending || p->quit; });
+        if (p->quit) return;
+        part_run(p);
+        p->pending = false;
+        p->cv.notify_all();
+    }
+}
+
 void reader_free(pss_reader *r)
 {
     if (!r) return;
+    for (pss_reader::Part *p : r->parts) {
+        if (p->worker.joinable()) {
+            {
+                std::lock_guard<std::mutex> lk(p->mu);
+                p->quit = true;
+            }
+            p->cv.notify_all();
+            p->worker.join();
+        }
+        p->res.release();
+        reader_free(p->reader);
+        delete p;
+    }
+    r->parts.clear();
     if (r->ctx) (void)hipSetDevice(r->device);
     for (auto &m : r->mem) reader_free_mem(m);
     if (r->d_descs) (void)hipFree(r->d_descs);
@@ -1032,10 +1104,147 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
     });
 }
 
+extern "C" int pss_reader_open_multi(const char *path, const int32_t *devices, int32_t n_devices, pss_reader **out)
+{
+    return guarded([&]() -> int {
+        if (!path || !out || !devices || n_devices < 1 || n_devices > 64) {
+            set_error("pss_reader_open_multi: bad arguments");
+            return PSS_EINVAL;
+        }
+        if (n_devices == 1) return pss_reader_open(path, devices[0], 0, 1, out);
+        // every part reads the file for its own chunks (seeking over the others'), all parts at once: the uploads of
+        // different devices overlap, parts sharing a device take turns on its staging buffers
+        const int G = n_devices;
+        std::vector<pss_reader *> rd(G, nullptr);
+        std::vector<int> rcs(G, PSS_OK);
+        std::vector<std::string> errs(G);
+        std::vector<int> errnos(G, 0);
+        std::vector<std::thread> th;
+        for (int k = 0; k < G; ++k)
+            th.emplace_back([&, k] {
+                rcs[k] = pss_reader_open(path, devices[k], k, G, &rd[k]);
+                if (rcs[k] != PSS_OK) {
+                    errs[k] = last_error();
+                    errnos[k] = errno;
+                }
+            });
+        for (auto &t : th) t.join();
+        for (int k = 0; k < G; ++k) {
+            if (rcs[k] == PSS_OK) continue;
+            set_error("%s", errs[k].c_str());
+            const int rc = rcs[k], en = errnos[k];
+            for (pss_reader *x : rd) reader_free(x);
+            errno = en;       // (PSS_EIO: the binding turns errno into the OSError subclass the reference raises)
+            return rc;
+        }
+        pss_reader *r = new pss_reader();
+        r->device = devices[0];
+        r->ctx = rd[0]->ctx;
+        for (int k = 0; k < G; ++k) {
+            pss_reader::Part *p = new pss_reader::Part();
+            p->reader = rd[k];
+            r->parts.push_back(p);
+        }
+        for (int k = 1; k < G; ++k) r->parts[k]->worker = std::thread(part_worker, r->parts[k]);      // part 0 runs on the caller
+        *out = r;
+        return PSS_OK;
+    });
+}
+
+namespace {
+
+// One batch over the parts of a multi-device reader: every worker answers for its chunks, the caller for part 0;
+// then the per-part results are merged query-major, part-major inside a query (pss_merge_packed's order).
+int multi_batch(pss_reader *r, const uint8_t *qbytes, const uint64_t *qoffsets, uint32_t nq, int mode, HostResult *out)
+{
+    std::lock_guard<std::mutex> batch(r->multi_mu);
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t G = r->parts.size();
+    for (size_t k = 0; k < G; ++k) {
+        pss_reader::Part *p = r->parts[k];
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->qbytes = qbytes;
+        p->qoffsets = qoffsets;
+        p->nq = nq;
+        p->mode = mode;
+        if (k) p->pending = true;
+    }
+    for (size_t k = 1; k < G; ++k) r->parts[k]->cv.notify_all();
+    part_run(r->parts[0]);
+    int rc = r->parts[0]->rc;
+    std::string err = r->parts[0]->err;
+    for (size_t k = 1; k < G; ++k) {
+        pss_reader::Part *p = r->parts[k];
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->cv.wait(lk, [&] { return !p->pending; });
+        if (p->rc != PSS_OK && rc == PSS_OK) {
+            rc = p->rc;
+            err = p->err;
+        }
+    }
+    if (rc != PSS_OK) {
+        set_error("%s", err.c_str());
+        return rc;
+    }
+    pss_search_stats st{};
+    st.queries = nq;
+    uint64_t E = 0, B = 0;
+    for (pss_reader::Part *p : r->parts) {
+        const pss_search_stats &ps = p->reader->last;
+        st.hits += ps.hits;
+        st.entries += ps.entries;
+        st.result_bytes += ps.result_bytes;
+        st.ms_device = std::max(st.ms_device, ps.ms_device);
+        st.ms_interval = std::max(st.ms_interval, ps.ms_interval);
+        E += p->res.n_entries;
+        B += p->res.n_bytes;
+    }
+    out->nq = nq;
+    out->qcount = static_cast<uint64_t *>(calloc(nq ? nq : 1, sizeof(uint64_t)));
+    if (!out->qcount) return PSS_ENOMEM;
+    if (mode == SEARCH_COUNTS) {
+        for (pss_reader::Part *p : r->parts)
+            for (uint32_t q = 0; q < nq; ++q) out->qcount[q] += p->res.qcount[q];
+    } else {
+        out->offsets = static_cast<uint64_t *>(malloc((E + 1) * sizeof(uint64_t)));
+        out->bytes = static_cast<uint8_t *>(malloc(B ? B : 1));
+        if (!out->offsets || !out->bytes) return PSS_ENOMEM;
+        std::vector<uint64_t> cursor(G, 0);
+        uint64_t e_out = 0, b_out = 0;
+        for (uint32_t q = 0; q < nq; ++q) {
+            for (size_t k = 0; k < G; ++k) {
+                const HostResult &pr = r->parts[k]->res;
+                const uint64_t c = pr.qcount[q];
+                if (!c) continue;
+                const uint64_t e0 = cursor[k], e1 = e0 + c;
+                const uint64_t b0 = pr.offsets[e0], b1 = pr.offsets[e1];
+                for (uint64_t e = e0; e < e1; ++e) out->offsets[e_out++] = b_out + (pr.offsets[e] - b0);
+                memcpy(out->bytes + b_out, pr.bytes + b0, (size_t)(b1 - b0));
+                b_out += b1 - b0;
+                cursor[k] = e1;
+                out->qcount[q] += c;
+            }
+        }
+        out->offsets[e_out] = b_out;
+        out->n_entries = E;
+        out->n_bytes = B;
+    }
+    for (pss_reader::Part *p : r->parts) p->res.release();
+    st.ms_host = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    r->last = st;
+    return PSS_OK;
+}
+
+}  // namespace
+
 extern "C" int pss_reader_add_chunk_device(pss_reader *r, const void *d_text, const void *d_sa, uint32_t n)
 {
     return guarded([&]() -> int {
         if (!r || (n && (!d_text || !d_sa))) return PSS_EINVAL;
+        if (!r->parts.empty()) {
+            set_error("pss_reader_add_chunk_device: not on a multi-device reader");
+            return PSS_EINVAL;
+        }
         if (n == 0) return PSS_OK;
         std::lock_guard<std::recursive_mutex> lk(r->ctx->mu);
         ChunkDesc cd{};
@@ -1057,7 +1266,7 @@ extern "C" int pss_reader_set_chunk_device(pss_reader *r, uint64_t index, const 
                                            uint32_t n)
 {
     return guarded([&]() -> int {
-        if (!r || !d_text || !d_sa || n == 0 || index > r->chunks.size()) {
+        if (!r || !d_text || !d_sa || n == 0 || index > r->chunks.size() || !r->parts.empty()) {
             set_error("pss_reader_set_chunk_device: bad arguments");
             return PSS_EINVAL;
         }
@@ -1085,17 +1294,113 @@ extern "C" int pss_reader_set_chunk_device(pss_reader *r, uint64_t index, const 
     });
 }
 
-extern "C" uint64_t pss_reader_num_chunks(const pss_reader *r) { return r ? r->chunks.size() : 0; }
+namespace {
+
+// Moves the suffix array of resident chunk `index` between the two tiers (HBM <-> pinned host memory the kernels read
+// over PCIe); the key samples stay in HBM either way.  `to_host` = evict, else promote.
+int reader_move_sa(pss_reader *r, uint64_t index, bool to_host)
+{
+    if (index >= r->chunks.size()) {
+        set_error("chunk %llu of %zu", (unsigned long long)index, r->chunks.size());
+        return PSS_EINVAL;
+    }
+    std::lock_guard<std::recursive_mutex> lk(r->ctx->mu);
+    PSS_HIP(hipSetDevice(r->device));
+    ChunkDesc &c = r->chunks[index];
+    pss_reader::Mem &m = r->mem[index];
+    if (m.sa_host == to_host || c.n == 0) return PSS_OK;
+    const size_t sa_bytes = round_up((size_t)c.n * 4 + 16, 8);
+    const size_t sk_bytes = c.skeys ? sample_count(c.n, c.shift) * 8 : 0;
+    hipStream_t s = r->ctx->stream;
+    if (to_host) {
+        void *host = nullptr, *sk = nullptr;
+        hipError_t e = hipHostMalloc(&host, sa_bytes, hipHostMallocPortable);
+        if (e == hipSuccess && sk_bytes) e = hipMalloc(&sk, sk_bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (host) (void)hipHostFree(host);
+            set_error("evict: no pinned host memory for the suffix array of chunk %llu: %s", (unsigned long long)index, hipGetErrorString(e));
+            return PSS_ENOMEM;
+        }
+        PSS_HIP(hipMemcpyAsync(host, m.sa, (size_t)c.n * 4, hipMemcpyDeviceToHost, s));
+        if (sk_bytes) PSS_HIP(hipMemcpyAsync(sk, c.skeys, sk_bytes, hipMemcpyDeviceToDevice, s));
+        PSS_HIP(hipStreamSynchronize(s));
+        (void)hipFree(m.sa);
+        m.sa = host;
+        m.skeys = sk;
+        m.sa_host = true;
+        m.hbm_bytes -= sa_bytes;
+        m.host_bytes = sa_bytes;
+        void *dp = nullptr;
+        PSS_HIP(hipHostGetDevicePointer(&dp, host, 0));
+        c.sa = static_cast<uint32_t *>(dp);
+        c.skeys = static_cast<uint64_t *>(sk);
+    } else {
+        void *dev = nullptr;
+        const hipError_t e = hipMalloc(&dev, sa_bytes + sk_bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("promote: no HBM for the suffix array of chunk %llu: %s", (unsigned long long)index, hipGetErrorString(e));
+            return PSS_ENOMEM;
+        }
+        uint64_t *sk = sk_bytes ? reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(dev) + sa_bytes) : nullptr;
+        PSS_HIP(hipMemcpyAsync(dev, m.sa, (size_t)c.n * 4, hipMemcpyHostToDevice, s));
+        if (sk_bytes) PSS_HIP(hipMemcpyAsync(sk, c.skeys, sk_bytes, hipMemcpyDeviceToDevice, s));
+        PSS_HIP(hipStreamSynchronize(s));
+        (void)hipHostFree(m.sa);
+        if (m.skeys) (void)hipFree(m.skeys);
+        m.sa = dev;
+        m.skeys = nullptr;
+        m.sa_host = false;
+        m.hbm_bytes += sa_bytes;
+        m.host_bytes = 0;
+        c.sa = static_cast<uint32_t *>(dev);
+        c.skeys = sk;
+    }
+    r->dirty = true;
+    return reader_sync_descs(r);
+}
+
+int reader_move_any(pss_reader *r, uint64_t index, bool to_host)
+{
+    if (!r) return PSS_EINVAL;
+    if (r->parts.empty()) return reader_move_sa(r, index, to_host);
+    const uint64_t G = r->parts.size();      // chunk c of the file lives in part c % G at position c / G
+    return reader_move_sa(r->parts[index % G]->reader, index / G, to_host);
+}
+
+}  // namespace
+
+extern "C" int pss_reader_evict_chunk(pss_reader *r, uint64_t index)
+{
+    return guarded([&]() -> int { return reader_move_any(r, index, true); });
+}
+extern "C" int pss_reader_promote_chunk(pss_reader *r, uint64_t index)
+{
+    return guarded([&]() -> int { return reader_move_any(r, index, false); });
+}
+
+extern "C" uint64_t pss_reader_num_chunks(const pss_reader *r)
+{
+    if (!r) return 0;
+    uint64_t nc = r->chunks.size();
+    for (const pss_reader::Part *p : r->parts) nc += p->reader->chunks.size();
+    return nc;
+}
 
 extern "C" int pss_reader_residency(const pss_reader *r, uint64_t *hbm_bytes, uint64_t *host_bytes, uint64_t *host_chunks)
 {
     if (!r) return PSS_EINVAL;
     uint64_t hb = 0, pb = 0, hc = 0;
-    for (const auto &m : r->mem) {
-        hb += m.hbm_bytes;
-        pb += m.host_bytes;
-        hc += m.sa_host ? 1 : 0;
-    }
+    auto add = [&](const pss_reader *x) {
+        for (const auto &m : x->mem) {
+            hb += m.hbm_bytes;
+            pb += m.host_bytes;
+            hc += m.sa_host ? 1 : 0;
+        }
+    };
+    add(r);
+    for (const pss_reader::Part *p : r->parts) add(p->reader);
     if (hbm_bytes) *hbm_bytes = hb;
     if (host_bytes) *host_bytes = pb;
     if (host_chunks) *host_chunks = hc;
@@ -1109,6 +1414,16 @@ extern "C" int pss_reader_search_batch(pss_reader *r, const uint8_t *qbytes, con
         if (!r || !out || (nq && !qoffsets)) {
             set_error("pss_reader_search_batch: bad arguments");
             return PSS_EINVAL;
+        }
+        if (!r->parts.empty()) {
+            pss_result *res = new pss_result();
+            const int rc = multi_batch(r, qbytes, qoffsets, nq, SEARCH_FULL, &res->r);
+            if (rc != PSS_OK) {
+                pss_result_free(res);
+                return rc;
+            }
+            *out = res;
+            return PSS_OK;
         }
         std::lock_guard<std::recursive_mutex> lk(r->ctx->mu);
         PSS_HIP(hipSetDevice(r->device));
@@ -1133,6 +1448,13 @@ extern "C" int pss_reader_count_batch(pss_reader *r, const uint8_t *qbytes, cons
             set_error("pss_reader_count_batch: bad arguments");
             return PSS_EINVAL;
         }
+        if (!r->parts.empty()) {
+            pss_result res;
+            const int rc = multi_batch(r, qbytes, qoffsets, nq, SEARCH_COUNTS, &res.r);
+            if (rc == PSS_OK && nq) memcpy(counts, res.r.qcount, (size_t)nq * sizeof(uint64_t));
+            res.r.release();
+            return rc;
+        }
         std::lock_guard<std::recursive_mutex> lk(r->ctx->mu);
         PSS_HIP(hipSetDevice(r->device));
         const uint32_t nc = (uint32_t)r->chunks.size();
@@ -1151,6 +1473,10 @@ extern "C" int pss_reader_search_batch_device(pss_reader *r, const uint8_t *qbyt
     return guarded([&]() -> int {
         if (!r || !out || (nq && !qoffsets)) {
             set_error("pss_reader_search_batch_device: bad arguments");
+            return PSS_EINVAL;
+        }
+        if (!r->parts.empty()) {
+            set_error("pss_reader_search_batch_device: a multi-device reader has no single device to leave the result on");
             return PSS_EINVAL;
         }
         std::lock_guard<std::recursive_mutex> lk(r->ctx->mu);

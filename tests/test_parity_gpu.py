@@ -446,6 +446,94 @@ def test_suffix_arrays_beyond_the_hbm_budget_stay_on_the_host(tmp_path, oracle, 
         assert r.residency['host_chunks'] == 0
 
 
+def test_multi_device_reader_in_one_process(tmp_path, oracle):
+    """Reader(path, devices=[...]): chunk c resident on devices[c % G], one host thread per device answers the batch,
+    the results are merged on the host -- no launcher, no torch.  On the one GPU of the test box the devices are
+    "virtual" ([0, 0, 0]: three parts taking turns on GPU 0).  Every API of the reader must return what the oracle and
+    the single-device reader return, per query, whatever G is; the part-major order inside a query is the only
+    difference (the reference's inter-chunk order is unspecified, src/lib.rs:280-284)."""
+    from tests.util import gen_corpus
+    src = tmp_path / 'c.txt'
+    src.write_bytes(gen_corpus(0, 1 << 19).tobytes())
+    p = str(tmp_path / 'c.idx')
+    w = pysubstringsearch.Writer(p, 1 << 16)
+    w.add_entries_from_file_lines(str(src))
+    w.close()
+    text = src.read_bytes()
+    rng = np.random.default_rng(21)
+    qs = [b'', b'e', b'\n', b'zzzzzz', b'a\n', b'th']
+    while len(qs) < 3000:
+        s = int(rng.integers(0, len(text) - 20))
+        qs.append(text[s:s + int(rng.integers(1, 14))])
+    o = oracle.OracleReader(p)
+    with pysubstringsearch.Reader(p) as single:
+        nchunks = single.num_chunks
+        for devs in ([0, 0], [0, 0, 0], [0] * 5):
+            with pysubstringsearch.Reader(p, devices=devs) as r:
+                assert r.num_chunks == nchunks and r.residency['hbm_bytes'] == single.residency['hbm_bytes']
+                for batch in (qs[:1], qs[5:6], qs[:50], qs):
+                    ents, counts = r.search_batch_raw(batch)
+                    oe, oc = o.search_multiple_bytes(batch)
+                    assert counts == oc.tolist()
+                    pos = 0
+                    se, _ = single.search_batch_raw(batch)
+                    for c in counts:      # per query: the same multiset as the oracle and the single-device reader
+                        assert sorted(ents[pos:pos + c]) == sorted(oe[pos:pos + c]) == sorted(se[pos:pos + c])
+                        pos += c
+                assert r.count_multiple([q.decode() for q in qs[:60]]) == o.search_multiple_bytes(qs[:60])[1].tolist()
+                assert sorted(r.search('th')) == sorted(o.search('th'))
+                pk = r.search_batch_packed(qs[:200])
+                assert int(pk.counts.sum()) == len(pk.offsets) - 1 == sum(o.search_multiple_bytes(qs[:200])[1].tolist())
+                st = r.last_stats()
+                assert st['queries'] == 200 and st['entries'] == len(pk.offsets) - 1
+                with pytest.raises(ValueError):
+                    r.search_batch_device(qs[:3])
+    with pytest.raises(ValueError):
+        pysubstringsearch.Reader(p, devices=[])
+    with pytest.raises(ValueError):
+        pysubstringsearch.Reader(p, devices=[0], device=0)
+    with pytest.raises(FileNotFoundError):
+        pysubstringsearch.Reader(str(tmp_path / 'missing.idx'), devices=[0, 0])
+
+
+def test_evict_and_promote_chunks(tmp_path, oracle):
+    """Explicit residency control: Reader.evict(c) moves the suffix array of chunk c to pinned host memory (the kernels
+    read it over PCIe), promote(c) brings it back; results never change, residency reports where things are.  Also
+    through a multi-device reader (chunk c lives in part c % G)."""
+    from tests.util import gen_corpus
+    src = tmp_path / 'c.txt'
+    src.write_bytes(gen_corpus(1, 1 << 18).tobytes())
+    p = str(tmp_path / 'c.idx')
+    w = pysubstringsearch.Writer(p, 1 << 16)
+    w.add_entries_from_file_lines(str(src))
+    w.close()
+    text = src.read_bytes()
+    rng = np.random.default_rng(5)
+    qs = [text[s:s + 6] for s in rng.integers(0, len(text) - 10, 500)]
+    o = oracle.OracleReader(p)
+    oe, oc = o.search_multiple_bytes(qs)
+
+    def same(r):
+        ents, counts = r.search_batch_raw(qs)
+        return counts == oc.tolist() and sorted(ents) == sorted(oe)
+
+    for devs in (None, [0, 0, 0]):
+        with (pysubstringsearch.Reader(p) if devs is None else pysubstringsearch.Reader(p, devices=devs)) as r:
+            full = r.residency
+            assert full['host_chunks'] == 0 and same(r)
+            r.evict(1)
+            r.evict(3)
+            r.evict(3)                                   # already there: no-op
+            res = r.residency
+            assert res['host_chunks'] == 2 and res['host_bytes'] > 0 and res['hbm_bytes'] < full['hbm_bytes'] and same(r)
+            r.promote(1)
+            assert r.residency['host_chunks'] == 1 and same(r)
+            r.promote(3)
+            assert r.residency == full and same(r)
+            with pytest.raises(ValueError):
+                r.evict(10 ** 6)
+
+
 def test_container_format_2(tmp_path, oracle):
     """Opt-in container with 64-bit lengths (no reference counterpart): same chunks, same suffix
     arrays, same search results as the reference container of the same entries; the Reader tells the
