@@ -19,6 +19,9 @@ ALGO = {   # algorithmic bytes per element of the kernels of the initial sort (D
     'msd_scatter_kernel<true>': 9, 'msd_scatter_kernel<false>': 16, 'msd_local_fast_kernel': 12,
     'msd_hist_kernel<true>': 1, 'msd_hist_kernel<false>': 8,
     'fs_scatter_kernel<0, 4>': 9, 'fs_scatter_kernel<4, 4>': 16, 'fs_scatter_kernel<4, 0>': 12,
+    # sample sort over 16-byte elements (ss_sort_impl.h)
+    'ss_digits1_kernel': 3, 'ss_scatter_kernel<true>': 19, 'ss_digits2_kernel': 18, 'ss_scatter_kernel<false>': 34,
+    'ss_local_kernel': 20,
 }
 n = 1 << 29
 kernels, total = {}, 0.0
