@@ -60,7 +60,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-KINDS = {'lines': 0, 'words': 1, 'runs': 2, 'periodic': 3}
+KINDS = {'lines': 0, 'words': 1, 'runs': 2, 'periodic': 3, 'repeat_line': 4, 'dup_blocks': 5}
 ALPHA = b'abcdefghijklmnopqrstuvwxyz0123456789 .'
 METRIC = 'queries/sec (batched) + index-build GB/s on 512MB chunk, 1/2/4/8 GPU'
 MASK64 = (1 << 64) - 1
@@ -422,8 +422,12 @@ def run_chunk(args, D):
         secondary = {'corpus': 'words', 'chunk_bytes': n, 'build_ms': round(best, 3),
                      'index_build_gbs': round(n / best / 1e6, 4), 'verified': w_ok, 'verified_by': w_how,
                      'traffic': w_traffic, 'traffic_gbs': None if not w_traffic else round(w_traffic / best / 1e6, 1),
+                     'initial_sort': ('sample sort over 16-byte [key | index] elements (ss_sort_impl.h)' if wd['ss'] else
+                                      'LSD passes with shrinking keys'),
+                     'initial_sort_ms': round(wd['ms_initial'], 3),
                      'sa_stats': {k: wd[k] for k in ('key_chars', 'initial_passes', 'rounds', 'text_rounds', 'round_passes',
-                                                     'sum_active', 'big_elems', 'mode')}}
+                                                     'sum_active', 'big_elems', 'mode', 'ss', 'ss_buckets', 'ss_max_bucket',
+                                                     'ss_tiles', 'ss_samples')}}
         del w_dT
 
     # configs[4]: the adversarial corpora (long runs of equal bytes; period 4096), outside the timed region,
@@ -431,17 +435,25 @@ def run_chunk(args, D):
     adversarial = None
     if world == 1 and args.corpus == 'lines' and not os.environ.get('PSS_BENCH_NO_SECONDARY'):
         adversarial = []
-        for kind in ('runs', 'periodic'):
+        for kind in ('runs', 'periodic', 'repeat_line', 'dup_blocks'):
             a_host = np.empty(n, dtype=np.uint8)
             _ffi.check(lib.pss_gen_corpus(KINDS[kind], a_host.ctypes.data, n, 0))
             a_dT = torch.from_numpy(a_host).cuda()
             ast = _ffi.SaStats()
             best = None
-            for _ in range(3):
+            for _ in range(3 if kind in ('runs', 'periodic') else 2):
                 _ffi.check(lib.pss_sa_build_device(a_dT.data_ptr(), dSA.data_ptr(), n, dev, 0, ctypes.byref(ast)))
                 best = ast.ms_total if best is None else min(best, ast.ms_total)
             ad = ast.as_dict()
             a_ok, a_how = verify_sa(dSA, a_host, kind, 0, load_big_goldens(), want_sha=False)
+            if kind in ('repeat_line', 'dup_blocks'):
+                # repeats that are not runs of one byte: no reduction yet, rank rounds over nearly every suffix
+                adversarial.append({'corpus': kind, 'chunk_bytes': n, 'build_ms': round(best, 3),
+                                    'index_build_gbs': round(n / best / 1e6, 3), 'verified': a_ok, 'verified_by': a_how,
+                                    'run_length_path': bool(ad['rle']), 'rounds': ad['rounds'], 'sum_active': ad['sum_active'],
+                                    'initial_sort': 'sample sort' if ad['ss'] else ('hybrid MSD' if ad['msd'] else 'LSD')})
+                del a_dT
+                continue
             os.environ['PSS_RLE'] = '0'
             try:
                 pd_ms = None

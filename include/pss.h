@@ -300,6 +300,8 @@ void pss_result_free(pss_result *res);
 #define PSS_CORPUS_WORDS 1     /* 65536-word vocabulary, skewed, realistic LCP */
 #define PSS_CORPUS_RUNS 2      /* lines of one repeated symbol from {a,b}, run <= 8192 */
 #define PSS_CORPUS_PERIODIC 3  /* "a"*4095 + "\n" repeated */
+#define PSS_CORPUS_REPEAT_LINE 4 /* one 40-byte line repeated (period 40, no runs of equal bytes) */
+#define PSS_CORPUS_DUP_BLOCKS 5  /* a 1 MiB block of `lines` text repeated, 16 single-byte edits per copy */
 /* Fills out[0..n) on the host; deterministic in (kind, n, chunk_index). */
 int pss_gen_corpus(int kind, uint8_t *out, uint64_t n, uint64_t chunk_index);
 

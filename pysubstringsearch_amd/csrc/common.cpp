@@ -75,6 +75,7 @@ void SearchKnobs::load()
     no_group_search = getenv("PSS_NO_GROUP_SEARCH") != nullptr;
     no_mid_pipeline = getenv("PSS_NO_MID_PIPELINE") != nullptr;
     no_pinned_results = getenv("PSS_NO_PINNED_RESULTS") != nullptr;
+    small_path_events = getenv("PSS_SEARCH_EVENTS") != nullptr;
     if (const char *e = getenv("PSS_LANE_SEARCH_MIN")) lane_search_min = strtoull(e, nullptr, 0);
 }
 

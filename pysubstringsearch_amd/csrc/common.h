@@ -53,6 +53,7 @@ struct SearchKnobs {
     bool no_group_search = false;   // PSS_NO_GROUP_SEARCH   never 16 lanes per pair
     bool no_mid_pipeline = false;   // PSS_NO_MID_PIPELINE   always the general multi-kernel pipeline
     bool no_pinned_results = false; // PSS_NO_PINNED_RESULTS large results into pageable memory
+    bool small_path_events = false; // PSS_SEARCH_EVENTS     HIP events around the fused single-query kernel (fills ms_device there)
     uint64_t lane_search_min = 8192;   // PSS_LANE_SEARCH_MIN  pairs from which one lane per pair searches
     void load();
 };

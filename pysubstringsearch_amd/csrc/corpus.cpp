@@ -137,6 +137,38 @@ void gen_periodic(uint8_t *out, uint64_t n)
     for (uint64_t i = 0; i < n; ++i) out[i] = (i % 4096 == 4095) ? '\n' : 'a';
 }
 
+// One 40-byte line (39 symbols of the `lines` alphabet + newline) repeated: every suffix is tied with the ones a
+// multiple of 40 bytes away for as long as the text lasts -- repeats with a period above 1 that are not runs of one byte.
+void gen_repeat_line(uint8_t *out, uint64_t n, uint64_t chunk)
+{
+    uint8_t line[40];
+    fill_lines(line, 40, kSeed + chunk);
+    for (int i = 0; i < 39; ++i)
+        if (line[i] == '\n') line[i] = ' ';
+    line[39] = '\n';
+    for (uint64_t i = 0; i < n; ++i) out[i] = line[i % 40];
+}
+
+// A 1 MiB block of `lines` text repeated, every copy after the first with 16 single-byte edits at pseudo-random
+// places: long duplicated stretches (tens of KiB between the edits of two copies), nothing periodic at small scale.
+void gen_dup_blocks(uint8_t *out, uint64_t n, uint64_t chunk)
+{
+    static const char ALPHA[] = "abcdefghijklmnopqrstuvwxyz0123456789 .";
+    constexpr uint64_t kBlk = 1ull << 20;
+    const uint64_t first = std::min(kBlk, n);
+    fill_lines(out, first, kSeed + chunk);
+    Xs64 g{(kSeed ^ 0xD1B54A32D192ED03ULL) + chunk};
+    for (uint64_t o = kBlk; o < n; o += kBlk) {
+        const uint64_t len = std::min(kBlk, n - o);
+        memcpy(out + o, out, len);
+        for (int e = 0; e < 16; ++e) {
+            const uint64_t pos = g.nx() % kBlk;
+            const uint8_t val = (uint8_t)ALPHA[g.nx() % 38];
+            if (pos < len) out[o + pos] = val;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int pss_gen_corpus(int kind, uint8_t *out, uint64_t n, uint64_t chunk_index)
@@ -147,6 +179,8 @@ extern "C" int pss_gen_corpus(int kind, uint8_t *out, uint64_t n, uint64_t chunk
         case PSS_CORPUS_WORDS: gen_words(out, n, chunk_index); break;
         case PSS_CORPUS_RUNS: gen_runs(out, n, chunk_index); break;
         case PSS_CORPUS_PERIODIC: gen_periodic(out, n); break;
+        case PSS_CORPUS_REPEAT_LINE: gen_repeat_line(out, n, chunk_index); break;
+        case PSS_CORPUS_DUP_BLOCKS: gen_dup_blocks(out, n, chunk_index); break;
         default: return PSS_EINVAL;
     }
     if (n) out[n - 1] = '\n';

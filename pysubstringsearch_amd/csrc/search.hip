@@ -1077,7 +1077,10 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
         u8 *v_arena = static_cast<u8 *>(ctx->pinned_dev);               // the same bytes, device view
         volatile u32 *h_overflow = reinterpret_cast<volatile u32 *>(h_arena + SM_OFF_FLAGS);
         *h_overflow = 0;
-        PSS_HIP(hipEventRecord(e0, s));
+        // (the events bracket the kernel for last_stats().ms_device; two records cost the single-query path a couple of
+        // microseconds of host time and two marker packets, so it only takes them when asked: PSS_SEARCH_EVENTS=1)
+        const bool timed = knobs.small_path_events;
+        if (timed) PSS_HIP(hipEventRecord(e0, s));
         const u8 *v_q = v_arena + SM_OFF_QUERY;
         const u64 *v_qoff = reinterpret_cast<const u64 *>(v_arena + SM_OFF_QUERY + 8192);
         u32 *v_flags = reinterpret_cast<u32 *>(v_arena + SM_OFF_FLAGS);
@@ -1096,7 +1099,7 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
             hipLaunchKernelGGL(search_small_kernel, dim3((u32)((nvq + waves_per_block - 1) / waves_per_block)), dim3(256),
                                0, s, d_chunks, nc, v_q, v_qoff, (u32)nvq, d_hdr, v_flags, v_rec, v_ent, d_bytes,
                                v_arena + SM_OFF_BYTES);
-        PSS_HIP(hipEventRecord(e2, s));
+        if (timed) PSS_HIP(hipEventRecord(e2, s));
         PSS_HIP(hipStreamSynchronize(s));
         if (!*h_overflow) {
             const SmallRecord *h_rec = reinterpret_cast<const SmallRecord *>(h_arena + SM_OFF_REC);
@@ -1141,7 +1144,7 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
             st->result_bytes = b_out;
             st->hits = e_out;   // hits before dedupe are not counted on this path
             float ms = 0.f;
-            PSS_HIP(hipEventElapsedTime(&ms, e0, e2));
+            if (timed) PSS_HIP(hipEventElapsedTime(&ms, e0, e2));
             st->ms_device = ms;
             st->ms_interval = ms;
             st->ms_host = host_ms();

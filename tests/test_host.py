@@ -192,11 +192,53 @@ def py_words(n, chunk=0):
     return bytes(out)
 
 
+def _py_lines_raw(n, seed):
+    alpha = b'abcdefghijklmnopqrstuvwxyz0123456789 .'
+    g = Xs(seed)
+    out = bytearray(n)
+    for i in range(n):
+        r = g.nx()
+        out[i] = 10 if r % 40 == 0 else alpha[(r >> 8) % 38]
+    return out
+
+
+def py_repeat_line(n, chunk=0):
+    line = _py_lines_raw(40, 88172645463325252 + chunk)
+    line = bytes(32 if c == 10 else c for c in line[:39]) + b'\n'
+    out = bytearray((line * (n // 40 + 1))[:n])
+    out[-1] = 10
+    return bytes(out)
+
+
+def py_dup_blocks(n, chunk=0):
+    alpha = b'abcdefghijklmnopqrstuvwxyz0123456789 .'
+    blk = 1 << 20
+    base = _py_lines_raw(min(blk, n), 88172645463325252 + chunk)
+    out = bytearray(base)
+    g = Xs(((88172645463325252 ^ 0xD1B54A32D192ED03) + chunk) & M64)
+    o = blk
+    while o < n:
+        ln = min(blk, n - o)
+        copy = bytearray(base[:ln])
+        for _ in range(16):
+            pos = g.nx() % blk
+            val = alpha[g.nx() % 38]
+            if pos < ln:
+                copy[pos] = val
+        out += copy
+        o += blk
+    out[-1] = 10
+    return bytes(out)
+
+
 def test_generators_match_python_spec():
     from tests.util import gen_corpus
     n = 20000
     assert gen_corpus(0, n, 3).tobytes() == py_lines(n, 3)
     assert gen_corpus(1, n, 2).tobytes() == py_words(n, 2)
+    assert gen_corpus(4, n, 1).tobytes() == py_repeat_line(n, 1)
+    m = (1 << 20) + 70000           # the block, then a copy with (some of) its 16 edits
+    assert gen_corpus(5, m, 2).tobytes() == py_dup_blocks(m, 2)
     per = gen_corpus(3, 10000).tobytes()
     assert per[:4096] == b'a' * 4095 + b'\n' and per[-1:] == b'\n' and set(per) == {97, 10}
     runs = gen_corpus(2, 50000).tobytes()
