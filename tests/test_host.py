@@ -356,3 +356,31 @@ def test_merge_packed_c_helper_rejects_inconsistent_input():
     rc = _ffi.lib.pss_merge_packed(1, 2, arr(counts.ctypes.data), arr(starts.ctypes.data), arr(blob.ctypes.data),
                                    ne.ctypes.data, nb.ctypes.data, oc.ctypes.data, oo.ctypes.data, ob.ctypes.data)
     assert rc == _ffi.PSS_EINVAL
+
+
+def test_host_logic_under_sanitizers(tmp_path):
+    """The host side of the library (capi.cpp: container writer / reader, argument checks, packed-result merge;
+    common.cpp; corpus.cpp) rebuilt with -fsanitize=address,undefined (`make asan`) and driven through the host tests of
+    this file in a child process: no report, same results.  CPU only -- GPU sanitizers are not available."""
+    import shutil
+    import subprocess
+    if not shutil.which('g++'):
+        pytest.skip('no g++')
+    asan_rt = subprocess.run(['gcc', '-print-file-name=libasan.so'], capture_output=True, text=True).stdout.strip()
+    ubsan_rt = subprocess.run(['gcc', '-print-file-name=libubsan.so'], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan_rt) or not os.path.exists(asan_rt):
+        pytest.skip('no libasan')
+    r = subprocess.run(['make', '-C', os.path.join(ROOT, 'pysubstringsearch_amd', 'csrc'), 'asan'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lib = os.path.join(ROOT, 'build', 'asan', 'libpss_asan.so')
+    env = dict(os.environ, PSS_LIBPSS=lib, LD_PRELOAD=asan_rt + ':' + ubsan_rt,
+               ASAN_OPTIONS='detect_leaks=0:abort_on_error=1', UBSAN_OPTIONS='halt_on_error=1:print_stacktrace=1')
+    tests = ['test_cabi_argument_contract_without_gpu', 'test_writer_argument_errors', 'test_chunk_limit_growth_rule',
+             'test_merge_packed_random', 'test_merge_packed_c_helper_rejects_inconsistent_input', 'test_generators_match_python_spec',
+             'test_file_not_found', 'test_handles_are_not_reference_cycles']
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_host.py'), '-x', '-q', '-m', 'not gpu',
+                        '-k', ' or '.join(tests)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert 'AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
+    assert f'{len(tests)} passed' in r.stdout, r.stdout[-500:]
+
