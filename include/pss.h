@@ -282,6 +282,13 @@ int pss_reader_search_batch_device(pss_reader *r, const uint8_t *qbytes, const u
 int pss_merge_packed(uint32_t world, uint64_t nq, const uint64_t *const *counts, const uint64_t *const *offsets,
                      const uint8_t *const *bytes, const uint64_t *num_entries, const uint64_t *num_bytes,
                      uint64_t *out_counts, uint64_t *out_offsets, uint8_t *out_bytes);
+/* The same merge with every buffer resident in the HBM of `device` (the collecting rank of a multi-GPU gather holds
+ * its own result and the ones RCCL delivered there): one merged result to bring down instead of `world`.
+ * d_starts[r] = u64[num_entries[r]] entry starts (pss_device_result.d_offsets); d_out_offsets receives
+ * sum(num_entries) + 1 entries, d_out_counts nq, d_out_bytes sum(num_bytes).  world <= 16. */
+int pss_merge_packed_device(int32_t device, uint32_t world, uint64_t nq, const void *const *d_counts,
+                            const void *const *d_starts, const void *const *d_bytes, const uint64_t *num_entries,
+                            const uint64_t *num_bytes, void *d_out_counts, void *d_out_offsets, void *d_out_bytes);
 int pss_reader_last_stats(const pss_reader *r, pss_search_stats *stats);
 /* Drops the chunks and closes the reader. */
 int pss_reader_close(pss_reader *r);

@@ -163,6 +163,7 @@ def _load() -> ctypes.CDLL:
         'pss_reader_count_batch': (ctypes.c_int, [vp, vp, vp, u32, vp]),
         'pss_reader_search_batch_device': (ctypes.c_int, [vp, vp, vp, u32, ctypes.POINTER(DeviceResult)]),
         'pss_merge_packed': (ctypes.c_int, [u32, u64, vp, vp, vp, vp, vp, vp, vp, vp]),
+        'pss_merge_packed_device': (ctypes.c_int, [i32, u32, u64, vp, vp, vp, vp, vp, vp, vp, vp]),
         'pss_reload_env': (ctypes.c_int, []),
         'pss_reader_last_stats': (ctypes.c_int, [vp, ctypes.POINTER(SearchStats)]),
         'pss_reader_close': (ctypes.c_int, [vp]),

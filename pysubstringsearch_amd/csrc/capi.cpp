@@ -1549,6 +1549,23 @@ extern "C" int pss_merge_packed(uint32_t world, uint64_t nq, const uint64_t *con
     });
 }
 
+extern "C" int pss_merge_packed_device(int32_t device, uint32_t world, uint64_t nq, const void *const *d_counts,
+                                       const void *const *d_starts, const void *const *d_bytes, const uint64_t *num_entries,
+                                       const uint64_t *num_bytes, void *d_out_counts, void *d_out_offsets, void *d_out_bytes)
+{
+    return guarded([&]() -> int {
+        if (!world || !d_counts || !d_starts || !d_bytes || !num_entries || !num_bytes || !d_out_counts || !d_out_offsets) {
+            set_error("pss_merge_packed_device: bad arguments");
+            return PSS_EINVAL;
+        }
+        DeviceCtx *ctx;
+        PSS_TRY(get_ctx(device, &ctx));
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+        return merge_packed_device(ctx, world, nq, d_counts, d_starts, d_bytes, num_entries, num_bytes, d_out_counts, d_out_offsets,
+                                   d_out_bytes);
+    });
+}
+
 // Test hook: re-reads the PSS_* environment switches of the search path (they are read once, when the
 // library first needs them -- not on every call).
 extern "C" int pss_reload_env(void)

@@ -54,4 +54,11 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, uint32_t nc, 
                         const uint64_t *qoffsets, uint32_t nq, HostResult *res, pss_search_stats *st,
                         SearchMode mode = SEARCH_FULL);
 
+// Merge of `world` packed results of the same nq queries, all resident on ctx's device, into one (query-major,
+// rank-major inside a query -- pss_merge_packed's order) on the same device.  starts[r] = entry starts (no closing
+// offset); out_offsets receives sum(num_entries) + 1 entries.  Synchronises the stream.
+int merge_packed_device(DeviceCtx *ctx, uint32_t world, uint64_t nq, const void *const *d_counts, const void *const *d_starts,
+                        const void *const *d_bytes, const uint64_t *num_entries, const uint64_t *num_bytes, void *d_out_counts,
+                        void *d_out_offsets, void *d_out_bytes);
+
 }  // namespace pss

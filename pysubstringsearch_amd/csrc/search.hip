@@ -1359,4 +1359,125 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
     return PSS_OK;
 }
 
+// ---- device-side merge of per-rank packed results (multi-GPU gather) ---------------------------------------------
+// The collecting rank of dist.gather_device holds `world` packed results of the same nq queries in its HBM (its own and
+// the ones RCCL delivered).  Merging them THERE -- query-major, rank-major inside a query: the order of pss_merge_packed --
+// leaves one result to bring down instead of `world`.
+
+struct MergeRank {
+    const u64 *counts;     // [nq]
+    const u64 *starts;     // [E_r] start of every entry in bytes
+    const u8 *bytes;
+    u64 E, B;
+    const u64 *ebase;      // [nq + 1] entries of this rank before query q (scan of counts)
+};
+struct MergeArgs {
+    MergeRank r[16];
+    u32 world;
+    u64 nq;
+};
+struct InCounts {
+    const u64 *c;
+    __device__ u64 operator()(u64 q) const { return c[q]; }
+};
+// bytes of segment (q, r), in (q-major, r-minor) order
+struct InSegBytes {
+    MergeArgs a;
+    __device__ u64 operator()(u64 i) const
+    {
+        const u64 q = i / a.world;
+        const MergeRank &m = a.r[i % a.world];
+        const u64 c = m.counts[q];
+        if (!c) return 0;
+        const u64 e0 = m.ebase[q], e1 = e0 + c;
+        return (e1 < m.E ? m.starts[e1] : m.B) - m.starts[e0];
+    }
+};
+
+__global__ __launch_bounds__(256) void merge_counts_kernel(MergeArgs a, u64 *out_counts)
+{
+    for (u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x; q < a.nq; q += (u64)gridDim.x * blockDim.x) {
+        u64 t = 0;
+        for (u32 r = 0; r < a.world; ++r) t += a.r[r].counts[q];
+        out_counts[q] = t;
+    }
+}
+
+// one wavefront per (query, rank) segment: its entries' offsets, then its bytes
+__global__ __launch_bounds__(256) void merge_copy_kernel(MergeArgs a, const u64 *qbase /* [nq + 1] entries before query q */,
+                                                           const u64 *sbase /* [nq * world + 1] bytes before segment */, u64 *out_offsets,
+                                                           u8 *out_bytes)
+{
+    const u64 nseg = a.nq * a.world;
+    const u32 lane = lane_id();
+    for (u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / kWave; i < nseg; i += ((u64)gridDim.x * blockDim.x) / kWave) {
+        const u64 q = i / a.world;
+        const u32 r = (u32)(i % a.world);
+        const MergeRank &m = a.r[r];
+        const u64 c = m.counts[q];
+        if (!c) continue;
+        u64 before = 0;
+        for (u32 x = 0; x < r; ++x) before += a.r[x].counts[q];
+        const u64 e0 = m.ebase[q], de = qbase[q] + before;
+        const u64 b0 = m.starts[e0], b1 = (e0 + c < m.E ? m.starts[e0 + c] : m.B), db = sbase[i];
+        for (u64 e = lane; e < c; e += kWave) out_offsets[de + e] = db + (m.starts[e0 + e] - b0);
+        for (u64 b = lane; b < b1 - b0; b += kWave) out_bytes[db + b] = m.bytes[b0 + b];
+    }
+}
+
+int merge_packed_device(DeviceCtx *ctx, u32 world, u64 nq, const void *const *d_counts, const void *const *d_starts,
+                        const void *const *d_bytes, const u64 *num_entries, const u64 *num_bytes, void *d_out_counts,
+                        void *d_out_offsets, void *d_out_bytes)
+{
+    if (world == 0 || world > 16) {
+        set_error("pss_merge_packed_device: 1 .. 16 ranks");
+        return PSS_EINVAL;
+    }
+    hipStream_t s = ctx->stream;
+    u64 E = 0, B = 0;
+    for (u32 r = 0; r < world; ++r) {
+        E += num_entries[r];
+        B += num_bytes[r];
+    }
+    u64 *out_counts = static_cast<u64 *>(d_out_counts), *out_offsets = static_cast<u64 *>(d_out_offsets);
+    if (nq == 0) {
+        PSS_HIP(hipMemsetAsync(out_offsets, 0, 8, s));
+        PSS_HIP(hipStreamSynchronize(s));
+        return PSS_OK;
+    }
+    const u64 nseg = nq * world;
+    // scratch: per-rank entry bases (world x (nq + 1)), query bases (nq + 1), segment bases (nseg + 1), scan partials
+    PSS_TRY(ctx->slot[Q_SMALL].reserve(SC_MAX_BLOCKS * 8 + 256));
+    PSS_TRY(ctx->slot[Q_START].reserve(((size_t)world * (nq + 1) + (nq + 1) + (nseg + 1)) * 8 + 256));
+    u64 *partial = ctx->slot[Q_SMALL].as<u64>(), *d_total = partial + SC_MAX_BLOCKS;
+    u64 *scr = ctx->slot[Q_START].as<u64>();
+    MergeArgs a;
+    memset(&a, 0, sizeof a);
+    a.world = world;
+    a.nq = nq;
+    for (u32 r = 0; r < world; ++r) {
+        a.r[r].counts = static_cast<const u64 *>(d_counts[r]);
+        a.r[r].starts = static_cast<const u64 *>(d_starts[r]);
+        a.r[r].bytes = static_cast<const u8 *>(d_bytes[r]);
+        a.r[r].E = num_entries[r];
+        a.r[r].B = num_bytes[r];
+        u64 *eb = scr + (size_t)r * (nq + 1);
+        a.r[r].ebase = eb;
+        PSS_TRY(device_excl_scan(ctx, InCounts{a.r[r].counts}, nq, partial, d_total, eb));
+    }
+    u64 *qbase = scr + (size_t)world * (nq + 1), *sbase = qbase + (nq + 1);
+    const u32 grid = (u32)std::min<u64>((nq + 255) / 256, (u64)ctx->num_cus * 8);
+    hipLaunchKernelGGL(merge_counts_kernel, dim3(grid), dim3(256), 0, s, a, out_counts);
+    PSS_TRY(device_excl_scan(ctx, InCounts{out_counts}, nq, partial, d_total, qbase));
+    PSS_TRY(device_excl_scan(ctx, InSegBytes{a}, nseg, partial, d_total, sbase));
+    const u32 grid2 = (u32)std::min<u64>((nseg + 3) / 4, (u64)ctx->num_cus * 16);
+    hipLaunchKernelGGL(merge_copy_kernel, dim3(grid2 ? grid2 : 1), dim3(256), 0, s, a, (const u64 *)qbase, (const u64 *)sbase, out_offsets,
+                       static_cast<u8 *>(d_out_bytes));
+    PSS_HIP(hipMemcpyAsync(out_offsets + E, &sbase[nseg], 8, hipMemcpyDeviceToDevice, s));      // total bytes closes the offsets
+    PSS_HIP(hipStreamSynchronize(s));
+    PSS_HIP(hipGetLastError());
+    (void)B;
+    return PSS_OK;
+}
+
 }  // namespace pss

@@ -168,6 +168,8 @@ def gather_device(result, group=None, dst: int = 0):
     if rank != dst:
         return None
     recv[dst] = (data, starts, counts)
+    if on_device and world > 1:
+        return merge_on_device([recv[r] for r in range(world)], nq)
     per_rank = []
     for r in range(world):
         d, s, c = recv[r]
@@ -184,6 +186,47 @@ def gather_device(result, group=None, dst: int = 0):
     if any(t[0].is_pinned() for t in per_rank if t[0].numel()):
         torch.cuda.synchronize()
     return merge_packed_starts([(d.numpy(), s.numpy(), c.numpy()) for d, s, c in per_rank])
+
+
+_merge_flip = 0
+
+
+def merge_on_device(per_rank, nq: int):
+    """``per_rank`` = [(data uint8, starts int64, counts int64)] device tensors of the same nq queries, all on one GPU
+    (the collecting rank's own result and the ones RCCL delivered): merged there by the engine
+    (``pss_merge_packed_device``: query-major, rank-major inside a query), then ONE download through pinned memory
+    instead of one per rank.  Returns (blob uint8, offsets int64[E + 1], counts int64[nq]) as numpy arrays -- views of
+    pinned staging buffers that alternate between two sets: a result stays valid until the call after the next one."""
+    import ctypes
+    import torch
+    from . import _ffi
+    world = len(per_rank)
+    dev = per_rank[0][0].device
+    E = sum(int(s.numel()) for _, s, _ in per_rank)
+    B = sum(int(d.numel()) for d, _, _ in per_rank)
+    out_counts = torch.empty(max(nq, 1), dtype=torch.int64, device=dev)
+    out_offsets = torch.empty(E + 1, dtype=torch.int64, device=dev)
+    out_bytes = torch.empty(max(B, 1), dtype=torch.uint8, device=dev)
+    vp = ctypes.c_void_p * world
+    u64 = ctypes.c_uint64 * world
+    torch.cuda.synchronize(dev)          # the engine works on its own stream
+    _ffi.check(_ffi.lib.pss_merge_packed_device(
+        dev.index or 0, world, nq,
+        vp(*[c.data_ptr() if c.numel() else None for _, _, c in per_rank]),
+        vp(*[s.data_ptr() if s.numel() else None for _, s, _ in per_rank]),
+        vp(*[d.data_ptr() if d.numel() else None for d, _, _ in per_rank]),
+        u64(*[int(s.numel()) for _, s, _ in per_rank]), u64(*[int(d.numel()) for d, _, _ in per_rank]),
+        out_counts.data_ptr(), out_offsets.data_ptr(), out_bytes.data_ptr()))
+    global _merge_flip
+    _merge_flip ^= 1
+    hd = _pinned(torch, B, f'md{_merge_flip}')
+    ho = _pinned(torch, (E + 1) * 8, f'mo{_merge_flip}').view(torch.int64)
+    hc = _pinned(torch, nq * 8, f'mc{_merge_flip}').view(torch.int64)
+    hd.copy_(out_bytes[:B], non_blocking=True)
+    ho.copy_(out_offsets, non_blocking=True)
+    hc.copy_(out_counts[:nq], non_blocking=True)
+    torch.cuda.synchronize(dev)
+    return hd.numpy(), ho.numpy(), hc.numpy()
 
 
 def gather_packed(blob, lens, counts, group=None, dst: int = 0, packed: bool = False):

@@ -1,0 +1,43 @@
+"""world_size-2 RCCL worker for tests/test_dist_gpu.py: one process per GPU, each a Reader over its shard of the index,
+the packed results gathered device to device and merged on the collecting rank's GPU."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from pysubstringsearch_amd import Writer, dist as pdist  # noqa: E402
+
+
+def main():
+    rank, world, port, idx, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+    torch.cuda.set_device(rank)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world,
+                            device_id=torch.device('cuda', rank))
+    r = pdist.ShardedReader(idx, device=rank)
+    queries = json.load(open(idx + '.queries.json'))
+    qs = [q.encode('latin-1') for q in queries]
+    res = {}
+    for name, batch in (('one', qs[:1]), ('few', qs[:40]), ('all', qs)):
+        got = r.search_multiple_bytes(batch)
+        if rank == 0:
+            res[name] = {'counts': [int(c) for c in got[1]], 'entries': [e.decode('latin-1') for e in got[0]]}
+        else:
+            assert got is None
+    # the multi-device Writer with two distinct ordinals: same bytes as the single-device file
+    if rank == 0:
+        w = Writer(idx + '.multi', 1 << 16, devices=[0, 1])
+        w.add_entries_from_file_lines(idx + '.txt')
+        w.close()
+        res['multi_writer_identical'] = open(idx + '.multi', 'rb').read() == open(idx, 'rb').read()
+        json.dump(res, open(out, 'w'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

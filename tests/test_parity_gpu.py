@@ -719,3 +719,29 @@ def test_dropped_writer_flushes_at_once(pss, oracle, tmp_path):
     finally:
         gc.enable()
 
+
+def test_device_merge_equals_host_merge():
+    """pss_merge_packed_device (the collecting rank of the RCCL gather merges the per-rank results in its HBM and brings
+    ONE result down) against the host merge pss_merge_packed on random packed results: empty ranks, empty queries,
+    one rank, sixteen ranks."""
+    import torch
+    from pysubstringsearch_amd import dist as pdist
+    rng = np.random.default_rng(8)
+    for world, nq in ((1, 50), (2, 1), (2, 777), (3, 5000), (8, 20000), (16, 300), (4, 0)):
+        per_rank_host, per_rank_dev = [], []
+        for r in range(world):
+            counts = rng.integers(0, 4, nq).astype(np.int64) * (rng.random(nq) < 0.6)
+            if r == 1:
+                counts[:] = 0                                # a rank with nothing
+            E = int(counts.sum())
+            lens = rng.integers(0, 40, E).astype(np.int64)
+            starts = np.zeros(E, dtype=np.int64)
+            if E:
+                starts[1:] = np.cumsum(lens)[:-1]
+            blob = rng.integers(0, 256, int(lens.sum()), dtype=np.uint8)
+            per_rank_host.append((blob, starts, counts))
+            per_rank_dev.append((torch.from_numpy(blob).cuda(), torch.from_numpy(starts).cuda(), torch.from_numpy(counts).cuda()))
+        hb, ho, hc = pdist.merge_packed_starts(per_rank_host) if nq else (np.zeros(0, np.uint8), np.zeros(1, np.int64), np.zeros(0, np.int64))
+        db, do, dc = pdist.merge_on_device(per_rank_dev, nq)
+        assert np.array_equal(dc, hc) and np.array_equal(do, ho) and np.array_equal(db, hb), (world, nq)
+
