@@ -443,6 +443,26 @@ int pipe_start(pss_writer *w)
         for (int i = 0; i < 2; ++i)
             if (!d.ev[i]) PSS_HIP(hipEventCreateWithFlags(&d.ev[i], hipEventDisableTiming));
     }
+    // Lanes on different ordinals must really be different devices: their contexts (workspace, streams) and their
+    // copy streams may not coincide, or two builders would scribble over one workspace / serialise on one stream.
+    for (size_t i = 0; i < w->devs.size(); ++i) {
+        DeviceCtx *ci = nullptr;
+        PSS_TRY(get_ctx(w->devs[i].device, &ci));
+        if (ci->device != w->devs[i].device) {
+            set_error("writer lane %zu: context of device %d answers for device %d", i, w->devs[i].device, ci->device);
+            return PSS_EDEVICE;
+        }
+        for (size_t j = 0; j < i; ++j) {
+            if (w->devs[j].device == w->devs[i].device) continue;
+            DeviceCtx *cj = nullptr;
+            PSS_TRY(get_ctx(w->devs[j].device, &cj));
+            if (ci == cj || ci->stream == cj->stream || w->devs[i].io_stream == w->devs[j].io_stream) {
+                set_error("writer lanes %zu and %zu (devices %d, %d) share a context or a stream", j, i, w->devs[j].device,
+                          w->devs[i].device);
+                return PSS_EDEVICE;
+            }
+        }
+    }
     w->started = true;
     for (size_t di = 0; di < w->devs.size(); ++di) w->devs[di].builder = std::thread(builder_main, w, di);
     w->record_thread = std::thread(record_main, w);
