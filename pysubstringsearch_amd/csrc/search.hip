@@ -1089,9 +1089,11 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
         const bool block_path = nvq <= SM_BLOCK_MAX_VQ && !knobs.no_block_path;
         // workgroups per pair: as many as keep the launch at <= 64 workgroups (every one of them searches the
         // interval first; on 15 chunks 32 per pair cost a miss 7 us, 4 per pair nothing measurable)
+        // (33 .. 64 pairs -- one query over that many chunks -- get up to 4 per pair, 256 workgroups at most: a pair of
+        // 1025 .. 4096 hits stays on this path instead of throwing the launch away for the general pipeline)
         u32 spread = 1;
         if (block_path)
-            while (spread < SM_SPREAD && nvq * spread * 2 <= 64) spread *= 2;
+            while (spread < SM_SPREAD && nvq * spread * 2 <= (nvq <= 32 ? 64u : 256u)) spread *= 2;
         if (block_path)
             hipLaunchKernelGGL(search_block_kernel, dim3((u32)nvq * spread), dim3(SM_BLOCK), 0, s, d_chunks, nc, v_q, v_qoff,
                                (u32)nvq, d_hdr, v_flags, v_rec, v_ent, d_bytes, v_arena + SM_OFF_BYTES, spread);

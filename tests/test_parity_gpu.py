@@ -745,3 +745,23 @@ def test_device_merge_equals_host_merge():
         db, do, dc = pdist.merge_on_device(per_rank_dev, nq)
         assert np.array_equal(dc, hc) and np.array_equal(do, ho) and np.array_equal(db, hb), (world, nq)
 
+
+def test_single_query_over_many_chunks_with_thousands_of_hits(tmp_path, oracle):
+    """One query over 33 .. 64 chunks (one workgroup per (query, chunk) pair, up to four with this many pairs) whose
+    pairs hold 1025 .. 4096 hits each: the fused one-kernel path answers it (no overflow back to the general pipeline),
+    and the result is the oracle's whatever path ran."""
+    from tests.util import gen_corpus
+    src = tmp_path / 'c.txt'
+    src.write_bytes(gen_corpus(0, 40 << 16).tobytes())
+    p = str(tmp_path / 'c.idx')
+    w = pysubstringsearch.Writer(p, 1 << 16)          # 40-odd chunks of 64 KiB
+    w.add_entries_from_file_lines(str(src))
+    w.close()
+    o = oracle.OracleReader(p)
+    with pysubstringsearch.Reader(p) as r:
+        assert 33 <= r.num_chunks <= 64
+        for q in ('e', 'a', ' ', 'th', 'zq9'):            # a single letter: ~1 700 hits in every 64 KiB chunk
+            got, exp = r.search(q), o.search(q)
+            assert len(got) == len(exp) and sorted(got) == sorted(exp), q
+        assert max(o.search_multiple_bytes([b'e'])[1]) > 33 * 1025 / 2
+
