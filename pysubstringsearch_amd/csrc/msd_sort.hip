@@ -358,6 +358,115 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_scatter_kernel(MsdArgs a)
     }
 }
 
+// The same pass over tiles of 16384 elements (1024 threads x 16): twice as many elements per bin and tile, so the runs
+// the output loop writes are 16 x 8 = 128 bytes on average -- whole lines instead of half lines; the pass is bound by
+// the 128-byte lines it touches.  LDS stages 8192 elements at a time: the tile goes through in two
+// pieces by destination position.
+constexpr int MSD_BLOCK2 = 1024;
+constexpr u32 MSD_TILE2 = MSD_BLOCK2 * MSD_IPT;      // 16384
+constexpr int MSD_PIECES2 = MSD_TILE2 / MSD_TILE;    // 2
+
+template <bool FROM_TEXT>
+__global__ __launch_bounds__(MSD_BLOCK2) void msd_scatter2_kernel(MsdArgs a)
+{
+    __shared__ __attribute__((aligned(16))) u64 exch[MSD_TILE];
+    __shared__ u32 hist[MSD_BINS], s_delta[MSD_BINS], s_off[MSD_BINS];
+    __shared__ u16 s_start[MSD_BINS];
+    __shared__ u32 scr[MSD_BLOCK2 / kWave + 1];
+    const u32 tid = threadIdx.x, r = blockIdx.x;
+    u32 e0, e1;
+    u32 tag = 0;
+    if (FROM_TEXT) {
+        if (r >= a.num_ranges1) return;
+        e0 = r * a.tiles_per_range1 * MSD_TILE;
+        const u64 end = (u64)(r + 1) * a.tiles_per_range1 * MSD_TILE;
+        e1 = end < a.n ? (u32)end : a.n;
+    } else {
+        if (r >= a.counters[0]) return;
+        e0 = a.ranges2[r].start;
+        e1 = a.ranges2[r].end;
+        tag = ((u32)a.dense[(size_t)a.ranges2[r].seg * MSD_BINS + tid] & (MSD_TAG_SPAN - 1u)) << 16;      // see msd_scatter_kernel
+    }
+    hist[tid] = tag;
+    s_off[tid] = FROM_TEXT ? a.T[(size_t)tid * a.num_ranges1 + r] + a.J1[tid] : a.T[(size_t)r * MSD_BINS + tid];
+    __syncthreads();
+    const int shift2 = a.idx_bits + a.key_bits - 2 * MSD_D;
+    const u64 low_mask2 = (1ull << shift2) - 1ull;
+    const int rest_bits = a.key_bits - MSD_D;
+    const u64 rest_mask = (1ull << rest_bits) - 1ull;
+    for (u32 base = e0; base < e1; base += MSD_TILE2) {
+        const u32 valid = min(MSD_TILE2, e1 - base);
+        u64 elem[MSD_IPT];
+        u32 dig[MSD_IPT], lp[MSD_IPT];
+        if (FROM_TEXT) {
+            const u32 i0 = base + tid * MSD_IPT;
+            u64 key[MSD_IPT] = {};
+            if (i0 < a.n) text_keys16(a.codes, i0, a.code_bits, a.key_chars, a.plus_one, a.key_drop, a.n, key);
+#pragma unroll
+            for (int k = 0; k < MSD_IPT; ++k) {
+                dig[k] = (u32)(key[k] >> rest_bits) & (MSD_BINS - 1u);
+                // through LDS: [key rest | digit | position in the tile]; the suffix index is base + position
+                elem[k] = ((key[k] & rest_mask) << 24) | ((u64)dig[k] << 14) | (u64)(tid * MSD_IPT + k);
+                lp[k] = (tid * MSD_IPT + k < valid) ? (atomicAdd(&hist[dig[k]], 1u) & 0xffffu) : 0xffffffffu;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < MSD_IPT; ++k) {
+                const u32 p = k * MSD_BLOCK2 + tid;
+                lp[k] = 0xffffffffu;
+                elem[k] = 0;
+                dig[k] = 0;
+                if (p < valid) {
+                    elem[k] = a.in[base + p];
+                    dig[k] = (u32)(elem[k] >> shift2) & (MSD_BINS - 1u);
+                    lp[k] = atomicAdd(&hist[dig[k]], 1u) & 0xffffu;
+                }
+            }
+        }
+        __syncthreads();                                    // (A) counts complete; previous tile fully written out
+        {
+            const u32 c = hist[tid] & 0xffffu;
+            const u32 ex = block_excl_sum<MSD_BLOCK2 / kWave>(c, scr, nullptr);
+            s_start[tid] = (u16)ex;
+            const u32 o = s_off[tid];
+            s_delta[tid] = o - ex;
+            s_off[tid] = o + c;
+            hist[tid] = tag;
+        }
+        __syncthreads();                                    // (B) bin starts published
+#pragma unroll
+        for (int k = 0; k < MSD_IPT; ++k)
+            if (lp[k] != 0xffffffffu) lp[k] += (u32)s_start[dig[k]];
+#pragma unroll
+        for (int h = 0; h < MSD_PIECES2; ++h) {
+            if (h * MSD_TILE >= valid) break;
+            if (h) __syncthreads();                         // the piece before this one is written out
+#pragma unroll
+            for (int k = 0; k < MSD_IPT; ++k) {
+                const u32 q = lp[k] - h * MSD_TILE;
+                if (q < MSD_TILE) exch[q] = elem[k];
+            }
+            __syncthreads();                                // (C) the piece in bin order
+#pragma unroll
+            for (int k = 0; k < (int)(MSD_TILE / MSD_BLOCK2); ++k) {
+                const u32 q = k * MSD_BLOCK2 + tid, p = h * MSD_TILE + q;
+                if (p < valid) {
+                    u64 e = exch[q];
+                    u32 d;
+                    if (FROM_TEXT) {
+                        d = (u32)(e >> 14) & (MSD_BINS - 1u);
+                        e = ((e >> 24) << a.idx_bits) | (u64)(base + ((u32)e & (MSD_TILE2 - 1u)));
+                    } else {
+                        d = (u32)(e >> shift2) & (MSD_BINS - 1u);
+                        e = (e & low_mask2) | ((u64)(hist[d] >> 16) << shift2);
+                    }
+                    a.out[s_delta[d] + p] = e;
+                }
+            }
+        }
+    }
+}
+
 // ---- tile plan ---------------------------------------------------------------------------------
 
 struct InNonEmpty {
@@ -1011,7 +1120,14 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     hipLaunchKernelGGL(msd_offsets1_kernel, dim3(MSD_BINS), dim3(256), 0, s, T, a.num_ranges1, seg_first);   // totals: scratch
     hipLaunchKernelGGL(msd_offsets1b_kernel, dim3(1), dim3(MSD_BINS), 0, s, (const u32 *)seg_first, J1, n);
     PSS_TRY(mark());
-    hipLaunchKernelGGL(msd_scatter_kernel<true>, dim3(a.num_ranges1), dim3(MSD_BLOCK), 0, s, a);
+    // 16384-element scatter tiles (whole-line runs) for the pass from the text: 2.2 -> 1.9 ms at 2^29.  The second pass
+    // reads as much as it writes and measured slower that way (2.8 -> 3.0 ms: one 1024-thread workgroup per CU, two more
+    // barriers per tile), it keeps the 8192-element kernel.  PSS_MSD_SCATTER=1: the 8192-element kernel for both, 2: the
+    // wide one for both.
+    const int scat = getenv("PSS_MSD_SCATTER") ? atoi(getenv("PSS_MSD_SCATTER")) : 0;
+    const bool wide = scat != 1;
+    if (wide) hipLaunchKernelGGL(msd_scatter2_kernel<true>, dim3(a.num_ranges1), dim3(MSD_BLOCK2), 0, s, a);
+    else hipLaunchKernelGGL(msd_scatter_kernel<true>, dim3(a.num_ranges1), dim3(MSD_BLOCK), 0, s, a);
     PSS_TRY(mark());
     // ---- G2: A[0] -> A[1], every G1 bucket by the next 10 bits ----
     hipLaunchKernelGGL(msd_ranges_kernel, dim3(1), dim3(MSD_BINS), 0, s, J1, ranges2, seg_first, counters);
@@ -1035,7 +1151,8 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     }
     if (maxb > MSD_MAX_BUCKET) return PSS_OK;      // not this text: the caller takes the LSD path
     PSS_TRY(mark());
-    hipLaunchKernelGGL(msd_scatter_kernel<false>, dim3((u32)max_ranges2), dim3(MSD_BLOCK), 0, s, a);
+    if (scat == 2) hipLaunchKernelGGL(msd_scatter2_kernel<false>, dim3((u32)max_ranges2), dim3(MSD_BLOCK2), 0, s, a);
+    else hipLaunchKernelGGL(msd_scatter_kernel<false>, dim3((u32)max_ranges2), dim3(MSD_BLOCK), 0, s, a);
     PSS_TRY(mark());
     const TilePlan tp{MSD_WIN, MSD_TILE_CAP};
     PSS_TRY(device_excl_scan(ctx, InTileHead{cstart, ne, n, tp}, ne, partial, d_total, ranks));

@@ -306,11 +306,23 @@ __global__ __launch_bounds__(SS_DBLOCK) void ss_digits2_kernel(SsArgs a)
 
 // ---- scatter passes --------------------------------------------------------------------------------------------
 
+#ifndef PSS_SS_STILE
+#define PSS_SS_STILE 8192
+#endif
+// A scatter tile is larger than what LDS can stage at once: it goes through in pieces by destination position
+// (positions [0, 2048), [2048, 4096), ...), 32 KiB of staging whatever the tile size.  What the tile size buys is the
+// length of the runs the output loop writes: the pass is bound by the 128-byte lines it touches, and 8192
+// elements over 1024 bins are runs of 8 x 16 bytes -- whole lines -- where 4096 gave half lines.
+constexpr u32 SS_STILE = PSS_SS_STILE;
+constexpr int SS_SIPT2 = SS_STILE / SS_SBLOCK;      // elements per thread and tile
+constexpr u32 SS_PIECE = 2048;
+constexpr int SS_PIECES = SS_STILE / SS_PIECE;
+
 template <bool FROM_TEXT>
 __global__ __launch_bounds__(SS_SBLOCK) void ss_scatter_kernel(SsArgs a)
 {
-    __shared__ E16 exch[SS_TILE];
-    __shared__ u16 dstage[SS_TILE];
+    __shared__ E16 exch[SS_PIECE];
+    __shared__ u16 dstage[SS_PIECE];
     __shared__ u32 hist[MSD_BINS], s_delta[MSD_BINS], s_off[MSD_BINS];
     __shared__ u16 s_start[MSD_BINS];
     __shared__ u32 scr[SS_SBLOCK / kWave + 1];
@@ -330,31 +342,43 @@ __global__ __launch_bounds__(SS_SBLOCK) void ss_scatter_kernel(SsArgs a)
     hist[tid] = 0;      // SS_SBLOCK == MSD_BINS
     s_off[tid] = FROM_TEXT ? a.T[(size_t)tid * a.num_ranges1 + r] + a.J1[tid] : a.T[(size_t)r * MSD_BINS + tid];
     __syncthreads();
-    for (u32 base = e0; base < e1; base += SS_TILE) {
-        const u32 valid = min(SS_TILE, e1 - base);
-        E16 e[SS_SIPT];
-        u32 dig[SS_SIPT], rank[SS_SIPT];
+    for (u32 base = e0; base < e1; base += SS_STILE) {
+        const u32 valid = min(SS_STILE, e1 - base);
+        E16 e[SS_SIPT2];
+        u32 dig[SS_SIPT2], lp[SS_SIPT2];
         if (FROM_TEXT) {
-            // four consecutive suffixes per thread (base is a multiple of 16)
-            const u32 i0 = base + tid * SS_SIPT;
-            if (tid * SS_SIPT < valid) {
-                u64 q[5];
-                ss_stream_at<5>(a.text.codes, i0, q);
-                ss_pack<SS_SIPT, 5>(q, i0, a.text, e);
-                const u64 dd = *reinterpret_cast<const u64 *>(a.digits + i0);
+            // SS_SIPT2 consecutive suffixes per thread (base is a multiple of 16)
+            const u32 i0 = base + tid * SS_SIPT2;
+            if (tid * SS_SIPT2 < valid) {
+                if (SS_SIPT2 >= 8) {
+                    u64 q[6];
+                    ss_stream_at<6>(a.text.codes, i0, q);
+                    ss_pack<SS_SIPT2, 6>(q, i0, a.text, e);
+                    const uint4 *dp = reinterpret_cast<const uint4 *>(a.digits + i0);
+                    const uint4 dd = dp[0], d2 = SS_SIPT2 > 8 ? dp[1] : dd;
+                    const u32 w[8] = {dd.x, dd.y, dd.z, dd.w, d2.x, d2.y, d2.z, d2.w};
 #pragma unroll
-                for (int k = 0; k < SS_SIPT; ++k) dig[k] = (u32)(dd >> (16 * k)) & 0xffffu;
+                    for (int k = 0; k < SS_SIPT2; ++k) dig[k] = (w[(k >> 1) & 7] >> (16 * (k & 1))) & 0xffffu;
+                } else {
+                    u64 q[5];
+                    ss_stream_at<5>(a.text.codes, i0, q);
+                    ss_pack<SS_SIPT2, 5>(q, i0, a.text, e);
+                    const u64 dd = *reinterpret_cast<const u64 *>(a.digits + i0);
+#pragma unroll
+                    for (int k = 0; k < SS_SIPT2; ++k) dig[k] = (u32)(dd >> (16 * (k & 3))) & 0xffffu;
+                }
             }
 #pragma unroll
-            for (int k = 0; k < SS_SIPT; ++k) rank[k] = (tid * SS_SIPT + k < valid) ? atomicAdd(&hist[dig[k]], 1u) : 0u;
+            for (int k = 0; k < SS_SIPT2; ++k) lp[k] = (tid * SS_SIPT2 + k < valid) ? atomicAdd(&hist[dig[k]], 1u) : 0xffffffffu;
         } else {
 #pragma unroll
-            for (int k = 0; k < SS_SIPT; ++k) {
+            for (int k = 0; k < SS_SIPT2; ++k) {
                 const u32 p = k * SS_SBLOCK + tid;
+                lp[k] = 0xffffffffu;
                 if (p < valid) {
                     e[k] = e16_load(&a.in[base + p]);
                     dig[k] = a.digits[base + p];
-                    rank[k] = atomicAdd(&hist[dig[k]], 1u);
+                    lp[k] = atomicAdd(&hist[dig[k]], 1u);
                 }
             }
         }
@@ -370,19 +394,26 @@ __global__ __launch_bounds__(SS_SBLOCK) void ss_scatter_kernel(SsArgs a)
         }
         __syncthreads();                                    // (B) bin starts published
 #pragma unroll
-        for (int k = 0; k < SS_SIPT; ++k) {
-            const bool ok = FROM_TEXT ? (tid * SS_SIPT + k < valid) : (k * SS_SBLOCK + tid < valid);
-            if (ok) {
-                const u32 lp = (u32)s_start[dig[k]] + rank[k];
-                e16_store(&exch[lp], e[k]);
-                dstage[lp] = (u16)dig[k];
-            }
-        }
-        __syncthreads();                                    // (C) tile in bin order
+        for (int k = 0; k < SS_SIPT2; ++k)
+            if (lp[k] != 0xffffffffu) lp[k] += (u32)s_start[dig[k]];      // rank inside the bin -> position in the tile
 #pragma unroll
-        for (int k = 0; k < SS_SIPT; ++k) {
-            const u32 p = k * SS_SBLOCK + tid;
-            if (p < valid) e16_store(&a.out[(size_t)s_delta[dstage[p]] + p], e16_load(&exch[p]));
+        for (int h = 0; h < SS_PIECES; ++h) {
+            if (h * SS_PIECE >= valid) break;
+            if (h) __syncthreads();                         // the piece before this one is written out
+#pragma unroll
+            for (int k = 0; k < SS_SIPT2; ++k) {
+                const u32 q = lp[k] - h * SS_PIECE;         // (an element of another piece, or none: q >= SS_PIECE)
+                if (q < SS_PIECE) {
+                    e16_store(&exch[q], e[k]);
+                    dstage[q] = (u16)dig[k];
+                }
+            }
+            __syncthreads();                                // (C) the piece in bin order
+#pragma unroll
+            for (int k = 0; k < (int)(SS_PIECE / SS_SBLOCK); ++k) {
+                const u32 q = k * SS_SBLOCK + tid, p = h * SS_PIECE + q;
+                if (p < valid) e16_store(&a.out[(size_t)s_delta[dstage[q]] + p], e16_load(&exch[q]));
+            }
         }
     }
 }
