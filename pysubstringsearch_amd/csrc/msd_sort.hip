@@ -362,20 +362,23 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_scatter_kernel(MsdArgs a)
 // the output loop writes are 16 x 8 = 128 bytes on average -- whole lines instead of half lines; the pass is bound by
 // the 128-byte lines it touches.  LDS stages 8192 elements at a time: the tile goes through in two
 // pieces by destination position.
-constexpr int MSD_BLOCK2 = 1024;
-constexpr u32 MSD_TILE2 = MSD_BLOCK2 * MSD_IPT;      // 16384
+constexpr u32 MSD_TILE2 = 16384;
 constexpr int MSD_PIECES2 = MSD_TILE2 / MSD_TILE;    // 2
 
-template <bool FROM_TEXT>
-__global__ __launch_bounds__(MSD_BLOCK2) void msd_scatter2_kernel(MsdArgs a)
+template <bool FROM_TEXT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void msd_scatter2_kernel(MsdArgs a)
 {
+    constexpr int IPT = MSD_TILE2 / BLOCK;               // 16 (1024 threads) or 32 (512)
+    constexpr int BPT = MSD_BINS / BLOCK;                // bins per thread in the scan
     __shared__ __attribute__((aligned(16))) u64 exch[MSD_TILE];
     __shared__ u32 hist[MSD_BINS], s_delta[MSD_BINS], s_off[MSD_BINS];
     __shared__ u16 s_start[MSD_BINS];
-    __shared__ u32 scr[MSD_BLOCK2 / kWave + 1];
+    __shared__ u32 scr[BLOCK / kWave + 1];
     const u32 tid = threadIdx.x, r = blockIdx.x;
     u32 e0, e1;
-    u32 tag = 0;
+    u32 tag[BPT];
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) tag[j] = 0;
     if (FROM_TEXT) {
         if (r >= a.num_ranges1) return;
         e0 = r * a.tiles_per_range1 * MSD_TILE;
@@ -385,10 +388,16 @@ __global__ __launch_bounds__(MSD_BLOCK2) void msd_scatter2_kernel(MsdArgs a)
         if (r >= a.counters[0]) return;
         e0 = a.ranges2[r].start;
         e1 = a.ranges2[r].end;
-        tag = ((u32)a.dense[(size_t)a.ranges2[r].seg * MSD_BINS + tid] & (MSD_TAG_SPAN - 1u)) << 16;      // see msd_scatter_kernel
+#pragma unroll
+        for (int j = 0; j < BPT; ++j)      // see msd_scatter_kernel
+            tag[j] = ((u32)a.dense[(size_t)a.ranges2[r].seg * MSD_BINS + BPT * tid + j] & (MSD_TAG_SPAN - 1u)) << 16;
     }
-    hist[tid] = tag;
-    s_off[tid] = FROM_TEXT ? a.T[(size_t)tid * a.num_ranges1 + r] + a.J1[tid] : a.T[(size_t)r * MSD_BINS + tid];
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) {
+        const u32 i = BPT * tid + j;
+        hist[i] = tag[j];
+        s_off[i] = FROM_TEXT ? a.T[(size_t)i * a.num_ranges1 + r] + a.J1[i] : a.T[(size_t)r * MSD_BINS + i];
+    }
     __syncthreads();
     const int shift2 = a.idx_bits + a.key_bits - 2 * MSD_D;
     const u64 low_mask2 = (1ull << shift2) - 1ull;
@@ -396,60 +405,72 @@ __global__ __launch_bounds__(MSD_BLOCK2) void msd_scatter2_kernel(MsdArgs a)
     const u64 rest_mask = (1ull << rest_bits) - 1ull;
     for (u32 base = e0; base < e1; base += MSD_TILE2) {
         const u32 valid = min(MSD_TILE2, e1 - base);
-        u64 elem[MSD_IPT];
-        u32 dig[MSD_IPT], lp[MSD_IPT];
+        u64 elem[IPT];
+        u32 lp[IPT];          // position in the tile (before the scan: rank inside the bin), digit in the top 10 bits
         if (FROM_TEXT) {
-            const u32 i0 = base + tid * MSD_IPT;
-            u64 key[MSD_IPT] = {};
-            if (i0 < a.n) text_keys16(a.codes, i0, a.code_bits, a.key_chars, a.plus_one, a.key_drop, a.n, key);
 #pragma unroll
-            for (int k = 0; k < MSD_IPT; ++k) {
-                dig[k] = (u32)(key[k] >> rest_bits) & (MSD_BINS - 1u);
-                // through LDS: [key rest | digit | position in the tile]; the suffix index is base + position
-                elem[k] = ((key[k] & rest_mask) << 24) | ((u64)dig[k] << 14) | (u64)(tid * MSD_IPT + k);
-                lp[k] = (tid * MSD_IPT + k < valid) ? (atomicAdd(&hist[dig[k]], 1u) & 0xffffu) : 0xffffffffu;
+            for (int g = 0; g < IPT / 16; ++g) {
+                const u32 i0 = base + tid * IPT + g * 16;
+                u64 key[16] = {};
+                if (i0 < a.n) text_keys16(a.codes, i0, a.code_bits, a.key_chars, a.plus_one, a.key_drop, a.n, key);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const u32 d = (u32)(key[k] >> rest_bits) & (MSD_BINS - 1u), pos = tid * IPT + g * 16 + k;
+                    // through LDS: [key rest | digit | position in the tile]; the suffix index is base + position
+                    elem[g * 16 + k] = ((key[k] & rest_mask) << 24) | ((u64)d << 14) | (u64)pos;
+                    lp[g * 16 + k] = pos < valid ? ((atomicAdd(&hist[d], 1u) & 0xffffu) | (d << 22)) : 0xffffffffu;
+                }
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < MSD_IPT; ++k) {
-                const u32 p = k * MSD_BLOCK2 + tid;
-                lp[k] = 0xffffffffu;
-                elem[k] = 0;
-                dig[k] = 0;
-                if (p < valid) {
-                    elem[k] = a.in[base + p];
-                    dig[k] = (u32)(elem[k] >> shift2) & (MSD_BINS - 1u);
-                    lp[k] = atomicAdd(&hist[dig[k]], 1u) & 0xffffu;
-                }
+            for (int k = 0; k < IPT; ++k) {
+                const u32 p = k * BLOCK + tid;
+                elem[k] = p < valid ? a.in[base + p] : 0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) {
+                const u32 p = k * BLOCK + tid;
+                const u32 d = (u32)(elem[k] >> shift2) & (MSD_BINS - 1u);
+                lp[k] = p < valid ? ((atomicAdd(&hist[d], 1u) & 0xffffu) | (d << 22)) : 0xffffffffu;
             }
         }
         __syncthreads();                                    // (A) counts complete; previous tile fully written out
         {
-            const u32 c = hist[tid] & 0xffffu;
-            const u32 ex = block_excl_sum<MSD_BLOCK2 / kWave>(c, scr, nullptr);
-            s_start[tid] = (u16)ex;
-            const u32 o = s_off[tid];
-            s_delta[tid] = o - ex;
-            s_off[tid] = o + c;
-            hist[tid] = tag;
+            u32 c[BPT], sum = 0;
+#pragma unroll
+            for (int j = 0; j < BPT; ++j) {
+                c[j] = hist[BPT * tid + j] & 0xffffu;
+                sum += c[j];
+            }
+            u32 ex = block_excl_sum<BLOCK / kWave>(sum, scr, nullptr);
+#pragma unroll
+            for (int j = 0; j < BPT; ++j) {
+                const u32 i = BPT * tid + j;
+                s_start[i] = (u16)ex;
+                const u32 o = s_off[i];
+                s_delta[i] = o - ex;
+                s_off[i] = o + c[j];
+                hist[i] = tag[j];
+                ex += c[j];
+            }
         }
         __syncthreads();                                    // (B) bin starts published
 #pragma unroll
-        for (int k = 0; k < MSD_IPT; ++k)
-            if (lp[k] != 0xffffffffu) lp[k] += (u32)s_start[dig[k]];
+        for (int k = 0; k < IPT; ++k)
+            if (lp[k] != 0xffffffffu) lp[k] = (lp[k] & 0xffffu) + (u32)s_start[lp[k] >> 22];
 #pragma unroll
         for (int h = 0; h < MSD_PIECES2; ++h) {
             if (h * MSD_TILE >= valid) break;
             if (h) __syncthreads();                         // the piece before this one is written out
 #pragma unroll
-            for (int k = 0; k < MSD_IPT; ++k) {
+            for (int k = 0; k < IPT; ++k) {
                 const u32 q = lp[k] - h * MSD_TILE;
                 if (q < MSD_TILE) exch[q] = elem[k];
             }
             __syncthreads();                                // (C) the piece in bin order
 #pragma unroll
-            for (int k = 0; k < (int)(MSD_TILE / MSD_BLOCK2); ++k) {
-                const u32 q = k * MSD_BLOCK2 + tid, p = h * MSD_TILE + q;
+            for (int k = 0; k < (int)(MSD_TILE / BLOCK); ++k) {
+                const u32 q = k * BLOCK + tid, p = h * MSD_TILE + q;
                 if (p < valid) {
                     u64 e = exch[q];
                     u32 d;
@@ -1120,13 +1141,11 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     hipLaunchKernelGGL(msd_offsets1_kernel, dim3(MSD_BINS), dim3(256), 0, s, T, a.num_ranges1, seg_first);   // totals: scratch
     hipLaunchKernelGGL(msd_offsets1b_kernel, dim3(1), dim3(MSD_BINS), 0, s, (const u32 *)seg_first, J1, n);
     PSS_TRY(mark());
-    // 16384-element scatter tiles (whole-line runs) for the pass from the text: 2.2 -> 1.9 ms at 2^29.  The second pass
-    // reads as much as it writes and measured slower that way (2.8 -> 3.0 ms: one 1024-thread workgroup per CU, two more
-    // barriers per tile), it keeps the 8192-element kernel.  PSS_MSD_SCATTER=1: the 8192-element kernel for both, 2: the
-    // wide one for both.
-    const int scat = getenv("PSS_MSD_SCATTER") ? atoi(getenv("PSS_MSD_SCATTER")) : 0;
-    const bool wide = scat != 1;
-    if (wide) hipLaunchKernelGGL(msd_scatter2_kernel<true>, dim3(a.num_ranges1), dim3(MSD_BLOCK2), 0, s, a);
+    // 16384-element scatter tiles (whole-line runs), 1024 threads: 2.2 -> 1.9 ms (from the text) and 2.8 -> 2.45 ms
+    // (second pass, with its sixteen loads per thread issued before the ranking atomics) at 2^29; 512 threads x 32 elements
+    // spill.  PSS_MSD_SCATTER=1: the 8192-element kernels.
+    const bool wide = !(getenv("PSS_MSD_SCATTER") && atoi(getenv("PSS_MSD_SCATTER")) == 1);
+    if (wide) hipLaunchKernelGGL((msd_scatter2_kernel<true, 1024>), dim3(a.num_ranges1), dim3(1024), 0, s, a);
     else hipLaunchKernelGGL(msd_scatter_kernel<true>, dim3(a.num_ranges1), dim3(MSD_BLOCK), 0, s, a);
     PSS_TRY(mark());
     // ---- G2: A[0] -> A[1], every G1 bucket by the next 10 bits ----
@@ -1151,7 +1170,7 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     }
     if (maxb > MSD_MAX_BUCKET) return PSS_OK;      // not this text: the caller takes the LSD path
     PSS_TRY(mark());
-    if (scat == 2) hipLaunchKernelGGL(msd_scatter2_kernel<false>, dim3((u32)max_ranges2), dim3(MSD_BLOCK2), 0, s, a);
+    if (wide) hipLaunchKernelGGL((msd_scatter2_kernel<false, 1024>), dim3((u32)max_ranges2), dim3(1024), 0, s, a);
     else hipLaunchKernelGGL(msd_scatter_kernel<false>, dim3((u32)max_ranges2), dim3(MSD_BLOCK), 0, s, a);
     PSS_TRY(mark());
     const TilePlan tp{MSD_WIN, MSD_TILE_CAP};

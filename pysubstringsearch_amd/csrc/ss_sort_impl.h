@@ -372,14 +372,15 @@ __global__ __launch_bounds__(SS_SBLOCK) void ss_scatter_kernel(SsArgs a)
             for (int k = 0; k < SS_SIPT2; ++k) lp[k] = (tid * SS_SIPT2 + k < valid) ? atomicAdd(&hist[dig[k]], 1u) : 0xffffffffu;
         } else {
 #pragma unroll
+            for (int k = 0; k < SS_SIPT2; ++k) {      // (every load of the tile in flight before the first ranking atomic)
+                const u32 p = k * SS_SBLOCK + tid;
+                e[k] = e16_load(&a.in[base + min(p, valid - 1)]);
+                dig[k] = a.digits[base + min(p, valid - 1)];
+            }
+#pragma unroll
             for (int k = 0; k < SS_SIPT2; ++k) {
                 const u32 p = k * SS_SBLOCK + tid;
-                lp[k] = 0xffffffffu;
-                if (p < valid) {
-                    e[k] = e16_load(&a.in[base + p]);
-                    dig[k] = a.digits[base + p];
-                    lp[k] = atomicAdd(&hist[dig[k]], 1u);
-                }
+                lp[k] = p < valid ? atomicAdd(&hist[dig[k]], 1u) : 0xffffffffu;
             }
         }
         __syncthreads();                                    // (A) counts complete; previous tile fully written out
