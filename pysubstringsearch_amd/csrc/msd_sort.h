@@ -54,11 +54,12 @@ struct SsBuffers {
 };
 // Sample members drawn for n suffixes (0: the path does not take texts of this size).
 uint32_t ss_sample_count(uint32_t n);
-// Symbols of code_bits each that a 16-byte element carries next to the index of one of n suffixes.
-int ss_key_chars(uint32_t n, int code_bits);
+// Symbols a 16-byte element carries next to the index of one of n suffixes when the text has radix - 1 distinct bytes
+// (the key is a base-radix number, code 0 = past the end of the text).
+int ss_key_chars(uint32_t n, uint32_t radix);
 // Same contract as suffix_sort_flags / msd_suffix_sort without `active` (bit 31 of sa_out[i] = "same key as my
 // predecessor"); the key is the first ss_key_chars() symbols.  `work`: msd_workspace_bytes(n).
-int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, const SsBuffers &buf, uint32_t *sa_out, void *work,
-                   uint32_t *h_small, bool profile, SsStats *stats, bool *accepted, MsdActive *active);
+int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t radix, uint32_t n, const SsBuffers &buf, uint32_t *sa_out,
+                   void *work, uint32_t *h_small, bool profile, SsStats *stats, bool *accepted, MsdActive *active);
 
 }  // namespace pss

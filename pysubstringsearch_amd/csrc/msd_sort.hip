@@ -1237,16 +1237,30 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
 
 struct SsGeometry {
     u32 B1, B2, os, S;
-    int ib, kc;
+    int ib, kc, key_bits;
+    u64 plo, phi;          // radix^(kc - 1)
 };
-static bool ss_geometry(uint32_t n, int b, SsGeometry *g)
+static bool ss_geometry(uint32_t n, uint32_t radix, SsGeometry *g)
 {
-    if (n < (1u << 16) || n > (1u << 30) || b < 1 || b > 9) return false;
+    if (n < (1u << 16) || n > (1u << 30) || radix < 2 || radix > 257) return false;
     int ib = 1;
     while ((1ull << ib) < (u64)n) ++ib;
-    int kc = (128 - ib) / b;
-    if (kc > SS_MAX_CHARS) kc = SS_MAX_CHARS;
+    // symbols per key: the largest kc with radix^kc <= 2^(128 - ib), at most SS_MAX_CHARS
+    const unsigned __int128 limit = (unsigned __int128)1 << (128 - ib);
+    unsigned __int128 pw = 1;
+    int kc = 0;
+    while (kc < SS_MAX_CHARS && pw <= limit / radix) {
+        pw *= radix;
+        ++kc;
+    }
     if (kc < 2) return false;
+    unsigned __int128 lead = 1;
+    for (int i = 0; i + 1 < kc; ++i) lead *= radix;
+    g->plo = (u64)lead;
+    g->phi = (u64)(lead >> 64);
+    int kb = 0;
+    while (kb < 128 && ((pw - 1) >> kb) != 0) ++kb;      // bits of the largest key
+    g->key_bits = kb;
     // joint buckets of ~512 elements (a tile holds 4088): B1 x B2 of them, both powers of two <= 1024
     int lb = 4;
     while (((u64)512 << lb) < (u64)n && lb < 20) ++lb;
@@ -1265,21 +1279,21 @@ static bool ss_geometry(uint32_t n, int b, SsGeometry *g)
 uint32_t ss_sample_count(uint32_t n)
 {
     SsGeometry g;
-    return ss_geometry(n, 8, &g) ? g.S : 0u;
+    return ss_geometry(n, 257, &g) ? g.S : 0u;
 }
-int ss_key_chars(uint32_t n, int code_bits)
+int ss_key_chars(uint32_t n, uint32_t radix)
 {
     SsGeometry g;
-    return ss_geometry(n, code_bits, &g) ? g.kc : 0;
+    return ss_geometry(n, radix, &g) ? g.kc : 0;
 }
 
-int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, const SsBuffers &buf, uint32_t *sa_out, void *work,
-                   uint32_t *h_small, bool profile, SsStats *stats, bool *accepted, MsdActive *active)
+int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t radix, uint32_t n, const SsBuffers &buf, uint32_t *sa_out,
+                   void *work, uint32_t *h_small, bool profile, SsStats *stats, bool *accepted, MsdActive *active)
 {
     *accepted = false;
     hipStream_t s = ctx->stream;
     SsGeometry g;
-    if (!ss_geometry(n, text->code_bits, &g)) return PSS_OK;      // not this text
+    if (!ss_geometry(n, radix, &g)) return PSS_OK;      // not this text
     static_assert(SS_SBLOCK == (int)MSD_BINS, "one bin per thread in the scatter passes");
     const size_t max_ranges2 = (size_t)n / MSD_G2_RANGE + MSD_BINS + 8;
     const size_t nbk = (size_t)MSD_BINS * MSD_BINS;
@@ -1322,7 +1336,7 @@ int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, const SsBuf
         return PSS_OK;
     };
 
-    SsText tx{text->codes, n, text->code_bits, g.kc, text->plus_one, g.ib};
+    SsText tx{text->codes, n, text->code_bits, g.kc, text->plus_one, g.ib, radix, g.plo, g.phi};
     const u32 S = g.S;
     E16 *E0 = static_cast<E16 *>(buf.E0), *E = static_cast<E16 *>(buf.E);
     PSS_TRY(mark());                                                                       // [0]
@@ -1343,7 +1357,7 @@ int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, const SsBuf
         int d1 = 0, d2 = 0;
         PSS_TRY(radix_sort_pairs(ctx, K, V, S, 64, 0xffu, nullptr, 0, buf.sort_work, &d1, false, &ss1));
         hipLaunchKernelGGL(ss_gather_hi_kernel, dim3((S + 255) / 256), dim3(256), 0, s, E0, (const u32 *)V[d1], S, K[d1]);
-        const int hi_bits = std::max(1, g.kc * text->code_bits + g.ib - 64);
+        const int hi_bits = std::min(64, std::max(1, g.key_bits + g.ib - 64));
         PSS_TRY(radix_sort_pairs(ctx, K, V, S, hi_bits, 0xffu, nullptr, d1, buf.sort_work, &d2, false, &ss1));
         hipLaunchKernelGGL(ss_gather_elems_kernel, dim3((S + 255) / 256), dim3(256), 0, s, E0, (const u32 *)V[d2], S, E);
     }

@@ -1889,7 +1889,8 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         TextKeys sk{codes, b, 0, plus_one, 0};
         SsStats sst;
         bool accepted = false;
-        PSS_TRY(ss_suffix_sort(ctx, &sk, n, sb, SA, ctx->slot[S_P0].p, h_small, profile, &sst, &accepted, &act));
+        PSS_TRY(ss_suffix_sort(ctx, &sk, plus_one ? 257u : sigma + 1u, n, sb, SA, ctx->slot[S_P0].p, h_small, profile, &sst, &accepted,
+                               &act));
         st.ss_buckets = sst.buckets;
         st.ss_max_bucket = sst.max_bucket;
         st.ss_samples = sst.samples;

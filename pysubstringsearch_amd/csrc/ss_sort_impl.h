@@ -61,16 +61,32 @@ __device__ __forceinline__ bool e16_same_key(const E16 &a, const E16 &b, int ib)
 struct SsText {
     const u8 *codes;       // recoded text, zero padded for >= 64 bytes past n
     u32 n;
-    int b, kc, plus_one;   // bits per symbol, symbols per key, raw bytes + 1 (sigma == 256)
+    int b, kc, plus_one;   // bits per symbol (text rounds), symbols per key, raw bytes + 1 (sigma == 256)
     int ib;                // index bits
+    // The key is the number sum c_j R^(kc - 1 - j) of its symbols in base R = code values (sigma + 1, the end-of-text
+    // code 0 included), not a string of b-bit fields: order preserving all the same, and denser whenever R is not a
+    // power of two -- 20 symbols of a 28-letter alphabet in 99 bits where 5-bit fields hold 19.
+    u32 radix;
+    u64 plo, phi;          // R^(kc - 1): what the leading symbol of a key is worth (the sliding window takes it out)
 };
+
+// (hi, lo) = (hi, lo) * m + c for a small multiplier: 128-bit arithmetic on two words
+__device__ __forceinline__ void mul128_add(u64 &hi, u64 &lo, u32 m, u32 c)
+{
+    const u64 carry = __umul64hi(lo, (u64)m);
+    lo *= (u64)m;
+    hi = hi * (u64)m + carry;
+    const u64 nl = lo + c;
+    hi += nl < lo ? 1ull : 0ull;
+    lo = nl;
+}
 
 // NE consecutive suffixes whose symbols start at byte 0 of the little-endian byte stream q (NQ words; byte j of the
 // stream = symbol j of the first suffix): element r = [ symbols r .. r + kc - 1 | idx0 + r ].
 template <int NE, int NQ>
 __device__ __forceinline__ void ss_pack(const u64 (&q)[NQ], u32 idx0, const SsText &t, E16 (&out)[NE])
 {
-    const int b = t.b, kc = t.kc;
+    const int kc = t.kc;
     auto sym = [&](int j) -> u32 { return (u32)(q[j >> 3] >> ((j & 7) * 8)) & 0xffu; };
     u64 wlo = 0, whi = 0;      // the 128-bit key window
 #pragma unroll
@@ -78,13 +94,9 @@ __device__ __forceinline__ void ss_pack(const u64 (&q)[NQ], u32 idx0, const SsTe
         if (j < kc) {
             u32 c = sym(j);
             if (t.plus_one) c = ((u64)idx0 + j < t.n) ? c + 1u : 0u;
-            whi = (whi << b) | (wlo >> (64 - b));
-            wlo = (wlo << b) | c;
+            mul128_add(whi, wlo, t.radix, c);
         }
     }
-    const int kb = kc * b;
-    const u64 mlo = kb >= 64 ? ~0ull : ((1ull << kb) - 1ull);
-    const u64 mhi = kb > 64 ? ((1ull << (kb - 64)) - 1ull) : 0ull;
     // the stream from byte kc on (kc is uniform): symbol kc + j is byte j of s
     constexpr int NS = (NE + 6) / 8;      // words holding bytes 0 .. NE - 2
     u64 s[NS > 0 ? NS : 1];
@@ -110,8 +122,14 @@ __device__ __forceinline__ void ss_pack(const u64 (&q)[NQ], u32 idx0, const SsTe
             const int j = r - 1;
             u32 c = (u32)(s[j >> 3] >> ((j & 7) * 8)) & 0xffu;
             if (t.plus_one) c = ((u64)idx0 + j + kc < t.n) ? c + 1u : 0u;
-            whi = ((whi << b) | (wlo >> (64 - b))) & mhi;
-            wlo = ((wlo << b) | c) & mlo;
+            // slide: take the leading symbol (symbol j of the stream) out, append the new one
+            u32 lead = sym(j);
+            if (t.plus_one) lead = ((u64)idx0 + j < t.n) ? lead + 1u : 0u;
+            u64 lhi = t.phi, llo = t.plo;
+            mul128_add(lhi, llo, lead, 0u);
+            whi = whi - lhi - (wlo < llo ? 1ull : 0ull);
+            wlo -= llo;
+            mul128_add(whi, wlo, t.radix, c);
         }
         out[r].hi = (whi << ib) | (wlo >> (64 - ib));
         out[r].lo = (wlo << ib) | (u64)(idx0 + (u32)r);
