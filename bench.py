@@ -399,6 +399,15 @@ def run_chunk(args, D):
     _ffi.check(lib.pss_sa_build_device(dT.data_ptr(), dSA.data_ptr(), n, dev, 1, ctypes.byref(st)))
     prof = st.as_dict()
 
+    # The timed steps rebuild chunks of one corpus, so from the second on the build goes straight to the initial sort the
+    # previous chunk took (pss_sa_stats.plan_hint).  The build of a first chunk, which takes the sizing sample, beside it:
+    os.environ['PSS_NO_PLAN_CACHE'] = '1'
+    sized_ms = None
+    for _ in range(3):
+        _ffi.check(lib.pss_sa_build_device(dT.data_ptr(), dSA.data_ptr(), n, dev, 0, ctypes.byref(st)))
+        sized_ms = st.ms_total if sized_ms is None else min(sized_ms, st.ms_total)
+    del os.environ['PSS_NO_PLAN_CACHE']
+
     # secondary corpus (natural-text-like LCP), outside the timed region, N = 1 only
     secondary = None
     if world == 1 and args.corpus == 'lines' and not os.environ.get('PSS_BENCH_NO_SECONDARY'):
@@ -566,6 +575,7 @@ def run_chunk(args, D):
             },
             'queries_per_sec': round(len(queries) * args.steps / search_s, 1),
             'build_ms': round(build_s / args.steps * 1e3, 3),
+            'build_ms_first_chunk': round(sized_ms, 3), 'plan_hint': int(sa_stats.get('plan_hint', 0)),
             'search_ms': round(search_s / args.steps * 1e3, 3),
             'entries_per_batch': last.get('entries'),
             'search_stats': last.get('search_stats'),

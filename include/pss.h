@@ -119,6 +119,9 @@ typedef struct pss_sa_stats {
     double ss_ms_g2;           /* ... second partition (digits 16 in / 2 out, scatter 18 in / 16 out) */
     double ss_ms_local;        /* ... local merge sort (16 B in, 4 B out) */
     double ms_initial;         /* device time from the start of the build to the end of the initial sort (always filled) */
+    uint64_t plan_hint;        /* 0: the sizing sample chose the initial sort; 1: the previous build on this device sorted
+                                  the same kind of text (same byte values, same size class) with the MSD sort and this
+                                  build went straight to it (PSS_NO_PLAN_CACHE=1: never) */
 } pss_sa_stats;
 
 /*

@@ -64,6 +64,7 @@ class SaStats(ctypes.Structure):
         ('ss_ms_g2', ctypes.c_double),
         ('ss_ms_local', ctypes.c_double),
         ('ms_initial', ctypes.c_double),
+        ('plan_hint', ctypes.c_uint64),
     ]
 
     def as_dict(self):

@@ -90,6 +90,12 @@ struct DeviceCtx {
     int ensure_search_stage();
     hipEvent_t search_ev[3] = {nullptr, nullptr, nullptr};   // timing events of the search path, created once
     void *small_hdr_ready = nullptr;     // arena whose small-path cursors have been zeroed (search.hip)
+    // Which initial sort the last build on this device took, and for what kind of text (the byte values present, the
+    // size class): consecutive chunks of one corpus take the same one, so the next build skips the sizing sample that
+    // would only say so again (sa_build.hip; a wrong guess is caught by the sorts' own exact checks and costs one restart).
+    uint32_t plan_present[8] = {};
+    uint32_t plan_logn = 0;
+    int plan_path = 0;                   // 0 none, 1 hybrid MSD
     // Two pinned staging buffers + a copy stream: file <-> HBM transfers are
     // double-buffered so the PCIe copy of piece i overlaps the file I/O of piece i+1.
     static constexpr size_t kStage = (size_t)64 << 20;

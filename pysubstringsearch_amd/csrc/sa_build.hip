@@ -1203,6 +1203,7 @@ struct Knobs {
     int mode = -1;              // PSS_MODE       dense / sparse / text tie resolution (-1 = choose)
     int text_rounds_max = 5;    // PSS_TEXT_ROUNDS
     int msd = -1;               // PSS_MSD        0: never the MSD initial sort, 1: whenever the key fits, unset: screened
+    bool no_plan = false;       // PSS_NO_PLAN_CACHE  always take the sizing sample (never reuse the previous build's choice of sort)
     int ss = -1;                // PSS_SS         0: never the sample sort over 16-byte elements, 1: whenever the text has the size for it,
                                 //                unset: n >= 2^24 and the MSD sort did not take the text
     bool no_msd_fuse = false;   // PSS_MSD_NO_FUSE  MSD sort flags ties in the suffix array; the rerank kernels read them
@@ -1224,6 +1225,7 @@ struct Knobs {
         if (const char *e = getenv("PSS_TEXT_ROUNDS")) k.text_rounds_max = atoi(e);
         if (const char *e = getenv("PSS_MSD")) k.msd = atoi(e);
         if (const char *e = getenv("PSS_SS")) k.ss = atoi(e);
+        k.no_plan = getenv("PSS_NO_PLAN_CACHE") != nullptr;
         k.no_msd_fuse = getenv("PSS_MSD_NO_FUSE") != nullptr;
         k.no_mid_tier = getenv("PSS_NO_MID_TIER") != nullptr;
         if (const char *e = getenv("PSS_RLE")) k.rle = atoi(e);
@@ -1788,7 +1790,26 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     SortStats ss;
     int key_drop = 0;
     bool msd_screen_ok = false, sampled = false;
-    if (n >= (1u << 24) && !forced_chars && knobs.key_chars == 0 && !knobs.no_sample) {
+    // The plan of the previous build on this device, if it was for the same kind of text (same byte values present, same
+    // size class) and every switch is at its default: 1 = it took the MSD sort.  The sizing sample (0.4 ms and a host
+    // round trip at n = 2^29) would only repeat what it said then; the MSD sort's own exact bucket check still decides.
+    // When it declines, the sample sort is next as always; if that declines too, the build starts over with the sample
+    // (the LSD passes want the key length it measures).
+    uint32_t present_bits[8] = {};
+    for (int c = 0; c < 256; ++c)
+        if (plus_one || lut[c]) present_bits[c >> 5] |= 1u << (c & 31);
+    uint32_t logn = 0;
+    while ((2u << logn) <= n && logn < 31) ++logn;
+    const bool plain = !forced_chars && knobs.key_chars == 0 && !knobs.no_sample && !knobs.no_flags && knobs.msd < 0 &&
+                       knobs.ss < 0 && knobs.key_drop < 0 && knobs.mode < 0 && !knobs.no_msd_fuse && !knobs.no_plan && (flags & 2u) == 0;
+    int hint = 0;
+    if (plain && n >= (1u << 24) && ctx->plan_path && ctx->plan_logn == logn && memcmp(ctx->plan_present, present_bits, 32) == 0)
+        hint = ctx->plan_path;
+    st.plan_hint = (uint64_t)hint;
+    if (hint) {
+        sampled = true;
+        msd_screen_ok = hint == 1;
+    } else if (n >= (1u << 24) && !forced_chars && knobs.key_chars == 0 && !knobs.no_sample) {
         PSS_TRY(size_initial_key(ctx, codes, n, b, kmax, plus_one, K, V, work, d_counters + 16, h_small, profile, &ss,
                                  &key_chars, &key_drop, &msd_screen_ok));
         st.key_chars = (u32)key_chars;
@@ -1822,7 +1843,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         const int kc = std::min(kb / b, kmax);                   // whole symbols only
         kb = kc * b;
         const bool fits = kc >= 1 && kb >= 21 && !plus_one;
-        const bool auto_ok = sampled && msd_screen_ok && key_bits0 <= 48 && kb + 8 >= key_bits0;
+        const bool auto_ok = sampled && msd_screen_ok && (hint == 1 || (key_bits0 <= 48 && kb + 8 >= key_bits0));
         if (fits && (knobs.msd == 1 || (knobs.msd < 0 && auto_ok))) {
             TextKeys mk{codes, b, kc, plus_one, 0};
             MsdStats ms;
@@ -1911,6 +1932,16 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
             ss.launches = 4;
             ss.elems = 4ull * n;
         }
+    }
+    if (hint && !msd_done) {
+        // Neither the remembered sort nor the sample sort took this text: forget the plan and size the key the long way.
+        ctx->plan_path = 0;
+        return sa_build_device(ctx, d_T, d_SA, n_in, flags, stats);
+    }
+    if (plain && n >= (1u << 24)) {
+        ctx->plan_path = st.msd ? 1 : 0;      // only the sort whose own exact check can refuse a text is taken unsampled
+        ctx->plan_logn = logn;
+        memcpy(ctx->plan_present, present_bits, 32);
     }
     if (msd_done) {
     } else if (ties) PSS_TRY(suffix_sort_flags(ctx, K, V, n, key_bits0, &tk, work, &cur, profile, &ss));

@@ -288,6 +288,43 @@ def test_sample_sort_is_chosen_for_natural_text(oracle):
         assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(t).tobytes()).hexdigest()
 
 
+def test_initial_sort_plan_is_reused_and_checked(oracle, monkeypatch):
+    """The second build of the same kind of text (same byte values present, same size class) skips the sizing sample and
+    goes straight to the MSD sort (plan_hint = 1), with the same bytes out.  A text with the same byte values but natural
+    text's distribution then gets the hint too; the MSD sort's exact bucket check refuses it and the build goes on to the
+    sample sort as it would have after the sample -- still libsais' bytes -- and forgets the plan.  PSS_NO_PLAN_CACHE=1
+    switches the memory off."""
+    n = 1 << 24
+    lines = gen_corpus(0, n)
+    want = hashlib.sha256(oracle.sa(lines).tobytes()).hexdigest()
+    _sa_device(lines, {})
+    st = {}
+    sa = _sa_device(lines, st)
+    assert (st['plan_hint'], st['msd']) == (1, 1)
+    assert hashlib.sha256(sa.tobytes()).hexdigest() == want
+    # same alphabet, crowded prefixes: a small vocabulary over the bytes of `lines`
+    rng = np.random.default_rng(9)
+    alphabet = np.unique(lines)
+    vocab = [alphabet[rng.integers(0, len(alphabet), int(rng.integers(3, 9)))] for _ in range(300)]
+    vocab.append(alphabet)                                   # every byte value occurs
+    picks = rng.integers(0, len(vocab), n // 4)
+    crowded = np.concatenate([vocab[-1]] + [vocab[i] for i in picks])[:n].copy()
+    assert len(crowded) == n and np.array_equal(np.unique(crowded), alphabet)
+    st = {}
+    sa = _sa_device(crowded, st)
+    assert (st['plan_hint'], st['msd'], st['ss']) == (1, 0, 1) and st['msd_max_bucket'] > 4088    # hinted, refused
+    assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(crowded).tobytes()).hexdigest()
+    st = {}
+    _sa_device(lines, st)
+    assert (st['plan_hint'], st['msd']) == (0, 1)             # the refusal cleared the plan
+    _sa_device(lines, {})
+    monkeypatch.setenv('PSS_NO_PLAN_CACHE', '1')              # (the build reads its switches on every call)
+    st = {}
+    sa = _sa_device(lines, st)
+    assert (st['plan_hint'], st['msd']) == (0, 1)
+    assert hashlib.sha256(sa.tobytes()).hexdigest() == want
+
+
 # ---- run-length path (rle_build.hip) ----
 
 def _runs_text(rng, n, alpha, maxrun, base=40):
