@@ -256,6 +256,17 @@ class Reader:
     def promote(self, chunk: int) -> None:
         _ffi.check(_lib.pss_reader_promote_chunk(self._handle(), int(chunk)))
 
+    def set_low_latency(self, on: bool = True) -> None:
+        """Extension: single queries (``search``) through a resident search kernel that waits for them in a pinned
+        mailbox -- no kernel launch, no stream synchronisation per query; same results.  The kernel leaves by itself
+        1 ms after the last query (include/pss.h, pss_reader_set_low_latency).  Off by default."""
+        _ffi.check(_lib.pss_reader_set_low_latency(self._handle(), 1 if on else 0))
+
+    def low_latency_stats(self) -> dict:
+        launches, served = ctypes.c_uint64(), ctypes.c_uint64()
+        _ffi.check(_lib.pss_reader_low_latency_stats(self._handle(), ctypes.byref(launches), ctypes.byref(served)))
+        return {'kernels_started': launches.value, 'queries_served': served.value}
+
     def _search_batch(self, patterns: typing.Sequence[bytes], as_str: bool):
         nq = len(patterns)
         if _pssglue is not None:

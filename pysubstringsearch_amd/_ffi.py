@@ -155,6 +155,8 @@ def _load() -> ctypes.CDLL:
         'pss_reader_open_multi': (ctypes.c_int, [cp, ctypes.POINTER(i32), i32, pvp]),
         'pss_reader_evict_chunk': (ctypes.c_int, [vp, u64]),
         'pss_reader_promote_chunk': (ctypes.c_int, [vp, u64]),
+        'pss_reader_set_low_latency': (ctypes.c_int, [vp, i32]),
+        'pss_reader_low_latency_stats': (ctypes.c_int, [vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]),
         'pss_reader_create': (ctypes.c_int, [i32, pvp]),
         'pss_reader_add_chunk_device': (ctypes.c_int, [vp, vp, vp, u32]),
         'pss_reader_set_chunk_device': (ctypes.c_int, [vp, u64, vp, vp, u32]),

@@ -758,6 +758,7 @@ struct pss_reader {
     ChunkDesc *d_descs = nullptr;
     size_t d_descs_cap = 0;
     bool dirty = true;
+    bool low_latency = false;            // single queries through the resident kernel (pss_reader_set_low_latency)
     pss_search_stats last{};
     // A reader over several devices (pss_reader_open_multi) is a front for one reader per device -- part k holds the
     // chunks c with c % G == k on devices[k] -- each with a worker thread that answers the batch for its chunks; the
@@ -938,6 +939,10 @@ void reader_free(pss_reader *r)
     }
     r->parts.clear();
     if (r->ctx) (void)hipSetDevice(r->device);
+    if (r->ctx) {
+        std::lock_guard<std::recursive_mutex> lk(r->ctx->mu);
+        if (r->ctx->resident.running && r->ctx->resident.chunks == r->d_descs) r->ctx->stop_resident();   // it reads r's chunk table
+    }
     for (auto &m : r->mem) reader_free_mem(m);
     if (r->d_descs) (void)hipFree(r->d_descs);
     delete r;
@@ -978,6 +983,7 @@ int reader_sync_descs(pss_reader *r)
 {
     const uint32_t nc = (uint32_t)r->chunks.size();
     if (!r->dirty || nc == 0) return PSS_OK;
+    r->ctx->stop_resident();             // (a resident search kernel keeps reading the table it was started with)
     if (r->d_descs_cap < nc) {
         if (r->d_descs) (void)hipFree(r->d_descs);
         r->d_descs = nullptr;
@@ -1450,7 +1456,8 @@ extern "C" int pss_reader_search_batch(pss_reader *r, const uint8_t *qbytes, con
         const uint32_t nc = (uint32_t)r->chunks.size();
         PSS_TRY(reader_sync_descs(r));
         pss_result *res = new pss_result();
-        const int rc = search_batch_device(r->ctx, r->d_descs, nc, qbytes, qoffsets, nq, &res->r, &r->last);
+        const int rc = search_batch_device(r->ctx, r->d_descs, nc, qbytes, qoffsets, nq, &res->r, &r->last, SEARCH_FULL,
+                                           r->low_latency);
         if (rc != PSS_OK) {
             pss_result_free(res);
             return rc;
@@ -1458,6 +1465,30 @@ extern "C" int pss_reader_search_batch(pss_reader *r, const uint8_t *qbytes, con
         *out = res;
         return PSS_OK;
     });
+}
+
+extern "C" int pss_reader_set_low_latency(pss_reader *r, int32_t on)
+{
+    return guarded([&]() -> int {
+        if (!r || !r->parts.empty()) {
+            set_error("pss_reader_set_low_latency: a single-device reader is required");
+            return PSS_EINVAL;
+        }
+        std::lock_guard<std::recursive_mutex> lk(r->ctx->mu);
+        PSS_HIP(hipSetDevice(r->device));
+        r->low_latency = on != 0;
+        if (!on) r->ctx->stop_resident();
+        return PSS_OK;
+    });
+}
+
+extern "C" int pss_reader_low_latency_stats(const pss_reader *r, uint64_t *launches, uint64_t *served)
+{
+    if (!r || !r->ctx) return PSS_EINVAL;
+    std::lock_guard<std::recursive_mutex> lk(r->ctx->mu);
+    if (launches) *launches = r->ctx->resident.launches;
+    if (served) *served = r->ctx->resident.served;
+    return PSS_OK;
 }
 
 extern "C" int pss_reader_count_batch(pss_reader *r, const uint8_t *qbytes, const uint64_t *qoffsets, uint32_t nq,

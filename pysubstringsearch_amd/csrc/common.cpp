@@ -77,6 +77,8 @@ void SearchKnobs::load()
     no_pinned_results = getenv("PSS_NO_PINNED_RESULTS") != nullptr;
     small_path_events = getenv("PSS_SEARCH_EVENTS") != nullptr;
     if (const char *e = getenv("PSS_LANE_SEARCH_MIN")) lane_search_min = strtoull(e, nullptr, 0);
+    if (const char *e = getenv("PSS_RESIDENT_IDLE_US")) resident_idle_us = (uint32_t)strtoul(e, nullptr, 0);
+    if (const char *e = getenv("PSS_RESIDENT_LIFE_US")) resident_life_us = (uint32_t)strtoul(e, nullptr, 0);
 }
 
 static SearchKnobs g_knobs;
@@ -189,6 +191,42 @@ int get_ctx(int device, DeviceCtx **out)
     return PSS_OK;
 }
 
+int DeviceCtx::ensure_resident()
+{
+    if (resident.arena) return PSS_OK;
+    PSS_HIP(hipStreamCreateWithFlags(&resident.stream, hipStreamNonBlocking));
+    // fine-grained: the kernel sees the host's writes, and the host the kernel's, while the kernel runs
+    PSS_HIP(hipHostMalloc(&resident.arena, kPinnedBytes, hipHostMallocCoherent | hipHostMallocMapped));
+    PSS_HIP(hipHostGetDevicePointer(&resident.arena_dev, resident.arena, 0));
+    memset(resident.arena, 0, kPinnedBytes);
+    return PSS_OK;
+}
+
+void DeviceCtx::Resident::post(const uint8_t *q, uint32_t plen)
+{
+    ResidentMailbox *mb = reinterpret_cast<ResidentMailbox *>(static_cast<uint8_t *>(arena) + kResidentMailboxOff);
+    if (plen != kResidentStop) {
+        if (plen <= sizeof mb->post.bytes) {
+            memcpy(mb->post.bytes, q, plen);
+        } else {
+            memcpy(mb->query, q, plen);
+            memset(mb->query + plen, 0, 32);
+        }
+    }
+    mb->post.plen = plen;
+    ++seq;
+    __atomic_store_n(&mb->post.seq_b, seq, __ATOMIC_RELEASE);
+    __atomic_store_n(&mb->post.seq_a, seq, __ATOMIC_RELEASE);
+}
+
+void DeviceCtx::stop_resident()
+{
+    if (!resident.running) return;
+    resident.post(nullptr, kResidentStop);
+    (void)hipStreamSynchronize(resident.stream);
+    resident.running = false;
+}
+
 void trim_all()
 {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
@@ -196,6 +234,7 @@ void trim_all()
         if (c.device < 0) continue;
         std::lock_guard<std::recursive_mutex> lk2(c.mu);
         (void)hipSetDevice(c.device);
+        c.stop_resident();               // (it works in one of the slots)
         for (auto &s : c.slot) s.release();
         // the fused small-batch path keeps its cursors in one of the slots and only zeroes them when the
         // arena's address changes: a fresh allocation may come back at the old address with garbage in it

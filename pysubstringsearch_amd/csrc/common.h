@@ -55,6 +55,8 @@ struct SearchKnobs {
     bool no_pinned_results = false; // PSS_NO_PINNED_RESULTS large results into pageable memory
     bool small_path_events = false; // PSS_SEARCH_EVENTS     HIP events around the fused single-query kernel (fills ms_device there)
     uint64_t lane_search_min = 8192;   // PSS_LANE_SEARCH_MIN  pairs from which one lane per pair searches
+    uint32_t resident_idle_us = 1000;  // PSS_RESIDENT_IDLE_US  resident search kernel: leaves after this long without a query ...
+    uint32_t resident_life_us = 50000; // PSS_RESIDENT_LIFE_US  ... and after this long in any case (the next query starts another)
     void load();
 };
 const SearchKnobs &search_knobs();
@@ -66,6 +68,29 @@ void reload_search_knobs();
 void *pinned_pool_alloc(size_t bytes, size_t *granted);
 void pinned_pool_free(void *p, size_t granted);
 void pinned_pool_trim();
+
+// Mailbox of the resident search kernel (search.hip, low-latency mode of a reader): fine-grained pinned host memory.
+// The host posts a query by filling `post` -- one 64-byte line the kernel polls with ONE load: the query's bytes (when
+// they fit; longer ones go to `query` and cost a second trip over PCIe), then the sequence number at BOTH ends of the
+// line, so whichever 32-byte half of a (possibly split) read carries a new number also carries what was written before
+// it.  plen = kResidentStop with a new sequence number tells the kernel to leave.  The kernel answers by writing the
+// sequence number to done_seq after its results; `exited` is its last word: a query posted after it, or one it raced
+// with, was not served.
+struct ResidentMailbox {
+    struct Post {
+        volatile uint32_t seq_a;
+        volatile uint32_t plen;
+        uint8_t bytes[52];
+        volatile uint32_t seq_b;
+    } post;
+    uint8_t query[256 + 64];         // queries of more than sizeof(Post::bytes) bytes
+    volatile uint32_t done_seq;      // kernel -> host: sequence number of the last query answered
+    volatile uint32_t exited;        //                 1: the kernel has left (lease over, or told to)
+    volatile uint32_t closing;       //                 1: the kernel is about to leave and looks once more
+    volatile uint32_t pad2[13];
+};
+static_assert(sizeof(ResidentMailbox::Post) == 64, "the posted line is one cache line");
+constexpr uint32_t kResidentStop = 0xffffffffu;
 
 // One per (process, device): a stream and named workspace slots.
 struct DeviceCtx {
@@ -90,6 +115,22 @@ struct DeviceCtx {
     int ensure_search_stage();
     hipEvent_t search_ev[3] = {nullptr, nullptr, nullptr};   // timing events of the search path, created once
     void *small_hdr_ready = nullptr;     // arena whose small-path cursors have been zeroed (search.hip)
+    // Resident search kernel (low-latency mode of a reader, search.hip): its own stream, its own fine-grained pinned
+    // arena (same layout as `pinned` on the small path + the mailbox), and what the running kernel was launched with.
+    struct Resident {
+        hipStream_t stream = nullptr;
+        void *arena = nullptr, *arena_dev = nullptr;
+        bool running = false;
+        const void *chunks = nullptr;    // launch arguments of the running kernel: a query for anything else restarts it
+        uint32_t nc = 0, spread = 0;
+        void *d_arena = nullptr;
+        uint32_t seq = 0;
+        uint64_t launches = 0, served = 0;
+        void post(const uint8_t *q, uint32_t plen);      // next sequence number, query (or kResidentStop) into the mailbox
+    } resident;
+    static constexpr size_t kResidentMailboxOff = 24576;   // inside the first 32 KiB of the arena (search.hip, SM_OFF_*)
+    int ensure_resident();               // stream + arena, once
+    void stop_resident();                // tells a running kernel to leave and waits for it (cheap when none runs)
     // Which initial sort the last build on this device took, and for what kind of text (the byte values present, the
     // size class): consecutive chunks of one corpus take the same one, so the next build skips the sizing sample that
     // would only say so again (sa_build.hip; a wrong guess is caught by the sorts' own exact checks and costs one restart).

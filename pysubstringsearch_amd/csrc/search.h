@@ -52,7 +52,7 @@ enum SearchMode {
 
 int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, uint32_t nc, const uint8_t *qbytes,
                         const uint64_t *qoffsets, uint32_t nq, HostResult *res, pss_search_stats *st,
-                        SearchMode mode = SEARCH_FULL);
+                        SearchMode mode = SEARCH_FULL, bool low_latency = false);
 
 // Merge of `world` packed results of the same nq queries, all resident on ctx's device, into one (query-major,
 // rank-major inside a query -- pss_merge_packed's order) on the same device.  starts[r] = entry starts (no closing

@@ -695,7 +695,8 @@ constexpr u32 SM_BYTE_CAP = 8u << 20;
 constexpr u32 SM_MAX_PLEN = 256;       // longest query the path takes (kept in LDS)
 
 struct SmallHeader {   // device memory; all zero between launches (the last wave to finish resets it)
-    u32 ent_cursor, byte_cursor, done, pad;
+    u32 ent_cursor, byte_cursor, done;
+    u32 leave;          // resident kernel: its first workgroup tells the others to leave
 };
 struct SmallRecord {
     u32 ent_start, ent_count;
@@ -706,11 +707,16 @@ struct SmallEntry {
 // layout of the pinned scratch (DeviceCtx::pinned) on this path
 constexpr size_t SM_OFF_FLAGS = 0;                                              // u32 overflow
 constexpr size_t SM_OFF_REC = 64;                                               // 2048 records (one per pair, or per (pair, sub-block))
+constexpr size_t SM_OFF_MAILBOX = DeviceCtx::kResidentMailboxOff;               // resident kernel only: ResidentMailbox
 constexpr size_t SM_OFF_QUERY = 32768;                                          // query bytes, then offsets at + 8192
 constexpr size_t SM_OFF_BYTES = 65536;                                          // first SM_BYTE_PREFIX result bytes
 constexpr size_t SM_OFF_ENT = SM_OFF_BYTES + SM_BYTE_PREFIX;                    // entry table
 static_assert(SM_OFF_REC + 2048 * sizeof(SmallRecord) <= SM_OFF_QUERY && SM_MAX_VQ <= 2048, "records must fit below the query staging");
 static_assert(SM_OFF_QUERY + 16384 <= SM_OFF_BYTES, "query staging must fit below the result prefix");
+static_assert(SM_OFF_REC + 2048 * sizeof(SmallRecord) <= SM_OFF_MAILBOX && SM_OFF_MAILBOX + sizeof(ResidentMailbox) <= SM_OFF_QUERY,
+              "the mailbox sits between the records and the query staging");
+static_assert(sizeof(ResidentMailbox::query) >= SM_MAX_PLEN + 32 && offsetof(ResidentMailbox, query) % 8 == 0,
+              "the mailbox holds the longest query of the path, padded");
 static_assert(SM_OFF_ENT + SM_ENT_CAP * sizeof(SmallEntry) <= DeviceCtx::kPinnedBytes, "entry table must fit the pinned scratch");
 
 __device__ __forceinline__ void small_pair(const ChunkDesc &ch, const u8 *pat, u32 plen, u32 vq, SmallHeader *hdr,
@@ -824,31 +830,20 @@ constexpr u32 SM_BLOCK_MAX_HITS = 1024;
 constexpr u32 SM_SPREAD = 32;
 constexpr u32 SM_MAX_REC = SM_BLOCK_MAX_VQ * SM_SPREAD;          // 2048 records
 
-__global__ __launch_bounds__(SM_BLOCK) void search_block_kernel(const ChunkDesc *chunks, u32 nc, const u8 *qbytes,
-                                                                  const u64 *qoff, u32 nvq, SmallHeader *hdr,
-                                                                  u32 *h_overflow, SmallRecord *rec, SmallEntry *ent,
-                                                                  u8 *bytes, u8 *hbytes, u32 spread)
+// One (pair, sub-block) of the block path: the query (plen bytes at qsrc, host memory) against chunk ch, hits
+// [1024 sub, 1024 (sub + 1)) of its interval into record ri.
+// Returns true when the workgroup wrote result bytes beyond the prefix that also goes to pinned host memory (they are
+// only in the device arena then).
+__device__ __forceinline__ bool block_pair(const ChunkDesc ch, const u8 *s_pat /* LDS, zero padded, visible */, u32 plen, u32 sub,
+                                           u32 ri, u32 spread, SmallHeader *hdr, u32 *h_overflow, SmallRecord *rec,
+                                           SmallEntry *ent, u8 *bytes, u8 *hbytes)
 {
     __shared__ u32 s_ls[SM_BLOCK_MAX_HITS];
     __shared__ u32 s_ll[SM_BLOCK_MAX_HITS];
-    __shared__ __attribute__((aligned(8))) u8 s_pat[SM_MAX_PLEN + 32];
     __shared__ u32 s_L, s_cnt, s_e0, s_b0;
     __shared__ u32 s_we[SM_BLOCK / kWave], s_wb[SM_BLOCK / kWave];
-    const u32 vq = blockIdx.x / spread, sub = blockIdx.x % spread;
     const u32 tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-    const u32 q = vq / nc, c = vq % nc;
-    const ChunkDesc ch = chunks[c];
-    const u64 o0 = qoff[q];
-    const u32 plen = (u32)(qoff[q + 1] - o0);
-    for (u32 i = tid * 8; i < SM_MAX_PLEN + 32; i += SM_BLOCK * 8) {
-        u64 v = 0;
-        if (i < plen) {
-            v = load_u64_unaligned(qbytes + o0 + i);
-            if (plen - i < 8) v &= (1ull << (8 * (plen - i))) - 1ull;
-        }
-        *reinterpret_cast<u64 *>(s_pat + i) = v;
-    }
-    __syncthreads();
+    bool beyond = false;
     const u8 *pat = s_pat;
     if (wave == 0) {
         u32 w0, w1;
@@ -865,7 +860,6 @@ __global__ __launch_bounds__(SM_BLOCK) void search_block_kernel(const ChunkDesc 
     const u32 first = sub * SM_BLOCK_MAX_HITS;                 // this workgroup's slice of the interval
     const u32 L = s_L + first;
     const u32 cnt = total > first ? min(total - first, SM_BLOCK_MAX_HITS) : 0u;
-    const u32 ri = blockIdx.x;                                  // record of (pair, sub-block)
     static_assert(SM_MAX_REC <= 2048, "one record per (pair, sub-block)");
     if (total > spread * SM_BLOCK_MAX_HITS) {
         if (tid == 0) *h_overflow = 1;
@@ -918,6 +912,7 @@ __global__ __launch_bounds__(SM_BLOCK) void search_block_kernel(const ChunkDesc 
         __syncthreads();
         const u32 e0 = s_e0, b0 = s_b0;
         if (e0 + n_ent <= SM_ENT_CAP && b0 + n_bytes <= SM_BYTE_CAP) {
+            beyond = b0 + n_bytes > SM_BYTE_PREFIX;
             // pass 2: pack
             u32 e = e0 + e_before, o = b0 + b_before;
             for (u32 j = j0; j < j1; ++j) {
@@ -929,10 +924,178 @@ __global__ __launch_bounds__(SM_BLOCK) void search_block_kernel(const ChunkDesc 
             }
         }
     }
-    if (tid == 0 && atomicAdd(&hdr->done, 1u) == nvq * spread - 1) {
+    return beyond;
+}
+
+__global__ __launch_bounds__(SM_BLOCK) void search_block_kernel(const ChunkDesc *chunks, u32 nc, const u8 *qbytes,
+                                                                  const u64 *qoff, u32 nvq, SmallHeader *hdr,
+                                                                  u32 *h_overflow, SmallRecord *rec, SmallEntry *ent,
+                                                                  u8 *bytes, u8 *hbytes, u32 spread)
+{
+    __shared__ __attribute__((aligned(8))) u8 s_pat[SM_MAX_PLEN + 32];
+    const u32 vq = blockIdx.x / spread, sub = blockIdx.x % spread;
+    const u32 q = vq / nc, c = vq % nc;
+    const u64 o0 = qoff[q];
+    const u32 plen = (u32)(qoff[q + 1] - o0);
+    for (u32 i = threadIdx.x * 8; i < SM_MAX_PLEN + 32; i += SM_BLOCK * 8) {
+        u64 v = 0;
+        if (i < plen) {
+            v = load_u64_unaligned(qbytes + o0 + i);
+            if (plen - i < 8) v &= (1ull << (8 * (plen - i))) - 1ull;
+        }
+        *reinterpret_cast<u64 *>(s_pat + i) = v;
+    }
+    __syncthreads();
+    block_pair(chunks[c], s_pat, plen, sub, blockIdx.x, spread, hdr, h_overflow, rec, ent, bytes, hbytes);
+    if (threadIdx.x == 0 && atomicAdd(&hdr->done, 1u) == nvq * spread - 1) {
         hdr->ent_cursor = 0;
         hdr->byte_cursor = 0;
         hdr->done = 0;
+    }
+}
+
+// ---- resident variant (low-latency mode of a reader) ----
+// The launch and the completion of a kernel are ~10 of the ~22 us a single query costs on the path above; a word in
+// pinned memory makes the round trip host -> running kernel -> host in 1.6 us on the same machine.  This kernel stays:
+// workgroup (chunk, sub-block) waits for a query in the mailbox (fine-grained pinned host memory, common.h), answers
+// it exactly as search_block_kernel does, and the last workgroup to finish writes the query's sequence number back --
+// the host spins on that word instead of launching and synchronising.  It is a LEASE, not a daemon: the first
+// workgroup watches the device's wall clock and makes everyone leave after idle_ticks without a query or life_ticks
+// in any case (a crashed host, or a device-wide synchronisation somewhere else in the process, waits for no longer
+// than that); `leave` in the header tells the other workgroups.  Leaving races with a query being posted: the first
+// workgroup announces `closing`, looks at the mailbox once more and only then writes `exited`; a host that sees
+// `exited` without its sequence number takes the query elsewhere (resident_query).
+// Memory: every access to the mailbox is a system-scope atomic (uncached, no fence: a system-scope fence writes back
+// and invalidates L2, ~4 us each here); results go to fine-grained host memory with ordinary stores, which are
+// write-through there, and the sequence number follows once every wave has seen its stores acknowledged
+// (s_waitcnt vmcnt(0)).  Result bytes beyond the pinned prefix stay in the device arena for a copy engine to fetch:
+// only a workgroup that wrote some pays for the write-back.
+__device__ __forceinline__ u32 sys_load(const volatile u32 *p)
+{
+    return __hip_atomic_load(const_cast<const u32 *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ u64 sys_load64(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void sys_store(volatile u32 *p, u32 v)
+{
+    __hip_atomic_store(const_cast<u32 *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// (The header lives in ordinary device memory, which the eight L2s only agree on between kernels: inside this one the
+// cursors are moved by device-scope atomics, so they are also RESET by device-scope stores -- a plain store would sit
+// in one XCD's L2 while the other workgroups' atomics keep counting from the old value.)
+__device__ __forceinline__ void dev_store(u32 *p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stores_done() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+
+__global__ __launch_bounds__(SM_BLOCK) void search_resident_kernel(const ChunkDesc *chunks, u32 nc, SmallHeader *hdr,
+                                                                     u32 *h_overflow, SmallRecord *rec, SmallEntry *ent,
+                                                                     u8 *bytes, u8 *hbytes, u32 spread, ResidentMailbox *mb,
+                                                                     u32 seen, u64 idle_ticks, u64 life_ticks)
+{
+    __shared__ __attribute__((aligned(8))) u8 s_pat[SM_MAX_PLEN + 32];
+    __shared__ u32 s_seq, s_plen, s_leave;
+    const u32 c = blockIdx.x / spread, sub = blockIdx.x % spread;
+    const u32 tid = threadIdx.x;
+    const bool first = blockIdx.x == 0;
+    const ChunkDesc ch = chunks[c];          // (every change of the reader's chunks stops this kernel first)
+    const u64 *line = reinterpret_cast<const u64 *>(&mb->post);
+    const u64 t_start = wall_clock64();
+    u64 t_last = t_start;
+    for (;;) {
+        if (tid < kWave) {
+            // wave 0 polls the posted line: lanes 0 .. 7 read its eight words with one load
+            u32 leave = 0, seq = seen, plen = 0;
+            u64 w = 0;
+            for (;;) {
+                if (tid < 8) w = sys_load64(line + tid);
+                const u32 seq_a = (u32)__shfl(w, 0), seq_b = (u32)(__shfl(w, 7) >> 32);
+                plen = (u32)(__shfl(w, 0) >> 32);
+                if (seq_a != seen && seq_a == seq_b) {
+                    seq = seq_a;
+                    break;
+                }
+                if (first) {
+                    const u64 now = wall_clock64();
+                    if (now - t_last > idle_ticks || now - t_start > life_ticks) {
+                        if (tid == 0) sys_store(&mb->closing, 1u);
+                        stores_done();
+                        if (tid < 8) w = sys_load64(line + tid);
+                        const u32 a2 = (u32)__shfl(w, 0), b2 = (u32)(__shfl(w, 7) >> 32);
+                        plen = (u32)(__shfl(w, 0) >> 32);
+                        if (a2 != seen && a2 == b2) {       // a query came in while the lease ran out: answer it first
+                            if (tid == 0) sys_store(&mb->closing, 0u);
+                            seq = a2;
+                            break;
+                        }
+                        leave = 1;
+                        break;
+                    }
+                } else if (__hip_atomic_load(&hdr->leave, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) {
+                    leave = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (!leave && plen == kResidentStop) leave = 1;            // (told to)
+            // (an add, not a store: told to leave by the host, the others may have counted themselves out already)
+            if (leave && first && tid == 0) __hip_atomic_fetch_add(&hdr->leave, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (!leave) {
+                plen = min(plen, SM_MAX_PLEN);
+                if (plen <= sizeof mb->post.bytes) {
+                    // bytes 8 .. 59 of the line: lane k holds bytes 8 k .. 8 k + 7
+                    if (tid >= 1 && tid < 8) {
+                        u64 v = w;
+                        if (tid == 7) v &= 0xffffffffull;
+                        *reinterpret_cast<u64 *>(s_pat + 8 * (tid - 1)) = v;
+                    }
+                } else {
+                    const u64 *src = reinterpret_cast<const u64 *>(mb->query);
+                    for (u32 i = tid; i < (SM_MAX_PLEN + 32) / 8; i += kWave) *reinterpret_cast<u64 *>(s_pat + 8 * i) = sys_load64(src + i);
+                }
+            }
+            if (tid == 0) {
+                s_seq = seq;
+                s_plen = plen;
+                s_leave = leave;
+            }
+        }
+        __syncthreads();
+        if (s_leave) break;
+        const u32 seq = s_seq, plen = s_plen;
+        seen = seq;
+        if (tid >= plen && tid < SM_MAX_PLEN + 32) s_pat[tid] = 0;     // zero padding behind the query
+        __syncthreads();
+        const bool beyond = block_pair(ch, s_pat, plen, sub, blockIdx.x, spread, hdr, h_overflow, rec, ent, bytes, hbytes);
+        (void)beyond;
+        stores_done();
+        __syncthreads();
+        // every wave's stores have reached L2; one wave writes the workgroup's XCD L2 back (results in pinned memory are
+        // ordinary stores and stay there otherwise) -- a write-back per wave costs 4 us, one per workgroup ~1
+        if (tid < kWave) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        if (tid == 0 && atomicAdd(&hdr->done, 1u) == nc * spread - 1) {
+            dev_store(&hdr->ent_cursor, 0u);
+            dev_store(&hdr->byte_cursor, 0u);
+            dev_store(&hdr->done, 0u);
+            stores_done();
+            sys_store(&mb->done_seq, seq);
+        }
+        t_last = wall_clock64();
+    }
+    // Every workgroup is leaving (`leave` counts them: 1 from the first, + 1 per other); the first one says so to the
+    // host once nobody can touch the arena any more, and leaves the header zero.  (A workgroup that saw a query the
+    // first one did not may have answered its part alone on the way out: the cursors it moved are reset here, the
+    // host sees `exited` without that query's sequence number and takes it elsewhere.)
+    if (tid == 0) {
+        if (!first) {
+            __hip_atomic_fetch_add(&hdr->leave, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (__hip_atomic_load(&hdr->leave, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != nc * spread)
+                __builtin_amdgcn_s_sleep(8);
+            dev_store(&hdr->ent_cursor, 0u);
+            dev_store(&hdr->byte_cursor, 0u);
+            dev_store(&hdr->done, 0u);
+            dev_store(&hdr->leave, 0u);
+            stores_done();
+            sys_store(&mb->exited, 1u);
+        }
     }
 }
 
@@ -968,6 +1131,10 @@ __global__ __launch_bounds__(256) void query_counts_kernel(u32 nc, u32 nq, const
 
 // --------------------------------------------------------------------- host --
 
+// device arena of the small paths: header of the launch path, result bytes (shared: the paths never run a query at the
+// same time), header of the resident kernel
+constexpr size_t SM_ARENA_RHDR = 64 + (size_t)SM_BYTE_CAP + 64;
+constexpr size_t SM_ARENA_BYTES = SM_ARENA_RHDR + 64;
 enum SSlot { Q_BYTES = 10, Q_OFF, Q_LO, Q_CNT, Q_HITOFF, Q_START, Q_LEN, Q_EIDX, Q_BOFF, Q_ENTOFF, Q_OUT, Q_SMALL, Q_QCOUNT, Q_ARENA = 28 };
 
 void HostResult::release()
@@ -1002,8 +1169,146 @@ static int alloc_result(HostResult *res, u64 E, u64 B, bool allow_pinned)
     return (res->offsets && res->bytes) ? PSS_OK : PSS_ENOMEM;
 }
 
+// The packed result of one small-path launch from what the kernel left in the pinned arena (records, entry table,
+// the first SM_BYTE_PREFIX result bytes) and, beyond that prefix, in the device arena.
+static int small_collect(DeviceCtx *ctx, const u8 *h_arena, const u8 *d_bytes, u64 nrec, u32 spread, u32 nc, HostResult *res,
+                         pss_search_stats *st)
+{
+    const SearchKnobs &knobs = search_knobs();
+    hipStream_t s = ctx->stream;
+    const SmallRecord *h_rec = reinterpret_cast<const SmallRecord *>(h_arena + SM_OFF_REC);
+    const SmallEntry *h_ent = reinterpret_cast<const SmallEntry *>(h_arena + SM_OFF_ENT);
+    u64 E = 0, B = 0;
+    for (u64 ri = 0; ri < nrec; ++ri) {
+        const SmallRecord r = h_rec[ri];
+        E += r.ent_count;
+        for (u32 k = 0; k < r.ent_count; ++k) B += h_ent[r.ent_start + k].len;
+    }
+    std::vector<u8> h_more;
+    const u8 *h_bytes = h_arena + SM_OFF_BYTES;
+    if (B > SM_BYTE_PREFIX) {
+        // the rest comes from the device arena with one copy: through the pinned staging when it fits
+        u8 *dst = nullptr;
+        if (B <= DeviceCtx::kStageR && !knobs.no_search_stage && ctx->ensure_search_stage() == PSS_OK) {
+            dst = static_cast<u8 *>(ctx->search_stage) + DeviceCtx::kStageQ;
+        } else {
+            h_more.resize(B);
+            dst = h_more.data();
+        }
+        PSS_HIP(hipMemcpyAsync(dst, d_bytes, B, hipMemcpyDeviceToHost, s));
+        PSS_HIP(hipStreamSynchronize(s));
+        h_bytes = dst;
+    }
+    PSS_TRY(alloc_result(res, E, B, false));
+    u64 e_out = 0, b_out = 0;
+    for (u64 ri = 0; ri < nrec; ++ri) {       // pairs in (query, chunk) order, sub-blocks in interval order
+        const SmallRecord r = h_rec[ri];
+        res->qcount[(ri / spread) / nc] += r.ent_count;
+        for (u32 k = 0; k < r.ent_count; ++k) {
+            const SmallEntry en = h_ent[r.ent_start + k];
+            res->offsets[e_out++] = b_out;
+            memcpy(res->bytes + b_out, h_bytes + en.byte_off, en.len);
+            b_out += en.len;
+        }
+    }
+    res->offsets[e_out] = b_out;
+    res->n_entries = e_out;
+    res->n_bytes = b_out;
+    st->entries = e_out;
+    st->result_bytes = b_out;
+    st->hits = e_out;   // hits before dedupe are not counted on this path
+    return PSS_OK;
+}
+
+// One query through the resident kernel (low-latency mode): start it if none is running for this chunk table, post the
+// query in the mailbox, spin on the answer.  *served = false: the kernel left without answering (its lease ran out as
+// the query came in) or the result does not fit the path -- the caller goes on as if this mode did not exist.
+static int resident_query(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const u8 *q, u32 plen, HostResult *res,
+                          pss_search_stats *st, bool *served)
+{
+    *served = false;
+    const SearchKnobs &knobs = search_knobs();
+    PSS_TRY(ctx->ensure_resident());
+    PSS_TRY(ctx->slot[Q_ARENA].reserve(SM_ARENA_BYTES));
+    u8 *arena = ctx->slot[Q_ARENA].as<u8>();
+    DeviceCtx::Resident &R = ctx->resident;
+    u8 *h_arena = static_cast<u8 *>(R.arena);
+    u8 *v_arena = static_cast<u8 *>(R.arena_dev);
+    ResidentMailbox *mb = reinterpret_cast<ResidentMailbox *>(h_arena + SM_OFF_MAILBOX);
+    volatile u32 *h_overflow = reinterpret_cast<volatile u32 *>(h_arena + SM_OFF_FLAGS);
+    // workgroups per chunk: every one of them spins while the kernel stays, so fewer than on the launch path
+    // (up to 4096 hits of a chunk on one chunk, 1024 on fifteen; more than that goes to the launch path)
+    u32 spread = 1;
+    while (spread < 4 && nc * spread * 2 <= 16) spread *= 2;
+    static u64 ticks_per_us = 0;
+    if (ticks_per_us == 0) {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) khz = 100000;
+        ticks_per_us = std::max<u64>(1, (u64)khz / 1000);
+    }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (R.running && (R.chunks != d_chunks || R.nc != nc || R.spread != spread || R.d_arena != arena)) ctx->stop_resident();
+        if (R.running && __atomic_load_n(&mb->exited, __ATOMIC_ACQUIRE)) {
+            PSS_HIP(hipStreamSynchronize(R.stream));
+            R.running = false;
+        }
+        if (!R.running) {
+            mb->exited = 0;
+            mb->closing = 0;
+            __atomic_thread_fence(__ATOMIC_SEQ_CST);
+            SmallHeader *d_hdr = reinterpret_cast<SmallHeader *>(arena + SM_ARENA_RHDR);
+            PSS_HIP(hipMemsetAsync(d_hdr, 0, 64, R.stream));
+            hipLaunchKernelGGL(search_resident_kernel, dim3(nc * spread), dim3(SM_BLOCK), 0, R.stream, d_chunks, nc, d_hdr,
+                               reinterpret_cast<u32 *>(v_arena + SM_OFF_FLAGS),
+                               reinterpret_cast<SmallRecord *>(v_arena + SM_OFF_REC),
+                               reinterpret_cast<SmallEntry *>(v_arena + SM_OFF_ENT), arena + 64, v_arena + SM_OFF_BYTES, spread,
+                               reinterpret_cast<ResidentMailbox *>(v_arena + SM_OFF_MAILBOX), R.seq,
+                               (u64)knobs.resident_idle_us * ticks_per_us, (u64)knobs.resident_life_us * ticks_per_us);
+            PSS_HIP(hipGetLastError());
+            R.running = true;
+            R.chunks = d_chunks;
+            R.nc = nc;
+            R.spread = spread;
+            R.d_arena = arena;
+            ++R.launches;
+        }
+        *h_overflow = 0;
+        R.post(q, plen);
+        const u32 seq = R.seq;
+        bool answered = false;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (u32 spins = 0;; ++spins) {
+            if (__atomic_load_n(&mb->done_seq, __ATOMIC_ACQUIRE) == seq) {
+                answered = true;
+                break;
+            }
+            if (__atomic_load_n(&mb->exited, __ATOMIC_ACQUIRE)) {
+                answered = __atomic_load_n(&mb->done_seq, __ATOMIC_ACQUIRE) == seq;   // (written before `exited`)
+                break;
+            }
+            __builtin_ia32_pause();
+            if ((spins & 0xfffu) == 0xfffu &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) {
+                ctx->stop_resident();
+                set_error("the resident search kernel did not answer within 5 s");
+                return PSS_EDEVICE;
+            }
+        }
+        if (answered) {
+            ++R.served;
+            if (*h_overflow) return PSS_OK;      // too many hits for this path: the launch path and its fallbacks take it
+            PSS_TRY(small_collect(ctx, h_arena, arena + 64, (u64)nc * spread, spread, nc, res, st));
+            *served = true;
+            return PSS_OK;
+        }
+        PSS_HIP(hipStreamSynchronize(R.stream));     // it left without this query: once more with a fresh one
+        R.running = false;
+    }
+    return PSS_OK;
+}
+
 int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const uint8_t *qbytes,
-                        const uint64_t *qoffsets, uint32_t nq, HostResult *res, pss_search_stats *st, SearchMode mode)
+                        const uint64_t *qoffsets, uint32_t nq, HostResult *res, pss_search_stats *st, SearchMode mode, bool low_latency)
 {
     const bool counts_only = mode == SEARCH_COUNTS;
     const bool device_only = mode == SEARCH_DEVICE;
@@ -1065,7 +1370,17 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
     const u64 waves_per_block = 256 / kWave;
     if (small) {
         // ---- fused small-batch path: one kernel, queries and results through pinned host memory ----
-        PSS_TRY(ctx->slot[Q_ARENA].reserve(64 + SM_BYTE_CAP + 64));
+        if (low_latency && nq == 1 && nvq <= SM_BLOCK_MAX_VQ && !knobs.no_block_path) {
+            // a reader in low-latency mode: the resident kernel answers without a launch (or declines)
+            bool served = false;
+            PSS_TRY(resident_query(ctx, d_chunks, nc, qbytes + qoffsets[0], (u32)(qoffsets[1] - qoffsets[0]), res, st, &served));
+            if (served) {
+                st->ms_host = host_ms();
+                return PSS_OK;
+            }
+            for (u32 i = 0; i < nq; ++i) res->qcount[i] = 0;
+        }
+        PSS_TRY(ctx->slot[Q_ARENA].reserve(SM_ARENA_BYTES));
         u8 *arena = ctx->slot[Q_ARENA].as<u8>();
         SmallHeader *d_hdr = reinterpret_cast<SmallHeader *>(arena);
         u8 *d_bytes = arena + 64;
@@ -1104,47 +1419,7 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
         if (timed) PSS_HIP(hipEventRecord(e2, s));
         PSS_HIP(hipStreamSynchronize(s));
         if (!*h_overflow) {
-            const SmallRecord *h_rec = reinterpret_cast<const SmallRecord *>(h_arena + SM_OFF_REC);
-            const SmallEntry *h_ent = reinterpret_cast<const SmallEntry *>(h_arena + SM_OFF_ENT);
-            u64 E = 0, B = 0;
-            for (u64 ri = 0; ri < nvq * spread; ++ri) {
-                const SmallRecord r = h_rec[ri];
-                E += r.ent_count;
-                for (u32 k = 0; k < r.ent_count; ++k) B += h_ent[r.ent_start + k].len;
-            }
-            std::vector<u8> h_more;
-            const u8 *h_bytes = h_arena + SM_OFF_BYTES;
-            if (B > SM_BYTE_PREFIX) {
-                // the rest comes from the device arena with one copy: through the pinned staging when it fits
-                u8 *dst = nullptr;
-                if (B <= DeviceCtx::kStageR && !knobs.no_search_stage && ctx->ensure_search_stage() == PSS_OK) {
-                    dst = static_cast<u8 *>(ctx->search_stage) + DeviceCtx::kStageQ;
-                } else {
-                    h_more.resize(B);
-                    dst = h_more.data();
-                }
-                PSS_HIP(hipMemcpyAsync(dst, d_bytes, B, hipMemcpyDeviceToHost, s));
-                PSS_HIP(hipStreamSynchronize(s));
-                h_bytes = dst;
-            }
-            PSS_TRY(alloc_result(res, E, B, false));
-            u64 e_out = 0, b_out = 0;
-            for (u64 ri = 0; ri < nvq * spread; ++ri) {       // pairs in (query, chunk) order, sub-blocks in interval order
-                const SmallRecord r = h_rec[ri];
-                res->qcount[(ri / spread) / nc] += r.ent_count;
-                for (u32 k = 0; k < r.ent_count; ++k) {
-                    const SmallEntry en = h_ent[r.ent_start + k];
-                    res->offsets[e_out++] = b_out;
-                    memcpy(res->bytes + b_out, h_bytes + en.byte_off, en.len);
-                    b_out += en.len;
-                }
-            }
-            res->offsets[e_out] = b_out;
-            res->n_entries = e_out;
-            res->n_bytes = b_out;
-            st->entries = e_out;
-            st->result_bytes = b_out;
-            st->hits = e_out;   // hits before dedupe are not counted on this path
+            PSS_TRY(small_collect(ctx, h_arena, d_bytes, nvq * spread, spread, nc, res, st));
             float ms = 0.f;
             if (timed) PSS_HIP(hipEventElapsedTime(&ms, e0, e2));
             st->ms_device = ms;

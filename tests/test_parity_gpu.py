@@ -534,6 +534,74 @@ def test_evict_and_promote_chunks(tmp_path, oracle):
                 r.evict(10 ** 6)
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('chunk', [1 << 16, 1 << 20])
+def test_low_latency_mode_matches_the_launch_path(tmp_path, oracle, monkeypatch, chunk):
+    """Reader.set_low_latency(): single queries go through the resident search kernel (a mailbox in pinned memory, no
+    launch per query).  Same results as the oracle for misses, single hits, hundreds of hits and queries with more hits
+    than the resident path holds (those fall back to the launch path); the kernel's lease runs out between bursts and a
+    new one starts; changing the reader's chunks (evict) and switching the mode off stop it; batches do not use it."""
+    import time
+    from pysubstringsearch_amd import _ffi
+    from tests.util import gen_corpus
+    monkeypatch.setenv('PSS_RESIDENT_IDLE_US', '2000')
+    _ffi.lib.pss_reload_env()
+    try:
+        src = tmp_path / 'c.txt'
+        src.write_bytes(gen_corpus(1, 1 << 20).tobytes())
+        p = str(tmp_path / 'c.idx')
+        w = pysubstringsearch.Writer(p, chunk)
+        w.add_entries_from_file_lines(str(src))
+        w.close()
+        text = src.read_bytes()
+        rng = np.random.default_rng(11)
+        qs = [text[s:s + int(k)] for s, k in zip(rng.integers(0, len(text) - 40, 120), rng.integers(1, 24, 120))]
+        qs = [q for q in qs if b'\n' not in q and q]
+        qs += [b'zzzzzzzzqq', b'e', b' ', text[100:103]]            # a miss; thousands of hits (beyond the resident path)
+        o = oracle.OracleReader(p)
+        want = [sorted(o.search_multiple_bytes([q])[0]) for q in qs]
+        with pysubstringsearch.Reader(p) as r:
+            plain = [sorted(r.search_batch_raw([q])[0]) for q in qs]
+            assert plain == want
+            r.set_low_latency(True)
+            s0 = r.low_latency_stats()
+            got = [sorted(r.search_batch_raw([q])[0]) for q in qs]
+            assert got == want
+            s1 = r.low_latency_stats()
+            assert s1['queries_served'] - s0['queries_served'] >= len(qs) - 8 and s1['kernels_started'] > s0['kernels_started']
+            # the lease: after a pause the kernel is gone, the next query starts another
+            time.sleep(0.05)
+            assert sorted(r.search_batch_raw([qs[0]])[0]) == want[0]
+            s2 = r.low_latency_stats()
+            assert s2['kernels_started'] == s1['kernels_started'] + 1
+            # a burst (of queries with few results: nothing here takes the milliseconds of the lease) stays on one kernel
+            few = [i for i in range(len(qs)) if len(want[i]) <= 5][:7]
+            assert len(few) == 7
+            for i in range(50):
+                assert sorted(r.search_batch_raw([qs[few[i % 7]]])[0]) == want[few[i % 7]]
+            s3 = r.low_latency_stats()
+            assert s3['queries_served'] == s2['queries_served'] + 50 and s3['kernels_started'] <= s2['kernels_started'] + 2
+            # batches keep to the ordinary path
+            ents, counts = r.search_batch_raw(qs[:20])
+            assert counts == [len(x) for x in want[:20]] and r.low_latency_stats()['queries_served'] == s3['queries_served']
+            # moving a chunk's suffix array restarts the kernel on the new table
+            r.evict(0)
+            assert sorted(r.search_batch_raw([qs[1]])[0]) == want[1]
+            r.promote(0)
+            assert sorted(r.search_batch_raw([qs[2]])[0]) == want[2]
+            assert r.search('zzzzzzzzqq') == []
+            r.set_low_latency(False)
+            s4 = r.low_latency_stats()
+            assert sorted(r.search_batch_raw([qs[4]])[0]) == want[4]
+            assert r.low_latency_stats() == s4
+            r.set_low_latency(True)
+            assert sorted(r.search_batch_raw([qs[5]])[0]) == want[5]      # ... and the reader closes with a kernel waiting
+        o.close()
+    finally:
+        monkeypatch.delenv('PSS_RESIDENT_IDLE_US')
+        _ffi.lib.pss_reload_env()
+
+
 def test_container_format_2(tmp_path, oracle):
     """Opt-in container with 64-bit lengths (no reference counterpart): same chunks, same suffix
     arrays, same search results as the reference container of the same entries; the Reader tells the

@@ -16,6 +16,8 @@ for c in range(nchunks):
     dT = torch.from_numpy(host).cuda()
     _ffi.check(lib.pss_sa_build_device(dT.data_ptr(), dSA.data_ptr(), n, 0, 0, None))
     _ffi.check(lib.pss_reader_add_chunk_device(h, dT.data_ptr(), dSA.data_ptr(), n))
+if len(sys.argv) > 3 and sys.argv[3] == 'resident':
+    r.set_low_latency(True)       # single queries through the resident kernel (include/pss.h)
 hit = host[1000:1008].tobytes().replace(b'\n', b'a')
 for name, q in [('miss', 'zzzzqqqq'), ('hit8', host[5000:5008].tobytes().decode()), ('hit4 (many)', host[7000:7004].tobytes().decode())]:
     if '\n' in q: q = q.replace('\n', 'a')
@@ -24,4 +26,6 @@ for name, q in [('miss', 'zzzzqqqq'), ('hit8', host[5000:5008].tobytes().decode(
     for _ in range(300):
         t0 = time.perf_counter(); res = r.search(q); ts.append(time.perf_counter() - t0); ls = r.last_stats(); dev.append(ls['ms_device']); hst.append(ls['ms_host'])
     ts.sort(); dev.sort(); hst.sort()
+    if len(sys.argv) > 3 and sys.argv[3] == 'resident':
+        name += ' ' + str(r.low_latency_stats())
     print(f'{name:12s} results={len(res):6d}  wall median {ts[150]*1e6:7.1f} us  p90 {ts[270]*1e6:7.1f} us | inside the library {hst[150]*1e3:7.1f} us | device(events) median {dev[150]*1e3:7.1f} us')
