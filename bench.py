@@ -38,7 +38,8 @@
 
       value            batched queries/s through the list API (what search_multiple returns)
       packed_queries_per_sec   the same batch through the packed (numpy) result API
-      single_query_us  latency of Reader.search for one query over all chunks (N = 1)
+      single_query_us  latency of Reader.search for one query over all chunks (N = 1); .low_latency_mode: the same with
+                       Reader.set_low_latency() (resident search kernel, no launch per query)
       index_build_gbs  15 chunks / max over ranks of the summed build time
       cpu_baseline     SURVEY 8(d)(ii): the oracle's restatement of Reader::search, queries
                        one at a time, one thread per chunk, suffix arrays in RAM and -- like
@@ -698,6 +699,25 @@ def run_corpus(args, D, steps=None, warmup=None):
         ts.sort()
         lat = {'median': round(ts[len(ts) // 2] * 1e6, 1), 'p90': round(ts[int(len(ts) * 0.9)] * 1e6, 1),
                'queries_per_sec': round(len(ts) / sum(ts), 1)}
+        # the same queries with the reader in low-latency mode (resident search kernel, include/pss.h): same results?
+        want = [reader.search_batch_raw([q])[0] for q in queries[:200]]
+        reader.set_low_latency(True)
+        reader.search_batch_raw([queries[0]])
+        ts = []
+        for q in queries[:1000]:
+            t0 = time.perf_counter()
+            reader.search_batch_raw([q])
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        same = all(reader.search_batch_raw([q])[0] == w for q, w in zip(queries[:200], want))
+        ll = reader.low_latency_stats()
+        reader.set_low_latency(False)
+        lat['low_latency_mode'] = {'median': round(ts[len(ts) // 2] * 1e6, 1), 'p90': round(ts[int(len(ts) * 0.9)] * 1e6, 1),
+                                   'queries_per_sec': round(len(ts) / sum(ts), 1), 'same_results': bool(same),
+                                   'kernels_started': ll['kernels_started'], 'queries_served': ll['queries_served']}
+        if not same:
+            verified = False
+            how = 'low-latency mode returned different results'
 
     rc, out = 0, None
     if rank == 0:

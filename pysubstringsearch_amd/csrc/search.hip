@@ -126,6 +126,42 @@ __device__ __forceinline__ u32 wave_bound(const u8 *text, u32 n, const u32 *sa, 
     return lo;
 }
 
+// Both bounds of the query's interval inside [lo, hi) at once: a probe that says "smaller", "starts with the query" or
+// "larger" serves both searches, and while the two bounds sit in the same gap between probes (a query with no or few
+// hits: nearly always) one chain of dependent loads finds both -- half the round trips of two wave_bound calls.
+__device__ __forceinline__ void wave_bounds(const u8 *text, u32 n, const u32 *sa, const u8 *pat, u32 plen, u32 lo, u32 hi,
+                                            u32 &L, u32 &U)
+{
+    const u32 lane = lane_id();
+    const u64 pat0 = load_u64_unaligned(pat);
+    while (hi > lo) {
+        const u32 s = hi - lo;
+        if (s <= kWave) {
+            int c = 1;
+            if (lane < s) c = cmp_suffix(text, n, sa[lo + lane], pat, plen, pat0);
+            L = lo + (u32)__popcll(__ballot(c < 0));
+            U = lo + (u32)__popcll(__ballot(c <= 0));
+            return;
+        }
+        const u32 p = lo + (u32)(((u64)(lane + 1) * s) / (kWave + 1));
+        const int c = cmp_suffix(text, n, sa[p], pat, plen, pat0);
+        const u32 kl = (u32)__popcll(__ballot(c < 0)), ku = (u32)__popcll(__ballot(c <= 0));
+        const u32 l_lo = (kl == 0) ? lo : (u32)__shfl((int)p, (int)kl - 1) + 1;
+        const u32 u_hi = (ku == kWave) ? hi : (u32)__shfl((int)p, (int)ku);
+        if (kl == ku) {
+            lo = l_lo;
+            hi = u_hi;
+            continue;
+        }
+        // the bounds part: L in (p[kl - 1], p[kl]], U in (p[ku - 1], p[ku]]
+        const u32 l_hi = (u32)__shfl((int)p, (int)kl), u_lo = (u32)__shfl((int)p, (int)ku - 1) + 1;
+        L = wave_bound(text, n, sa, pat, plen, l_lo, l_hi, false);
+        U = wave_bound(text, n, sa, pat, plen, u_lo, u_hi, true);
+        return;
+    }
+    L = U = lo;
+}
+
 // ---- key samples: confine a query to a window of the suffix array -----------------------
 //
 // key8(i) = first 8 bytes of suffix sa[i], big-endian, zero padded past the end of the text, is
@@ -385,8 +421,8 @@ __global__ __launch_bounds__(256) void search_interval_kernel(const ChunkDesc *c
     const u32 plen = (u32)(qoff[q + 1] - qoff[q]);
     u32 w0, w1;
     sample_window_wave(ch, pat, plen, w0, w1);
-    const u32 L = wave_bound(ch.text, ch.n, ch.sa, pat, plen, w0, w1, false);
-    const u32 U = wave_bound(ch.text, ch.n, ch.sa, pat, plen, L, w1, true);
+    u32 L, U;
+    wave_bounds(ch.text, ch.n, ch.sa, pat, plen, w0, w1, L, U);
     if (lane_id() == 0) {
         lo_out[vq] = L;
         cnt_out[vq] = U - L;
@@ -512,6 +548,56 @@ __device__ __forceinline__ bool hit_entry(const ChunkDesc &ch, const u8 *pat, u3
     if (e >= ch.n) e = ch.n - 1;
     line_len = e >= line_start ? e - line_start : 0;
     return true;
+}
+
+// The entry around text offset di, bounds only (lib.rs:266-273): [start, start + len).  Whether the hit is the first
+// of its entry is the caller's business (block_pair settles that among the hits themselves).  Both 64-byte loads --
+// behind the hit and ahead of it -- are issued before either is looked at: one round trip for entries of < 64 bytes
+// on each side.
+__device__ __forceinline__ void entry_bounds(const ChunkDesc &ch, u32 di, u32 &line_start, u32 &line_len)
+{
+    const u64 NL = 0x0a0a0a0a0a0a0a0aull;
+    u64 fw[8], bw[8];
+    load_words64(ch.text + di, fw);
+    u32 p = di;
+    if (p >= 64) load_words64(ch.text + p - 64, bw);
+    for (;;) {
+        if (p < 64) {                                            // the first bytes of the chunk
+            while (p > 0 && ch.text[p - 1] != '\n') --p;
+            break;
+        }
+        bool found = false;
+#pragma unroll
+        for (int k = 7; k >= 0; --k) {
+            const u64 nlm = zero_bytes(bw[k] ^ NL);
+            if (nlm && !found) {
+                p = p - 64 + 8 * k + (u32)((63 - __builtin_clzll(nlm)) >> 3) + 1;
+                found = true;
+            }
+        }
+        if (found) break;
+        p -= 64;
+        if (p >= 64) load_words64(ch.text + p - 64, bw);
+    }
+    line_start = p;
+    u32 e = di;
+    for (;;) {
+        bool found = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const u64 nlm = zero_bytes(fw[k] ^ NL);
+            if (nlm && !found) {
+                e += 8 * k + (u32)(__builtin_ctzll(nlm) >> 3);
+                found = true;
+            }
+        }
+        if (found) break;
+        e += 64;
+        if (e >= ch.n) break;
+        load_words64(ch.text + e, fw);
+    }
+    if (e >= ch.n) e = ch.n - 1;
+    line_len = e >= line_start ? e - line_start : 0;
 }
 
 // Copies one entry (l bytes, unaligned on both sides) to dst and, when dst2 is given, to a second
@@ -701,6 +787,15 @@ struct SmallHeader {   // device memory; all zero between launches (the last wav
 struct SmallRecord {
     u32 ent_start, ent_count;
 };
+// Space for n_ent entries and n_bytes result bytes: both cursors move with ONE atomic (they share a 64-bit word), one
+// round trip to L2 instead of two in a row.
+__device__ __forceinline__ void small_take(SmallHeader *hdr, u32 n_ent, u32 n_bytes, u32 &e0, u32 &b0)
+{
+    static_assert(offsetof(SmallHeader, ent_cursor) == 0 && offsetof(SmallHeader, byte_cursor) == 4, "the cursors share a word");
+    const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(hdr), (unsigned long long)n_ent | ((unsigned long long)n_bytes << 32));
+    e0 = (u32)old;
+    b0 = (u32)(old >> 32);
+}
 struct SmallEntry {
     u32 byte_off, len;
 };
@@ -726,8 +821,8 @@ __device__ __forceinline__ void small_pair(const ChunkDesc &ch, const u8 *pat, u
     const u32 lane = lane_id();
     u32 w0, w1;
     sample_window_wave(ch, pat, plen, w0, w1);
-    const u32 L = wave_bound(ch.text, ch.n, ch.sa, pat, plen, w0, w1, false);
-    const u32 U = wave_bound(ch.text, ch.n, ch.sa, pat, plen, L, w1, true);
+    u32 L, U;
+    wave_bounds(ch.text, ch.n, ch.sa, pat, plen, w0, w1, L, U);
     const u32 cnt = U - L;
     if (cnt == 0) {
         if (lane == 0) rec[vq] = SmallRecord{0, 0};
@@ -753,8 +848,7 @@ __device__ __forceinline__ void small_pair(const ChunkDesc &ch, const u8 *pat, u
     n_bytes = __shfl(n_bytes, 63);
     u32 e0 = 0, b0 = 0;
     if (lane == 0) {
-        e0 = atomicAdd(&hdr->ent_cursor, n_ent);
-        b0 = atomicAdd(&hdr->byte_cursor, n_bytes);
+        small_take(hdr, n_ent, n_bytes, e0, b0);
         if (e0 + n_ent > SM_ENT_CAP || b0 + n_bytes > SM_BYTE_CAP) *h_overflow = 1;
         else rec[vq] = SmallRecord{e0, n_ent};
     }
@@ -828,11 +922,20 @@ constexpr u32 SM_BLOCK_MAX_HITS = 1024;
 // this one-kernel path instead of falling back to the multi-kernel pipeline.  The record of (pair, k)
 // holds its entries; read in (pair, k) order they are in suffix-array order.
 constexpr u32 SM_SPREAD = 32;
+constexpr u32 SM_STAGE_BYTES = 48 * 1024;     // LDS stage of a workgroup's result bytes
 constexpr u32 SM_MAX_REC = SM_BLOCK_MAX_VQ * SM_SPREAD;          // 2048 records
 
 // One (pair, sub-block) of the block path: the query (plen bytes at qsrc, host memory) against chunk ch, hits
 // [1024 sub, 1024 (sub + 1)) of its interval into record ri.
-// Returns true when the workgroup wrote result bytes beyond the prefix that also goes to pinned host memory (they are
+// (Records and the overflow flag go out as system-scope stores: the resident kernel, which does not end, then owes the
+// host a write-back of its L2 only when it produced entries.)
+__device__ __forceinline__ void put_record(SmallRecord *rec, u32 ent_start, u32 ent_count)
+{
+    __hip_atomic_store(reinterpret_cast<u64 *>(rec), (u64)ent_start | ((u64)ent_count << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void put_flag(u32 *flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// Returns true when the workgroup wrote entries (entry table and result bytes, ordinary stores) that also goes to pinned host memory (they are
 // only in the device arena then).
 __device__ __forceinline__ bool block_pair(const ChunkDesc ch, const u8 *s_pat /* LDS, zero padded, visible */, u32 plen, u32 sub,
                                            u32 ri, u32 spread, SmallHeader *hdr, u32 *h_overflow, SmallRecord *rec,
@@ -842,14 +945,23 @@ __device__ __forceinline__ bool block_pair(const ChunkDesc ch, const u8 *s_pat /
     __shared__ u32 s_ll[SM_BLOCK_MAX_HITS];
     __shared__ u32 s_L, s_cnt, s_e0, s_b0;
     __shared__ u32 s_we[SM_BLOCK / kWave], s_wb[SM_BLOCK / kWave];
+    // first hit (smallest text offset) of every entry among the hits of this pair: open-addressing table keyed by the
+    // entry's start, 2 slots per possible hit
+    constexpr u32 HS = 2 * SM_BLOCK_MAX_HITS;
+    __shared__ u32 s_hkey[HS], s_hmin[HS];
+    __shared__ __attribute__((aligned(16))) u8 s_stage[SM_STAGE_BYTES];
     const u32 tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-    bool beyond = false;
+    bool wrote = false;
     const u8 *pat = s_pat;
+    for (u32 i = tid; i < HS; i += SM_BLOCK) {
+        s_hkey[i] = 0;
+        s_hmin[i] = 0xffffffffu;
+    }
     if (wave == 0) {
         u32 w0, w1;
         sample_window_wave(ch, pat, plen, w0, w1);
-        const u32 L = wave_bound(ch.text, ch.n, ch.sa, pat, plen, w0, w1, false);
-        const u32 U = wave_bound(ch.text, ch.n, ch.sa, pat, plen, L, w1, true);
+        u32 L, U;
+        wave_bounds(ch.text, ch.n, ch.sa, pat, plen, w0, w1, L, U);
         if (lane == 0) {
             s_L = L;
             s_cnt = U - L;
@@ -862,16 +974,41 @@ __device__ __forceinline__ bool block_pair(const ChunkDesc ch, const u8 *s_pat /
     const u32 cnt = total > first ? min(total - first, SM_BLOCK_MAX_HITS) : 0u;
     static_assert(SM_MAX_REC <= 2048, "one record per (pair, sub-block)");
     if (total > spread * SM_BLOCK_MAX_HITS) {
-        if (tid == 0) *h_overflow = 1;
+        if (tid == 0) put_flag(h_overflow);
     } else if (cnt == 0) {
-        if (tid == 0) rec[ri] = SmallRecord{0, 0};
+        if (tid == 0) put_record(rec + ri, 0, 0);
     } else {
-        // pass 1: entry bounds of every hit, one hit per thread and round
-        for (u32 j = tid; j < cnt; j += SM_BLOCK) {
-            u32 ls = 0, ll = 0;
-            const bool keep = hit_entry(ch, pat, plen, ch.sa[L + j], ls, ll);
-            s_ls[j] = ls;
-            s_ll[j] = keep ? ll : kSkip;
+        // pass 1: entry bounds of every hit, one hit per thread
+        static_assert(SM_BLOCK_MAX_HITS == SM_BLOCK, "one hit per thread");
+        if (total <= SM_BLOCK_MAX_HITS) {
+            // This workgroup holds every hit of the pair, so "an earlier occurrence of the query in the same entry"
+            // (lib.rs:262,274: one result per entry) is a question about the hits themselves: the hit with the
+            // smallest text offset among those with the same entry start stays.  Scanning each entry for earlier
+            // occurrences instead (hit_entry) is what made 245 hits cost 16 us here: divergent candidate loops, a
+            // wave at the pace of the union of its lanes' paths.
+            u32 di = 0, ls = 0, ll = 0, slot = 0;
+            if (tid < cnt) {
+                di = ch.sa[L + tid];
+                entry_bounds(ch, di, ls, ll);
+                slot = (ls * 2654435761u) >> (32 - 11);
+                static_assert(HS == 2048, "11-bit hash");
+                for (;;) {
+                    const u32 old = atomicCAS(&s_hkey[slot], 0u, ls + 1u);
+                    if (old == 0u || old == ls + 1u) break;
+                    slot = (slot + 1) & (HS - 1);
+                }
+                atomicMin(&s_hmin[slot], di);
+                s_ls[tid] = ls;
+            }
+            __syncthreads();
+            if (tid < cnt) s_ll[tid] = (s_hmin[slot] == di) ? ll : kSkip;
+        } else {
+            for (u32 j = tid; j < cnt; j += SM_BLOCK) {
+                u32 ls = 0, ll = 0;
+                const bool keep = hit_entry(ch, pat, plen, ch.sa[L + j], ls, ll);
+                s_ls[j] = ls;
+                s_ll[j] = keep ? ll : kSkip;
+            }
         }
         __syncthreads();
         // entries / bytes before each thread's run of consecutive hits (suffix-array order)
@@ -902,29 +1039,51 @@ __device__ __forceinline__ bool block_pair(const ChunkDesc ch, const u8 *s_pat /
             n_bytes += s_wb[w];
         }
         if (tid == 0) {
-            const u32 e0 = atomicAdd(&hdr->ent_cursor, n_ent);
-            const u32 b0 = atomicAdd(&hdr->byte_cursor, n_bytes);
+            u32 e0, b0;
+            small_take(hdr, n_ent, n_bytes, e0, b0);
             s_e0 = e0;
             s_b0 = b0;
-            if (e0 + n_ent > SM_ENT_CAP || b0 + n_bytes > SM_BYTE_CAP) *h_overflow = 1;
-            else rec[ri] = SmallRecord{e0, n_ent};
+            if (e0 + n_ent > SM_ENT_CAP || b0 + n_bytes > SM_BYTE_CAP) put_flag(h_overflow);
+            else put_record(rec + ri, e0, n_ent);
         }
         __syncthreads();
         const u32 e0 = s_e0, b0 = s_b0;
         if (e0 + n_ent <= SM_ENT_CAP && b0 + n_bytes <= SM_BYTE_CAP) {
-            beyond = b0 + n_bytes > SM_BYTE_PREFIX;
-            // pass 2: pack
+            wrote = n_ent != 0;
+            // pass 2: pack.  When the workgroup's bytes fit the LDS stage, entries are assembled there (unaligned
+            // pieces, byte tails) and leave as one run of aligned 16-byte stores per destination; else entry by entry.
+            const bool staged = n_bytes <= SM_STAGE_BYTES - 16;
+            const u32 skew = b0 & 15u;                          // keeps stage and destinations 16-byte congruent
             u32 e = e0 + e_before, o = b0 + b_before;
             for (u32 j = j0; j < j1; ++j) {
                 const u32 ll = s_ll[j];
                 if (ll == kSkip) continue;
                 ent[e++] = SmallEntry{o, ll};
-                copy_entry(bytes + o, ch.text + s_ls[j], ll, o + ll <= SM_BYTE_PREFIX ? hbytes + o : nullptr);
+                if (staged) copy_entry(s_stage + skew + (o - b0), ch.text + s_ls[j], ll);
+                else copy_entry(bytes + o, ch.text + s_ls[j], ll, o + ll <= SM_BYTE_PREFIX ? hbytes + o : nullptr);
                 o += ll;
+            }
+            if (staged) {
+                __syncthreads();
+                const u32 end = skew + n_bytes;                  // stage bytes [skew, end) -> arena bytes [b0, b0 + n_bytes)
+                u8 *d0 = bytes + (b0 - skew), *d1 = hbytes + (b0 - skew);
+                const bool pinned_too = b0 + n_bytes <= SM_BYTE_PREFIX;   // (else the host takes everything from the device arena)
+                for (u32 at = tid * 16; at < end; at += SM_BLOCK * 16) {
+                    if (at >= skew && at + 16 <= end) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(s_stage + at);
+                        *reinterpret_cast<uint4 *>(d0 + at) = v;
+                        if (pinned_too) *reinterpret_cast<uint4 *>(d1 + at) = v;
+                    } else {
+                        for (u32 b = max(at, skew); b < min(at + 16, end); ++b) {
+                            d0[b] = s_stage[b];
+                            if (pinned_too) d1[b] = s_stage[b];
+                        }
+                    }
+                }
             }
         }
     }
-    return beyond;
+    return wrote;
 }
 
 __global__ __launch_bounds__(SM_BLOCK) void search_block_kernel(const ChunkDesc *chunks, u32 nc, const u8 *qbytes,
@@ -968,8 +1127,9 @@ __global__ __launch_bounds__(SM_BLOCK) void search_block_kernel(const ChunkDesc 
 // Memory: every access to the mailbox is a system-scope atomic (uncached, no fence: a system-scope fence writes back
 // and invalidates L2, ~4 us each here); results go to fine-grained host memory with ordinary stores, which are
 // write-through there, and the sequence number follows once every wave has seen its stores acknowledged
-// (s_waitcnt vmcnt(0)).  Result bytes beyond the pinned prefix stay in the device arena for a copy engine to fetch:
-// only a workgroup that wrote some pays for the write-back.
+// (s_waitcnt vmcnt(0)).  Entries and result bytes are ordinary stores (to pinned memory and to the device arena, where
+// a copy engine fetches what does not fit the pinned prefix): only a workgroup that wrote some pays for the write-back
+// of its L2.
 __device__ __forceinline__ u32 sys_load(const volatile u32 *p)
 {
     return __hip_atomic_load(const_cast<const u32 *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1004,7 +1164,9 @@ __global__ __launch_bounds__(SM_BLOCK) void search_resident_kernel(const ChunkDe
             // wave 0 polls the posted line: lanes 0 .. 7 read its eight words with one load
             u32 leave = 0, seq = seen, plen = 0;
             u64 w = 0;
-            for (;;) {
+            // (the answer waits for the LAST workgroup to notice the query: nothing but the load in the loop -- the clock
+            // and the leave flag are looked at every eighth time round)
+            for (u32 spin = 0;; ++spin) {
                 if (tid < 8) w = sys_load64(line + tid);
                 const u32 seq_a = (u32)__shfl(w, 0), seq_b = (u32)(__shfl(w, 7) >> 32);
                 plen = (u32)(__shfl(w, 0) >> 32);
@@ -1012,6 +1174,7 @@ __global__ __launch_bounds__(SM_BLOCK) void search_resident_kernel(const ChunkDe
                     seq = seq_a;
                     break;
                 }
+                if ((spin & 7u) != 7u) continue;
                 if (first) {
                     const u64 now = wall_clock64();
                     if (now - t_last > idle_ticks || now - t_start > life_ticks) {
@@ -1032,7 +1195,6 @@ __global__ __launch_bounds__(SM_BLOCK) void search_resident_kernel(const ChunkDe
                     leave = 1;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(4);
             }
             if (!leave && plen == kResidentStop) leave = 1;            // (told to)
             // (an add, not a store: told to leave by the host, the others may have counted themselves out already)
@@ -1063,13 +1225,13 @@ __global__ __launch_bounds__(SM_BLOCK) void search_resident_kernel(const ChunkDe
         seen = seq;
         if (tid >= plen && tid < SM_MAX_PLEN + 32) s_pat[tid] = 0;     // zero padding behind the query
         __syncthreads();
-        const bool beyond = block_pair(ch, s_pat, plen, sub, blockIdx.x, spread, hdr, h_overflow, rec, ent, bytes, hbytes);
-        (void)beyond;
+        const bool wrote = block_pair(ch, s_pat, plen, sub, blockIdx.x, spread, hdr, h_overflow, rec, ent, bytes, hbytes);
         stores_done();
         __syncthreads();
-        // every wave's stores have reached L2; one wave writes the workgroup's XCD L2 back (results in pinned memory are
-        // ordinary stores and stay there otherwise) -- a write-back per wave costs 4 us, one per workgroup ~1
-        if (tid < kWave) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        // every wave's stores have reached L2; one wave writes the workgroup's XCD L2 back (the entry table and the
+        // result bytes are ordinary stores and stay there otherwise) -- a write-back per wave costs 4 us, one per
+        // workgroup ~1, a workgroup without entries none (its record went out as a system-scope store)
+        if (wrote && tid < kWave) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         if (tid == 0 && atomicAdd(&hdr->done, 1u) == nc * spread - 1) {
             dev_store(&hdr->ent_cursor, 0u);
             dev_store(&hdr->byte_cursor, 0u);
@@ -1204,12 +1366,14 @@ static int small_collect(DeviceCtx *ctx, const u8 *h_arena, const u8 *d_bytes, u
     for (u64 ri = 0; ri < nrec; ++ri) {       // pairs in (query, chunk) order, sub-blocks in interval order
         const SmallRecord r = h_rec[ri];
         res->qcount[(ri / spread) / nc] += r.ent_count;
+        if (r.ent_count == 0) continue;
+        // the entries of one record are packed back to back in the arena: one copy for all of them
+        const u64 first = b_out;
         for (u32 k = 0; k < r.ent_count; ++k) {
-            const SmallEntry en = h_ent[r.ent_start + k];
             res->offsets[e_out++] = b_out;
-            memcpy(res->bytes + b_out, h_bytes + en.byte_off, en.len);
-            b_out += en.len;
+            b_out += h_ent[r.ent_start + k].len;
         }
+        memcpy(res->bytes + first, h_bytes + h_ent[r.ent_start].byte_off, b_out - first);
     }
     res->offsets[e_out] = b_out;
     res->n_entries = e_out;
@@ -1273,6 +1437,7 @@ static int resident_query(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, con
             ++R.launches;
         }
         *h_overflow = 0;
+        const auto t_post = std::chrono::steady_clock::now();
         R.post(q, plen);
         const u32 seq = R.seq;
         bool answered = false;
@@ -1295,6 +1460,9 @@ static int resident_query(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, con
             }
         }
         if (answered) {
+            // (no HIP events on this path: the time from the post to the answer as the host saw it)
+            st->ms_device = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_post).count();
+            st->ms_interval = st->ms_device;
             ++R.served;
             if (*h_overflow) return PSS_OK;      // too many hits for this path: the launch path and its fallbacks take it
             PSS_TRY(small_collect(ctx, h_arena, arena + 64, (u64)nc * spread, spread, nc, res, st));

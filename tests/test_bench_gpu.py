@@ -57,6 +57,8 @@ def test_bench_single_gpu_contract():
     assert c['config']['chunks'] == 5 and c['packed_queries_per_sec'] > 0 and c['single_query_us']['median'] > 0
     assert c['cpu_baseline']['value'] > 0 and c['cpu_baseline']['disk_queries_per_sec'] > 0
     assert c['roofline']['frac'] is None and len(c['per_rank_build_ms']) == 1
+    ll = c['single_query_us']['low_latency_mode']                     # the resident search kernel: same results, no launch per query
+    assert ll['same_results'] is True and ll['median'] > 0 and ll['queries_served'] >= 1000 and ll['kernels_started'] >= 1
 
 
 def _check_two_ranks(d):

@@ -3,7 +3,9 @@ queries are prefixes of 2..8 bytes taken from the text, so the result count fall
 The reference's README quotes 14.9 us (159 results), 497 us (5 943) on a 500 MB index and 10.1 ms (62 834)
 on 15 chunks (README.md:48-59).
 
-    python tests/tools/latency_hits.py [logn] [chunks]
+    python tests/tools/latency_hits.py [logn] [chunks] [resident]
+
+`resident`: the reader in low-latency mode (Reader.set_low_latency: resident search kernel, no launch per query).
 """
 import ctypes, json, sys, time
 import numpy as np
@@ -22,6 +24,9 @@ for c in range(nchunks):
     dT = torch.from_numpy(host).cuda()
     _ffi.check(lib.pss_sa_build_device(dT.data_ptr(), dSA.data_ptr(), n, 0, 0, None))
     _ffi.check(lib.pss_reader_add_chunk_device(h, dT.data_ptr(), dSA.data_ptr(), n))
+resident = len(sys.argv) > 3 and sys.argv[3] == 'resident'
+if resident:
+    r.set_low_latency(True)
 base = host[70000:70008].tobytes().replace(b'\n', b'a').decode()
 out = []
 for ln in (8, 5, 4, 3, 2):
@@ -39,4 +44,5 @@ for ln in (8, 5, 4, 3, 2):
            'library_us': round(hst[m] * 1e3, 1), 'device_us': round(dev[m] * 1e3, 1)}
     out.append(row)
     print(row, flush=True)
-print(json.dumps({'logn': logn, 'chunks': nchunks, 'rows': out}))
+print(json.dumps({'logn': logn, 'chunks': nchunks, 'low_latency_mode': resident,
+                  'low_latency_stats': r.low_latency_stats() if resident else None, 'rows': out}))
