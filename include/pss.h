@@ -119,6 +119,10 @@ typedef struct pss_sa_stats {
     double ss_ms_g2;           /* ... second partition (digits 16 in / 2 out, scatter 18 in / 16 out) */
     double ss_ms_local;        /* ... local merge sort (16 B in, 4 B out) */
     double ms_initial;         /* device time from the start of the build to the end of the initial sort (always filled) */
+    uint64_t period;           /* word length p when the head of the text repeats one word of 2 .. 1024 bytes (else 0) ... */
+    uint64_t period_extent;    /* ... how far that repetition reaches from the start of the text ... */
+    uint64_t period_path;      /* ... 1: it covers the text (at most 1024 bytes behind it) and the suffix array was written
+                                  in closed form (rle_build.h): rotation blocks + a host sort of the last few suffixes */
     uint64_t plan_hint;        /* 0: the sizing sample chose the initial sort; 1: the previous build on this device sorted
                                   the same kind of text (same byte values, same size class) with the MSD sort and this
                                   build went straight to it (PSS_NO_PLAN_CACHE=1: never) */

@@ -64,6 +64,9 @@ class SaStats(ctypes.Structure):
         ('ss_ms_g2', ctypes.c_double),
         ('ss_ms_local', ctypes.c_double),
         ('ms_initial', ctypes.c_double),
+        ('period', ctypes.c_uint64),
+        ('period_extent', ctypes.c_uint64),
+        ('period_path', ctypes.c_uint64),
         ('plan_hint', ctypes.c_uint64),
     ]
 

@@ -514,4 +514,179 @@ int rle_suffix_array(DeviceCtx *ctx, const uint8_t *T, uint32_t n, uint32_t S, u
     return PSS_OK;
 }
 
+// ------------------------------------------------------------------ periodic prefix (rle_build.h) --
+
+uint32_t period_of_head(const uint8_t *head, uint32_t len)
+{
+    for (u32 p = 2; p <= kPeriodMax && 4 * p <= len; ++p) {
+        bool ok = true;
+        for (u32 i = 0; i + p < len; ++i)
+            if (head[i] != head[i + p]) {
+                ok = false;
+                break;
+            }
+        if (ok) return p;
+    }
+    return 0;
+}
+
+// first i with T[i] != T[i + p] (n - p when there is none), into *first by atomicMin
+__global__ __launch_bounds__(256) void period_extent_kernel(const u8 *T, u32 n, u32 p, u32 *first)
+{
+    const u64 lim = (u64)n - p;
+    u32 best = 0xffffffffu;
+    for (u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < lim; i += (u64)gridDim.x * blockDim.x * 16) {
+        if (best != 0xffffffffu) break;
+        const u64 e = i + 16 < lim ? i + 16 : lim;
+        for (u64 j = i; j < e; ++j)
+            if (T[j] != T[j + p]) {
+                best = (u32)j;
+                break;
+            }
+    }
+    best = ~wave_incl_max(~best);                      // lane 63: the wave's smallest
+    if ((threadIdx.x & 63u) == 63u && best != 0xffffffffu) atomicMin(first, best);
+}
+
+int period_extent(DeviceCtx *ctx, const uint8_t *T, uint32_t n, uint32_t p, uint32_t *m)
+{
+    hipStream_t s = ctx->stream;
+    PSS_TRY(ctx->slot[S_RLE].reserve(1u << 20));
+    u32 *d_first = ctx->slot[S_RLE].as<u32>();
+    // (a word of the pinned scratch that neither the alphabet counts nor the head of the text, both still needed, sit in)
+    u32 *h = reinterpret_cast<u32 *>(static_cast<u8 *>(ctx->pinned) + 32768 + 16384 - 64);
+    PSS_HIP(hipMemsetAsync(d_first, 0xff, 4, s));
+    hipLaunchKernelGGL(period_extent_kernel, dim3(ctx->num_cus * 8), dim3(256), 0, s, T, n, p, d_first);
+    PSS_HIP(hipMemcpyAsync(h, d_first, 4, hipMemcpyDeviceToHost, s));
+    PSS_HIP(hipStreamSynchronize(s));
+    *m = h[0] == 0xffffffffu ? n : h[0] + p;
+    return PSS_OK;
+}
+
+struct PeriodBlock {      // one rotation's suffixes in the suffix array: SA[out .. out + count)
+    u32 out, count, cls;
+};
+
+// SA[o] for every o inside a rotation block: block k holds the long suffixes of class cls -- cls, cls + p, ... --
+// ascending or descending.  Eight consecutive outputs per thread: one search of the block table, then a walk.
+__global__ __launch_bounds__(256) void period_fill_kernel(const PeriodBlock *blocks, u32 nb, u32 p, u32 desc, u32 n, u32 *SA)
+{
+    __shared__ PeriodBlock s_blk[kPeriodMax];
+    for (u32 i = threadIdx.x; i < nb; i += blockDim.x) s_blk[i] = blocks[i];
+    __syncthreads();
+    for (u64 o0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 8; o0 < n; o0 += (u64)gridDim.x * blockDim.x * 8) {
+        u32 lo = 0, hi = nb;                                    // last block that starts at or before o0
+        while (hi - lo > 1) {
+            const u32 mid = (lo + hi) >> 1;
+            if (s_blk[mid].out <= (u32)o0) lo = mid; else hi = mid;
+        }
+        u32 k = lo;
+        const u32 oe = (u32)(o0 + 8 < n ? o0 + 8 : n);
+        for (u32 o = (u32)o0; o < oe; ++o) {
+            while (k + 1 < nb && s_blk[k + 1].out <= o) ++k;
+            const PeriodBlock b = s_blk[k];
+            if (o < b.out || o >= b.out + b.count) continue;  // a slot of one of the late suffixes (period_late_kernel)
+            const u32 q = o - b.out;
+            SA[o] = b.cls + p * (desc ? b.count - 1 - q : q);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void period_late_kernel(const u32 *pos, const u32 *val, u32 cnt, u32 *SA)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) SA[pos[i]] = val[i];
+}
+
+int period_suffix_array(DeviceCtx *ctx, const uint8_t *T, uint32_t n, uint32_t p, uint32_t m, const uint8_t *W, uint32_t *SA,
+                        bool *accepted)
+{
+    *accepted = false;
+    hipStream_t s = ctx->stream;
+    if (p < 2 || p > kPeriodMax || m > n || n - m > kPeriodTailMax) return PSS_OK;
+    const u32 t = n - m;
+    // A suffix is "long" when the repetition goes on for more than `margin` bytes behind its start: every comparison
+    // with a late suffix, and with a long one of another rotation, is then decided inside the repetition.
+    const u32 margin = 2 * p + 2 * t + 1;
+    if ((u64)margin * 4 > m) return PSS_OK;
+    const u32 long_end = m - margin;                 // long suffixes: [0, long_end); late ones: [long_end, n)
+    const u32 nl = n - long_end;
+    std::vector<u8> late(nl);
+    PSS_HIP(hipMemcpyAsync(late.data(), T + long_end, nl, hipMemcpyDeviceToHost, s));
+    PSS_HIP(hipStreamSynchronize(s));
+    // Inside a rotation class, suffix j = i + k p agrees with suffix i for as long as j's repetition lasts; then j sees
+    // the byte that ends the repetition (or the end of the text, which sorts first) and i another turn of the word.
+    const bool desc = m == n || late[m - long_end] < W[m % p];
+    // items to order: the p rotation blocks and the nl late suffixes
+    struct Item {
+        u32 late;       // 1: a late suffix, start = text offset; 0: the rotation block of class start
+        u32 start;
+    };
+    std::vector<Item> items;
+    items.reserve((size_t)p + nl);
+    for (u32 c = 0; c < p; ++c)
+        if (c < long_end) items.push_back(Item{0, c});
+    for (u32 i = long_end; i < n; ++i) items.push_back(Item{1, i});
+    auto rot = [&](u32 c, u32 k) { return W[(c + k) % p]; };
+    auto at = [&](u32 i, u32 k) { return late[i - long_end + k]; };
+    auto less = [&](const Item &a, const Item &b) {
+        if (!a.late && !b.late) {                    // two rotations of a primitive word differ within p bytes
+            for (u32 k = 0; k < p; ++k) {
+                const u8 x = rot(a.start, k), y = rot(b.start, k);
+                if (x != y) return x < y;
+            }
+            return false;
+        }
+        if (a.late && b.late) {
+            const u32 la = n - a.start, lb = n - b.start, l = std::min(la, lb);
+            const int c = memcmp(&late[a.start - long_end], &late[b.start - long_end], l);
+            return c ? c < 0 : la < lb;
+        }
+        // a late suffix against a block: against the word repeated for as long as the late suffix lasts; a late
+        // suffix that is a prefix of that is the shorter one
+        const Item &x = a.late ? a : b, &blk = a.late ? b : a;
+        const u32 lx = n - x.start;
+        int c = 0;
+        for (u32 k = 0; k < lx && c == 0; ++k) {
+            const u8 u = at(x.start, k), v = rot(blk.start, k);
+            if (u != v) c = u < v ? -1 : 1;
+        }
+        const bool x_first = c <= 0;
+        return a.late ? x_first : !x_first;
+    };
+    std::sort(items.begin(), items.end(), less);
+    std::vector<PeriodBlock> blocks;
+    std::vector<u32> pos, val;
+    u32 out = 0;
+    for (const Item &it : items) {
+        if (it.late) {
+            pos.push_back(out);
+            val.push_back(it.start);
+            ++out;
+        } else {
+            const u32 cnt = (long_end - it.start + p - 1) / p;         // suffixes it.start, it.start + p, ... < long_end
+            blocks.push_back(PeriodBlock{out, cnt, it.start});
+            out += cnt;
+        }
+    }
+    if (out != n || blocks.empty()) {
+        set_error("period_suffix_array: internal count mismatch");
+        return PSS_EDEVICE;
+    }
+    const size_t need = blocks.size() * sizeof(PeriodBlock) + 2 * pos.size() * 4 + 256;
+    PSS_TRY(ctx->slot[S_RLE].reserve(std::max<size_t>(need, 1u << 20)));
+    u8 *d = ctx->slot[S_RLE].as<u8>();
+    PeriodBlock *d_blocks = reinterpret_cast<PeriodBlock *>(d);
+    u32 *d_pos = reinterpret_cast<u32 *>(d + round_up(blocks.size() * sizeof(PeriodBlock), 256));
+    u32 *d_val = d_pos + pos.size();
+    PSS_HIP(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(PeriodBlock), hipMemcpyHostToDevice, s));
+    PSS_HIP(hipMemcpyAsync(d_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, s));
+    PSS_HIP(hipMemcpyAsync(d_val, val.data(), val.size() * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(period_fill_kernel, dim3(ctx->num_cus * 8), dim3(256), 0, s, d_blocks, (u32)blocks.size(), p, desc ? 1u : 0u, n, SA);
+    hipLaunchKernelGGL(period_late_kernel, dim3((u32)((pos.size() + 255) / 256)), dim3(256), 0, s, d_pos, d_val, (u32)pos.size(), SA);
+    PSS_HIP(hipStreamSynchronize(s));      // (the tables on the host side are about to go away)
+    *accepted = true;
+    return PSS_OK;
+}
+
 }  // namespace pss

@@ -1208,6 +1208,7 @@ struct Knobs {
                                 //                unset: n >= 2^24 and the MSD sort did not take the text
     bool no_msd_fuse = false;   // PSS_MSD_NO_FUSE  MSD sort flags ties in the suffix array; the rerank kernels read them
     bool no_mid_tier = false;   // PSS_NO_MID_TIER  groups above 512 members all take the chained radix sorts
+    int period = -1;            // PSS_PERIOD     0: never the closed form for texts that repeat one word (rle_build.h)
     int rle = -1;               // PSS_RLE        0: never the run-length path, 1: always, unset: when runs average >= 8 bytes
     bool timing = false;        // PSS_TIMING     per-round trace on stderr
     static Knobs read()
@@ -1229,6 +1230,7 @@ struct Knobs {
         k.no_msd_fuse = getenv("PSS_MSD_NO_FUSE") != nullptr;
         k.no_mid_tier = getenv("PSS_NO_MID_TIER") != nullptr;
         if (const char *e = getenv("PSS_RLE")) k.rle = atoi(e);
+        if (const char *e = getenv("PSS_PERIOD")) k.period = atoi(e);
         k.timing = getenv("PSS_TIMING") != nullptr;
         return k;
     }
@@ -1738,6 +1740,11 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     hipLaunchKernelGGL(sa_symbols_kernel, dim3(grid_stream), dim3(256), 0, s, T, n, d_present, d_present + 256, d_runs);
     PSS_HIP(hipMemcpyAsync(h_small, d_present, 2048, hipMemcpyDeviceToHost, s));
     PSS_HIP(hipMemcpyAsync(h_small + 512, d_runs, 4, hipMemcpyDeviceToHost, s));
+    // (the head of the text rides along: does it repeat one word?  -- see below)
+    u8 *h_head = static_cast<u8 *>(ctx->pinned) + 32768;         // the search path's query staging; builds and searches take turns
+    const u32 head_len = std::min<u32>(n, kPeriodProbe);
+    const bool look_for_period = knobs.period != 0 && n >= 4 * kPeriodProbe;
+    if (look_for_period) PSS_HIP(hipMemcpyAsync(h_head, T, head_len, hipMemcpyDeviceToHost, s));
     PSS_HIP(hipStreamSynchronize(s));
     // Long runs of equal bytes (every suffix inside a run is tied with its neighbours for as long as the run
     // lasts: the worst case of prefix doubling): sort the run heads as a string of one symbol per run, then
@@ -1760,6 +1767,35 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         st.ms_total = ms;
         if (stats) *stats = st;
         return PSS_OK;
+    }
+    // One word written over and over (a text whose first m bytes have a small period, with at most a few bytes behind):
+    // the worst case of prefix doubling that is not a run of one byte.  The head of the text says whether it is worth
+    // a pass to find out how far the repetition goes; if it covers the text, the suffix array has a closed form
+    // (rle_build.h).
+    if (look_for_period) {
+        const u32 p = period_of_head(h_head, head_len);
+        if (p) {
+            u32 m = 0;
+            PSS_TRY(period_extent(ctx, T, n, p, &m));
+            st.period = p;
+            st.period_extent = m;
+            bool accepted = false;
+            if (n - m <= kPeriodTailMax) {
+                std::vector<u8> word(h_head, h_head + p);           // (period_extent reuses the pinned scratch)
+                PSS_TRY(period_suffix_array(ctx, T, n, p, m, word.data(), SA, &accepted));
+            }
+            if (accepted) {
+                st.period_path = 1;
+                for (int c = 0; c < 256; ++c) st.sigma += h_small[c] ? 1u : 0u;
+                PSS_HIP(hipEventRecord(timer.ev1, s));
+                PSS_HIP(hipStreamSynchronize(s));
+                float ms = 0.f;
+                PSS_HIP(hipEventElapsedTime(&ms, timer.ev0, timer.ev1));
+                st.ms_total = ms;
+                if (stats) *stats = st;
+                return PSS_OK;
+            }
+        }
     }
     u8 lut[256];
     u32 sigma = 0;

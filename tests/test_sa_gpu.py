@@ -211,6 +211,7 @@ def test_msd_crowded_bins_and_oversized_buckets(oracle, monkeypatch):
     lines (every joint bucket one crowded bin: the general local kernel takes those tiles), and a text
     whose 20-bit prefixes are so skewed that a bucket exceeds a tile (the LSD passes run instead)."""
     monkeypatch.setenv('PSS_MSD', '1')
+    monkeypatch.setenv('PSS_PERIOD', '0')          # (one line repeated: the closed form would take it from the sort under test)
     rng = np.random.default_rng(11)
     line = bytes(rng.integers(97, 123, 200).astype(np.uint8)) + b'\n'
     t = np.frombuffer(line * 3000, dtype=np.uint8).copy()              # 3000 copies: buckets of <= 3000 equal keys
@@ -323,6 +324,85 @@ def test_initial_sort_plan_is_reused_and_checked(oracle, monkeypatch):
     sa = _sa_device(lines, st)
     assert (st['plan_hint'], st['msd']) == (0, 1)
     assert hashlib.sha256(sa.tobytes()).hexdigest() == want
+
+
+# ---- texts that repeat one word (rle_build.hip, periodic prefix) ----
+
+def _periodic(word, n, tail=b''):
+    body = (word * (n // len(word) + 2))[:n - len(tail)]
+    return np.frombuffer(body + tail, dtype=np.uint8).copy()
+
+
+@pytest.mark.parametrize('case', range(14))
+def test_periodic_text_closed_form(oracle, case):
+    """A text that repeats one word of 2 .. 1024 bytes (with up to 1024 other bytes behind the repetition) gets its
+    suffix array in closed form -- rotation blocks, ascending or descending by the byte that ends the repetition, the
+    last suffixes sorted on the host -- and it is libsais' for: words whose rotations share long prefixes, tails that
+    sort before / after the word's continuation, tails that look like the word for a while, the pure repetition (no
+    tail), repetitions cut mid-word, the longest word and tail the path takes, and shapes it must decline (the
+    repetition ends early; the word is longer than 1024)."""
+    rng = np.random.default_rng(case)
+    n = 1 << 17
+    taken = True
+    if case == 0:
+        t = _periodic(b'ab', n)
+    elif case == 1:
+        t = _periodic(b'abc', n + 1, b'\n')
+    elif case == 2:
+        t = _periodic(b'aab' * 5 + b'aac', n, b'a')                       # tail byte < continuation
+    elif case == 3:
+        t = _periodic(b'aab' * 5 + b'aac', n, b'z')                       # tail byte > continuation
+    elif case == 4:
+        w = bytes(rng.integers(97, 100, 40).astype(np.uint8))
+        t = _periodic(w, n - 3, b'\n')
+    elif case == 5:
+        w = bytes(rng.integers(97, 123, 1024).astype(np.uint8))           # longest word
+        t = _periodic(w, n, bytes(rng.integers(97, 123, 1024).astype(np.uint8)))      # longest tail
+    elif case == 6:
+        w = b'the quick brown fox jumps over the lazy dog\n'
+        t = _periodic(w, n, w[5:17] + b'X')                                # tail = the word again, from elsewhere, then a break
+    elif case == 7:
+        w = b'xyxyxz'
+        t = _periodic(w, n, b'xyxyxy')                                     # tail continues a rotation's prefix
+    elif case == 8:
+        t = _periodic(bytes([0, 255, 0, 7]), n, bytes([255, 0]))
+    elif case == 9:
+        t = _periodic(b'abcabd', 40000)                                    # small text
+    elif case == 10:
+        t = gen_corpus(4, 1 << 20)                                         # `repeat_line`: the generator's last byte breaks the word
+    elif case == 11:
+        w = bytes(rng.integers(97, 123, 1025).astype(np.uint8))           # word too long: declined
+        t, taken = _periodic(w, n), False
+    elif case == 12:
+        t = _periodic(b'abcde', n)
+        t[n // 2] = ord('z')                                               # the repetition ends half way: declined
+        taken = False
+    else:
+        t = _periodic(b'ab', n, b'a' + bytes(rng.integers(97, 99, 1024).astype(np.uint8)))   # ('a' where 'b' was due) tail too long: declined
+        taken = False
+    st = {}
+    sa = _sa_device(t, st)
+    assert st['period_path'] == (1 if taken else 0), (case, st['period'], st['period_extent'])
+    assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(t).tobytes()).hexdigest(), case
+
+
+def test_periodic_text_random_words_and_tails(oracle):
+    """Eighty random shapes of the same: word length 2 .. 300 over 2 .. 4 letters (rotations with long common prefixes),
+    tails of 0 .. 200 bytes over the same letters (so they often continue the word for a while), lengths that cut the
+    word anywhere."""
+    rng = np.random.default_rng(2024)
+    took = 0
+    for _ in range(80):
+        sigma = int(rng.integers(2, 5))
+        w = bytes(rng.integers(97, 97 + sigma, int(rng.integers(2, 301))).astype(np.uint8))
+        tail = bytes(rng.integers(97, 97 + sigma, int(rng.integers(0, 201))).astype(np.uint8))
+        n = int(rng.integers(4 * 8192, 60000))
+        t = _periodic(w, n, tail)
+        st = {}
+        sa = _sa_device(t, st)
+        took += st['period_path']
+        assert np.array_equal(sa, oracle.sa(t)), (w, tail, n, st['period'], st['period_extent'])
+    assert took >= 60          # (a random word that is itself a repetition has a shorter period; a few are declined for size)
 
 
 # ---- run-length path (rle_build.hip) ----

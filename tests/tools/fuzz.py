@@ -35,8 +35,16 @@ def make_text(rng):
             parts.append(np.full(int(nprng.integers(1, 1 + max(1, n // 8))), syms[nprng.integers(0, sigma)], dtype=np.uint8))
         t = np.concatenate(parts)[:n]
     elif kind == 'periodic':
-        period = syms[nprng.integers(0, sigma, int(nprng.integers(1, 300)))]
+        # one word repeated, half of the time long enough for the closed form of rle_build.h (n >= 2^15), with a
+        # tail of other bytes behind the repetition (up to past what that path accepts)
+        if rng.random() < 0.5:
+            n = max(n, int(2 ** rng.uniform(15, 17)))
+        period = syms[nprng.integers(0, sigma, int(nprng.integers(1, rng.choice([8, 300, 1100]))))]
         t = np.tile(period, n // len(period) + 1)[:n]
+        if rng.random() < 0.6:
+            tail = syms[nprng.integers(0, sigma, int(nprng.integers(0, rng.choice([4, 200, 1100]))))]
+            if len(tail) and len(tail) < n:
+                t[n - len(tail):] = tail
     else:
         base = syms[nprng.integers(0, sigma, max(1, n // rng.choice([2, 3, 7, 50])))]
         parts = []
@@ -74,7 +82,7 @@ def build(path, entries, limit, W):
 
 
 KNOBS = ('PSS_MODE', 'PSS_KEY_CHARS', 'PSS_KEY_DROP', 'PSS_TEXT_ROUNDS', 'PSS_NO_TIES_PASS', 'PSS_NO_SMALL_PATH', 'PSS_MSD',
-         'PSS_MSD_NO_FUSE', 'PSS_MSD_SLOW_LOCAL', 'PSS_NO_PINNED_RESULTS', 'PSS_NO_MID_TIER', 'PSS_RLE', 'PSS_RLE_SORT')
+         'PSS_MSD_NO_FUSE', 'PSS_MSD_SLOW_LOCAL', 'PSS_NO_PINNED_RESULTS', 'PSS_NO_MID_TIER', 'PSS_RLE', 'PSS_RLE_SORT', 'PSS_PERIOD')
 
 
 def random_knobs(rng):
@@ -111,6 +119,8 @@ def random_knobs(rng):
         os.environ['PSS_RLE'] = rng.choice(['0', '1', '1'])      # run-length path forced on / off
         if rng.random() < 0.4:
             os.environ['PSS_RLE_SORT'] = '1'                     # ... with the radix-sort expansion
+    if rng.random() < 0.3:
+        os.environ['PSS_PERIOD'] = '0'                           # never the closed form for one repeated word
     _ffi.lib.pss_reload_env()
 
 
