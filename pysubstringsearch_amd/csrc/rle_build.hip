@@ -518,6 +518,11 @@ int rle_suffix_array(DeviceCtx *ctx, const uint8_t *T, uint32_t n, uint32_t S, u
 
 uint32_t period_of_head(const uint8_t *head, uint32_t len)
 {
+    // (a head of one byte repeated has period 1: runs are the run-length path's business, and the word found below
+    // must be primitive -- the smallest period -- for its rotations to be distinct)
+    bool run = len > 1;
+    for (u32 i = 1; i < len && run; ++i) run = head[i] == head[0];
+    if (run) return 0;
     for (u32 p = 2; p <= kPeriodMax && 4 * p <= len; ++p) {
         bool ok = true;
         for (u32 i = 0; i + p < len; ++i)

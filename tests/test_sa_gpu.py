@@ -333,8 +333,8 @@ def _periodic(word, n, tail=b''):
     return np.frombuffer(body + tail, dtype=np.uint8).copy()
 
 
-@pytest.mark.parametrize('case', range(14))
-def test_periodic_text_closed_form(oracle, case):
+@pytest.mark.parametrize('case', range(15))
+def test_periodic_text_closed_form(oracle, monkeypatch, case):
     """A text that repeats one word of 2 .. 1024 bytes (with up to 1024 other bytes behind the repetition) gets its
     suffix array in closed form -- rotation blocks, ascending or descending by the byte that ends the repetition, the
     last suffixes sorted on the host -- and it is libsais' for: words whose rotations share long prefixes, tails that
@@ -377,6 +377,9 @@ def test_periodic_text_closed_form(oracle, case):
         t = _periodic(b'abcde', n)
         t[n // 2] = ord('z')                                               # the repetition ends half way: declined
         taken = False
+    elif case == 14:
+        monkeypatch.setenv('PSS_RLE', '0')                                 # one byte repeated, the run-length path switched off:
+        t, taken = _periodic(b'a', 40000), False                           # "aa" is not a word (period 1): declined
     else:
         t = _periodic(b'ab', n, b'a' + bytes(rng.integers(97, 99, 1024).astype(np.uint8)))   # ('a' where 'b' was due) tail too long: declined
         taken = False
