@@ -497,8 +497,8 @@ def run_chunk(args, D):
         if prof['msd']:
             # hybrid MSD initial sort (msd_sort.hip): partition from the text (1 B in, 8 B out per suffix), partition of
             # the 8-byte elements (8 in, 8 out), LDS-resident local sort (8 in, 4 out)
-            cands.append((prof['msd_ms_g1'], 'msd_scatter_kernel<true>', 1, n, 9))
-            cands.append((prof['msd_ms_g2'], 'msd_scatter_kernel<false>', 1, n, 16))
+            cands.append((prof['msd_ms_g1'], 'msd_scatter2_kernel<true, 1024>', 1, n, 9))
+            cands.append((prof['msd_ms_g2'], 'msd_scatter2_kernel<false, 1024>', 1, n, 16))
             cands.append((prof['msd_ms_local'], 'msd_local_fast_kernel', 1, n, 12))
         roof = None
         if cands:
@@ -585,7 +585,7 @@ def run_chunk(args, D):
                                                   'msd', 'msd_buckets', 'msd_max_bucket', 'msd_tiles', 'msd_slow_tiles')},
             'initial_sort': 'hybrid MSD (2 partition passes over 8-byte [key|index] elements + LDS local sort)' if sa_stats['msd']
                             else 'LSD passes with shrinking keys',
-            'kernel_ms': ({'msd_scatter_kernel<true>': round(prof['msd_ms_g1'], 3), 'msd_scatter_kernel<false>': round(prof['msd_ms_g2'], 3),
+            'kernel_ms': ({'msd_scatter2_kernel<true, 1024>': round(prof['msd_ms_g1'], 3), 'msd_scatter2_kernel<false, 1024>': round(prof['msd_ms_g2'], 3),
                            'msd_local_fast_kernel': round(prof['msd_ms_local'], 3)} if prof['msd'] else None),
             'roofline': roof,
             'build_roofline': build_roof,
