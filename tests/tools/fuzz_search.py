@@ -98,6 +98,23 @@ def one_case(seed, tmp):
         pk = r.search_batch_packed(qb)
         assert pk.counts.tolist() == counts and len(pk.offsets) == len(ents) + 1
         assert bytes(pk.data) == b''.join(ents)
+        # single queries, on the launch path and through the resident kernel of the low-latency mode (a short lease
+        # now and then, so that kernels come and go between queries)
+        if rng.random() < 0.5:
+            os.environ['PSS_RESIDENT_IDLE_US'] = str(rng.choice([20, 200, 1000]))
+            _ffi.lib.pss_reload_env()
+        pos, starts = 0, []
+        for c in counts:
+            starts.append(pos)
+            pos += c
+        pick = [rng.randrange(len(qb)) for _ in range(min(len(qb), 60))]
+        for mode in (False, True):
+            r.set_low_latency(mode)
+            for i in pick:
+                e1, c1 = r.search_batch_raw([qb[i]])
+                assert c1 == [counts[i]] and sorted(e1) == sorted(oe[starts[i]:starts[i] + counts[i]]), ('single query differs', mode)
+        r.set_low_latency(False)
+        os.environ.pop('PSS_RESIDENT_IDLE_US', None)
     # shards: the union over ranks is the whole result, per query
     k = rng.choice([2, 3, 8])
     per = [0] * len(qb)
