@@ -219,7 +219,9 @@ struct pss_writer {
     int rc = PSS_OK;              // first failure of any stage (sticky)
     int err_no = 0;
     std::string err;
-    std::vector<std::pair<uint8_t *, size_t>> free_text;   // host text buffers back from written jobs
+    std::vector<std::pair<uint8_t *, size_t>> free_text;   // host text buffers back from written jobs (at most G + 1 kept)
+    size_t inflight_text = 0;            // bytes of host text owned by jobs that are queued, building or being written
+    size_t text_budget = (size_t)8 << 30;   // ... bounded by this (PSS_WRITER_HOST_BUDGET), not only by 2 G jobs
     std::thread record_thread;
     void *stage[2] = {nullptr, nullptr};                    // pinned staging of the record thread
 };
@@ -409,7 +411,9 @@ void record_main(pss_writer *w)
         if (!skip) rc = guarded([&]() -> int { return write_record(w, job); });
         lk.lock();
         w_fail(w, rc);
-        w->free_text.emplace_back(job.text, job.text_alloc);
+        w->inflight_text -= job.text_alloc;
+        if (w->free_text.size() <= w->devs.size()) w->free_text.emplace_back(job.text, job.text_alloc);
+        else free(job.text);
         w->jobs.pop_front();
         w->written += 1;
         w->cv.notify_all();
@@ -522,12 +526,17 @@ int w_dump(pss_writer *w)
     }
     std::unique_lock<std::mutex> lk(w->mu);
     // the SA buffer this chunk builds into was last used by chunk k - 2 G: its record must be out
-    w->cv.wait(lk, [&] { return w->next_seq - w->written < 2 * G; });
+    // ... and the host text of the chunks in flight stays inside the budget (chunks of 2 GiB on eight devices would
+    // otherwise park 16 x 2 GiB of text that the builders have long uploaded); one job always goes through
+    w->cv.wait(lk, [&] {
+        return w->next_seq - w->written < 2 * G && (w->jobs.empty() || w->inflight_text + w->alloc <= w->text_budget);
+    });
     PSS_TRY(w_report(w));
     WJob job;
     job.seq = w->next_seq++;
     job.text = w->buf;
     job.text_alloc = w->alloc;
+    w->inflight_text += w->alloc;
     job.n = w->len;
     job.state = WJob::QUEUED;
     w->jobs.push_back(job);
@@ -581,6 +590,7 @@ extern "C" int pss_writer_open_multi(const char *path, int64_t max_chunk_len, co
         w->devs.resize((size_t)n_devices);
         for (int i = 0; i < n_devices; ++i) w->devs[(size_t)i].device = devices[i];
         w->version = format_version;
+        if (const char *ev = getenv("PSS_WRITER_HOST_BUDGET")) w->text_budget = (size_t)strtoull(ev, nullptr, 0);
         *out = w;
         return PSS_OK;
     });

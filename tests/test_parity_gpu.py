@@ -691,6 +691,18 @@ def test_multi_device_writer_is_byte_identical(tmp_path, oracle, devices):
         assert open(single, 'rb').read() == open(orc, 'rb').read(), limit
     with pysubstringsearch.Reader(multi) as r:
         assert r.num_chunks >= 4 and r.search('after finalize') == ['after finalize']
+    # the host text of the chunks in flight is bounded by bytes too (PSS_WRITER_HOST_BUDGET): with room for one chunk
+    # only, the pipeline degrades to one job at a time and still writes the same file
+    os.environ['PSS_WRITER_HOST_BUDGET'] = '1'
+    try:
+        w = pysubstringsearch.Writer(multi + '3', 1 << 20, devices=devices)
+        fill(w)
+        w.finalize()
+        w.add_entry('after finalize')
+        w.close()
+    finally:
+        del os.environ['PSS_WRITER_HOST_BUDGET']
+    assert open(multi + '3', 'rb').read() == open(single + '2', 'rb').read()
     with pytest.raises(ValueError):
         pysubstringsearch.Writer(multi, devices=[])
     with pytest.raises(ValueError):
