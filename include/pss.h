@@ -125,7 +125,9 @@ typedef struct pss_sa_stats {
                                   in closed form (rle_build.h): rotation blocks + a host sort of the last few suffixes */
     uint64_t plan_hint;        /* 0: the sizing sample chose the initial sort; 1: the previous build on this device sorted
                                   the same kind of text (same byte values, same size class) with the MSD sort and this
-                                  build went straight to it (PSS_NO_PLAN_CACHE=1: never) */
+                                  build went straight to it (PSS_NO_PLAN_CACHE=1: never); 2: ... and recoded the text with
+                                  the remembered alphabet inside the sort's first pass, without an alphabet pass of its
+                                  own (the pass checks that every byte has a code; PSS_NO_PLAN_FRONT=1: never) */
 } pss_sa_stats;
 
 /*

@@ -137,6 +137,8 @@ struct DeviceCtx {
     uint32_t plan_present[8] = {};
     uint32_t plan_logn = 0;
     int plan_path = 0;                   // 0 none, 1 hybrid MSD
+    uint8_t plan_lut[256] = {};          // ... and its byte -> code table (the next build recodes with it inside the sort)
+    uint32_t plan_sigma = 0;
     // Two pinned staging buffers + a copy stream: file <-> HBM transfers are
     // double-buffered so the PCIe copy of piece i overlaps the file I/O of piece i+1.
     static constexpr size_t kStage = (size_t)64 << 20;

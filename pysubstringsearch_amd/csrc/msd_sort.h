@@ -10,6 +10,7 @@ struct MsdStats {
     uint32_t max_bucket = 0;   // largest of them
     uint32_t tiles = 0;        // local-sort workgroups
     uint32_t slow_tiles = 0;   // of them, tiles the counting kernel handed to the general (ballot LSD) kernel
+    uint32_t bad_symbol = 0;   // MsdFront: a byte of the text had no code in the table it was given
     double ms_g1 = 0, ms_g2 = 0, ms_local = 0;   // profile mode: the two partition scatters and the local sort
 };
 
@@ -33,8 +34,17 @@ int msd_max_key_bits(uint32_t n);
 // keys is unspecified (suffix_sort_flags leaves them by index; nothing downstream relies on that).
 // *accepted = false (and sa_out untouched) when some joint bucket exceeds what a workgroup sorts in
 // LDS: the caller then uses suffix_sort_flags.  h_small: >= 32 bytes of pinned host memory.
+// `front` (optional): the codes do not exist yet -- the first histogram pass makes them on its way through the raw text
+// (codes[i] = lut[T[i]], the buffer behind text->codes is written; its padding past n must be zero already) and raises
+// *bad when a byte has no code in `lut` (then the sort declines: *accepted = false, stats->bad_symbol = 1).
+struct MsdFront {
+    const uint8_t *raw;     // T, 16-byte aligned
+    const uint8_t *lut;     // device, [256]
+    uint32_t *bad;          // device, zeroed by the caller
+};
 int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bits, uint64_t *A[2], uint32_t *sa_out,
-                    void *work, uint32_t *h_small, bool profile, MsdStats *stats, bool *accepted, MsdActive *active = nullptr);
+                    void *work, uint32_t *h_small, bool profile, MsdStats *stats, bool *accepted, MsdActive *active = nullptr,
+                    const MsdFront *front = nullptr);
 
 // ---- sample sort over 16-byte elements (ss_sort_impl.h): the initial sort of natural text ----
 

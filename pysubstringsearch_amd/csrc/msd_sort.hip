@@ -81,6 +81,11 @@ struct MsdArgs {
     const u64 *dense;    // G2 scatter: [2^20] number of every joint bucket among the non-empty ones
     const u64 *in;
     u64 *out;
+    // MsdFront: the first histogram pass recodes the raw text on its way through
+    const u8 *raw;
+    const u8 *lut;
+    u8 *codes_out;
+    u32 *bad;
 };
 
 // ---- tile machinery of the two global passes -----------------------------------------------------
@@ -191,6 +196,95 @@ __global__ __launch_bounds__(MSD_BLOCK) void msd_hist_kernel(MsdArgs a)
         if (FROM_TEXT) a.T[(size_t)i * a.num_ranges1 + r] = hist[i];
         else a.T[(size_t)r * MSD_BINS + i] = hist[i];
     }
+}
+
+// The first histogram pass when the codes do not exist yet (MsdFront): the same windows, read from the raw text through
+// the byte -> code table (in LDS), and the codes of the thread's own 16 bytes written out on the way -- the recode pass
+// and the alphabet pass before it (0.4 ms and a host round trip at n = 2^29) fold into this one.  A byte without a code
+// raises *bad; the caller then throws the sort away.
+__global__ __launch_bounds__(MSD_BLOCK) void msd_hist_raw_kernel(MsdArgs a)
+{
+    __shared__ u32 hist[MSD_BINS];
+    __shared__ u8 s_lut[256];
+    const u32 tid = threadIdx.x, r = blockIdx.x;
+    if (r >= a.num_ranges1) return;
+    const u32 e0 = r * a.tiles_per_range1 * MSD_TILE;
+    const u64 end = (u64)(r + 1) * a.tiles_per_range1 * MSD_TILE;
+    const u32 e1 = end < a.n ? (u32)end : a.n;
+    for (u32 i = tid; i < MSD_BINS; i += MSD_BLOCK) hist[i] = 0;
+    if (tid < 256) s_lut[tid] = a.lut[tid];
+    __syncthreads();
+    const int b = a.code_bits;
+    const int m = (MSD_D + b - 1) / b;
+    const u32 wmask = (m * b >= 32) ? ~0u : ((1u << (m * b)) - 1u);
+    const int down = m * b - MSD_D;
+    auto tr = [&](u32 w) -> u32 {
+        return (u32)s_lut[w & 0xffu] | ((u32)s_lut[(w >> 8) & 0xffu] << 8) | ((u32)s_lut[(w >> 16) & 0xffu] << 16) |
+               ((u32)s_lut[w >> 24] << 24);
+    };
+    // 32 raw bytes at i: two 16-byte loads when they lie inside the text, byte by byte (zero past the end) at its end
+    auto load32 = [&](u32 i, uint4 &lo, uint4 &hi) {
+        if ((u64)i + 32 <= a.n) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(a.raw + i);
+            lo = p[0];
+            hi = p[1];
+        } else {
+            u32 w[8] = {};
+            for (u32 k = 0; k < 32 && i + k < a.n; ++k) w[k >> 2] |= (u32)a.raw[i + k] << (8u * (k & 3u));
+            lo = make_uint4(w[0], w[1], w[2], w[3]);
+            hi = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+    };
+    bool bad = false;
+    uint4 nlo = make_uint4(0, 0, 0, 0), nhi = nlo;
+    if (e0 + tid * MSD_IPT < e1) load32(e0 + tid * MSD_IPT, nlo, nhi);
+    for (u32 base = e0; base < e1; base += MSD_TILE) {
+        const u32 i0 = base + tid * MSD_IPT;
+        uint4 lo = nlo, hi = nhi;
+        if ((u64)i0 + MSD_TILE < e1) load32(i0 + MSD_TILE, nlo, nhi);
+        if (i0 >= e1) continue;
+        lo = make_uint4(tr(lo.x), tr(lo.y), tr(lo.z), tr(lo.w));
+        hi = make_uint4(tr(hi.x), tr(hi.y), tr(hi.z), tr(hi.w));
+        // my own 16 bytes: codes out, and every one of them inside the text must have got a code
+        const u32 own = min(16u, a.n - i0);
+        if (own == 16) {
+            *reinterpret_cast<uint4 *>(a.codes_out + i0) = lo;
+            const u32 z = ((lo.x - 0x01010101u) & ~lo.x) | ((lo.y - 0x01010101u) & ~lo.y) | ((lo.z - 0x01010101u) & ~lo.z) |
+                          ((lo.w - 0x01010101u) & ~lo.w);
+            bad |= (z & 0x80808080u) != 0;
+        } else {
+            const u32 w[4] = {lo.x, lo.y, lo.z, lo.w};
+            for (u32 k = 0; k < own; ++k) {
+                const u8 c = (u8)(w[k >> 2] >> (8u * (k & 3u)));
+                a.codes_out[i0 + k] = c;
+                bad |= c == 0;
+            }
+            // (a raw byte past the end reads as 0 and translates to lut[0]: the window must see 0 there)
+            u32 ww[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            for (u32 k = own; k < 32; ++k) ww[k >> 2] &= ~(0xffu << (8u * (k & 3u)));
+            lo = make_uint4(ww[0], ww[1], ww[2], ww[3]);
+            hi = make_uint4(ww[4], ww[5], ww[6], ww[7]);
+        }
+        if (own == 16 && (u64)i0 + 32 > a.n) {            // the window's second half crosses the end of the text
+            u32 ww[4] = {hi.x, hi.y, hi.z, hi.w};
+            for (u32 k = 0; k < 16; ++k)
+                if (i0 + 16 + k >= a.n) ww[k >> 2] &= ~(0xffu << (8u * (k & 3u)));
+            hi = make_uint4(ww[0], ww[1], ww[2], ww[3]);
+        }
+        const u64 q[4] = {(u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32),
+                          (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32)};
+        auto sym = [&](u32 j) -> u32 { return (u32)(q[j >> 3] >> ((j & 7u) * 8u)) & 0xffu; };
+        u32 win = 0;
+        for (int t = 0; t < m; ++t) win = (win << b) | sym((u32)t);
+#pragma unroll
+        for (int k = 0; k < MSD_IPT; ++k) {
+            if (k > 0) win = ((win << b) | sym((u32)(m - 1 + k))) & wmask;
+            if (i0 + k < e1) atomicAdd(&hist[win >> down], 1u);
+        }
+    }
+    if (__ballot(bad) && (tid & 63u) == 0) atomicOr(a.bad, 1u);
+    __syncthreads();
+    for (u32 i = tid; i < MSD_BINS; i += MSD_BLOCK) a.T[(size_t)i * a.num_ranges1 + r] = hist[i];
 }
 
 // G1 offsets, step 1: one workgroup per digit turns its row of per-range counts into exclusive prefixes
@@ -1063,7 +1157,8 @@ int msd_max_key_bits(uint32_t n)
 }
 
 int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bits, uint64_t *A[2], uint32_t *sa_out,
-                    void *work, uint32_t *h_small, bool profile, MsdStats *stats, bool *accepted, MsdActive *active)
+                    void *work, uint32_t *h_small, bool profile, MsdStats *stats, bool *accepted, MsdActive *active,
+                    const MsdFront *front)
 {
     *accepted = false;
     hipStream_t s = ctx->stream;
@@ -1136,7 +1231,15 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     PSS_HIP(hipMemsetAsync(counters, 0, 64, s));
     // ---- G1: text -> A[0] by the top 10 key bits ----
     a.out = A[0];
-    hipLaunchKernelGGL(msd_hist_kernel<true>, dim3(a.num_ranges1), dim3(MSD_BLOCK), 0, s, a);
+    if (front) {
+        a.raw = front->raw;
+        a.lut = front->lut;
+        a.codes_out = const_cast<u8 *>(text->codes);
+        a.bad = front->bad;
+        hipLaunchKernelGGL(msd_hist_raw_kernel, dim3(a.num_ranges1), dim3(MSD_BLOCK), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(msd_hist_kernel<true>, dim3(a.num_ranges1), dim3(MSD_BLOCK), 0, s, a);
+    }
     static_assert(MSD_G1_RANGES <= 1024, "msd_offsets1_kernel takes four ranges per thread");
     hipLaunchKernelGGL(msd_offsets1_kernel, dim3(MSD_BINS), dim3(256), 0, s, T, a.num_ranges1, seg_first);   // totals: scratch
     hipLaunchKernelGGL(msd_offsets1b_kernel, dim3(1), dim3(MSD_BINS), 0, s, (const u32 *)seg_first, J1, n);
@@ -1161,13 +1264,16 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     hipLaunchKernelGGL(msd_compact_kernel, dim3(1024), dim3(256), 0, s, J, (u32)nbk, ranks, cstart, counters);
     PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
     PSS_HIP(hipMemcpyAsync(h_small + 2, counters, 16, hipMemcpyDeviceToHost, s));
+    if (front) PSS_HIP(hipMemcpyAsync(h_small + 6, front->bad, 4, hipMemcpyDeviceToHost, s));
     PSS_HIP(hipStreamSynchronize(s));
     const u32 ne = h_small[0];
     const u32 maxb = h_small[3];
     if (stats) {
         stats->buckets = ne;
         stats->max_bucket = maxb;
+        stats->bad_symbol = front ? h_small[6] : 0u;
     }
+    if (front && h_small[6]) return PSS_OK;        // a byte the table has no code for: nothing of this sort can be used
     if (maxb > MSD_MAX_BUCKET) return PSS_OK;      // not this text: the caller takes the LSD path
     PSS_TRY(mark());
     if (wide) hipLaunchKernelGGL((msd_scatter2_kernel<false, 1024>), dim3((u32)max_ranges2), dim3(1024), 0, s, a);

@@ -1204,6 +1204,7 @@ struct Knobs {
     int text_rounds_max = 5;    // PSS_TEXT_ROUNDS
     int msd = -1;               // PSS_MSD        0: never the MSD initial sort, 1: whenever the key fits, unset: screened
     bool no_plan = false;       // PSS_NO_PLAN_CACHE  always take the sizing sample (never reuse the previous build's choice of sort)
+    bool no_front = false;      // PSS_NO_PLAN_FRONT  reuse the choice of sort, but not the alphabet (separate alphabet and recode passes)
     int ss = -1;                // PSS_SS         0: never the sample sort over 16-byte elements, 1: whenever the text has the size for it,
                                 //                unset: n >= 2^24 and the MSD sort did not take the text
     bool no_msd_fuse = false;   // PSS_MSD_NO_FUSE  MSD sort flags ties in the suffix array; the rerank kernels read them
@@ -1227,6 +1228,7 @@ struct Knobs {
         if (const char *e = getenv("PSS_MSD")) k.msd = atoi(e);
         if (const char *e = getenv("PSS_SS")) k.ss = atoi(e);
         k.no_plan = getenv("PSS_NO_PLAN_CACHE") != nullptr;
+        k.no_front = getenv("PSS_NO_PLAN_FRONT") != nullptr;
         k.no_msd_fuse = getenv("PSS_MSD_NO_FUSE") != nullptr;
         k.no_mid_tier = getenv("PSS_NO_MID_TIER") != nullptr;
         if (const char *e = getenv("PSS_RLE")) k.rle = atoi(e);
@@ -1735,71 +1737,92 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     // ---- 0. alphabet ----
     const int grid_stream = ctx->num_cus * 8;
     u32 *d_runs = d_counters + 40;
-    PSS_HIP(hipMemsetAsync(d_present, 0, 2048, s));
-    PSS_HIP(hipMemsetAsync(d_runs, 0, 4, s));
-    hipLaunchKernelGGL(sa_symbols_kernel, dim3(grid_stream), dim3(256), 0, s, T, n, d_present, d_present + 256, d_runs);
-    PSS_HIP(hipMemcpyAsync(h_small, d_present, 2048, hipMemcpyDeviceToHost, s));
-    PSS_HIP(hipMemcpyAsync(h_small + 512, d_runs, 4, hipMemcpyDeviceToHost, s));
-    // (the head of the text rides along: does it repeat one word?  -- see below)
-    u8 *h_head = static_cast<u8 *>(ctx->pinned) + 32768;         // the search path's query staging; builds and searches take turns
-    const u32 head_len = std::min<u32>(n, kPeriodProbe);
-    const bool look_for_period = knobs.period != 0 && n >= 4 * kPeriodProbe;
-    if (look_for_period) PSS_HIP(hipMemcpyAsync(h_head, T, head_len, hipMemcpyDeviceToHost, s));
-    PSS_HIP(hipStreamSynchronize(s));
-    // Long runs of equal bytes (every suffix inside a run is tied with its neighbours for as long as the run
-    // lasts: the worst case of prefix doubling): sort the run heads as a string of one symbol per run, then
-    // every other suffix falls into place with one short radix sort (rle_build.hip).
-    const u32 text_runs = h_small[512];
-    st.runs = text_runs;
-    if (knobs.rle == 1 || (knobs.rle < 0 && n >= 4096 && (u64)text_runs * 8 <= (u64)n)) {
-        RleStats rls;
-        PSS_TRY(rle_suffix_array(ctx, T, n, text_runs, SA, profile, &rls, &st));
-        st.rle = rls.columns ? 2 : 1;
-        st.rle_id_bits = rls.id_bits;
-        st.rle_ms_table = rls.ms_table;
-        st.rle_ms_reduced = rls.ms_reduced;
-        st.rle_ms_expand = rls.ms_expand;
-        for (int c = 0; c < 256; ++c) st.sigma += h_small[c] ? 1u : 0u;
-        PSS_HIP(hipEventRecord(timer.ev1, s));
+    // The plan of the previous build on this device (see step 1): when it took the MSD sort on a text of this size class
+    // and every switch is at its default, this build does not look at its alphabet first either -- it recodes with the
+    // remembered byte -> code table inside the sort's first histogram pass (msd_hist_raw_kernel: the alphabet pass, the
+    // recode pass and a host round trip fold into it, 0.4 ms at n = 2^29), which also checks that every byte has a code
+    // there.  A text over a subset of the remembered alphabet is sorted correctly with the larger table; a new byte, a
+    // crowded bucket, or anything else the sort declines for starts the build over without the plan -- the run-length
+    // and periodic-text checks, which this shortcut skips, then take place as always.
+    uint32_t logn = 0;
+    while ((2u << logn) <= n && logn < 31) ++logn;
+    const bool plain = knobs.key_chars == 0 && !knobs.no_sample && !knobs.no_flags && knobs.msd < 0 && knobs.ss < 0 &&
+                       knobs.key_drop < 0 && knobs.mode < 0 && !knobs.no_msd_fuse && !knobs.no_plan && knobs.rle < 0 &&
+                       knobs.period != 0 && (flags & 2u) == 0;
+    const bool fronted = plain && !knobs.no_front && n >= (1u << 24) && ctx->plan_path == 1 && ctx->plan_logn == logn &&
+                         (reinterpret_cast<uintptr_t>(T) & 15u) == 0;
+    if (!fronted) {
+        PSS_HIP(hipMemsetAsync(d_present, 0, 2048, s));
+        PSS_HIP(hipMemsetAsync(d_runs, 0, 4, s));
+        hipLaunchKernelGGL(sa_symbols_kernel, dim3(grid_stream), dim3(256), 0, s, T, n, d_present, d_present + 256, d_runs);
+        PSS_HIP(hipMemcpyAsync(h_small, d_present, 2048, hipMemcpyDeviceToHost, s));
+        PSS_HIP(hipMemcpyAsync(h_small + 512, d_runs, 4, hipMemcpyDeviceToHost, s));
+        // (the head of the text rides along: does it repeat one word?  -- see below)
+        u8 *h_head = static_cast<u8 *>(ctx->pinned) + 32768;         // the search path's query staging; builds and searches take turns
+        const u32 head_len = std::min<u32>(n, kPeriodProbe);
+        const bool look_for_period = knobs.period != 0 && n >= 4 * kPeriodProbe;
+        if (look_for_period) PSS_HIP(hipMemcpyAsync(h_head, T, head_len, hipMemcpyDeviceToHost, s));
         PSS_HIP(hipStreamSynchronize(s));
-        float ms = 0.f;
-        PSS_HIP(hipEventElapsedTime(&ms, timer.ev0, timer.ev1));
-        st.ms_total = ms;
-        if (stats) *stats = st;
-        return PSS_OK;
-    }
-    // One word written over and over (a text whose first m bytes have a small period, with at most a few bytes behind):
-    // the worst case of prefix doubling that is not a run of one byte.  The head of the text says whether it is worth
-    // a pass to find out how far the repetition goes; if it covers the text, the suffix array has a closed form
-    // (rle_build.h).
-    if (look_for_period) {
-        const u32 p = period_of_head(h_head, head_len);
-        if (p) {
-            u32 m = 0;
-            PSS_TRY(period_extent(ctx, T, n, p, &m));
-            st.period = p;
-            st.period_extent = m;
-            bool accepted = false;
-            if (n - m <= kPeriodTailMax) {
-                std::vector<u8> word(h_head, h_head + p);           // (period_extent reuses the pinned scratch)
-                PSS_TRY(period_suffix_array(ctx, T, n, p, m, word.data(), SA, &accepted));
-            }
-            if (accepted) {
-                st.period_path = 1;
-                for (int c = 0; c < 256; ++c) st.sigma += h_small[c] ? 1u : 0u;
-                PSS_HIP(hipEventRecord(timer.ev1, s));
-                PSS_HIP(hipStreamSynchronize(s));
-                float ms = 0.f;
-                PSS_HIP(hipEventElapsedTime(&ms, timer.ev0, timer.ev1));
-                st.ms_total = ms;
-                if (stats) *stats = st;
-                return PSS_OK;
+        // Long runs of equal bytes (every suffix inside a run is tied with its neighbours for as long as the run
+        // lasts: the worst case of prefix doubling): sort the run heads as a string of one symbol per run, then
+        // every other suffix falls into place with one short radix sort (rle_build.hip).
+        const u32 text_runs = h_small[512];
+        st.runs = text_runs;
+        if (knobs.rle == 1 || (knobs.rle < 0 && n >= 4096 && (u64)text_runs * 8 <= (u64)n)) {
+            RleStats rls;
+            PSS_TRY(rle_suffix_array(ctx, T, n, text_runs, SA, profile, &rls, &st));
+            st.rle = rls.columns ? 2 : 1;
+            st.rle_id_bits = rls.id_bits;
+            st.rle_ms_table = rls.ms_table;
+            st.rle_ms_reduced = rls.ms_reduced;
+            st.rle_ms_expand = rls.ms_expand;
+            for (int c = 0; c < 256; ++c) st.sigma += h_small[c] ? 1u : 0u;
+            PSS_HIP(hipEventRecord(timer.ev1, s));
+            PSS_HIP(hipStreamSynchronize(s));
+            float ms = 0.f;
+            PSS_HIP(hipEventElapsedTime(&ms, timer.ev0, timer.ev1));
+            st.ms_total = ms;
+            if (stats) *stats = st;
+            return PSS_OK;
+        }
+        // One word written over and over (a text whose first m bytes have a small period, with at most a few bytes behind):
+        // the worst case of prefix doubling that is not a run of one byte.  The head of the text says whether it is worth
+        // a pass to find out how far the repetition goes; if it covers the text, the suffix array has a closed form
+        // (rle_build.h).
+        if (look_for_period) {
+            const u32 p = period_of_head(h_head, head_len);
+            if (p) {
+                u32 m = 0;
+                PSS_TRY(period_extent(ctx, T, n, p, &m));
+                st.period = p;
+                st.period_extent = m;
+                bool accepted = false;
+                if (n - m <= kPeriodTailMax) {
+                    std::vector<u8> word(h_head, h_head + p);           // (period_extent reuses the pinned scratch)
+                    PSS_TRY(period_suffix_array(ctx, T, n, p, m, word.data(), SA, &accepted));
+                }
+                if (accepted) {
+                    st.period_path = 1;
+                    for (int c = 0; c < 256; ++c) st.sigma += h_small[c] ? 1u : 0u;
+                    PSS_HIP(hipEventRecord(timer.ev1, s));
+                    PSS_HIP(hipStreamSynchronize(s));
+                    float ms = 0.f;
+                    PSS_HIP(hipEventElapsedTime(&ms, timer.ev0, timer.ev1));
+                    st.ms_total = ms;
+                    if (stats) *stats = st;
+                    return PSS_OK;
+                }
             }
         }
     }
     u8 lut[256];
     u32 sigma = 0;
-    for (int c = 0; c < 256; ++c) lut[c] = h_small[c] ? (u8)(++sigma) : 0;   // codes 1..sigma
+    if (fronted) {
+        memcpy(lut, ctx->plan_lut, 256);
+        sigma = ctx->plan_sigma;
+    } else {
+        for (int c = 0; c < 256; ++c) lut[c] = h_small[c] ? (u8)(++sigma) : 0;   // codes 1..sigma
+    }
     int b = 1;
     while ((1u << b) <= sigma) ++b;               // codes 0..sigma need b bits
     int plus_one = 0;
@@ -1812,7 +1835,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     }
     int kmax = 64 / b;
     if (kmax > 16) kmax = 16;
-    int key_chars = choose_key_chars(h_small + 256, n, b, kmax);
+    int key_chars = fronted ? kmax : choose_key_chars(h_small + 256, n, b, kmax);
     const bool forced_chars = knobs.key_chars >= 1 && knobs.key_chars <= kmax;
     if (forced_chars) key_chars = knobs.key_chars;
     st.sigma = sigma;
@@ -1820,7 +1843,15 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     st.key_chars = (u32)key_chars;
     memcpy(h_small + 1024, lut, 256);
     PSS_HIP(hipMemcpyAsync(d_lut, h_small + 1024, 256, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(sa_recode_kernel, dim3(grid_stream), dim3(256), 0, s, T, n, (u32)n_pad, d_lut, codes);
+    u32 *d_bad = d_counters + 44;
+    if (fronted) {
+        // the codes are made by the sort (below); their padding past n and the flag for a byte without a code
+        const size_t tail0 = (size_t)n & ~(size_t)15;
+        PSS_HIP(hipMemsetAsync(codes + tail0, 0, n_pad - tail0, s));
+        PSS_HIP(hipMemsetAsync(d_bad, 0, 4, s));
+    } else {
+        hipLaunchKernelGGL(sa_recode_kernel, dim3(grid_stream), dim3(256), 0, s, T, n, (u32)n_pad, d_lut, codes);
+    }
 
     // ---- 1. initial sort on the first key_chars symbols ----
     SortStats ss;
@@ -1834,14 +1865,11 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     uint32_t present_bits[8] = {};
     for (int c = 0; c < 256; ++c)
         if (plus_one || lut[c]) present_bits[c >> 5] |= 1u << (c & 31);
-    uint32_t logn = 0;
-    while ((2u << logn) <= n && logn < 31) ++logn;
-    const bool plain = !forced_chars && knobs.key_chars == 0 && !knobs.no_sample && !knobs.no_flags && knobs.msd < 0 &&
-                       knobs.ss < 0 && knobs.key_drop < 0 && knobs.mode < 0 && !knobs.no_msd_fuse && !knobs.no_plan && (flags & 2u) == 0;
     int hint = 0;
-    if (plain && n >= (1u << 24) && ctx->plan_path && ctx->plan_logn == logn && memcmp(ctx->plan_present, present_bits, 32) == 0)
+    if (fronted) hint = 1;
+    else if (plain && n >= (1u << 24) && ctx->plan_path && ctx->plan_logn == logn && memcmp(ctx->plan_present, present_bits, 32) == 0)
         hint = ctx->plan_path;
-    st.plan_hint = (uint64_t)hint;
+    st.plan_hint = (uint64_t)(fronted ? 2 : hint);
     if (hint) {
         sampled = true;
         msd_screen_ok = hint == 1;
@@ -1894,8 +1922,15 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
             act.grp = ctx->slot[S_GRP2].as<u32>();
             act.st_pos = reinterpret_cast<u32 *>(K[0]);
             act.st_idx = reinterpret_cast<u32 *>(K[0]) + n;
+            const MsdFront front{T, d_lut, d_bad};
             PSS_TRY(msd_suffix_sort(ctx, &mk, n, kb, K, SA, ctx->slot[S_P0].p, h_small, profile, &ms, &accepted,
-                                    knobs.no_msd_fuse ? nullptr : &act));
+                                    knobs.no_msd_fuse ? nullptr : &act, fronted ? &front : nullptr));
+            if (fronted && !accepted) {
+                // the plan did not hold for this text (a byte outside the remembered alphabet, a crowded bucket): all
+                // over again without it -- the alphabet pass, the run-length and periodic-text checks, the sample
+                ctx->plan_path = 0;
+                return sa_build_device(ctx, d_T, d_SA, n_in, flags, stats);
+            }
             msd_fused = accepted && !knobs.no_msd_fuse;
             msd_active = act.count;
             st.msd_buckets = ms.buckets;
@@ -1917,6 +1952,10 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
                 ss.elems = 3ull * n;
             }
         }
+    }
+    if (fronted && !msd_done) {              // (the sort was not even tried: nothing has made the codes)
+        ctx->plan_path = 0;
+        return sa_build_device(ctx, d_T, d_SA, n_in, flags, stats);
     }
     // Natural text (some 20-bit prefix holds far more suffixes than a tile, and a 64-bit key leaves most suffixes tied
     // anyway): sample sort over 16-byte [key | index] elements (ss_sort_impl.h) -- splitters from a sorted sample cut the
@@ -1974,10 +2013,12 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         ctx->plan_path = 0;
         return sa_build_device(ctx, d_T, d_SA, n_in, flags, stats);
     }
-    if (plain && n >= (1u << 24)) {
+    if (plain && n >= (1u << 24) && !fronted) {
         ctx->plan_path = st.msd ? 1 : 0;      // only the sort whose own exact check can refuse a text is taken unsampled
         ctx->plan_logn = logn;
         memcpy(ctx->plan_present, present_bits, 32);
+        memcpy(ctx->plan_lut, lut, 256);
+        ctx->plan_sigma = sigma;
     }
     if (msd_done) {
     } else if (ties) PSS_TRY(suffix_sort_flags(ctx, K, V, n, key_bits0, &tk, work, &cur, profile, &ss));

@@ -289,20 +289,49 @@ def test_sample_sort_is_chosen_for_natural_text(oracle):
         assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(t).tobytes()).hexdigest()
 
 
-def test_initial_sort_plan_is_reused_and_checked(oracle, monkeypatch):
-    """The second build of the same kind of text (same byte values present, same size class) skips the sizing sample and
-    goes straight to the MSD sort (plan_hint = 1), with the same bytes out.  A text with the same byte values but natural
-    text's distribution then gets the hint too; the MSD sort's exact bucket check refuses it and the build goes on to the
-    sample sort as it would have after the sample -- still libsais' bytes -- and forgets the plan.  PSS_NO_PLAN_CACHE=1
-    switches the memory off."""
+@pytest.mark.parametrize('front', [True, False])
+def test_initial_sort_plan_is_reused_and_checked(oracle, monkeypatch, front):
+    """The second build of the same kind of text (same size class, every switch at its default) goes straight to the MSD
+    sort with the remembered alphabet: no alphabet pass, no recode pass, no sizing sample -- the sort's first histogram
+    pass recodes the raw text and checks that every byte has a code (plan_hint = 2; with PSS_NO_PLAN_FRONT=1 the
+    alphabet is looked at first and only the sample is skipped: plan_hint = 1).  Same bytes out.  A text with the same
+    byte values but natural text's distribution gets the plan too; the MSD sort's exact bucket check refuses it and the
+    build goes on (plan_hint 1) or starts over (2) -- still libsais' bytes -- and forgets the plan.  So does a text with
+    a byte the plan has no code for, and a text over a subset of the remembered alphabet is sorted with the larger table.
+    PSS_NO_PLAN_CACHE=1 switches the memory off."""
+    if not front:
+        monkeypatch.setenv('PSS_NO_PLAN_FRONT', '1')
     n = 1 << 24
     lines = gen_corpus(0, n)
     want = hashlib.sha256(oracle.sa(lines).tobytes()).hexdigest()
     _sa_device(lines, {})
     st = {}
     sa = _sa_device(lines, st)
-    assert (st['plan_hint'], st['msd']) == (1, 1)
+    assert (st['plan_hint'], st['msd']) == (2 if front else 1, 1)
     assert hashlib.sha256(sa.tobytes()).hexdigest() == want
+    if front:
+        # an unaligned text pointer keeps the separate passes
+        import torch
+        from pysubstringsearch_amd import _ffi
+        import ctypes
+        buf = torch.from_numpy(np.concatenate([np.zeros(3, np.uint8), lines])).cuda()
+        dSA = torch.empty(n, dtype=torch.int32, device='cuda')
+        s2 = _ffi.SaStats()
+        _ffi.check(_ffi.lib.pss_sa_build_device(buf.data_ptr() + 3, dSA.data_ptr(), n, 0, 0, ctypes.byref(s2)))
+        assert s2.plan_hint == 1 and hashlib.sha256(dSA.cpu().numpy().tobytes()).hexdigest() == want
+        # a byte the remembered alphabet does not have ('~' at one place): refused inside the first pass, rebuilt from scratch
+        odd = lines.copy()
+        odd[n // 3] = 126
+        assert 126 not in np.unique(lines)
+        st = {}
+        sa = _sa_device(odd, st)
+        assert (st['plan_hint'], st['msd']) == (0, 1)
+        assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(odd).tobytes()).hexdigest()
+        # ... which is the plan now; the old text is over a subset of that alphabet and takes the larger table
+        st = {}
+        sa = _sa_device(lines, st)
+        assert (st['plan_hint'], st['msd'], st['sigma']) == (2, 1, len(np.unique(odd)))
+        assert hashlib.sha256(sa.tobytes()).hexdigest() == want
     # same alphabet, crowded prefixes: a small vocabulary over the bytes of `lines`
     rng = np.random.default_rng(9)
     alphabet = np.unique(lines)
@@ -313,7 +342,10 @@ def test_initial_sort_plan_is_reused_and_checked(oracle, monkeypatch):
     assert len(crowded) == n and np.array_equal(np.unique(crowded), alphabet)
     st = {}
     sa = _sa_device(crowded, st)
-    assert (st['plan_hint'], st['msd'], st['ss']) == (1, 0, 1) and st['msd_max_bucket'] > 4088    # hinted, refused
+    if front:
+        assert (st['plan_hint'], st['msd'], st['ss']) == (0, 0, 1)                                 # planned, refused, rebuilt
+    else:
+        assert (st['plan_hint'], st['msd'], st['ss']) == (1, 0, 1) and st['msd_max_bucket'] > 4088    # hinted, refused
     assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(crowded).tobytes()).hexdigest()
     st = {}
     _sa_device(lines, st)
