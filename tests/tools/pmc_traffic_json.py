@@ -18,6 +18,7 @@ for f in sorted(glob.glob(f'{root}/g*/*counter_collection.csv')):
 ALGO = {   # algorithmic bytes per element of the kernels of the initial sort
     'msd_scatter_kernel<true>': 9, 'msd_scatter_kernel<false>': 16, 'msd_local_fast_kernel': 12,
     'msd_scatter2_kernel<true, 1024>': 9, 'msd_scatter2_kernel<false, 1024>': 16,
+    'msd_hist_raw_kernel': 2,
     'msd_hist_kernel<true>': 1, 'msd_hist_kernel<false>': 8,
     'fs_scatter_kernel<0, 4>': 9, 'fs_scatter_kernel<4, 4>': 16, 'fs_scatter_kernel<4, 0>': 12,
     # sample sort over 16-byte elements (ss_sort_impl.h)
