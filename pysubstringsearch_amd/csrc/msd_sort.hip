@@ -928,14 +928,20 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
         }
     };
     prefetch(cur);
+    // Six barriers per tile, not nine: the counters are zeroed for the NEXT tile while this one is permuted (they are not
+    // read after the ranking), the tile's bookkeeping (failure flag, record count -> blk_cnt) is settled behind the next
+    // tile's first barrier -- by then every wave has left this tile's output -- and nothing separates the tiles otherwise
+    // (the next write to the element array is three barriers into the next tile).
+    for (u32 i = tid; i < LS_WORDS; i += MSD_BLOCK) hist[i] = 0;
+    if (tid == 0) {
+        s_fail = 0;
+        scr[MSD_WAVES + 3] = 0;            // records the tile has emitted
+    }
+    lds_barrier();
+    u32 prev_t = 0;
+    bool prev_ok = false;
     for (;;) {
         const u32 count = cur.count, e0 = cur.e0;
-        for (u32 i = tid; i < LS_WORDS; i += MSD_BLOCK) hist[i] = 0;
-        if (tid == 0) {
-            s_fail = 0;
-            scr[MSD_WAVES + 3] = 0;        // records this tile has emitted
-        }
-        lds_barrier();
         const u32 rows = (count + MSD_BLOCK - 1) / MSD_BLOCK;          // uniform over the workgroup
         int seg_bits = 0;
         while ((1u << seg_bits) < cur.nb) ++seg_bits;
@@ -960,6 +966,11 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
         const bool more = t + stride < nt;
         if (more) prefetch(nxt);
         lds_barrier();
+        if (tid == 0) {                    // the previous tile is over for every wave: its record count, the flags for this one
+            if (em && prev_ok) em->blk_cnt[prev_t] = scr[MSD_WAVES + 3];
+            s_fail = 0;
+            scr[MSD_WAVES + 3] = 0;
+        }
         {
             // exclusive scan over the 4096 bins in place: four adjacent words = eight bins per thread
             u32 c[8];
@@ -1066,6 +1077,7 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
                 }
             }
         }
+        for (u32 i = tid; i < LS_WORDS; i += MSD_BLOCK) hist[i] = 0;      // (bin starts: last read in the ranking) for the next tile
         lds_barrier();
         if (!failed) {
             // Output (msd_emit_tile with the loads of LS_GROUP rows in flight): suffix indices to sa_out[e0 ..]; a record for
@@ -1110,15 +1122,16 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
                 }
             }
         }
-        if (em) {
-            lds_barrier();
-            if (tid == 0 && !failed) em->blk_cnt[t] = scr[MSD_WAVES + 3];
-        }
+        prev_t = t;
+        prev_ok = !failed;
         if (!more) break;
         t += stride;
         cur = nxt;
         nxt = t + stride < nt ? tiles[t + stride] : MsdTile{0, 0, 0, 0};
-        lds_barrier();          // the output has read exch / s_fail: the next tile may overwrite them
+    }
+    if (em) {
+        lds_barrier();
+        if (tid == 0 && prev_ok) em->blk_cnt[prev_t] = scr[MSD_WAVES + 3];
     }
 }
 
