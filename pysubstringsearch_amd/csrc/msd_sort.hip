@@ -1548,10 +1548,9 @@ int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t radix, uint32_
     (void)active;
     (void)blk_cnt;
     (void)dst_off;
-    MsdEmit em{};
     PSS_TRY(mark());                                                                       // [4]
     hipLaunchKernelGGL(ss_local_kernel, dim3(nt), dim3(SL_BLOCK), 0, s, (const E16 *)buf.A[1], (const MsdTile *)tiles_all, nt, g.ib,
-                       sa_out, 0, em);
+                       sa_out);
     PSS_TRY(mark());                                                                       // [5]
     hipLaunchKernelGGL(ss_boundary_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, (const MsdTile *)tiles_all, nt, tx, sa_out);
     PSS_HIP(hipGetLastError());

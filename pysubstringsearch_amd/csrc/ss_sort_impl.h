@@ -477,17 +477,13 @@ __device__ __forceinline__ void sl_cswap(E16 &a, E16 &b)
     b = y;
 }
 
-__global__ __launch_bounds__(SL_BLOCK, SL_BLOCK == 512 ? 4 : 8) void ss_local_kernel(const E16 *in, const MsdTile *tiles, u32 nt, int ib, u32 *sa_out,
-                                                             int fused, MsdEmit em_val)
+__global__ __launch_bounds__(SL_BLOCK, SL_BLOCK == 512 ? 4 : 8) void ss_local_kernel(const E16 *in, const MsdTile *tiles, u32 nt, int ib, u32 *sa_out)
 {
-    const MsdEmit *em = fused ? &em_val : nullptr;
     __shared__ E16 buf[SS_TILE];
-    __shared__ u32 s_count;
     const u32 tid = threadIdx.x;
     const u32 t = blockIdx.x;
     if (t >= nt) return;
     const u32 e0 = tiles[t].e0, count = tiles[t].count;
-    if (tid == 0) s_count = 0;
     // coalesced load, positions past the tile = +infinity
 #pragma unroll
     for (int k = 0; k < SL_IPT; ++k) {
@@ -559,8 +555,8 @@ __global__ __launch_bounds__(SL_BLOCK, SL_BLOCK == 512 ? 4 : 8) void ss_local_ke
         }
         __syncthreads();
     }
-    // output: suffix indices, coalesced; a record for every element tied with a neighbour (same key bits) when the first
-    // rerank is fused, else bit 31 = "same key as my predecessor" (the contract of msd_emit_tile)
+    // output: suffix indices, coalesced, bit 31 = "same key as my predecessor" (ties come back as flags, not as the
+    // records of the MSD sort's fused first rerank: a group of equal keys can cross a tile border here -- ss_boundary)
     const u32 imask = (u32)((1ull << ib) - 1ull);
 #pragma unroll
     for (int k = 0; k < SL_IPT; ++k) {
@@ -569,20 +565,8 @@ __global__ __launch_bounds__(SL_BLOCK, SL_BLOCK == 512 ? 4 : 8) void ss_local_ke
             const E16 x = e16_load(&buf[sl_slot(p)]);
             const bool tie = p > 0 && e16_same_key(e16_load(&buf[sl_slot(p - 1)]), x, ib);
             const u32 sfx = (u32)x.lo & imask;
-            sa_out[e0 + p] = sfx | ((tie && em == nullptr) ? 0x80000000u : 0u);
-            if (em != nullptr) {
-                const bool tie_next = p + 1 < count && e16_same_key(e16_load(&buf[sl_slot(p + 1)]), x, ib);
-                if (tie || tie_next) {
-                    const u32 slot = e0 + atomicAdd(&s_count, 1u);
-                    em->st_pos[slot] = e0 + p;
-                    em->st_idx[slot] = sfx | (tie ? 0x80000000u : 0u);
-                }
-            }
+            sa_out[e0 + p] = sfx | (tie ? 0x80000000u : 0u);
         }
-    }
-    if (em) {
-        __syncthreads();
-        if (tid == 0) em->blk_cnt[t] = s_count;
     }
 }
 
