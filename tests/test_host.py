@@ -293,6 +293,9 @@ def test_cabi_argument_contract_without_gpu():
     assert lib.pss_reader_open(b'x', 0, 2, 2, ctypes.byref(h)) == _ffi.PSS_EINVAL      # shard index out of range
     assert lib.pss_gen_corpus(99, t.ctypes.data, 1, 0) == _ffi.PSS_EINVAL
     assert lib.pss_result_num_entries(None) == 0 and lib.pss_reader_num_chunks(None) == 0
+    assert lib.pss_reader_set_low_latency(None, 1) == _ffi.PSS_EINVAL
+    assert lib.pss_reader_low_latency_stats(None, None, None) == _ffi.PSS_EINVAL
+    assert lib.pss_reader_evict_chunk(None, 0) == _ffi.PSS_EINVAL
     lib.pss_result_free(None)
     assert lib.pss_reader_close(None) == _ffi.PSS_OK and lib.pss_writer_close(None) == _ffi.PSS_OK
 

@@ -596,6 +596,9 @@ def test_low_latency_mode_matches_the_launch_path(tmp_path, oracle, monkeypatch,
             assert r.low_latency_stats() == s4
             r.set_low_latency(True)
             assert sorted(r.search_batch_raw([qs[5]])[0]) == want[5]      # ... and the reader closes with a kernel waiting
+        with pysubstringsearch.Reader(p, devices=[0, 0]) as r:            # several devices in one process: not this mode
+            with pytest.raises(ValueError):
+                r.set_low_latency(True)
         o.close()
     finally:
         monkeypatch.delenv('PSS_RESIDENT_IDLE_US')
