@@ -749,13 +749,18 @@ constexpr int GS_LDS = GS_T + 2 * GS_CAP;
 constexpr int GS_PER = GS_LDS / 256;   // LDS elements owned by one thread in the extent scans
 static_assert(GS_LDS % 256 == 0, "extent scans assume an even split");
 
+// K32: the keys are ranks (rank rounds: < 2^32, the high word is zero) -- 4-byte keys in LDS, 32-bit compares in the
+// counting loop, which is all the kernel does on groups of hundreds (duplicated blocks: 33.5 ms per round with 8-byte keys).
+template <bool K32>
 __global__ __launch_bounds__(256) void group_sort_kernel(const u64 *key, const u32 *idx, const u32 *grp, u32 m,
                                                            u64 *okey, u32 *oidx, u8 *big, u32 *blk_big, u32 *blk_heads)
 {
-    __shared__ u64 s_key[GS_LDS];
+    using KT = typename std::conditional<K32, u32, u64>::type;
+    __shared__ KT s_key[GS_LDS];
     __shared__ u32 s_grp[GS_LDS];
     __shared__ u16 s_start[GS_LDS];   // LDS index of the head of i's group
     __shared__ u16 s_end[GS_LDS];     // LDS index one past the last member of i's group
+    __shared__ u8 s_mixed[GS_LDS];    // at a group's head: some member's key differs from its predecessor's
     __shared__ u32 s_wave[2][4];
     __shared__ u32 s_cnt[2];
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -765,7 +770,8 @@ __global__ __launch_bounds__(256) void group_sort_kernel(const u64 *key, const u
     const u32 hi = hi_want < m ? hi_want : m;
     const u32 cnt = hi - lo;                       // valid LDS elements
     for (u32 i = tid; i < (u32)GS_LDS; i += 256) {
-        s_key[i] = (i < cnt) ? key[lo + i] : 0;
+        s_key[i] = (i < cnt) ? (KT)key[lo + i] : (KT)0;
+        s_mixed[i] = 0;
         s_grp[i] = (i < cnt) ? grp[lo + i] : 0xffffffffu;
     }
     if (tid < 2) s_cnt[tid] = 0;
@@ -813,11 +819,20 @@ __global__ __launch_bounds__(256) void group_sort_kernel(const u64 *key, const u
         if ((hm >> q) & 1u) next_head = i0 + q;
     }
     __syncthreads();
+    // A group whose members all carry the same key stays as it is (ties keep their order): no counting.  That is the
+    // common case where whole blocks of text are duplicated -- every copy of a suffix has the same rank h symbols on --
+    // and it is cheap to know: one pass over neighbouring members.
+#pragma unroll
+    for (int q = 0; q < GS_PER; ++q) {
+        const u32 i = i0 + q;
+        if (i > 0 && i < cnt && s_grp[i] == s_grp[i - 1] && s_key[i] != s_key[i - 1]) s_mixed[s_start[i]] = 1;
+    }
+    __syncthreads();
     const u32 wend = (base + GS_T < m) ? base + GS_T : m;
     u32 nb = 0, nh = 0;
     for (u32 j = base + tid; j < wend; j += 256) {
         const u32 i = j - lo;
-        const u64 k = s_key[i];
+        const KT k = s_key[i];
         const u32 gs = s_start[i], ge = s_end[i];          // LDS indices, [gs, ge)
         // a group touching the edge of the LDS range continues outside (unless that edge is the data's edge)
         const bool open = (gs == 0 && lo > 0) || (ge >= cnt && hi < m);
@@ -828,10 +843,13 @@ __global__ __launch_bounds__(256) void group_sort_kernel(const u64 *key, const u
             ++nb;
             if (gs == i) ++nh;
         } else {
-            u32 rank = 0;
-            for (u32 q = gs; q < ge; ++q) {
-                const u64 kq = s_key[q];
-                rank += (kq < k || (kq == k && q < i)) ? 1u : 0u;
+            u32 rank = i - gs;
+            if (s_mixed[gs]) {
+                rank = 0;
+                for (u32 q = gs; q < ge; ++q) {
+                    const KT kq = s_key[q];
+                    rank += (kq < k || (kq == k && q < i)) ? 1u : 0u;
+                }
             }
             okey[lo + gs + rank] = k;
             oidx[lo + gs + rank] = idx[j];
@@ -1465,8 +1483,12 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
                 hipLaunchKernelGGL(text_keys_kernel, dim3(grid), dim3(256), 0, s, V[src], m, n, h32, codes, b, kt, plus_one, K[src]);
             else
                 hipLaunchKernelGGL(rank_keys_kernel, dim3(grid), dim3(256), 0, s, V[src], m, n, h32, ISA, K[src]);
-            hipLaunchKernelGGL(group_sort_kernel, dim3(nblk), dim3(256), 0, s, K[src], V[src], G[gcur], m, K[src ^ 1],
-                               V[src ^ 1], d_big, d_blk_big, d_blk_heads);
+            if (use_text)
+                hipLaunchKernelGGL(group_sort_kernel<false>, dim3(nblk), dim3(256), 0, s, K[src], V[src], G[gcur], m, K[src ^ 1],
+                                   V[src ^ 1], d_big, d_blk_big, d_blk_heads);
+            else
+                hipLaunchKernelGGL(group_sort_kernel<true>, dim3(nblk), dim3(256), 0, s, K[src], V[src], G[gcur], m, K[src ^ 1],
+                                   V[src ^ 1], d_big, d_blk_big, d_blk_heads);
             if (!knobs.no_mid_tier) {
                 // groups of up to MID_CAP members: one workgroup each, in LDS (no host round trip: the list and its
                 // length stay on the device, the workgroups persist and walk over it)
