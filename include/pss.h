@@ -214,14 +214,14 @@ int pss_reader_evict_chunk(pss_reader *r, uint64_t index);
 int pss_reader_promote_chunk(pss_reader *r, uint64_t index);
 /* Low-latency mode for single queries (off by default; single-device readers).  Launching a kernel and waiting for its
  * completion are about half of what one query costs (~10 of ~22 us); with this mode on, the first single query of a
- * burst starts a RESIDENT search kernel -- one workgroup per (chunk, 1024 hits) that waits for queries in a mailbox in
+ * burst starts a RESIDENT search kernel -- one workgroup per chunk that waits for queries in a mailbox in
  * pinned host memory -- and the following ones are posted there and answered without a launch (results are the same
  * bytes either way).  The kernel holds a lease, not the GPU: it leaves by itself after PSS_RESIDENT_IDLE_US (1000)
  * without a query and after PSS_RESIDENT_LIFE_US (50000) in any case, so a crashed host or a device-wide
  * synchronisation elsewhere in the process waits no longer than that; the next single query starts another.  Batches,
  * counts, device-resident results, queries with more hits than the path holds, and every call that changes the
  * reader's chunks go through the ordinary path (and stop the kernel where they must).  While it waits, the kernel
- * occupies one workgroup slot per (chunk, sub-block) -- 4 on a one-chunk reader, 15 on fifteen chunks -- and nothing
+ * occupies one workgroup slot per chunk (a chunk with more than 1024 hits sends the query to the ordinary path) and nothing
  * else.  pss_reader_low_latency_stats: kernels started / queries answered by one, per device. */
 int pss_reader_set_low_latency(pss_reader *r, int32_t on);
 int pss_reader_low_latency_stats(const pss_reader *r, uint64_t *launches, uint64_t *served);

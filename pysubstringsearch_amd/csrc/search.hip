@@ -1116,7 +1116,7 @@ __global__ __launch_bounds__(SM_BLOCK) void search_block_kernel(const ChunkDesc 
 // ---- resident variant (low-latency mode of a reader) ----
 // The launch and the completion of a kernel are ~10 of the ~22 us a single query costs on the path above; a word in
 // pinned memory makes the round trip host -> running kernel -> host in 1.6 us on the same machine.  This kernel stays:
-// workgroup (chunk, sub-block) waits for a query in the mailbox (fine-grained pinned host memory, common.h), answers
+// workgroup c (one per chunk) waits for a query in the mailbox (fine-grained pinned host memory, common.h), answers
 // it exactly as search_block_kernel does, and the last workgroup to finish writes the query's sequence number back --
 // the host spins on that word instead of launching and synchronising.  It is a LEASE, not a daemon: the first
 // workgroup watches the device's wall clock and makes everyone leave after idle_ticks without a query or life_ticks
@@ -1232,10 +1232,10 @@ __global__ __launch_bounds__(SM_BLOCK) void search_resident_kernel(const ChunkDe
         // result bytes are ordinary stores and stay there otherwise) -- a write-back per wave costs 4 us, one per
         // workgroup ~1, a workgroup without entries none (its record went out as a system-scope store)
         if (wrote && tid < kWave) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-        if (tid == 0 && atomicAdd(&hdr->done, 1u) == nc * spread - 1) {
+        if (tid == 0 && (nc * spread == 1 || atomicAdd(&hdr->done, 1u) == nc * spread - 1)) {
             dev_store(&hdr->ent_cursor, 0u);
             dev_store(&hdr->byte_cursor, 0u);
-            dev_store(&hdr->done, 0u);
+            if (nc * spread != 1) dev_store(&hdr->done, 0u);
             stores_done();
             sys_store(&mb->done_seq, seq);
         }
@@ -1400,10 +1400,10 @@ static int resident_query(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, con
     u8 *v_arena = static_cast<u8 *>(R.arena_dev);
     ResidentMailbox *mb = reinterpret_cast<ResidentMailbox *>(h_arena + SM_OFF_MAILBOX);
     volatile u32 *h_overflow = reinterpret_cast<volatile u32 *>(h_arena + SM_OFF_FLAGS);
-    // workgroups per chunk: every one of them spins while the kernel stays, so fewer than on the launch path
-    // (up to 4096 hits of a chunk on one chunk, 1024 on fifteen; more than that goes to the launch path)
-    u32 spread = 1;
-    while (spread < 4 && nc * spread * 2 <= 16) spread *= 2;
+    // One workgroup per chunk (the launch path gives a pair up to 32): every one of them spins while the kernel stays,
+    // the answer waits for the LAST of them to notice the query, and a reader of one chunk then needs no counter of
+    // finished workgroups at all.  A chunk with more than 1024 hits goes to the launch path.
+    const u32 spread = 1;
     static u64 ticks_per_us = 0;
     if (ticks_per_us == 0) {
         int khz = 0;
