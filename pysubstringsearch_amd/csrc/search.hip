@@ -939,8 +939,11 @@ __device__ __forceinline__ void put_flag(u32 *flag) { __hip_atomic_store(flag, 1
 // only in the device arena then).
 __device__ __forceinline__ bool block_pair(const ChunkDesc ch, const u8 *s_pat /* LDS, zero padded, visible */, u32 plen, u32 sub,
                                            u32 ri, u32 spread, SmallHeader *hdr, u32 *h_overflow, SmallRecord *rec,
-                                           SmallEntry *ent, u8 *bytes, u8 *hbytes)
+                                           SmallEntry *ent, u8 *bytes, u8 *hbytes, bool alone = false)
 {
+    // alone: this workgroup is the whole launch (the resident kernel of a one-chunk reader) -- its entries start at 0 without
+    // a trip to the cursors, and a result of a few entries goes to the pinned prefix as system-scope stores and nowhere
+    // else: nothing is left in L2 for a write-back (the function then returns false)
     __shared__ u32 s_ls[SM_BLOCK_MAX_HITS];
     __shared__ u32 s_ll[SM_BLOCK_MAX_HITS];
     __shared__ u32 s_L, s_cnt, s_e0, s_b0;
@@ -1039,8 +1042,8 @@ __device__ __forceinline__ bool block_pair(const ChunkDesc ch, const u8 *s_pat /
             n_bytes += s_wb[w];
         }
         if (tid == 0) {
-            u32 e0, b0;
-            small_take(hdr, n_ent, n_bytes, e0, b0);
+            u32 e0 = 0, b0 = 0;
+            if (!alone) small_take(hdr, n_ent, n_bytes, e0, b0);
             s_e0 = e0;
             s_b0 = b0;
             if (e0 + n_ent > SM_ENT_CAP || b0 + n_bytes > SM_BYTE_CAP) put_flag(h_overflow);
@@ -1049,7 +1052,10 @@ __device__ __forceinline__ bool block_pair(const ChunkDesc ch, const u8 *s_pat /
         __syncthreads();
         const u32 e0 = s_e0, b0 = s_b0;
         if (e0 + n_ent <= SM_ENT_CAP && b0 + n_bytes <= SM_BYTE_CAP) {
-            wrote = n_ent != 0;
+            // (only a few entries: every system-scope store is a transaction of its own on the bus -- 10 KiB of result
+            // took 260 us that way, 24 through L2 and one write-back)
+            const bool direct = alone && n_bytes <= 512 && n_ent <= 16;
+            wrote = n_ent != 0 && !direct;
             // pass 2: pack.  When the workgroup's bytes fit the LDS stage, entries are assembled there (unaligned
             // pieces, byte tails) and leave as one run of aligned 16-byte stores per destination; else entry by entry.
             const bool staged = n_bytes <= SM_STAGE_BYTES - 16;
@@ -1058,7 +1064,9 @@ __device__ __forceinline__ bool block_pair(const ChunkDesc ch, const u8 *s_pat /
             for (u32 j = j0; j < j1; ++j) {
                 const u32 ll = s_ll[j];
                 if (ll == kSkip) continue;
-                ent[e++] = SmallEntry{o, ll};
+                if (direct) __hip_atomic_store(reinterpret_cast<u64 *>(ent + e), (u64)o | ((u64)ll << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                else ent[e] = SmallEntry{o, ll};
+                ++e;
                 if (staged) copy_entry(s_stage + skew + (o - b0), ch.text + s_ls[j], ll);
                 else copy_entry(bytes + o, ch.text + s_ls[j], ll, o + ll <= SM_BYTE_PREFIX ? hbytes + o : nullptr);
                 o += ll;
@@ -1068,6 +1076,15 @@ __device__ __forceinline__ bool block_pair(const ChunkDesc ch, const u8 *s_pat /
                 const u32 end = skew + n_bytes;                  // stage bytes [skew, end) -> arena bytes [b0, b0 + n_bytes)
                 u8 *d0 = bytes + (b0 - skew), *d1 = hbytes + (b0 - skew);
                 const bool pinned_too = b0 + n_bytes <= SM_BYTE_PREFIX;   // (else the host takes everything from the device arena)
+                if (direct) {
+                    // (b0 = 0: whole 16-byte blocks, the last one padded with whatever the stage holds)
+                    for (u32 at = tid * 16; at < end; at += SM_BLOCK * 16) {
+                        const u64 *sp = reinterpret_cast<const u64 *>(s_stage + at);
+                        u64 *dp = reinterpret_cast<u64 *>(hbytes + at);
+                        __hip_atomic_store(dp, sp[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(dp + 1, sp[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                } else
                 for (u32 at = tid * 16; at < end; at += SM_BLOCK * 16) {
                     if (at >= skew && at + 16 <= end) {
                         const uint4 v = *reinterpret_cast<const uint4 *>(s_stage + at);
@@ -1225,7 +1242,8 @@ __global__ __launch_bounds__(SM_BLOCK) void search_resident_kernel(const ChunkDe
         seen = seq;
         if (tid >= plen && tid < SM_MAX_PLEN + 32) s_pat[tid] = 0;     // zero padding behind the query
         __syncthreads();
-        const bool wrote = block_pair(ch, s_pat, plen, sub, blockIdx.x, spread, hdr, h_overflow, rec, ent, bytes, hbytes);
+        const bool wrote = block_pair(ch, s_pat, plen, sub, blockIdx.x, spread, hdr, h_overflow, rec, ent, bytes, hbytes,
+                                      nc * spread == 1);
         stores_done();
         __syncthreads();
         // every wave's stores have reached L2; one wave writes the workgroup's XCD L2 back (the entry table and the
@@ -1233,10 +1251,12 @@ __global__ __launch_bounds__(SM_BLOCK) void search_resident_kernel(const ChunkDe
         // workgroup ~1, a workgroup without entries none (its record went out as a system-scope store)
         if (wrote && tid < kWave) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         if (tid == 0 && (nc * spread == 1 || atomicAdd(&hdr->done, 1u) == nc * spread - 1)) {
-            dev_store(&hdr->ent_cursor, 0u);
-            dev_store(&hdr->byte_cursor, 0u);
-            if (nc * spread != 1) dev_store(&hdr->done, 0u);
-            stores_done();
+            if (nc * spread != 1) {          // (a workgroup on its own never moves the cursors)
+                dev_store(&hdr->ent_cursor, 0u);
+                dev_store(&hdr->byte_cursor, 0u);
+                dev_store(&hdr->done, 0u);
+                stores_done();
+            }
             sys_store(&mb->done_seq, seq);
         }
         t_last = wall_clock64();
