@@ -852,6 +852,11 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(args.gpus))      # nothing has touched a GPU yet (torch is not even imported)
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        try:                                            # (a leftover of an earlier job on this port)
+            os.remove(os.path.join('/tmp', 'pss_bench_abort_%s' % os.environ.get('MASTER_PORT', '0')))
+        except OSError:
+            pass
     D = Dist(args)
     if args.config == 'chunk':
         rc, out = run_chunk(args, D)
@@ -862,7 +867,56 @@ def main():
             import torch
             torch.cuda.empty_cache()
             q0, args.queries = args.queries, args.corpus15_queries
-            rc2, out2 = run_corpus(args, D, steps=min(args.steps, 3), warmup=min(args.warmup, 1))
+            # With more than one rank this leg gathers results over RCCL: a rank that fails or hangs in it must not cost the
+            # line its headline.  An exception here, a SIGTERM from the launcher (torchrun and launch_ranks send one to
+            # every rank when one dies) or no end within PSS_BENCH_CORPUS15_TIMEOUT seconds (900), and rank 0 prints the
+            # configs[1] result it already has, with the reason in place of the corpus15 object.  The watching is done by a
+            # thread: the main thread may be stuck inside a collective, where no Python signal handler would ever run.
+            flag = os.path.join('/tmp', 'pss_bench_abort_%s' % os.environ.get('MASTER_PORT', '0'))
+
+            def bail(reason, tell=True):
+                if tell and D.world > 1:                      # the other ranks of this node: stop waiting for me
+                    try:
+                        with open(flag, 'w') as f:
+                            f.write(f'rank {D.rank}: {reason}')
+                    except OSError:
+                        pass
+                if out is not None:
+                    out['corpus15'] = {'error': reason}
+                    print(json.dumps(out), flush=True)
+                os._exit(rc)
+            done = None
+            if D.world > 1:
+                import signal
+                import threading
+                done = threading.Event()
+                signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})
+                limit = time.time() + float(os.environ.get('PSS_BENCH_CORPUS15_TIMEOUT', '900'))
+
+                def watch():
+                    while not done.is_set():
+                        if signal.sigtimedwait({signal.SIGTERM}, 0.5) is not None:
+                            bail('terminated by the launcher during the corpus15 leg (another rank failed)')
+                        if os.path.exists(flag):
+                            try:
+                                why = open(flag).read()[:300]
+                            except OSError:
+                                why = 'another rank gave up'
+                            bail(why, tell=False)
+                        if time.time() > limit:
+                            bail('the corpus15 leg did not finish in time')
+                threading.Thread(target=watch, daemon=True).start()
+            try:
+                if os.environ.get('PSS_BENCH_FAIL_CORPUS15') == str(D.rank):      # test hook: this rank fails in the leg
+                    raise RuntimeError('PSS_BENCH_FAIL_CORPUS15')
+                rc2, out2 = run_corpus(args, D, steps=min(args.steps, 3), warmup=min(args.warmup, 1))
+            except Exception as e:      # noqa: BLE001
+                if D.world == 1:
+                    raise
+                bail(f'{type(e).__name__}: {e}'[:300])
+            if done is not None:
+                done.set()
+                signal.pthread_sigmask(signal.SIG_UNBLOCK, {signal.SIGTERM})
             args.queries = q0
             rc = rc or rc2
             if out is not None and out2 is not None:

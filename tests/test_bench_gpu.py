@@ -86,6 +86,20 @@ def test_bench_two_ranks_self_launch():
     _check_two_ranks(_last_json(r.stdout))
 
 
+def test_bench_two_ranks_keep_the_headline_when_the_corpus_leg_fails():
+    """A rank that fails inside the configs[2]/[3] leg (test hook) must not cost the line its configs[1] result: rank 0
+    still prints one line, with the reason in place of the corpus15 object, and the run ends -- by the other rank's
+    exception or, if that one hangs in a collective, by the timeout."""
+    env = dict(os.environ, PSS_BENCH_BACKEND='gloo', PSS_BENCH_FAIL_CORPUS15='1', PSS_BENCH_CORPUS15_TIMEOUT='60')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--logn', '22', '--queries', '500',
+           '--chunks', '5', '--corpus15-queries', '3000']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    d = _last_json(r.stdout)
+    assert d['n_gpus'] == 2 and d['value'] > 0 and 'error' in d['corpus15']
+
+
 def test_bench_two_ranks_under_torchrun():
     env = dict(os.environ, PSS_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
