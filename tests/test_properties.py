@@ -147,3 +147,82 @@ run_text = st.lists(st.tuples(st.sampled_from([0, 10, 97, 98, 255]), st.integers
 @given(st.one_of(run_text, small_alphabet_bytes.filter(lambda b: len(b) > 0)))
 def test_run_length_reduction_gives_the_suffix_array(t):
     assert rle_suffix_array(t) == brute_sa(t)
+
+
+# ---- the argument behind the closed form for texts that repeat one word (rle_build.hip, period_suffix_array), on the CPU ----
+
+def periodic_suffix_array(t: bytes):
+    """Suffix array of a text whose first m bytes have smallest period p (>= 2), exactly as period_suffix_array derives it:
+    suffixes that start more than margin = 2p + 2(n - m) + 1 bytes before the repetition ends form one block per rotation
+    of the word, the blocks ordered like the rotations, inside a block by position -- ascending or descending, decided by the
+    byte that ends the repetition; the remaining suffixes are sorted directly and fall between the blocks (compared with
+    a block = with its rotation repeated for as long as the late suffix lasts, the late one first on a tie).  Returns None
+    when the text is not of that shape."""
+    n = len(t)
+    p = next((q for q in range(1, n) if all(t[i] == t[i + q] for i in range(min(n - q, 4 * q + 8)))), 0)
+    if p < 2 or 4 * p > n:
+        return None
+    m = next((i + p for i in range(n - p) if t[i] != t[i + p]), n)
+    # p must be the smallest period of the repetition
+    for q in range(1, p):
+        if all(t[i] == t[i + q] for i in range(m - q)):
+            return None
+    tail = n - m
+    margin = 2 * p + 2 * tail + 1
+    if 4 * margin > m:
+        return None
+    long_end = m - margin
+    W = t[:p]
+    desc = m == n or t[m] < W[m % p]
+    blocks = [c for c in range(p) if c < long_end]
+    late = list(range(long_end, n))
+
+    def rot(c, k):
+        return W[(c + k) % p]
+
+    import functools
+
+    def cmp(a, b):                      # items: ('b', class) or ('l', start)
+        if a[0] == 'b' and b[0] == 'b':
+            x, y = [rot(a[1], k) for k in range(p)], [rot(b[1], k) for k in range(p)]
+            return -1 if x < y else (1 if x > y else 0)
+        if a[0] == 'l' and b[0] == 'l':
+            x, y = t[a[1]:], t[b[1]:]
+            return -1 if x < y else (1 if x > y else 0)
+        late_first = a[0] == 'l'
+        x, blk = (a, b) if late_first else (b, a)
+        s = t[x[1]:]
+        r = bytes(rot(blk[1], k) for k in range(len(s)))
+        c = -1 if s <= r else 1        # the late suffix first on a tie (it is the shorter one)
+        return c if late_first else -c
+
+    items = sorted([('b', c) for c in blocks] + [('l', i) for i in late], key=functools.cmp_to_key(cmp))
+    sa = []
+    for kind, v in items:
+        if kind == 'l':
+            sa.append(v)
+        else:
+            members = list(range(v, long_end, p))
+            sa.extend(reversed(members) if desc else members)
+    return sa
+
+
+periodic_text = st.tuples(st.binary(min_size=2, max_size=7).filter(lambda w: len(set(w)) > 1), st.integers(30, 140),
+                          st.binary(min_size=0, max_size=5)).map(lambda x: (x[0] * (x[1] // len(x[0]) + 2))[:x[1]] + x[2])
+two_letter_periodic = st.tuples(st.lists(st.sampled_from([97, 98]), min_size=2, max_size=9).map(bytes).filter(lambda w: len(set(w)) > 1),
+                                st.integers(40, 160), st.lists(st.sampled_from([97, 98]), min_size=0, max_size=6).map(bytes)).map(
+    lambda x: (x[0] * (x[1] // len(x[0]) + 2))[:x[1]] + x[2])
+
+
+@settings(max_examples=400, deadline=None)
+@given(st.one_of(periodic_text, two_letter_periodic))
+def test_closed_form_for_one_repeated_word_gives_the_suffix_array(t):
+    sa = periodic_suffix_array(t)
+    if sa is not None:                  # (texts that are not of the shape are somebody else's business)
+        assert sa == brute_sa(t)
+
+
+def test_closed_form_is_exercised():
+    """The property above is not vacuous: plain repetitions, with and without a tail, are of the shape."""
+    for t in (b'ab' * 40, b'abc' * 30 + b'x', b'aab' * 25 + b'a', (b'abaab' * 30)[:-2] + b'bb', b'ba' * 35 + b'ab'):
+        assert periodic_suffix_array(t) == brute_sa(t), t
