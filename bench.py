@@ -15,6 +15,11 @@
                        GPU + sha256 of the 2 GiB array against tests/golden/sa_big.json
                        (or against libsais run on the spot for small --logn).  A build
                        whose result is wrong prints no value.
+      build_ms_first_chunk, plan_hint
+                       the timed steps rebuild chunks of one kind of text, so from the second on the build
+                       runs under the plan of the previous chunk (its alphabet and its choice of sort, checked
+                       inside the sort's first pass: pss_sa_stats.plan_hint); the time of a build that
+                       starts from nothing (alphabet pass, recode, sizing sample) is reported beside it
       roofline         dominant kernel (the scatter instantiation with the largest summed
                        duration) over its HIP-event duration, against the 8 TB/s HBM peak
       build_roofline   the whole build against the same peak
@@ -27,7 +32,8 @@
     before anything touches a GPU); under torchrun (WORLD_SIZE set) it is one of the ranks.
 
     The same line carries BASELINE configs[2] / [3] under "corpus15" (the leg below with at most
-    3 steps; --no-corpus15 skips it): queries/s on the 7.5 GB corpus next to the CPU path.
+    3 steps; --no-corpus15 skips it): queries/s on the 7.5 GB corpus next to the CPU path.  At N > 1 a
+    failure or hang of that leg does not cost the line its configs[1] result ("corpus15": {"error": ...}).
 
 --config corpus15 (BASELINE.json configs[2] / [3], strong scaling)
     The 7.5 GB corpus: 15 `lines` chunks of 512 MiB, chunk c on rank c mod N (built there,
