@@ -516,8 +516,12 @@ __global__ __launch_bounds__(SL_BLOCK, SL_BLOCK == 512 ? 4 : 8) void ss_local_ke
         const u32 pair0 = o0 & ~(2 * L - 1);             // first position of the pair of runs
         const u32 d = o0 - pair0;                        // outputs of the pair before mine
         const u32 A = pair0, B = pair0 + L;
-        // runs made of padding only need no work: everything from `count` on is +infinity already
-        const bool live = pair0 < count;
+        // Positions from `count` on hold +infinity at every level (the elements fill a prefix of the tile, and a sorted
+        // run keeps its padding at its end): a thread whose outputs all lie there has nothing to merge -- at the top
+        // levels that is a quarter of the waves of an average tile (3050 of 4096 slots): 11.0 -> 10.8 ms.  (Sorting
+        // tiles of <= 3072 / 3584 elements with six / seven elements per thread instead -- three instantiations of the
+        // rounds in one kernel -- was slower: 11.7 ms.)
+        const bool live = o0 < count;
         if (live) {
             // merge path: the smallest a in [lo, hi] with NOT A[a] < B[d - 1 - a].  The kernel is bound by VALU issue (128-bit
             // compares and selects: ~450 instructions per thread and round) with the LDS busy half of the time; measured
