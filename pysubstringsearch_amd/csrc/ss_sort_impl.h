@@ -32,7 +32,15 @@ constexpr int SS_SBLOCK = 1024;                      // scatter passes: one work
 constexpr int SS_SIPT = SS_TILE / SS_SBLOCK;         // 4
 constexpr int SS_DBLOCK = 512;                       // digit passes
 constexpr u32 SS_DTILE1 = SS_DBLOCK * 16;            // G1 digits: 16 consecutive suffixes per thread
-constexpr u32 SS_WIN = 3072;                         // tile plan: see msd_tile_head
+// Tile plan (msd_tile_head): the buckets that start inside one window of SS_WIN slots form a tile -- W elements on
+// average, give or take what the buckets at its two ends overhang -- unless that exceeds the tile, in which case the
+// window's last bucket becomes a tile of its own.  The merge sort costs per tile, not per element, so the window is as
+// wide as the overflows allow: at 2^29 (buckets of 512 +- 256) 3072 -> 175 995 tiles, 3456 -> 161 659 (local sort 11.0 ->
+// 10.0 ms), 3584 -> 160 905 but more of them single buckets (10.2 ms).
+#ifndef PSS_SS_WIN
+#define PSS_SS_WIN 3456
+#endif
+constexpr u32 SS_WIN = PSS_SS_WIN;
 constexpr u32 SS_TILE_CAP = 4088;
 constexpr u32 SS_MAX_BUCKET = 4088;
 
