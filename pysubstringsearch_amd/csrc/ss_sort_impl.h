@@ -28,6 +28,8 @@
 
 constexpr int SS_MAX_CHARS = 32;                     // symbols packed into a key at most (byte window of the packers)
 constexpr u32 SS_TILE = 4096;                        // elements of one workgroup tile (64 KiB of LDS)
+constexpr int SS_CELL_BITS = 12;                     // ss_digits1: lookup on the top bits of the key before the search
+constexpr u32 SS_CELLS = 1u << SS_CELL_BITS;
 constexpr int SS_SBLOCK = 1024;                      // scatter passes: one workgroup per CU (the tile fills most of its LDS)
 constexpr int SS_SIPT = SS_TILE / SS_SBLOCK;         // 4
 constexpr int SS_DBLOCK = 512;                       // digit passes
@@ -251,6 +253,9 @@ __global__ __launch_bounds__(SS_DBLOCK) void ss_digits1_kernel(SsArgs a)
     __shared__ E16 spl[MSD_BINS];
     __shared__ u64 win[MSD_BINS];
     __shared__ u32 hist[MSD_BINS];
+    // cell[c] = splitters whose high word lies below c << 52: the top twelve bits of an element's high word say which
+    // few splitters it can fall between -- a lookup and a short search instead of ten steps over all of them
+    __shared__ u16 cell[SS_CELLS + 1];
     const u32 tid = threadIdx.x, r = blockIdx.x;
     if (r >= a.num_ranges1) return;
     for (u32 i = tid; i < MSD_BINS; i += SS_DBLOCK) {
@@ -258,6 +263,20 @@ __global__ __launch_bounds__(SS_DBLOCK) void ss_digits1_kernel(SsArgs a)
         const E16 sp = e16_sel(i + 1 < a.B1, e16_load(&a.sample[(size_t)min(i + 1, a.B1 - 1) * a.spb]), e16_inf());
         spl[i] = sp;
         win[i] = sp.hi;
+    }
+    __syncthreads();
+    for (u32 c = tid; c <= SS_CELLS; c += SS_DBLOCK) {
+        u32 lo = 0, hi = a.B1 - 1;                      // first splitter with high word >= c << 52 (all of them: B1 - 1)
+        if (c < SS_CELLS) {
+            const u64 v = (u64)c << (64 - SS_CELL_BITS);
+            while (lo < hi) {
+                const u32 mid = (lo + hi) >> 1;
+                if (win[mid] < v) lo = mid + 1; else hi = mid;
+            }
+        } else {
+            lo = a.B1 - 1;
+        }
+        cell[c] = (u16)lo;
     }
     __syncthreads();
     const u32 n = a.text.n;
@@ -282,13 +301,29 @@ __global__ __launch_bounds__(SS_DBLOCK) void ss_digits1_kernel(SsArgs a)
             for (int i = 0; i < 6; ++i) qh[i] = h ? (i + 1 < 6 ? q[i + 1] : 0ull) : q[i];
             E16 e[8];
             ss_pack<8, 6>(qh, i0 + 8 * h, a.text, e);
-            u32 pos[8];
+            // pos = splitters whose high word is <= the element's: those of the cells below (table), then an upper-bound
+            // search among the splitters of the element's own cell -- as many steps as the fullest cell of the wave needs
+            u32 pos[8], cnt[8], most = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) pos[k] = 0;
-            for (u32 step = a.B1 >> 1; step; step >>= 1) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) pos[k] += e[k].hi < win[pos[k] + step - 1] ? 0u : step;
+            for (int k = 0; k < 8; ++k) {
+                const u32 c = (u32)(e[k].hi >> (64 - SS_CELL_BITS));
+                pos[k] = cell[c];
+                cnt[k] = cell[c + 1] - pos[k];
+                most = max(most, cnt[k]);
             }
+            most = (u32)__shfl((int)wave_incl_max(most), 63);
+            u32 off[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) off[k] = 0;
+            for (u32 step = most ? 1u << (31 - __builtin_clz(most)) : 0u; step; step >>= 1) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const u32 t = off[k] + step;
+                    if (t <= cnt[k] && !(e[k].hi < win[pos[k] + t - 1])) off[k] = t;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pos[k] += off[k];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 pos[k] = ss_settle(win, spl, pos[k], e[k].hi, e[k]);
