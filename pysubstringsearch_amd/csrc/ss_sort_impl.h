@@ -284,10 +284,12 @@ __global__ __launch_bounds__(SS_DBLOCK) void ss_digits1_kernel(SsArgs a)
     const u64 e1 = min(e0 + (u64)a.tiles_per_range1 * SS_DTILE1, (u64)n);
     for (u64 base = e0; base < e1; base += SS_DTILE1) {
         const u32 i0 = (u32)base + tid * 16;
-        if (i0 >= n) continue;
+        // (a thread past the end of the text goes through the motions on the start of the text: the wave-wide maximum
+        // below needs every lane)
+        const bool live = i0 < n;
         u64 q[6];
         {
-            const uint4 *p = reinterpret_cast<const uint4 *>(a.text.codes + i0);
+            const uint4 *p = reinterpret_cast<const uint4 *>(a.text.codes + (live ? i0 : 0u));
             const uint4 v0 = p[0], v1 = p[1], v2 = p[2];
             q[0] = (u64)v0.x | ((u64)v0.y << 32); q[1] = (u64)v0.z | ((u64)v0.w << 32);
             q[2] = (u64)v1.x | ((u64)v1.y << 32); q[3] = (u64)v1.z | ((u64)v1.w << 32);
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(SS_DBLOCK) void ss_digits1_kernel(SsArgs a)
 #pragma unroll
             for (int i = 0; i < 6; ++i) qh[i] = h ? (i + 1 < 6 ? q[i + 1] : 0ull) : q[i];
             E16 e[8];
-            ss_pack<8, 6>(qh, i0 + 8 * h, a.text, e);
+            ss_pack<8, 6>(qh, (live ? i0 : 0u) + 8 * h, a.text, e);
             // pos = splitters whose high word is <= the element's: those of the cells below (table), then an upper-bound
             // search among the splitters of the element's own cell -- as many steps as the fullest cell of the wave needs
             u32 pos[8], cnt[8], most = 0;
@@ -328,30 +330,73 @@ __global__ __launch_bounds__(SS_DBLOCK) void ss_digits1_kernel(SsArgs a)
             for (int k = 0; k < 8; ++k) {
                 pos[k] = ss_settle(win, spl, pos[k], e[k].hi, e[k]);
                 dg[8 * h + k] = pos[k];
-                if (i0 + 8 * h + k < n) atomicAdd(&hist[pos[k]], 1u);
+                if (live && i0 + 8 * h + k < n) atomicAdd(&hist[pos[k]], 1u);
             }
         }
         uint4 d0, d1;
         d0.x = dg[0] | (dg[1] << 16); d0.y = dg[2] | (dg[3] << 16); d0.z = dg[4] | (dg[5] << 16); d0.w = dg[6] | (dg[7] << 16);
         d1.x = dg[8] | (dg[9] << 16); d1.y = dg[10] | (dg[11] << 16); d1.z = dg[12] | (dg[13] << 16); d1.w = dg[14] | (dg[15] << 16);
-        uint4 *dp = reinterpret_cast<uint4 *>(a.digits + i0);      // (the digit array is padded to a multiple of 16 entries)
-        dp[0] = d0;
-        dp[1] = d1;
+        if (live) {
+            uint4 *dp = reinterpret_cast<uint4 *>(a.digits + i0);  // (the digit array is padded to a multiple of 16 entries)
+            dp[0] = d0;
+            dp[1] = d1;
+        }
     }
     __syncthreads();
     for (u32 i = tid; i < MSD_BINS; i += SS_DBLOCK) a.T[(size_t)i * a.num_ranges1 + r] = hist[i];      // digit-major (msd_offsets1)
+}
+
+// cell of a 128-bit number relative to `base`, 2^sh numbers per cell: 0 below the base, the last cell from its start on
+__device__ __forceinline__ u32 ss_cell_of(const E16 &x, const E16 &base, int sh)
+{
+    if (e16_lt(x, base)) return 0u;
+    const u64 lo = x.lo - base.lo;
+    const u64 hi = x.hi - base.hi - (x.lo < base.lo ? 1ull : 0ull);
+    u64 t_lo, t_hi;
+    if (sh == 0) {
+        t_lo = lo;
+        t_hi = hi;
+    } else if (sh < 64) {
+        t_lo = (lo >> sh) | (hi << (64 - sh));
+        t_hi = hi >> sh;
+    } else {
+        t_lo = hi >> (sh - 64);
+        t_hi = 0;
+    }
+    return (t_hi || t_lo >= SS_CELLS) ? SS_CELLS - 1u : (u32)t_lo;
 }
 
 __global__ __launch_bounds__(SS_DBLOCK) void ss_digits2_kernel(SsArgs a)
 {
     __shared__ E16 spl[MSD_BINS];
     __shared__ u32 hist[MSD_BINS];
+    // the same shortcut as in ss_digits1, on the key relative to the bucket: the splitters of this first-level bucket
+    // span [spl[0], spl[B2 - 2]], cut into SS_CELLS cells of 2^sh numbers; cell[c] = splitters in the cells below c
+    __shared__ u16 cell[SS_CELLS + 1];
     const u32 tid = threadIdx.x, r = blockIdx.x;
     if (r >= a.counters[0]) return;
     const u32 seg = a.ranges2[r].seg, e0 = a.ranges2[r].start, e1 = a.ranges2[r].end;
     for (u32 i = tid; i < MSD_BINS; i += SS_DBLOCK) {
         hist[i] = 0;
         spl[i] = e16_sel(i + 1 < a.B2, e16_load(&a.sample[(size_t)seg * a.spb + (size_t)min(i + 1, a.B2 - 1) * a.st2]), e16_inf());
+    }
+    __syncthreads();
+    const u32 nspl = a.B2 - 1;                          // real splitters
+    const E16 cbase = spl[0];
+    int csh = 0;
+    {
+        const E16 top = spl[nspl ? nspl - 1 : 0];
+        const u64 dlo = top.lo - cbase.lo, dhi = top.hi - cbase.hi - (top.lo < cbase.lo ? 1ull : 0ull);
+        const int bits = dhi ? 128 - __builtin_clzll(dhi) : (dlo ? 64 - __builtin_clzll(dlo) : 0);
+        csh = bits > SS_CELL_BITS ? bits - SS_CELL_BITS : 0;
+    }
+    for (u32 c = tid; c <= SS_CELLS; c += SS_DBLOCK) {
+        u32 lo = 0, hi = nspl;                          // first splitter whose cell is >= c
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (ss_cell_of(spl[mid], cbase, csh) < c) lo = mid + 1; else hi = mid;
+        }
+        cell[c] = (u16)lo;
     }
     __syncthreads();
     for (u32 base = e0; base < e1; base += SS_DBLOCK * 8) {
@@ -361,16 +406,27 @@ __global__ __launch_bounds__(SS_DBLOCK) void ss_digits2_kernel(SsArgs a)
             const u32 p = base + k * SS_DBLOCK + tid;
             e[k] = e16_sel(p < e1, e16_load(&a.in[min(p, e1 - 1)]), e16_inf());
         }
-        u32 pos[8];
+        // pos = splitters <= the element: those of the cells below its own (table), then an upper-bound search among
+        // the splitters of its cell, as many steps as the fullest cell of the wave needs
+        u32 pos[8], cnt[8], off[8], most = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) pos[k] = 0;
-        for (u32 step = a.B2 >> 1; step; step >>= 1) {
+        for (int k = 0; k < 8; ++k) {
+            const u32 c = ss_cell_of(e[k], cbase, csh);
+            pos[k] = cell[c];
+            cnt[k] = cell[c + 1] - pos[k];
+            off[k] = 0;
+            most = max(most, cnt[k]);
+        }
+        most = (u32)__shfl((int)wave_incl_max(most), 63);
+        for (u32 step = most ? 1u << (31 - __builtin_clz(most)) : 0u; step; step >>= 1) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const E16 sp = spl[pos[k] + step - 1];
-                pos[k] += e16_lt(e[k], sp) ? 0u : step;
+                const u32 t = off[k] + step;
+                if (t <= cnt[k] && !e16_lt(e[k], spl[pos[k] + t - 1])) off[k] = t;
             }
         }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pos[k] += off[k];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const u32 p = base + k * SS_DBLOCK + tid;
