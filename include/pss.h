@@ -128,6 +128,21 @@ typedef struct pss_sa_stats {
                                   build went straight to it (PSS_NO_PLAN_CACHE=1: never); 2: ... and recoded the text with
                                   the remembered alphabet inside the sort's first pass, without an alphabet pass of its
                                   own (the pass checks that every byte has a code; PSS_NO_PLAN_FRONT=1: never) */
+    /* anchor round (ties that outlive the text rounds -- duplicated stretches of text -- are resolved by ONE round
+     * keyed by the ranks of a content-defined sample of positions, the anchors, instead of log2(repeat length) rank
+     * rounds over the whole text; anchor_impl.h) */
+    uint64_t anchor;           /* 1 when it ran */
+    uint64_t anchor_omega;     /* window of the minimizers (every window of this many positions holds an anchor) */
+    uint64_t anchor_w;         /* bytes hashed per position */
+    uint64_t anchor_count;     /* anchors (also filled when the path declined: more than n / 5) */
+    uint64_t anchor_active;    /* suffixes still tied when the round ran */
+    uint64_t anchor_depth;     /* symbols every tied group shared at that point */
+    uint64_t anchor_text_rounds; /* text rounds of the anchors' own sort (names of 2 omega + w - 1 symbols) */
+    uint64_t anchor_rounds;    /* rank rounds over the string of anchor names */
+    uint64_t anchor_sum_active;  /* anchors still tied, summed over those rounds */
+    uint64_t anchor_left;      /* suffixes the round left tied (always 0; a non-zero value is an internal error that the
+                                  rank rounds then repair) */
+    double anchor_ms;          /* device time of the anchors' selection and sort */
 } pss_sa_stats;
 
 /*
@@ -331,6 +346,7 @@ void pss_result_free(pss_result *res);
 #define PSS_CORPUS_PERIODIC 3  /* "a"*4095 + "\n" repeated */
 #define PSS_CORPUS_REPEAT_LINE 4 /* one 40-byte line repeated (period 40, no runs of equal bytes) */
 #define PSS_CORPUS_DUP_BLOCKS 5  /* a 1 MiB block of `lines` text repeated, 16 single-byte edits per copy */
+#define PSS_CORPUS_MIXED 6       /* `words` whose middle third is one 60-byte line repeated, then 64 KiB blocks copied from the first third */
 /* Fills out[0..n) on the host; deterministic in (kind, n, chunk_index). */
 int pss_gen_corpus(int kind, uint8_t *out, uint64_t n, uint64_t chunk_index);
 

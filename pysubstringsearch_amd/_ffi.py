@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get('PSS_LIBPSS') or os.path.join(_HERE, 'libpss.so')   # 
 PSS_OK, PSS_EINVAL, PSS_ENOMEM, PSS_EIO, PSS_ETOOBIG, PSS_EDEVICE, PSS_EFORMAT = 0, -1, -2, -3, -4, -5, -6
 
 CORPUS_LINES, CORPUS_WORDS, CORPUS_RUNS, CORPUS_PERIODIC = 0, 1, 2, 3
+CORPUS_REPEAT_LINE, CORPUS_DUP_BLOCKS, CORPUS_MIXED = 4, 5, 6
 
 
 class SaStats(ctypes.Structure):
@@ -68,6 +69,17 @@ class SaStats(ctypes.Structure):
         ('period_extent', ctypes.c_uint64),
         ('period_path', ctypes.c_uint64),
         ('plan_hint', ctypes.c_uint64),
+        ('anchor', ctypes.c_uint64),
+        ('anchor_omega', ctypes.c_uint64),
+        ('anchor_w', ctypes.c_uint64),
+        ('anchor_count', ctypes.c_uint64),
+        ('anchor_active', ctypes.c_uint64),
+        ('anchor_depth', ctypes.c_uint64),
+        ('anchor_text_rounds', ctypes.c_uint64),
+        ('anchor_rounds', ctypes.c_uint64),
+        ('anchor_sum_active', ctypes.c_uint64),
+        ('anchor_left', ctypes.c_uint64),
+        ('anchor_ms', ctypes.c_double),
     ]
 
     def as_dict(self):

@@ -169,6 +169,31 @@ void gen_dup_blocks(uint8_t *out, uint64_t n, uint64_t chunk)
     }
 }
 
+// Natural text with a repetitive middle: `words`, whose middle third is replaced -- first half by ONE 60-byte line written
+// over and over (a periodic stretch inside a text that is not periodic), second half by 64 KiB blocks copied from the
+// first third of the chunk (64 source blocks drawn at random: every block comes back about twenty times, LCPs of up to
+// 64 KiB between suffixes that no run, period or whole-text detector sees).
+void gen_mixed(uint8_t *out, uint64_t n, uint64_t chunk)
+{
+    gen_words(out, n, chunk);
+    const uint64_t a = n / 3, b = 2 * (n / 3), mid = a + (b - a) / 2;
+    if (b - a < 4096) return;
+    uint8_t line[60];
+    fill_lines(line, 60, (kSeed ^ 0x9E3779B97F4A7C15ULL) + chunk);
+    for (int i = 0; i < 59; ++i)
+        if (line[i] == '\n') line[i] = ' ';
+    line[59] = '\n';
+    for (uint64_t i = a; i < mid; ++i) out[i] = line[(i - a) % 60];
+    constexpr uint64_t kBlk = 64ull << 10;
+    const uint64_t sources = std::max<uint64_t>(1, std::min<uint64_t>(64, a / kBlk));
+    const uint64_t blk = std::min(kBlk, a);                 // (tiny texts: whatever the first third holds)
+    Xs64 g{(kSeed ^ 0xC2B2AE3D27D4EB4FULL) + chunk};
+    for (uint64_t o = mid; o < b; o += blk) {
+        const uint64_t src = (g.nx() % sources) * blk;
+        memcpy(out + o, out + src, std::min(blk, b - o));
+    }
+}
+
 }  // namespace
 
 extern "C" int pss_gen_corpus(int kind, uint8_t *out, uint64_t n, uint64_t chunk_index)
@@ -181,6 +206,7 @@ extern "C" int pss_gen_corpus(int kind, uint8_t *out, uint64_t n, uint64_t chunk
         case PSS_CORPUS_PERIODIC: gen_periodic(out, n); break;
         case PSS_CORPUS_REPEAT_LINE: gen_repeat_line(out, n, chunk_index); break;
         case PSS_CORPUS_DUP_BLOCKS: gen_dup_blocks(out, n, chunk_index); break;
+        case PSS_CORPUS_MIXED: gen_mixed(out, n, chunk_index); break;
         default: return PSS_EINVAL;
     }
     if (n) out[n - 1] = '\n';

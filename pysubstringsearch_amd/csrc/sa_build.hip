@@ -41,6 +41,7 @@
 #include "radix_sort.h"
 #include "sa_build.h"
 #include "scan.h"
+#include "anchor_impl.h"
 
 #include <algorithm>
 #include <cmath>
@@ -715,12 +716,24 @@ __global__ __launch_bounds__(256) void build_keys_kernel(KeyArgs a)
 // TEXT_ROUNDS_MAX rounds (repetitive data) the ISA is built once and the
 // doubling rounds take over.
 
+// sub_pos (anchors, anchor_impl.h): element value v stands for the suffix at text position sub_pos[v].
 __global__ __launch_bounds__(256) void text_keys_kernel(const u32 *idx, u32 m, u32 n, u32 h, const u8 *codes, int b,
-                                                          int k, int plus_one, u64 *keys)
+                                                          int k, int plus_one, u64 *keys, const u32 *sub_pos)
 {
     for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < m; t += gridDim.x * blockDim.x) {
-        const u64 j = (u64)idx[t] + h;
+        const u32 v = idx[t];
+        const u64 j = (u64)(sub_pos ? sub_pos[v] : v) + h;
         keys[t] = (j < n) ? text_key_at(codes, (u32)j, b, k, plus_one, n) : 0ull;
+    }
+}
+
+// Initial keys of a subset sort: the first k symbols of the suffixes at pos[0 .. m), value = ordinal.
+__global__ __launch_bounds__(256) void subset_keys_kernel(const u32 *pos, u32 m, u32 n, const u8 *codes, int b, int k,
+                                                            int plus_one, u64 *keys, u32 *vals)
+{
+    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < m; t += gridDim.x * blockDim.x) {
+        keys[t] = text_key_at(codes, pos[t], b, k, plus_one, n);
+        vals[t] = t;
     }
 }
 
@@ -1179,7 +1192,7 @@ static void rerank_geometry(u32 m, RerankArgs &a)
     a.num_ranges = (a.num_tiles + a.tiles_per_range - 1) / a.tiles_per_range;
 }
 
-enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK, S_GRP2 = 26, S_BIG = 27, S_SCR = 29, S_SSA = 30, S_SSB = 31 };      // (10 .. 23, 28: search.hip; 24, 25: capi.cpp)
+enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK, S_GRP2 = 26, S_BIG = 27, S_SCR = 29, S_SSA = 30, S_SSB = 31, S_ANC = 32 };      // (10 .. 23, 28: search.hip; 24, 25: capi.cpp)
 
 // Initial key width.  Model the text as i.i.d. with per-symbol collision
 // probability c = sum p_i^2 (from the sampled counts): two suffixes agree on k
@@ -1229,6 +1242,9 @@ struct Knobs {
     bool no_mid_tier = false;   // PSS_NO_MID_TIER  groups above 512 members all take the chained radix sorts
     int period = -1;            // PSS_PERIOD     0: never the closed form for texts that repeat one word (rle_build.h)
     int rle = -1;               // PSS_RLE        0: never the run-length path, 1: always, unset: when runs average >= 8 bytes
+    int anchor = -1;            // PSS_ANCHOR     0: never the anchor round for ties that outlive the text rounds (rank rounds over the
+                                //                whole text instead), 1: whenever ties outlive them, unset: texts of >= 2^20 bytes
+    int anchor_omega = 0;       // PSS_ANCHOR_OMEGA  force the window of the minimizers (0 = as wide as the known common prefix allows)
     bool timing = false;        // PSS_TIMING     per-round trace on stderr
     static Knobs read()
     {
@@ -1251,6 +1267,8 @@ struct Knobs {
         k.no_mid_tier = getenv("PSS_NO_MID_TIER") != nullptr;
         if (const char *e = getenv("PSS_RLE")) k.rle = atoi(e);
         if (const char *e = getenv("PSS_PERIOD")) k.period = atoi(e);
+        if (const char *e = getenv("PSS_ANCHOR")) k.anchor = atoi(e);
+        if (const char *e = getenv("PSS_ANCHOR_OMEGA")) k.anchor_omega = atoi(e);
         k.timing = getenv("PSS_TIMING") != nullptr;
         return k;
     }
@@ -1331,7 +1349,18 @@ struct RoundsIO {
     u32 *d_counters;
     u32 *h_small;
     bool profile;
+    // Subset sort (anchors, anchor_impl.h): the n elements are the suffixes at text positions sub_pos[0 .. n) of a text of
+    // text_n symbols; element values are the ordinals.  Text rounds run until every group shares stop_text_h symbols,
+    // whatever they resolve; then the group ranks are the symbols of an integer string (element v is followed by v + 1)
+    // whose suffixes the rank rounds sort, starting over from h = 1.
+    const u32 *sub_pos = nullptr;
+    u32 text_n = 0;
+    u64 stop_text_h = 0;
+    u32 *grp2 = nullptr;        // second group-rank buffer (nullptr: slot S_GRP2 of the context)
 };
+
+static int anchor_rank_keys(DeviceCtx *ctx, const Knobs &knobs, const RoundsIO &outer, u64 h, u32 *akey, pss_sa_stats &st,
+                            bool *ok);
 
 static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortStats &ss, pss_sa_stats &st)
 {
@@ -1345,6 +1374,9 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
     u32 *GRP = io.GRP;
     const u8 *codes = io.codes;
     const bool rank_only = codes == nullptr;
+    const bool subset = io.sub_pos != nullptr;
+    const u32 text_n = subset ? io.text_n : n;
+    bool anchored = false;       // the anchor round has run: nothing may be left tied
     const int b = io.b, plus_one = io.plus_one, key_chars = io.key_chars;
     const bool profile = io.profile;
     u8 *work = io.work;
@@ -1405,8 +1437,11 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
         ra.pos_out = P[pcur ^ 1];
         ra.idx_out = V[cur ^ 1];
         if (round == 0) {
-            PSS_TRY(ctx->slot[S_GRP2].reserve((size_t)n * 4));
-            G[1] = ctx->slot[S_GRP2].as<u32>();
+            if (io.grp2) G[1] = io.grp2;
+            else {
+                PSS_TRY(ctx->slot[S_GRP2].reserve((size_t)n * 4));
+                G[1] = ctx->slot[S_GRP2].as<u32>();
+            }
         }
         ra.grp_out = G[gcur ^ 1];
         const bool fused0 = round == 0 && msd_fused;     // the MSD local sort already produced this round's active list
@@ -1427,6 +1462,7 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
             if (m_next == 0) mode = M_SPARSE;                                   // nothing left: no ISA at all
             if (mode == M_TEXT && text_rounds_max <= 0) mode = M_DENSE;
             if (rank_only && m_next) mode = M_DENSE;                            // no text to pack keys from
+            if (subset && m_next) mode = h < io.stop_text_h ? M_TEXT : M_DENSE;
             was_text = mode == M_TEXT;
         }
         if (fused0) {
@@ -1463,7 +1499,7 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
         // Text rounds advance h linearly; they pay off while each round resolves most ties
         // (natural-language LCPs).  When a round leaves more than 60 % of its list tied, or large
         // groups dominate, the data is repetitive: rank rounds, logarithmic in the LCP, take over.
-        auto local_round = [&](bool use_text, bool *bail) -> int {
+        auto local_round = [&](bool use_text, bool *bail, const u32 *key_of_suffix = nullptr) -> int {
             *bail = false;
             const u32 nblk = (m + GS_T - 1) / GS_T;
             PSS_TRY(ctx->slot[S_SCR].reserve((size_t)m + (size_t)nblk * 24 + (SC_MAX_BLOCKS + 8) * 8 + 4096 +
@@ -1480,7 +1516,10 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
             u64 *d_total = d_partial + SC_MAX_BLOCKS;
             const u32 h32 = (u32)std::min<u64>(h, 0xffffffffull);
             if (use_text)
-                hipLaunchKernelGGL(text_keys_kernel, dim3(grid), dim3(256), 0, s, V[src], m, n, h32, codes, b, kt, plus_one, K[src]);
+                hipLaunchKernelGGL(text_keys_kernel, dim3(grid), dim3(256), 0, s, V[src], m, text_n, h32, codes, b, kt, plus_one,
+                                   K[src], io.sub_pos);
+            else if (key_of_suffix)      // anchor round: the key of suffix i is key_of_suffix[i] (the rank of the anchor its window chose)
+                hipLaunchKernelGGL(rank_keys_kernel, dim3(grid), dim3(256), 0, s, V[src], m, n, 0u, key_of_suffix, K[src]);
             else
                 hipLaunchKernelGGL(rank_keys_kernel, dim3(grid), dim3(256), 0, s, V[src], m, n, h32, ISA, K[src]);
             if (use_text)
@@ -1509,7 +1548,7 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
                         (unsigned long long)h, m, nbig, 100.0 * nbig / m);
             last_big_frac = (double)nbig / (double)m;
             if (nbig == 0) return PSS_OK;
-            if (use_text && (u64)nbig * 2 > (u64)m && (text_rounds > 0 || (u64)nbig * 4 > (u64)m * 3)) {
+            if (use_text && !subset && (u64)nbig * 2 > (u64)m && (text_rounds > 0 || (u64)nbig * 4 > (u64)m * 3)) {
                 *bail = true;
                 return PSS_OK;
             }
@@ -1554,9 +1593,33 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
         if (mode == M_TEXT) {
             const bool text_progress = text_rounds == 0 || (u64)m * 10 <= (u64)m_text_prev * 6;
             bool bail = true;
-            if (text_rounds < text_rounds_max && text_progress) {
+            if (anchored) {
+                // cannot happen: the anchor round leaves no ties.  Counted (tests assert zero) and resolved by rank rounds.
+                st.anchor_left += m;
+            } else if (subset) {
+                if (h < io.stop_text_h) PSS_TRY(local_round(true, &bail));
+            } else if (text_rounds < text_rounds_max && text_progress) {
                 m_text_prev = m;
                 PSS_TRY(local_round(true, &bail));
+            }
+            if (bail && !anchored && !subset && knobs.anchor != 0 && (knobs.anchor == 1 || n >= (1u << 20))) {
+                // Ties that outlive the text rounds are repeats: one round keyed by the ranks of the anchors (anchor_impl.h)
+                // instead of log2(length of the repeat) rank rounds over the whole text.  The key array takes the place
+                // of the inverse suffix array, which this path never builds.
+                bool ok = false;
+                PSS_TRY(anchor_rank_keys(ctx, knobs, io, h, ISA, st, &ok));
+                if (ok) {
+                    st.anchor_active = m;
+                    bool b2 = false;
+                    PSS_TRY(local_round(false, &b2, ISA));
+                    anchored = true;
+                    keyed_grp = false;
+                    cur = src ^ 1;
+                    st.rounds += 1;
+                    st.sum_active += m;
+                    PSS_HIP(hipGetLastError());
+                    continue;
+                }
             }
             if (!bail) {
                 keyed_grp = false;
@@ -1573,6 +1636,7 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
             hipLaunchKernelGGL(isa_from_sa_kernel, dim3(grid_all), dim3(256), 0, s, SA, n, ISA);
             hipLaunchKernelGGL(isa_active_kernel, dim3(grid), dim3(256), 0, s, V[src], G[gcur], m, ISA);
             mode = M_DENSE;
+            if (subset) h = 1;       // from here on the elements are the symbols of an integer string
         }
         // Rank rounds: group-local unless large groups dominate (repetitive data) -- then one
         // global radix sort on (group rank, rank) with constant digits skipped is cheaper than
@@ -1650,6 +1714,122 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
         h *= 2;
     }
     st.mode = was_text ? (mode == M_TEXT ? 2u : 3u) : (u64)mode;
+    return PSS_OK;
+}
+
+// The key of the anchor round (anchor_impl.h): akey[i] = rank, among the anchor suffixes, of the anchor the window at i
+// chose -- for every position i of the text.  `h`: symbols every tied group of the caller's active list shares; it bounds
+// the window (omega + w - 1 <= h).  The caller's key buffers K[0], K[1] (8 n bytes each, scratch between two rounds) hold
+// the anchors' own sort; `akey`: 4 n bytes.  *ok = false: declined (window too narrow, too many anchors) -- nothing is lost
+// but the time of the selection pass.
+static int anchor_rank_keys(DeviceCtx *ctx, const Knobs &knobs, const RoundsIO &outer, u64 h, u32 *akey, pss_sa_stats &st,
+                            bool *ok)
+{
+    *ok = false;
+    hipStream_t s = ctx->stream;
+    const u32 n = outer.n;
+    const u8 *codes = outer.codes;
+    int w = h >= 28 ? 8 : 4;
+    u64 omega64 = h >= (u64)w ? h - (u64)w + 1 : 0;
+    if (knobs.anchor_omega > 0) omega64 = std::min<u64>(omega64, (u64)knobs.anchor_omega);
+    const u32 omega = (u32)std::min<u64>(omega64, 64);       // wider windows: fewer anchors, but names of 2 omega + w - 1 symbols
+    if (omega < (knobs.anchor == 1 ? 2u : 11u) || n < 64) return PSS_OK;
+    const u32 num_tiles = (n + ANC_TILE - 1) / ANC_TILE;
+    const size_t n16 = round_up((size_t)n, 16) + 16;
+    const u32 m_cap = n / 5 + 64;
+    PSS_TRY(ctx->slot[S_ANC].reserve(n16 + round_up((size_t)num_tiles * 4, 64) + ((size_t)num_tiles + 2) * 8 +
+                                     (SC_MAX_BLOCKS + 8) * 8 + (size_t)m_cap * 4 + 1024));
+    u8 *base = ctx->slot[S_ANC].as<u8>();
+    size_t o = 0;
+    auto carve = [&](size_t bytes) { u8 *p = base + o; o = round_up(o + bytes, 64); return p; };
+    u8 *d_dist = carve(n16);
+    u32 *d_tile_cnt = reinterpret_cast<u32 *>(carve((size_t)num_tiles * 4));
+    u64 *d_tile_off = reinterpret_cast<u64 *>(carve(((size_t)num_tiles + 2) * 8));
+    u64 *d_partial = reinterpret_cast<u64 *>(carve((SC_MAX_BLOCKS + 8) * 8));
+    u64 *d_total = d_partial + SC_MAX_BLOCKS;
+    u32 *d_Q = reinterpret_cast<u32 *>(carve((size_t)m_cap * 4));
+    BuildTimer tm;
+    PSS_HIP(hipEventCreate(&tm.ev0));
+    PSS_HIP(hipEventCreate(&tm.ev1));
+    PSS_HIP(hipEventRecord(tm.ev0, s));
+    const u32 n_read = (u32)(round_up((size_t)n, 16) + 64);      // the recoded text's padding (zero)
+    const u32 grid = std::min<u32>(num_tiles, (u32)ctx->num_cus * 4);
+    hipLaunchKernelGGL(anc_select_kernel, dim3(grid), dim3(256), 0, s, codes, n, n_read, omega, w, d_dist, d_tile_cnt, num_tiles);
+    PSS_TRY(device_excl_scan(ctx, InU32{d_tile_cnt}, num_tiles, d_partial, d_total, d_tile_off));
+    u32 *h_small = outer.h_small;
+    PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
+    PSS_HIP(hipStreamSynchronize(s));
+    const u32 m = h_small[0];
+    st.anchor_count = m;
+    st.anchor_omega = omega;
+    st.anchor_w = (u64)w;
+    if (knobs.timing) fprintf(stderr, "[pss] anchors: h=%llu omega=%u w=%d anchors=%u (n / %.1f)\n", (unsigned long long)h, omega, w, m, (double)n / std::max(1u, m));
+    if (m == 0 || m > n / 5) return PSS_OK;
+    hipLaunchKernelGGL(anc_walk_kernel<false>, dim3(grid), dim3(256), 0, s, d_dist, n, d_tile_off, num_tiles, d_Q,
+                       (const u32 *)nullptr, (u32 *)nullptr);
+    // the anchors' own sort, in the caller's two key buffers
+    u8 *b0 = reinterpret_cast<u8 *>(outer.K[0]), *b1 = reinterpret_cast<u8 *>(outer.K[1]);
+    const size_t m8 = round_up((size_t)m * 8, 256), m4 = round_up((size_t)m * 4 + 64, 256);
+    u64 *AK[2] = {reinterpret_cast<u64 *>(b0), reinterpret_cast<u64 *>(b0 + m8)};
+    u32 *AV[2] = {reinterpret_cast<u32 *>(b1), reinterpret_cast<u32 *>(b1 + m4)};
+    u32 *A_isa = reinterpret_cast<u32 *>(b1 + 2 * m4);
+    u32 *AP[2] = {reinterpret_cast<u32 *>(b1 + 3 * m4), reinterpret_cast<u32 *>(b1 + 4 * m4)};
+    u32 *A_grp = reinterpret_cast<u32 *>(b1 + 5 * m4);
+    u32 *A_grp2 = reinterpret_cast<u32 *>(b1 + 6 * m4);
+    u32 *A_sa = reinterpret_cast<u32 *>(b1 + 7 * m4);
+    u32 *A_rank = reinterpret_cast<u32 *>(b1 + 8 * m4);
+    if (2 * m8 > (size_t)n * 8 || 9 * m4 > (size_t)n * 8) return PSS_OK;      // (tiny texts)
+    int kt = 64 / outer.b;
+    if (kt > 16) kt = 16;
+    const u32 gk = (u32)std::min<u64>((u64)ctx->num_cus * 8, ((u64)m + 255) / 256);
+    hipLaunchKernelGGL(subset_keys_kernel, dim3(gk), dim3(256), 0, s, d_Q, m, n, codes, outer.b, kt, outer.plus_one, AK[0], AV[0]);
+    int cur = 0;
+    SortStats ss;
+    PSS_TRY(radix_sort_pairs(ctx, AK, AV, m, kt * outer.b, 0xffffffffu, nullptr, 0, outer.work, &cur, false, &ss));
+    RoundsIO io;
+    io.n = m;
+    io.SA = A_sa;
+    io.K[0] = AK[0]; io.K[1] = AK[1];
+    io.V[0] = AV[0]; io.V[1] = AV[1];
+    io.ISA = A_isa;
+    io.P[0] = AP[0]; io.P[1] = AP[1];
+    io.GRP = A_grp;
+    io.grp2 = A_grp2;
+    io.codes = codes;
+    io.b = outer.b; io.plus_one = outer.plus_one; io.key_chars = kt; io.key_drop = 0;
+    io.h0 = (u64)kt;
+    io.cur = cur;
+    io.final_buf = -1;
+    io.v_scratch = nullptr;
+    io.ties = false;
+    io.msd_fused = false;
+    io.msd_active = 0;
+    io.no_sparse = true;
+    io.work = outer.work;
+    io.d_agg_head = outer.d_agg_head; io.d_agg_cnt = outer.d_agg_cnt; io.d_red = outer.d_red; io.d_counters = outer.d_counters;
+    io.h_small = outer.h_small;
+    io.profile = false;
+    io.sub_pos = d_Q;
+    io.text_n = n;
+    io.stop_text_h = 2ull * omega + (u64)w - 1;
+    pss_sa_stats sub;
+    memset(&sub, 0, sizeof sub);
+    SortStats ss2;
+    PSS_TRY(refine_rounds(ctx, knobs, io, ss2, sub));
+    st.anchor_text_rounds = sub.text_rounds;
+    st.anchor_rounds = sub.rounds - sub.text_rounds;
+    st.anchor_sum_active = sub.sum_active;
+    hipLaunchKernelGGL(isa_from_sa_kernel, dim3(gk), dim3(256), 0, s, A_sa, m, A_rank);
+    hipLaunchKernelGGL(anc_walk_kernel<true>, dim3(grid), dim3(256), 0, s, d_dist, n, d_tile_off, num_tiles, (u32 *)nullptr,
+                       (const u32 *)A_rank, akey);
+    PSS_HIP(hipEventRecord(tm.ev1, s));
+    PSS_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    PSS_HIP(hipEventElapsedTime(&ms, tm.ev0, tm.ev1));
+    st.anchor_ms += ms;
+    st.anchor = 1;
+    st.anchor_depth = h;
+    *ok = true;
     return PSS_OK;
 }
 

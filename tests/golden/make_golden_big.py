@@ -28,7 +28,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import numpy as np  # noqa: E402
 
-KIND_IDS = {'lines': 0, 'words': 1, 'runs': 2, 'periodic': 3, 'repeat_line': 4, 'dup_blocks': 5}
+KIND_IDS = {'lines': 0, 'words': 1, 'runs': 2, 'periodic': 3, 'repeat_line': 4, 'dup_blocks': 5, 'mixed': 6}
 
 
 def poly64(sa: np.ndarray) -> int:
@@ -80,6 +80,7 @@ def main():
     jobs += [('lines', c, args.logn) for c in range(1, args.lines_chunks)]
     jobs += [('words', c, args.logn) for c in range(1, args.words_chunks)]
     jobs += [('repeat_line', 0, args.logn), ('dup_blocks', 0, args.logn)]      # general repeats (round 3)
+    jobs += [('mixed', 0, args.logn)]                                          # natural text with a repetitive middle (round 4)
     done = {}
     if os.path.exists(args.out):
         for r in json.load(open(args.out))['chunks']:
