@@ -67,7 +67,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-KINDS = {'lines': 0, 'words': 1, 'runs': 2, 'periodic': 3, 'repeat_line': 4, 'dup_blocks': 5}
+KINDS = {'lines': 0, 'words': 1, 'runs': 2, 'periodic': 3, 'repeat_line': 4, 'dup_blocks': 5, 'mixed': 6}
 ALPHA = b'abcdefghijklmnopqrstuvwxyz0123456789 .'
 METRIC = 'queries/sec (batched) + index-build GB/s on 512MB chunk, 1/2/4/8 GPU'
 MASK64 = (1 << 64) - 1
@@ -451,7 +451,7 @@ def run_chunk(args, D):
     adversarial = None
     if world == 1 and args.corpus == 'lines' and not os.environ.get('PSS_BENCH_NO_SECONDARY'):
         adversarial = []
-        for kind in ('runs', 'periodic', 'repeat_line', 'dup_blocks'):
+        for kind in ('runs', 'periodic', 'repeat_line', 'dup_blocks', 'mixed'):
             a_host = np.empty(n, dtype=np.uint8)
             _ffi.check(lib.pss_gen_corpus(KINDS[kind], a_host.ctypes.data, n, 0))
             a_dT = torch.from_numpy(a_host).cuda()
@@ -462,12 +462,16 @@ def run_chunk(args, D):
                 best = ast.ms_total if best is None else min(best, ast.ms_total)
             ad = ast.as_dict()
             a_ok, a_how = verify_sa(dSA, a_host, kind, 0, load_big_goldens(), want_sha=False)
-            if kind in ('repeat_line', 'dup_blocks'):
-                # repeats that are not runs of one byte: no reduction yet, rank rounds over nearly every suffix
+            if kind in ('repeat_line', 'dup_blocks', 'mixed'):
+                # repeats that are not runs of one byte: one word repeated (closed form), duplicated blocks and natural
+                # text with a repetitive middle (anchor round: anchor_impl.h)
                 adversarial.append({'corpus': kind, 'chunk_bytes': n, 'build_ms': round(best, 3),
                                     'index_build_gbs': round(n / best / 1e6, 3), 'verified': a_ok, 'verified_by': a_how,
                                     'run_length_path': bool(ad['rle']), 'rounds': ad['rounds'], 'sum_active': ad['sum_active'],
-                                    'initial_sort': 'sample sort' if ad['ss'] else ('hybrid MSD' if ad['msd'] else 'LSD')})
+                                    'initial_sort': 'sample sort' if ad['ss'] else ('hybrid MSD' if ad['msd'] else 'LSD'),
+                                    'anchor_round': bool(ad['anchor']), 'anchors': ad['anchor_count'],
+                                    'anchor_window': ad['anchor_omega'], 'anchor_rank_rounds': ad['anchor_rounds'],
+                                    'anchor_ms': round(ad['anchor_ms'], 2), 'anchor_left_tied': ad['anchor_left']})
                 del a_dT
                 continue
             os.environ['PSS_RLE'] = '0'

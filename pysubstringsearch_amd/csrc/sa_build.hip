@@ -878,6 +878,198 @@ __global__ __launch_bounds__(256) void group_sort_kernel(const u64 *key, const u
     }
 }
 
+// ---- rank rounds: the same job by a segmented MERGE sort --------------------------------------------------
+// group_sort_kernel ranks a member by counting the smaller members of its group: O(group) LDS reads per member --
+// built for the groups of a few suffixes natural text leaves.  Repeats make groups as large as the number of copies,
+// and a rank round over duplicated blocks (512 copies: 512 reads per member) spent 40 ms in it at n = 2^29.  Here the
+// whole LDS range (the window and its halos, 3072 elements) is sorted ONCE by the 56-bit number
+//     [ LDS index of the element's group head : 12 | key : 32 | the element's own LDS index : 12 ]
+// -- groups are contiguous and their heads ascend, so the sort permutes every group inside its own slots and nothing
+// else; ties keep their order (the index), members of open or oversized groups carry key 0 and stay where they are.
+// Eight elements per thread through a sorting network, then merge rounds with a merge-path search per thread (the
+// scheme of ss_local_kernel, on 8-byte elements); a pair of runs whose border is a group border is in order already
+// and is skipped.  The cost does not depend on the group sizes.  Every window writes the slots of its own 2048
+// positions (a group that straddles two windows is sorted by both, identically).
+constexpr int GM_BLOCK = 384, GM_IPT = 8, GM_WAVES = GM_BLOCK / kWave;
+static_assert(GM_BLOCK * GM_IPT == GS_LDS, "one thread per eight elements of the LDS range");
+static_assert(GS_LDS <= 4096, "12-bit LDS indices");
+__device__ __forceinline__ u32 gm_slot(u32 p) { return p + (p >> 3); }      // a thread's eight elements: 72-byte stride, no bank conflicts
+__device__ __forceinline__ void gm_cswap(u64 &a, u64 &b)
+{
+    const bool sw = b < a;
+    const u64 x = sw ? b : a, y = sw ? a : b;
+    a = x;
+    b = y;
+}
+
+__global__ __launch_bounds__(GM_BLOCK) void group_msort32_kernel(const u64 *key, const u32 *idx, const u32 *grp, u32 m, u64 *okey,
+                                                                   u32 *oidx, u8 *big, u32 *blk_big, u32 *blk_heads)
+{
+    __shared__ u64 s_e[GS_LDS + GS_LDS / 8];
+    __shared__ u32 s_idx[GS_LDS];
+    __shared__ u32 s_bigm[GS_LDS / 32];
+    __shared__ u32 s_wave[2][GM_WAVES];
+    __shared__ u32 s_cnt[2];
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const u32 base = blockIdx.x * GS_T;
+    const u32 lo = base >= (u32)GS_CAP ? base - GS_CAP : 0;
+    const u32 hi_want = base + GS_T + GS_CAP;
+    const u32 hi = hi_want < m ? hi_want : m;
+    const u32 cnt = hi - lo;                       // valid LDS elements
+    const u32 wend = (base + GS_T < m) ? base + GS_T : m;
+    for (u32 i = tid; i < (u32)GS_LDS; i += GM_BLOCK) s_idx[i] = (i < cnt) ? idx[lo + i] : 0u;
+    if (tid < GS_LDS / 32) s_bigm[tid] = 0;
+    if (tid < 2) s_cnt[tid] = 0;
+    // my eight consecutive elements: group ranks (and the one before), head flags
+    const u32 i0 = tid * GM_IPT;
+    u32 g[GM_IPT + 1];
+    g[0] = (i0 > 0 && i0 - 1 < cnt) ? grp[lo + i0 - 1] : 0xffffffffu;
+    u32 k32[GM_IPT];
+#pragma unroll
+    for (int q = 0; q < GM_IPT; ++q) {
+        const u32 i = i0 + q;
+        g[q + 1] = (i < cnt) ? grp[lo + i] : 0xffffffffu;
+        k32[q] = (i < cnt) ? (u32)key[lo + i] : 0u;
+    }
+    u32 hm = 0;
+#pragma unroll
+    for (int q = 0; q < GM_IPT; ++q) {
+        const u32 i = i0 + q;
+        const bool head = i == 0 || i >= cnt || g[q + 1] != g[q];
+        hm |= (head ? 1u : 0u) << q;
+    }
+    // last head at or before i / first head after i: the two scans of group_sort_kernel, over GM_WAVES waves
+    const u32 my_last = hm ? i0 + (31 - __builtin_clz(hm)) + 1 : 0;
+    const u32 incl = wave_incl_max(my_last);
+    if (lane == 63) s_wave[0][wave] = incl;
+    const u32 my_first_rev = hm ? GS_LDS - (i0 + (u32)__builtin_ctz(hm)) : 0;
+    const u32 rincl = wave_incl_max(__shfl(my_first_rev, 63 - (int)lane));
+    if (lane == 63) s_wave[1][GM_WAVES - 1 - wave] = rincl;
+    __syncthreads();
+    u32 carry = 0;
+    for (u32 w = 0; w < wave; ++w) carry = max(carry, s_wave[0][w]);
+    u32 excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = 0;
+    u32 last_head1 = max(carry, excl);
+    u32 rcarry = 0;
+    for (u32 w = 0; w < GM_WAVES - 1 - wave; ++w) rcarry = max(rcarry, s_wave[1][w]);
+    u32 rexcl = __shfl_up(rincl, 1);
+    if (lane == 0) rexcl = 0;
+    const u32 rmine = __shfl(rexcl, 63 - (int)lane);
+    const u32 next_rev = max(rcarry, rmine);
+    u32 next_head = next_rev ? GS_LDS - next_rev : GS_LDS;
+    u32 gs[GM_IPT], ge[GM_IPT];
+#pragma unroll
+    for (int q = 0; q < GM_IPT; ++q) {
+        if ((hm >> q) & 1u) last_head1 = i0 + q + 1;
+        gs[q] = last_head1 - 1;
+    }
+#pragma unroll
+    for (int q = GM_IPT - 1; q >= 0; --q) {
+        ge[q] = next_head;
+        if ((hm >> q) & 1u) next_head = i0 + q;
+    }
+    u64 v[GM_IPT];
+    u32 bigbits = 0, nb = 0, nh = 0;
+#pragma unroll
+    for (int q = 0; q < GM_IPT; ++q) {
+        const u32 i = i0 + q;
+        if (i >= cnt) {
+            v[q] = ~0ull;
+            continue;
+        }
+        // a group touching the edge of the LDS range continues outside (unless that edge is the data's edge)
+        const bool open = (gs[q] == 0 && lo > 0) || (ge[q] >= cnt && hi < m);
+        const bool isb = open || ge[q] - gs[q] > (u32)GS_CAP;
+        v[q] = ((u64)gs[q] << 44) | ((u64)(isb ? 0u : k32[q]) << 12) | (u64)i;
+        if (isb) {
+            bigbits |= 1u << q;
+            const u32 j = lo + i;
+            if (j >= base && j < wend) {
+                ++nb;
+                if (gs[q] == i) ++nh;
+            }
+        }
+    }
+    if (bigbits) atomicOr(&s_bigm[i0 >> 5], bigbits << (i0 & 31u));
+    // eight elements in registers: odd-even merge sort network (19 compare-exchanges)
+    gm_cswap(v[0], v[1]); gm_cswap(v[2], v[3]); gm_cswap(v[4], v[5]); gm_cswap(v[6], v[7]);
+    gm_cswap(v[0], v[2]); gm_cswap(v[1], v[3]); gm_cswap(v[4], v[6]); gm_cswap(v[5], v[7]);
+    gm_cswap(v[1], v[2]); gm_cswap(v[5], v[6]);
+    gm_cswap(v[0], v[4]); gm_cswap(v[1], v[5]); gm_cswap(v[2], v[6]); gm_cswap(v[3], v[7]);
+    gm_cswap(v[2], v[4]); gm_cswap(v[3], v[5]);
+    gm_cswap(v[1], v[2]); gm_cswap(v[3], v[4]); gm_cswap(v[5], v[6]);
+#pragma unroll
+    for (int q = 0; q < GM_IPT; ++q) s_e[gm_slot(i0 + q)] = v[q];
+    __syncthreads();
+    const bool live = i0 < cnt;                    // the padding stays at the end of every run
+    for (u32 L = GM_IPT; L < (u32)GS_LDS; L <<= 1) {
+        const u32 pair0 = i0 & ~(2 * L - 1);
+        const u32 d = i0 - pair0;
+        const u32 A = pair0, B = pair0 + L;
+        const u32 lenA = min(L, (u32)GS_LDS - A), lenB = B < (u32)GS_LDS ? min(L, (u32)GS_LDS - B) : 0u;
+        // nothing to merge: no second run, or the border between the runs is a border between groups
+        bool work = live && lenB != 0;
+        if (work) work = (s_e[gm_slot(B - 1)] >> 44) == (s_e[gm_slot(B)] >> 44);
+        if (work) {
+            u32 a_lo = d > lenB ? d - lenB : 0, a_hi = d < lenA ? d : lenA;
+            while (a_lo < a_hi) {
+                const u32 mid = (a_lo + a_hi) >> 1;
+                const u64 x = s_e[gm_slot(A + mid)], y = s_e[gm_slot(B + d - 1 - mid)];
+                if (x < y) a_lo = mid + 1; else a_hi = mid;
+            }
+            u32 ai = a_lo, bi = d - a_lo;
+            u64 va = ai < lenA ? s_e[gm_slot(A + ai)] : ~0ull;
+            u64 vb = bi < lenB ? s_e[gm_slot(B + bi)] : ~0ull;
+#pragma unroll
+            for (int q = 0; q < GM_IPT; ++q) {
+                const bool ta = !(vb < va);
+                v[q] = ta ? va : vb;
+                ai += ta ? 1u : 0u;
+                bi += ta ? 0u : 1u;
+                if (q + 1 < GM_IPT) {
+                    const u32 ni = ta ? ai : bi;
+                    const u32 len = ta ? lenA : lenB;
+                    const u64 nx = ni < len ? s_e[gm_slot((ta ? A : B) + min(ni, len - 1))] : ~0ull;
+                    va = ta ? nx : va;
+                    vb = ta ? vb : nx;
+                }
+            }
+        }
+        __syncthreads();
+        if (work) {
+#pragma unroll
+            for (int q = 0; q < GM_IPT; ++q) s_e[gm_slot(i0 + q)] = v[q];
+        }
+        __syncthreads();
+    }
+    // output: the slots of my own window
+#pragma unroll
+    for (int q = 0; q < GM_IPT; ++q) {
+        const u32 r = q * GM_BLOCK + tid;
+        const u32 j = lo + r;
+        if (r < cnt && j >= base && j < wend) {
+            if ((s_bigm[r >> 5] >> (r & 31u)) & 1u) {
+                okey[j] = key[j];
+                oidx[j] = s_idx[r];
+                big[j] = 1;
+            } else {
+                const u64 e = s_e[gm_slot(r)];
+                okey[j] = (e >> 12) & 0xffffffffull;
+                oidx[j] = s_idx[(u32)e & 0xfffu];
+                big[j] = 0;
+            }
+        }
+    }
+    if (nb) atomicAdd(&s_cnt[0], nb);
+    if (nh) atomicAdd(&s_cnt[1], nh);
+    __syncthreads();
+    if (tid == 0) {
+        blk_big[blockIdx.x] = s_cnt[0];
+        blk_heads[blockIdx.x] = s_cnt[1];
+    }
+}
+
 // ---- middle tier: groups of up to MID_CAP members sorted by one workgroup in LDS -----------------
 // group_sort ranks groups of <= GS_CAP members by direct counting (O(size) LDS reads per member) and hands
 // everything larger to two chained global radix sorts (key, then group): a dozen passes of 24 B per member.
@@ -1245,6 +1437,7 @@ struct Knobs {
     int anchor = -1;            // PSS_ANCHOR     0: never the anchor round for ties that outlive the text rounds (rank rounds over the
                                 //                whole text instead), 1: whenever ties outlive them, unset: texts of >= 2^20 bytes
     int anchor_omega = 0;       // PSS_ANCHOR_OMEGA  force the window of the minimizers (0 = as wide as the known common prefix allows)
+    bool count_sort = false;    // PSS_COUNT_SORT  rank rounds: groups ranked by counting (group_sort_kernel) instead of the merge sort
     bool timing = false;        // PSS_TIMING     per-round trace on stderr
     static Knobs read()
     {
@@ -1269,6 +1462,7 @@ struct Knobs {
         if (const char *e = getenv("PSS_PERIOD")) k.period = atoi(e);
         if (const char *e = getenv("PSS_ANCHOR")) k.anchor = atoi(e);
         if (const char *e = getenv("PSS_ANCHOR_OMEGA")) k.anchor_omega = atoi(e);
+        k.count_sort = getenv("PSS_COUNT_SORT") != nullptr;
         k.timing = getenv("PSS_TIMING") != nullptr;
         return k;
     }
@@ -1525,8 +1719,11 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
             if (use_text)
                 hipLaunchKernelGGL(group_sort_kernel<false>, dim3(nblk), dim3(256), 0, s, K[src], V[src], G[gcur], m, K[src ^ 1],
                                    V[src ^ 1], d_big, d_blk_big, d_blk_heads);
-            else
+            else if (knobs.count_sort)
                 hipLaunchKernelGGL(group_sort_kernel<true>, dim3(nblk), dim3(256), 0, s, K[src], V[src], G[gcur], m, K[src ^ 1],
+                                   V[src ^ 1], d_big, d_blk_big, d_blk_heads);
+            else
+                hipLaunchKernelGGL(group_msort32_kernel, dim3(nblk), dim3(GM_BLOCK), 0, s, K[src], V[src], G[gcur], m, K[src ^ 1],
                                    V[src ^ 1], d_big, d_blk_big, d_blk_heads);
             if (!knobs.no_mid_tier) {
                 // groups of up to MID_CAP members: one workgroup each, in LDS (no host round trip: the list and its

@@ -543,3 +543,87 @@ def test_rle_path_is_chosen_for_long_runs_only(oracle, monkeypatch):
     st = {}
     sa0 = _sa_device(t, st)
     assert st['rle'] == 0 and np.array_equal(sa0, sa)
+
+
+def _repeat_cases(rng, nrng):
+    """Texts whose ties outlive the text rounds: copies of blocks (with and without edits), periodic stretches inside
+    other text, two stretches of the same word with different ends, copies mixed with runs of one byte."""
+    out = []
+    for alpha, n in ((2, 70000), (4, 200000), (26, 300000), (39, 1 << 20), (200, 150000), (256, 400000)):
+        base = nrng.integers(0, alpha, n, dtype=np.uint8)
+        if alpha == 26:
+            base = base + np.uint8(97)
+        blk = int(rng.choice([300, 4000, 50000]))
+        t = np.resize(base[:blk], n).copy()                      # one block repeated ...
+        for p in nrng.integers(0, n, 25):                        # ... with sparse edits
+            t[p] = base[p]
+        out.append(t)
+        t = base.copy()                                          # a periodic stretch inside random text
+        a, b = sorted(int(x) for x in nrng.integers(0, n, 2))
+        t[a:b] = np.resize(base[:int(rng.choice([2, 7, 60, 333]))], b - a)
+        out.append(t)
+        t = base.copy()                                          # the same word twice, different lengths and ends
+        q = n // 4
+        word = base[:int(rng.choice([5, 13, 64]))]
+        t[q:2 * q] = np.resize(word, q)
+        t[3 * q:3 * q + q // 2] = np.resize(word, q // 2)
+        out.append(t)
+        t = base.copy()                                          # blocks copied from elsewhere + runs
+        for _ in range(12):
+            s_, d_ = (int(x) for x in nrng.integers(0, n - 5000, 2))
+            t[d_:d_ + 5000] = t[s_:s_ + 5000].copy()
+        for _ in range(10):
+            s_ = int(nrng.integers(0, n - 700))
+            t[s_:s_ + int(nrng.integers(20, 700))] = t[s_]
+        out.append(t)
+    return out
+
+
+@pytest.mark.parametrize('omega', [None, '9', '17', '40'])
+@pytest.mark.parametrize('count_sort', [False, True])
+def test_anchor_round_forced(oracle, monkeypatch, omega, count_sort):
+    """PSS_ANCHOR=1: whenever ties outlive the text rounds, ONE round keyed by the ranks of the anchors (minimizers of
+    the text, anchor_impl.h) finishes the suffix array -- at any size, with the window forced narrower than the known
+    common prefix allows, with either group sort of the rank rounds.  Nothing may be left tied by that round."""
+    import ctypes
+    import random
+
+    import torch
+
+    from pysubstringsearch_amd import _ffi
+    monkeypatch.setenv('PSS_ANCHOR', '1')
+    if omega:
+        monkeypatch.setenv('PSS_ANCHOR_OMEGA', omega)
+    if count_sort:
+        monkeypatch.setenv('PSS_COUNT_SORT', '1')
+    rng = random.Random(5)
+    nrng = np.random.default_rng(5)
+    took = 0
+    for t in _repeat_cases(rng, nrng) + [gen_corpus(6, 1 << 20), gen_corpus(5, 1 << 21), gen_corpus(6, 3 << 20, 2)]:
+        t = np.ascontiguousarray(t)
+        dT = torch.from_numpy(t).cuda()
+        dSA = torch.empty(t.size, dtype=torch.int32, device='cuda')
+        st = _ffi.SaStats()
+        _ffi.check(_ffi.lib.pss_sa_build_device(dT.data_ptr(), dSA.data_ptr(), t.size, 0, 0, ctypes.byref(st)))
+        assert st.anchor_left == 0
+        took += int(st.anchor)
+        assert (dSA.cpu().numpy() == oracle.sa(t)).all()
+    assert took >= 10
+
+
+def test_anchor_round_is_chosen_for_long_repeats_only(oracle):
+    """Default switches: texts of >= 2^20 bytes whose ties outlive the text rounds take the anchor round; natural text
+    and high-entropy lines do not."""
+    import ctypes
+
+    import torch
+
+    from pysubstringsearch_amd import _ffi
+    for kind, n, want in ((5, 1 << 22, 1), (6, 1 << 22, 1), (1, 1 << 22, 0), (0, 1 << 22, 0), (5, 1 << 18, 0)):
+        t = gen_corpus(kind, n)
+        dT = torch.from_numpy(t).cuda()
+        dSA = torch.empty(n, dtype=torch.int32, device='cuda')
+        st = _ffi.SaStats()
+        _ffi.check(_ffi.lib.pss_sa_build_device(dT.data_ptr(), dSA.data_ptr(), n, 0, 0, ctypes.byref(st)))
+        assert int(st.anchor) == want and st.anchor_left == 0, (kind, n, st.anchor)
+        assert (dSA.cpu().numpy() == oracle.sa(t)).all()
