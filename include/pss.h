@@ -142,6 +142,7 @@ typedef struct pss_sa_stats {
     uint64_t anchor_sum_active;  /* anchors still tied, summed over those rounds */
     uint64_t anchor_left;      /* suffixes the round left tied (always 0; a non-zero value is an internal error that the
                                   rank rounds then repair) */
+    uint64_t anchor_levels;    /* anchor levels stacked: 1 = anchors of the text; 2 = anchors of the string of their names, ... */
     double anchor_ms;          /* device time of the anchors' selection and sort */
 } pss_sa_stats;
 

@@ -79,6 +79,7 @@ class SaStats(ctypes.Structure):
         ('anchor_rounds', ctypes.c_uint64),
         ('anchor_sum_active', ctypes.c_uint64),
         ('anchor_left', ctypes.c_uint64),
+        ('anchor_levels', ctypes.c_uint64),
         ('anchor_ms', ctypes.c_double),
     ]
 

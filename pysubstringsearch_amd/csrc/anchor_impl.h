@@ -25,6 +25,12 @@
 //     (the last position of the text is always an anchor and its name holds the end of the text, so no name sequence
 //     is a prefix of another).
 //
+// The same construction serves one level up (round 4, late): the anchors' names ARE a string of 32-bit symbols; when its
+// rank rounds have reached depth 32 with many elements still tied, minimizers of THAT string (w = 1 symbol, omega = 16:
+// names at depth 2 omega = 32 are the ranks the rounds have just produced) give a string 8.5 times shorter, and so on:
+// every level costs five rank rounds and one anchor round over its own length, the lengths fall geometrically, and the
+// number of passes over any level no longer depends on the length of the repeats.
+//
 // Everything is exact for every text (PSS_ANCHOR=1 sends any text through it in the tests and the fuzzer); a text whose
 // windows choose more than n / 5 anchors (a hash that keeps falling, a stretch of period 2) declines, and the rank rounds
 // over the whole text run as before.
@@ -46,6 +52,9 @@ __device__ __forceinline__ u32 anc_hash(u64 x, int w)
 // d[s] = M(s) - s for every window start s < n; tile_cnt[t] = anchors first chosen by a window of tile t
 // (windows s with s == 0 or M(s) != M(s - 1)).  `text`: the recoded text, 16-byte aligned, readable (and zero)
 // up to n_read >= n, n_read % 16 == 0.
+// SYMS: the string is an array of 32-bit symbols (the names of a coarser level's anchors, or the symbols of the run-length
+// path's reduced string) and H hashes ONE symbol (w = 1); `text` is then that array.
+template <bool SYMS>
 __global__ __launch_bounds__(256) void anc_select_kernel(const u8 *text, u32 n, u32 n_read, u32 omega, int w, u8 *d,
                                                            u32 *tile_cnt, u32 num_tiles)
 {
@@ -57,6 +66,13 @@ __global__ __launch_bounds__(256) void anc_select_kernel(const u8 *text, u32 n, 
     const u32 tid = threadIdx.x;
     for (u32 tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
         const u32 tile0 = tile * ANC_TILE;
+        if (SYMS) {
+            const u32 *sym = reinterpret_cast<const u32 *>(text);
+            for (u32 j = tid; j < ANC_TILE + omega; j += 256) {
+                const long long p = (long long)tile0 - 1 + j;
+                s_h[j] = (p < 0 || p >= (long long)n) ? ANC_HMAX : anc_hash((u64)sym[p], 4);
+            }
+        } else {
         const u32 nvec = (ANC_TILE + omega + 16 + 8 + 15) / 16 + 1;
         for (u32 v = tid; v < nvec; v += 256) {
             const long long pos = (long long)tile0 - 16 + 16ll * v;
@@ -83,6 +99,7 @@ __global__ __launch_bounds__(256) void anc_select_kernel(const u8 *text, u32 n, 
                     }
                 }
             }
+        }
         }
         __syncthreads();
         // my 17 windows: starts A + k, A = tile0 + 16 tid - 1, k = 0 (the neighbour's last, for the flag of my first) .. 16

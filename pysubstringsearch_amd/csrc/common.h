@@ -101,7 +101,7 @@ struct DeviceCtx {
     int device = -1;
     hipStream_t stream = nullptr;
     int num_cus = 256;
-    static constexpr int kSlots = 40;
+    static constexpr int kSlots = 48;
     DevBuf slot[kSlots];
     static constexpr size_t kPinnedBytes = (size_t)640 << 10;   // 64 KiB of counters / small tables / query staging, 64 KiB of
                                                                 // result bytes, 512 KiB of entry records (search.hip, SM_OFF_*)

@@ -1384,7 +1384,7 @@ static void rerank_geometry(u32 m, RerankArgs &a)
     a.num_ranges = (a.num_tiles + a.tiles_per_range - 1) / a.tiles_per_range;
 }
 
-enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK, S_GRP2 = 26, S_BIG = 27, S_SCR = 29, S_SSA = 30, S_SSB = 31, S_ANC = 32 };      // (10 .. 23, 28: search.hip; 24, 25: capi.cpp)
+enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK, S_GRP2 = 26, S_BIG = 27, S_SCR = 29, S_SSA = 30, S_SSB = 31, S_ANC = 32 /* .. 38: one per level */, S_X0 = 39 /* .. 45 */ };      // (10 .. 23, 28: search.hip; 24, 25: capi.cpp)
 
 // Initial key width.  Model the text as i.i.d. with per-symbol collision
 // probability c = sum p_i^2 (from the sampled counts): two suffixes agree on k
@@ -1551,10 +1551,11 @@ struct RoundsIO {
     u32 text_n = 0;
     u64 stop_text_h = 0;
     u32 *grp2 = nullptr;        // second group-rank buffer (nullptr: slot S_GRP2 of the context)
+    int level = 0;              // 0: the text (or the run-length path's reduced string); k: the names of level k - 1's anchors
 };
 
-static int anchor_rank_keys(DeviceCtx *ctx, const Knobs &knobs, const RoundsIO &outer, u64 h, u32 *akey, pss_sa_stats &st,
-                            bool *ok);
+static int anchor_rank_keys(DeviceCtx *ctx, const Knobs &knobs, const RoundsIO &outer, u64 h, const u32 *syms,
+                            const u32 *cur_ranks, u32 *akey, pss_sa_stats &st, bool *ok);
 
 static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortStats &ss, pss_sa_stats &st)
 {
@@ -1616,6 +1617,16 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
     u64 **Kr = K;
     u64 h = io.h0;               // symbols every group is known to share
     const u32 grid_all = (u32)grid_stream;
+    // Integer strings (rank rounds only): the ranks the first round leaves ARE the string, up to renaming -- kept for the
+    // minimizers of an anchor level on top of this one (anchor_impl.h), should the rounds reach depth 32 with much left tied.
+    u32 *X0 = nullptr;
+    auto snapshot_symbols = [&]() -> int {
+        if (knobs.anchor == 0 || io.level >= 6 || n < (knobs.anchor == 1 ? 64u : (1u << 20))) return PSS_OK;
+        PSS_TRY(ctx->slot[S_X0 + io.level].reserve((size_t)n * 4));
+        X0 = ctx->slot[S_X0 + io.level].as<u32>();
+        PSS_HIP(hipMemcpyAsync(X0, ISA, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        return PSS_OK;
+    };
     for (int round = 0;; ++round) {
         if (round > 96) {
             set_error("sa_build: no convergence after 96 rounds (internal error)");
@@ -1672,6 +1683,14 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
         PSS_HIP(hipGetLastError());
         if (round == 0 && final_buf >= 0) V[final_buf] = v_scratch;   // later rounds must not scribble over SA
         if (m_next == 0) break;
+        if (anchored && mode == M_DENSE) {
+            // cannot happen: the anchor round leaves no ties (and its keys took the place of the inverse array)
+            st.anchor_left += m_next;
+            set_error("sa_build: %u elements tied after the anchor round of level %d (internal error)", m_next, io.level);
+            return PSS_EDEVICE;
+        }
+        if (round == 0 && mode == M_DENSE && subset) h = 1;           // (no text round was needed: the elements are symbols already)
+        if (round == 0 && mode == M_DENSE && (subset || rank_only)) PSS_TRY(snapshot_symbols());
         if (h >= (u64)n) {
             set_error("sa_build: %u suffixes unresolved at h=%llu >= n (internal error)", m_next,
                       (unsigned long long)h);
@@ -1804,7 +1823,7 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
                 // instead of log2(length of the repeat) rank rounds over the whole text.  The key array takes the place
                 // of the inverse suffix array, which this path never builds.
                 bool ok = false;
-                PSS_TRY(anchor_rank_keys(ctx, knobs, io, h, ISA, st, &ok));
+                PSS_TRY(anchor_rank_keys(ctx, knobs, io, h, nullptr, nullptr, ISA, st, &ok));
                 if (ok) {
                     st.anchor_active = m;
                     bool b2 = false;
@@ -1833,7 +1852,27 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
             hipLaunchKernelGGL(isa_from_sa_kernel, dim3(grid_all), dim3(256), 0, s, SA, n, ISA);
             hipLaunchKernelGGL(isa_active_kernel, dim3(grid), dim3(256), 0, s, V[src], G[gcur], m, ISA);
             mode = M_DENSE;
-            if (subset) h = 1;       // from here on the elements are the symbols of an integer string
+            if (subset) {
+                h = 1;               // from here on the elements are the symbols of an integer string
+                PSS_TRY(snapshot_symbols());
+            }
+        }
+        if (mode == M_DENSE && X0 && !anchored && h >= 32 && (u64)m * 16 >= (u64)n && m >= (knobs.anchor == 1 ? 64u : (1u << 19))) {
+            // a level up: minimizers of this string of symbols, named by the ranks the rounds have reached
+            bool ok = false;
+            PSS_TRY(anchor_rank_keys(ctx, knobs, io, h, X0, ISA, ISA, st, &ok));
+            if (ok) {
+                bool b2 = false;
+                PSS_TRY(local_round(false, &b2, ISA));
+                anchored = true;
+                keyed_grp = false;
+                cur = src ^ 1;
+                st.rounds += 1;
+                st.sum_active += m;
+                PSS_HIP(hipGetLastError());
+                continue;
+            }
+            X0 = nullptr;            // declined: plain rounds to the end
         }
         // Rank rounds: group-local unless large groups dominate (repetitive data) -- then one
         // global radix sort on (group rank, rank) with constant digits skipped is cheaper than
@@ -1915,28 +1954,51 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
 }
 
 // The key of the anchor round (anchor_impl.h): akey[i] = rank, among the anchor suffixes, of the anchor the window at i
-// chose -- for every position i of the text.  `h`: symbols every tied group of the caller's active list shares; it bounds
-// the window (omega + w - 1 <= h).  The caller's key buffers K[0], K[1] (8 n bytes each, scratch between two rounds) hold
-// the anchors' own sort; `akey`: 4 n bytes.  *ok = false: declined (window too narrow, too many anchors) -- nothing is lost
-// but the time of the selection pass.
-static int anchor_rank_keys(DeviceCtx *ctx, const Knobs &knobs, const RoundsIO &outer, u64 h, u32 *akey, pss_sa_stats &st,
-                            bool *ok)
+// chose -- for every position i of the string.  `h`: symbols every tied group of the caller's active list shares.
+//   syms == nullptr  the string is the text (outer.codes): w = 4 or 8 bytes hashed per position, omega + w - 1 <= h; the
+//                    anchors are named by a sort of their own (text rounds to 2 omega + w - 1 symbols), then their names
+//                    are a string of 32-bit symbols whose suffixes the rank rounds sort;
+//   syms != nullptr  the string is that array of 32-bit symbols (a level up: the names of a coarser level's anchors):
+//                    w = 1, omega = h / 2, and the anchors' names are the ranks the caller's rounds have reached
+//                    (cur_ranks, depth h >= 2 omega).
+// The caller's key buffers K[0], K[1] (8 n bytes each, scratch between two rounds) hold the anchors' own sort; `akey`:
+// 4 n bytes (may be cur_ranks).  *ok = false: declined (window too narrow, too many anchors) -- nothing is lost but the
+// time of the selection pass.
+__global__ __launch_bounds__(256) void gather_names_kernel(const u32 *pos, u32 m, const u32 *ranks, u64 *keys, u32 *vals)
+{
+    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < m; t += gridDim.x * blockDim.x) {
+        keys[t] = ranks[pos[t]];
+        vals[t] = t;
+    }
+}
+
+static int anchor_rank_keys(DeviceCtx *ctx, const Knobs &knobs, const RoundsIO &outer, u64 h, const u32 *syms,
+                            const u32 *cur_ranks, u32 *akey, pss_sa_stats &st, bool *ok)
 {
     *ok = false;
     hipStream_t s = ctx->stream;
     const u32 n = outer.n;
     const u8 *codes = outer.codes;
-    int w = h >= 28 ? 8 : 4;
-    u64 omega64 = h >= (u64)w ? h - (u64)w + 1 : 0;
+    const bool forced = knobs.anchor == 1;
+    int w;
+    u64 omega64;
+    if (syms) {
+        w = 1;
+        omega64 = h / 2;
+    } else {
+        w = h >= 28 ? 8 : 4;
+        omega64 = h >= (u64)w ? h - (u64)w + 1 : 0;
+    }
     if (knobs.anchor_omega > 0) omega64 = std::min<u64>(omega64, (u64)knobs.anchor_omega);
     const u32 omega = (u32)std::min<u64>(omega64, 64);       // wider windows: fewer anchors, but names of 2 omega + w - 1 symbols
-    if (omega < (knobs.anchor == 1 ? 2u : 11u) || n < 64) return PSS_OK;
+    if (omega < (forced ? 2u : 11u) || n < 64 || outer.level >= 6) return PSS_OK;
     const u32 num_tiles = (n + ANC_TILE - 1) / ANC_TILE;
     const size_t n16 = round_up((size_t)n, 16) + 16;
     const u32 m_cap = n / 5 + 64;
-    PSS_TRY(ctx->slot[S_ANC].reserve(n16 + round_up((size_t)num_tiles * 4, 64) + ((size_t)num_tiles + 2) * 8 +
-                                     (SC_MAX_BLOCKS + 8) * 8 + (size_t)m_cap * 4 + 1024));
-    u8 *base = ctx->slot[S_ANC].as<u8>();
+    DevBuf &slot = ctx->slot[S_ANC + outer.level];
+    PSS_TRY(slot.reserve(n16 + round_up((size_t)num_tiles * 4, 64) + ((size_t)num_tiles + 2) * 8 + (SC_MAX_BLOCKS + 8) * 8 +
+                         (size_t)m_cap * 4 + 1024));
+    u8 *base = slot.as<u8>();
     size_t o = 0;
     auto carve = [&](size_t bytes) { u8 *p = base + o; o = round_up(o + bytes, 64); return p; };
     u8 *d_dist = carve(n16);
@@ -1951,16 +2013,25 @@ static int anchor_rank_keys(DeviceCtx *ctx, const Knobs &knobs, const RoundsIO &
     PSS_HIP(hipEventRecord(tm.ev0, s));
     const u32 n_read = (u32)(round_up((size_t)n, 16) + 64);      // the recoded text's padding (zero)
     const u32 grid = std::min<u32>(num_tiles, (u32)ctx->num_cus * 4);
-    hipLaunchKernelGGL(anc_select_kernel, dim3(grid), dim3(256), 0, s, codes, n, n_read, omega, w, d_dist, d_tile_cnt, num_tiles);
+    if (syms)
+        hipLaunchKernelGGL(anc_select_kernel<true>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const u8 *>(syms), n, n, omega, w,
+                           d_dist, d_tile_cnt, num_tiles);
+    else
+        hipLaunchKernelGGL(anc_select_kernel<false>, dim3(grid), dim3(256), 0, s, codes, n, n_read, omega, w, d_dist, d_tile_cnt,
+                           num_tiles);
     PSS_TRY(device_excl_scan(ctx, InU32{d_tile_cnt}, num_tiles, d_partial, d_total, d_tile_off));
     u32 *h_small = outer.h_small;
     PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
     PSS_HIP(hipStreamSynchronize(s));
     const u32 m = h_small[0];
-    st.anchor_count = m;
-    st.anchor_omega = omega;
-    st.anchor_w = (u64)w;
-    if (knobs.timing) fprintf(stderr, "[pss] anchors: h=%llu omega=%u w=%d anchors=%u (n / %.1f)\n", (unsigned long long)h, omega, w, m, (double)n / std::max(1u, m));
+    if (outer.level == 0) {
+        st.anchor_count = m;
+        st.anchor_omega = omega;
+        st.anchor_w = (u64)w;
+    }
+    if (knobs.timing)
+        fprintf(stderr, "[pss] anchors (level %d): n=%u h=%llu omega=%u w=%d anchors=%u (n / %.1f)\n", outer.level, n,
+                (unsigned long long)h, omega, w, m, (double)n / std::max(1u, m));
     if (m == 0 || m > n / 5) return PSS_OK;
     hipLaunchKernelGGL(anc_walk_kernel<false>, dim3(grid), dim3(256), 0, s, d_dist, n, d_tile_off, num_tiles, d_Q,
                        (const u32 *)nullptr, (u32 *)nullptr);
@@ -1975,15 +2046,31 @@ static int anchor_rank_keys(DeviceCtx *ctx, const Knobs &knobs, const RoundsIO &
     u32 *A_grp2 = reinterpret_cast<u32 *>(b1 + 6 * m4);
     u32 *A_sa = reinterpret_cast<u32 *>(b1 + 7 * m4);
     u32 *A_rank = reinterpret_cast<u32 *>(b1 + 8 * m4);
-    if (2 * m8 > (size_t)n * 8 || 9 * m4 > (size_t)n * 8) return PSS_OK;      // (tiny texts)
+    if (2 * m8 > (size_t)n * 8 || 9 * m4 > (size_t)n * 8) return PSS_OK;      // (tiny strings)
     int kt = 64 / outer.b;
     if (kt > 16) kt = 16;
     const u32 gk = (u32)std::min<u64>((u64)ctx->num_cus * 8, ((u64)m + 255) / 256);
-    hipLaunchKernelGGL(subset_keys_kernel, dim3(gk), dim3(256), 0, s, d_Q, m, n, codes, outer.b, kt, outer.plus_one, AK[0], AV[0]);
     int cur = 0;
     SortStats ss;
-    PSS_TRY(radix_sort_pairs(ctx, AK, AV, m, kt * outer.b, 0xffffffffu, nullptr, 0, outer.work, &cur, false, &ss));
     RoundsIO io;
+    if (syms) {
+        hipLaunchKernelGGL(gather_names_kernel, dim3(gk), dim3(256), 0, s, d_Q, m, cur_ranks, AK[0], AV[0]);
+        int bits = 1;
+        while ((1ull << bits) <= (u64)n) ++bits;
+        PSS_TRY(radix_sort_pairs(ctx, AK, AV, m, bits, 0xffffffffu, nullptr, 0, outer.work, &cur, false, &ss));
+        io.codes = nullptr;
+        io.b = 8; io.plus_one = 0; io.key_chars = 1;
+        io.h0 = 1;
+    } else {
+        hipLaunchKernelGGL(subset_keys_kernel, dim3(gk), dim3(256), 0, s, d_Q, m, n, codes, outer.b, kt, outer.plus_one, AK[0], AV[0]);
+        PSS_TRY(radix_sort_pairs(ctx, AK, AV, m, kt * outer.b, 0xffffffffu, nullptr, 0, outer.work, &cur, false, &ss));
+        io.codes = codes;
+        io.b = outer.b; io.plus_one = outer.plus_one; io.key_chars = kt;
+        io.h0 = (u64)kt;
+        io.sub_pos = d_Q;
+        io.text_n = n;
+        io.stop_text_h = 2ull * omega + (u64)w - 1;
+    }
     io.n = m;
     io.SA = A_sa;
     io.K[0] = AK[0]; io.K[1] = AK[1];
@@ -1992,9 +2079,7 @@ static int anchor_rank_keys(DeviceCtx *ctx, const Knobs &knobs, const RoundsIO &
     io.P[0] = AP[0]; io.P[1] = AP[1];
     io.GRP = A_grp;
     io.grp2 = A_grp2;
-    io.codes = codes;
-    io.b = outer.b; io.plus_one = outer.plus_one; io.key_chars = kt; io.key_drop = 0;
-    io.h0 = (u64)kt;
+    io.key_drop = 0;
     io.cur = cur;
     io.final_buf = -1;
     io.v_scratch = nullptr;
@@ -2006,16 +2091,16 @@ static int anchor_rank_keys(DeviceCtx *ctx, const Knobs &knobs, const RoundsIO &
     io.d_agg_head = outer.d_agg_head; io.d_agg_cnt = outer.d_agg_cnt; io.d_red = outer.d_red; io.d_counters = outer.d_counters;
     io.h_small = outer.h_small;
     io.profile = false;
-    io.sub_pos = d_Q;
-    io.text_n = n;
-    io.stop_text_h = 2ull * omega + (u64)w - 1;
+    io.level = outer.level + 1;
     pss_sa_stats sub;
     memset(&sub, 0, sizeof sub);
     SortStats ss2;
     PSS_TRY(refine_rounds(ctx, knobs, io, ss2, sub));
-    st.anchor_text_rounds = sub.text_rounds;
-    st.anchor_rounds = sub.rounds - sub.text_rounds;
-    st.anchor_sum_active = sub.sum_active;
+    st.anchor_text_rounds += sub.text_rounds;
+    st.anchor_rounds += sub.rounds - sub.text_rounds + sub.anchor_rounds;
+    st.anchor_sum_active += sub.sum_active + sub.anchor_sum_active;
+    st.anchor_left += sub.anchor_left;
+    st.anchor_levels = std::max<uint64_t>(st.anchor_levels, 1 + sub.anchor_levels);
     hipLaunchKernelGGL(isa_from_sa_kernel, dim3(gk), dim3(256), 0, s, A_sa, m, A_rank);
     hipLaunchKernelGGL(anc_walk_kernel<true>, dim3(grid), dim3(256), 0, s, d_dist, n, d_tile_off, num_tiles, (u32 *)nullptr,
                        (const u32 *)A_rank, akey);
@@ -2023,9 +2108,11 @@ static int anchor_rank_keys(DeviceCtx *ctx, const Knobs &knobs, const RoundsIO &
     PSS_HIP(hipStreamSynchronize(s));
     float ms = 0.f;
     PSS_HIP(hipEventElapsedTime(&ms, tm.ev0, tm.ev1));
-    st.anchor_ms += ms;
+    if (outer.level == 0) {
+        st.anchor_ms += ms;
+        st.anchor_depth = h;
+    }
     st.anchor = 1;
-    st.anchor_depth = h;
     *ok = true;
     return PSS_OK;
 }

@@ -50,7 +50,7 @@ def make_case(rng: random.Random):
     if alpha == 26:
         base += 97
     if kind == 0:       # duplicated blocks with edits
-        blk = rng.choice([200, 1000, 5000, 40000])
+        blk = min(n, rng.choice([200, 1000, 5000, 40000]))
         src = base[:blk].copy()
         parts = []
         while sum(p.size for p in parts) < n:
@@ -81,7 +81,7 @@ def make_case(rng: random.Random):
         t[q:2 * q] = np.resize(word, q)
         t[3 * q:3 * q + q // 2] = np.resize(word, q // 2)
     elif kind == 4:     # whole text = one block repeated (no edits) + tail
-        blk = rng.choice([37, 1000, 9999])
+        blk = min(n, rng.choice([37, 1000, 9999]))
         t = np.resize(base[:blk], n).copy()
         t[-rng.randrange(1, 50):] = nrng.integers(0, alpha)
     elif kind == 5:     # runs mixed with copies
@@ -117,7 +117,7 @@ def main():
         bad += 0 if not flag else 1
         print(f'case {c}: kind={kind} alpha={alpha} n={t.size} omega={omega} ok={ok} ok0={ok0} anchor={st["anchor"]} '
               f'w={st["anchor_w"]} om={st["anchor_omega"]} depth={st["anchor_depth"]} anchors={st["anchor_count"]} '
-              f'active={st["anchor_active"]} left={st["anchor_left"]} arounds={st["anchor_text_rounds"]}+{st["anchor_rounds"]} '
+              f'active={st["anchor_active"]} left={st["anchor_left"]} arounds={st["anchor_text_rounds"]}+{st["anchor_rounds"]} lv={st["anchor_levels"]} '
               f'rounds={st["rounds"]} vs {st0["rounds"]} ms={st["ms_total"]:.2f} vs {st0["ms_total"]:.2f}{flag}', flush=True)
     print(f'{cases} cases, {took} took the anchor round, {bad} bad')
     sys.exit(1 if bad else 0)
