@@ -41,6 +41,15 @@ typedef struct pss_result pss_result;
 /* Number of visible HIP devices (0 when none / runtime unusable). */
 int pss_device_count(void);
 
+/* The devices a handle opened with device == -1 uses -- what the reference-shaped call (`Reader(path)`, `Writer(path)`,
+ * no device argument) gets; the reference fans out over every core of the machine without being asked (rayon's global
+ * pool, src/lib.rs:205-207):
+ *   PSS_DEVICES=all | 0,1,...   every visible device / the listed ordinals (one may be listed more than once);
+ *   else PSS_DEVICE=k or LOCAL_RANK=k (a launcher runs one process per GPU): device k mod count;
+ *   else every visible device.
+ * Writes at most cap ordinals to out and returns how many (>= 1). */
+int32_t pss_default_devices(int32_t *out, int32_t cap);
+
 /* Copies the calling thread's last error message into buf (NUL-terminated,
  * truncated to cap); returns the untruncated length. */
 size_t pss_last_error(char *buf, size_t cap);
@@ -143,6 +152,8 @@ typedef struct pss_sa_stats {
     uint64_t anchor_left;      /* suffixes the round left tied (always 0; a non-zero value is an internal error that the
                                   rank rounds then repair) */
     uint64_t anchor_levels;    /* anchor levels stacked: 1 = anchors of the text; 2 = anchors of the string of their names, ... */
+    uint64_t probe_pairs;      /* before the first text round: neighbours of the active list sampled from one group ... */
+    uint64_t probe_same;       /* ... and those that share 48 more symbols (most of them: the ties are repeats, no text round) */
     double anchor_ms;          /* device time of the anchors' selection and sort */
 } pss_sa_stats;
 

@@ -26,7 +26,7 @@ try:   # C loop for result lists (csrc/pyglue.c); plain Python slicing if it was
 except ImportError:   # pragma: no cover
     _pssglue = None
 
-__all__ = ['Writer', 'Reader', 'PackedResult', 'DeviceResult', 'device_count', 'release_workspace']
+__all__ = ['Writer', 'Reader', 'PackedResult', 'DeviceResult', 'device_count', 'default_devices', 'release_workspace']
 
 
 def device_count() -> int:
@@ -39,13 +39,18 @@ def release_workspace() -> None:
     _ffi.check(_lib.pss_release_workspace())
 
 
+def default_devices() -> typing.List[int]:
+    """The devices ``Reader(path)`` / ``Writer(path)`` use when neither ``device`` nor ``devices`` is given
+    (include/pss.h, pss_default_devices): ``PSS_DEVICES=all|0,1,...``; else the one a launcher pinned this process to
+    (``PSS_DEVICE`` / ``LOCAL_RANK``); else every visible device -- the reference's ``search`` uses every core of the
+    machine without being asked (src/lib.rs:205-207)."""
+    arr = (ctypes.c_int32 * 64)()
+    k = _lib.pss_default_devices(arr, 64)
+    return [int(arr[i]) for i in range(k)]
+
+
 def _default_device() -> int:
-    for var in ('PSS_DEVICE', 'LOCAL_RANK'):
-        v = os.environ.get(var)
-        if v is not None and v.isdigit():
-            n = device_count()
-            return int(v) % n if n else int(v)
-    return 0
+    return default_devices()[0]
 
 
 def _utf8(value, name: str) -> bytes:
@@ -94,7 +99,8 @@ class Writer:
             if not devs:
                 raise ValueError('devices must not be empty')
         else:
-            devs = [_default_device() if device is None else device]
+            devs = default_devices() if device is None else [device]      # no argument: every device the process may use
+        self.devices = list(devs)
         arr = (ctypes.c_int32 * len(devs))(*devs)
         rc = _lib.pss_writer_open_multi(
             path, -1 if max_chunk_len is None else max_chunk_len, arr, len(devs), format_version, ctypes.byref(self._h))
@@ -212,11 +218,16 @@ class Reader:
             devs = [int(d) for d in devices]
             if not devs:
                 raise ValueError('devices must not be empty')
+        elif device is None and tuple(shard) == (0, 1):
+            devs = default_devices()        # no argument: every device the process may use (one under a launcher)
+        else:
+            devs = [_default_device() if device is None else int(device)]
+        self.devices = list(devs)
+        if len(devs) > 1:
             arr = (ctypes.c_int32 * len(devs))(*devs)
             rc = _lib.pss_reader_open_multi(path, arr, len(devs), ctypes.byref(self._h))
         else:
-            rc = _lib.pss_reader_open(
-                path, _default_device() if device is None else device, shard[0], shard[1], ctypes.byref(self._h))
+            rc = _lib.pss_reader_open(path, devs[0], shard[0], shard[1], ctypes.byref(self._h))
         _ffi.check(rc, index_file_path)
 
     @property
@@ -229,6 +240,7 @@ class Reader:
     def _from_handle(cls, handle) -> 'Reader':
         r = cls.__new__(cls)
         r._h = handle
+        r.devices = []
         return r
 
     def _handle(self):

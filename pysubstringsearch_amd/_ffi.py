@@ -80,6 +80,8 @@ class SaStats(ctypes.Structure):
         ('anchor_sum_active', ctypes.c_uint64),
         ('anchor_left', ctypes.c_uint64),
         ('anchor_levels', ctypes.c_uint64),
+        ('probe_pairs', ctypes.c_uint64),
+        ('probe_same', ctypes.c_uint64),
         ('anchor_ms', ctypes.c_double),
     ]
 
@@ -153,6 +155,7 @@ def _load() -> ctypes.CDLL:
     pvp = ctypes.POINTER(vp)
     sig = {
         'pss_device_count': (ctypes.c_int, []),
+        'pss_default_devices': (i32, [ctypes.POINTER(i32), i32]),
         'pss_release_workspace': (ctypes.c_int, []),
         'pss_last_error': (ctypes.c_size_t, [cp, ctypes.c_size_t]),
         'pss_sa_build': (i32, [vp, vp, i32, i32]),

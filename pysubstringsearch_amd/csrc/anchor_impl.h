@@ -49,6 +49,43 @@ __device__ __forceinline__ u32 anc_hash(u64 x, int w)
     return (u32)((x * 0x9E3779B97F4A7C15ull) >> 33);      // 31 bits: below ANC_HMAX
 }
 
+// Leftmost minima of the G consecutive windows [j0 + k, j0 + k + omega), k < G <= omega, of h[]: the windows share the core
+// [j0 + G - 1, j0 + omega); to its left the positions j0 + k .. j0 + G - 2, to its right j0 + omega .. j0 + omega + k - 1 --
+// omega + 2 (G - 1) reads instead of G omega.
+template <int G>
+__device__ __forceinline__ void anc_window_mins(const u32 *h, u32 j0, u32 omega, u32 (&out)[G])
+{
+    u32 cv = h[j0 + G - 1], ci = j0 + G - 1;
+    for (u32 q = j0 + G; q < j0 + omega; ++q) {
+        const u32 hq = h[q];
+        if (hq < cv) { cv = hq; ci = q; }
+    }
+    u32 lv[G], li[G];
+    u32 v = ANC_HMAX, vi = 0;
+    bool have = false;
+#pragma unroll
+    for (int k = G - 2; k >= 0; --k) {
+        const u32 hq = h[j0 + k];
+        if (!have || hq <= v) { v = hq; vi = j0 + k; have = true; }      // <=: the leftmost of equals
+        lv[k] = v;
+        li[k] = vi;
+    }
+    u32 rv = 0, ri = 0;
+    bool rhave = false;
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        if (k > 0) {
+            const u32 q = j0 + omega + k - 1;
+            const u32 hq = h[q];
+            if (!rhave || hq < rv) { rv = hq; ri = q; rhave = true; }
+        }
+        u32 bv = cv, bi = ci;                                            // core, unless the left part is as small ...
+        if (k < G - 1 && lv[k] <= cv) { bv = lv[k]; bi = li[k]; }
+        if (rhave && rv < bv) { bv = rv; bi = ri; }                      // ... or the right part smaller
+        out[k] = bi;
+    }
+}
+
 // d[s] = M(s) - s for every window start s < n; tile_cnt[t] = anchors first chosen by a window of tile t
 // (windows s with s == 0 or M(s) != M(s - 1)).  `text`: the recoded text, 16-byte aligned, readable (and zero)
 // up to n_read >= n, n_read % 16 == 0.
@@ -106,37 +143,15 @@ __global__ __launch_bounds__(256) void anc_select_kernel(const u8 *text, u32 n, 
         const u32 jA = 16u * tid;                   // index of position A in s_h
         u32 mk[17];                                 // M(A + k) as an index into s_h
         if (omega >= 17) {
-            // windows [A + k, A + k + omega) share the core [A + 16, A + omega); to its left the positions A + k .. A + 15,
-            // to its right A + omega .. A + omega + k - 1
-            u32 cv = s_h[jA + 16], ci = jA + 16;
-            for (u32 q = jA + 17; q < jA + omega; ++q) {
-                const u32 hq = s_h[q];
-                if (hq < cv) { cv = hq; ci = q; }
-            }
-            u32 lv[16], li[16];
-            u32 v = ANC_HMAX, vi = 0;
-            bool have = false;
+            anc_window_mins<17>(s_h, jA, omega, mk);
+        } else if (omega >= 9) {
+            u32 m0[9], m1[8];
+            anc_window_mins<9>(s_h, jA, omega, m0);
+            anc_window_mins<8>(s_h, jA + 9, omega, m1);
 #pragma unroll
-            for (int k = 15; k >= 0; --k) {
-                const u32 hq = s_h[jA + k];
-                if (!have || hq <= v) { v = hq; vi = jA + k; have = true; }      // <=: the leftmost of equals
-                lv[k] = v;
-                li[k] = vi;
-            }
-            u32 rv = 0, ri = 0;
-            bool rhave = false;
+            for (int k = 0; k < 9; ++k) mk[k] = m0[k];
 #pragma unroll
-            for (int k = 0; k <= 16; ++k) {
-                if (k > 0) {
-                    const u32 q = jA + omega + k - 1;
-                    const u32 hq = s_h[q];
-                    if (!rhave || hq < rv) { rv = hq; ri = q; rhave = true; }
-                }
-                u32 bv = cv, bi = ci;                                            // core, unless the left part is as small ...
-                if (k < 16 && lv[k] <= cv) { bv = lv[k]; bi = li[k]; }
-                if (rhave && rv < bv) { bv = rv; bi = ri; }                      // ... or the right part smaller
-                mk[k] = bi;
-            }
+            for (int k = 0; k < 8; ++k) mk[9 + k] = m1[k];
         } else {
 #pragma unroll
             for (int k = 0; k <= 16; ++k) {

@@ -89,6 +89,58 @@ extern "C" int pss_device_count(void)
     return c;
 }
 
+// Which devices a handle opened without an explicit device uses (include/pss.h).  The reference fans every search over
+// all the cores of the machine without being told to (rayon's global pool, src/lib.rs:205-207): the unchanged drop-in
+// call uses every GPU the process can see, unless a launcher pinned it to one.
+extern "C" int32_t pss_default_devices(int32_t *out, int32_t cap)
+{
+    if (!out || cap < 1) return 0;
+    const int count = pss_device_count();
+    auto digits = [](const char *v) {
+        if (!v || !*v) return false;
+        for (const char *c = v; *c; ++c)
+            if (*c < '0' || *c > '9') return false;
+        return true;
+    };
+    if (const char *e = getenv("PSS_DEVICES")) {
+        if (strcmp(e, "all") != 0 && *e) {
+            // a comma-separated list of ordinals (one may be named more than once: "virtual devices")
+            int32_t k = 0;
+            bool ok = true;
+            const char *c = e;
+            while (ok && *c && k < cap) {
+                char *end = nullptr;
+                const long v = strtol(c, &end, 10);
+                if (end == c || v < 0 || (count > 0 && v >= count)) { ok = false; break; }
+                out[k++] = (int32_t)v;
+                c = end;
+                if (*c == ',') ++c;
+                else if (*c) ok = false;
+            }
+            if (ok && k > 0) return k;
+        }
+        if (strcmp(e, "all") == 0) {
+            int32_t k = 0;
+            for (; k < count && k < cap; ++k) out[k] = k;
+            if (k > 0) return k;
+        }
+        // (anything else: as if unset)
+    } else {
+        for (const char *var : {"PSS_DEVICE", "LOCAL_RANK"}) {       // one process per GPU under a launcher
+            const char *v = getenv(var);
+            if (digits(v)) {
+                const long d = strtol(v, nullptr, 10);
+                out[0] = (int32_t)(count > 0 ? d % count : d);
+                return 1;
+            }
+        }
+    }
+    int32_t k = 0;
+    for (; k < count && k < cap; ++k) out[k] = k;
+    if (k == 0) out[k++] = 0;       // no usable device: the first compute call says so
+    return k;
+}
+
 extern "C" size_t pss_last_error(char *buf, size_t cap)
 {
     const std::string &e = last_error();
@@ -563,6 +615,11 @@ extern "C" int pss_writer_open_multi(const char *path, int64_t max_chunk_len, co
             set_error("pss_writer_open: bad arguments (format_version must be 1 or 2, 1..64 devices)");
             return PSS_EINVAL;
         }
+        int32_t defaults[64];
+        if (n_devices == 1 && devices[0] == -1) {      // the default list (PSS_DEVICES / a launcher's pin / every visible device)
+            n_devices = pss_default_devices(defaults, 64);
+            devices = defaults;
+        }
         for (int i = 0; i < n_devices; ++i)
             if (devices[i] < 0) {
                 set_error("pss_writer_open: device %d out of range", devices[i]);
@@ -1028,6 +1085,12 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
         if (!path || !out || shard_count < 1 || shard_index < 0 || shard_index >= shard_count) {
             set_error("pss_reader_open: bad arguments");
             return PSS_EINVAL;
+        }
+        if (device == -1) {             // the default list (PSS_DEVICES / a launcher's pin / every visible device)
+            int32_t defaults[64];
+            const int32_t k = pss_default_devices(defaults, 64);
+            if (k > 1 && shard_count == 1) return pss_reader_open_multi(path, defaults, k, out);
+            device = defaults[0];       // (a shard is one process's share: one device)
         }
         errno = 0;
         FILE *fp = fopen(path, "rb");   // File::open, lib.rs:165 (NotFound -> FileNotFoundError)

@@ -1314,6 +1314,39 @@ __global__ __launch_bounds__(256) void isa_active_kernel(const u32 *idx, const u
     for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < m; t += gridDim.x * blockDim.x) ISA[idx[t]] = grp[t];
 }
 
+// ---- are the ties repeats? -------------------------------------------------------------------------------------
+// Before the first text round: a few thousand neighbours of the active list that sit in the same group are compared
+// for 48 symbols beyond what they are known to share.  Natural text parts ways within a dozen symbols (a text round
+// resolves most of its ties); copies of a block or of a line do not, and every text round over them is a pass over
+// the whole list for nothing (33 ms at n = 2^29) -- those go straight to the anchor round.
+// out[0] = pairs looked at, out[1] = pairs equal on all 48 symbols.
+__global__ __launch_bounds__(256) void probe_repeats_kernel(const u32 *idx, const u32 *grp, u32 m, u32 samples, u32 n, u32 h,
+                                                              const u8 *codes, u32 *out)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 pair = 0, same = 0;
+    if (t < samples && m >= 2) {
+        const u32 stride = (m - 1) / samples;
+        u64 x = ((u64)t + 1) * 0x9E3779B97F4A7C15ull;
+        x ^= x >> 29;
+        const u32 at = stride ? t * stride + (u32)(x % stride) : t % (m - 1);
+        if (grp[at] == grp[at + 1]) {
+            pair = 1;
+            const u64 i = (u64)idx[at] + h, j = (u64)idx[at + 1] + h;
+            if (i + 48 <= n && j + 48 <= n) {
+                same = 1;
+                for (u32 c = 0; c < 48; ++c)
+                    if (codes[i + c] != codes[j + c]) { same = 0; break; }
+            }
+        }
+    }
+    const u64 bp = __ballot(pair != 0), bs = __ballot(same != 0);
+    if (lane_id() == 0) {
+        if (bp) atomicAdd(&out[0], (u32)__popcll(bp));
+        if (bs) atomicAdd(&out[1], (u32)__popcll(bs));
+    }
+}
+
 // ---- sizing the initial sort from a sample ---------------------------------
 // The initial sort costs one pass per 8 key bits; every suffix it leaves tied
 // costs about ten times a pass's per-element price in the rounds.  How many
@@ -1437,6 +1470,7 @@ struct Knobs {
     int anchor = -1;            // PSS_ANCHOR     0: never the anchor round for ties that outlive the text rounds (rank rounds over the
                                 //                whole text instead), 1: whenever ties outlive them, unset: texts of >= 2^20 bytes
     int anchor_omega = 0;       // PSS_ANCHOR_OMEGA  force the window of the minimizers (0 = as wide as the known common prefix allows)
+    bool no_probe = false;      // PSS_NO_PROBE   always a text round before the anchor round (no sampling of the ties)
     bool count_sort = false;    // PSS_COUNT_SORT  rank rounds: groups ranked by counting (group_sort_kernel) instead of the merge sort
     bool timing = false;        // PSS_TIMING     per-round trace on stderr
     static Knobs read()
@@ -1462,6 +1496,7 @@ struct Knobs {
         if (const char *e = getenv("PSS_PERIOD")) k.period = atoi(e);
         if (const char *e = getenv("PSS_ANCHOR")) k.anchor = atoi(e);
         if (const char *e = getenv("PSS_ANCHOR_OMEGA")) k.anchor_omega = atoi(e);
+        k.no_probe = getenv("PSS_NO_PROBE") != nullptr;
         k.count_sort = getenv("PSS_COUNT_SORT") != nullptr;
         k.timing = getenv("PSS_TIMING") != nullptr;
         return k;
@@ -1809,16 +1844,33 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
         if (mode == M_TEXT) {
             const bool text_progress = text_rounds == 0 || (u64)m * 10 <= (u64)m_text_prev * 6;
             bool bail = true;
+            const bool anchors_on = !subset && knobs.anchor != 0 && (knobs.anchor == 1 || n >= (1u << 20));
+            bool skip_text = false;
+            if (anchors_on && !anchored && text_rounds == 0 && !knobs.no_probe && m >= 4096 && (u64)m * 16 >= (u64)n && h >= 14) {
+                // are these ties repeats (see probe_repeats_kernel)?  Then no text round will resolve them.
+                u32 *d_probe = d_counters + 48;
+                PSS_HIP(hipMemsetAsync(d_probe, 0, 8, s));
+                const u32 samples = 8192;
+                hipLaunchKernelGGL(probe_repeats_kernel, dim3(samples / 256), dim3(256), 0, s, V[src], G[gcur], m, samples, n,
+                                   (u32)std::min<u64>(h, 0xffffffffull), codes, d_probe);
+                PSS_HIP(hipMemcpyAsync(h_small, d_probe, 8, hipMemcpyDeviceToHost, s));
+                PSS_HIP(hipStreamSynchronize(s));
+                st.probe_pairs = h_small[0];
+                st.probe_same = h_small[1];
+                skip_text = h_small[0] >= 64 && (u64)h_small[1] * 2 > (u64)h_small[0];
+                if (knobs.timing) fprintf(stderr, "[pss] probe: %u of %u sampled pairs share 48 more symbols%s\n", h_small[1], h_small[0], skip_text ? ": no text rounds" : "");
+            }
             if (anchored) {
                 // cannot happen: the anchor round leaves no ties.  Counted (tests assert zero) and resolved by rank rounds.
                 st.anchor_left += m;
+            } else if (skip_text) {
             } else if (subset) {
                 if (h < io.stop_text_h) PSS_TRY(local_round(true, &bail));
             } else if (text_rounds < text_rounds_max && text_progress) {
                 m_text_prev = m;
                 PSS_TRY(local_round(true, &bail));
             }
-            if (bail && !anchored && !subset && knobs.anchor != 0 && (knobs.anchor == 1 || n >= (1u << 20))) {
+            if (bail && !anchored && anchors_on) {
                 // Ties that outlive the text rounds are repeats: one round keyed by the ranks of the anchors (anchor_impl.h)
                 // instead of log2(length of the repeat) rank rounds over the whole text.  The key array takes the place
                 // of the inverse suffix array, which this path never builds.

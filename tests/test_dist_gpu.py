@@ -62,3 +62,10 @@ def test_rccl_gather_and_multi_device_handles(tmp_path, oracle):
         ents, counts = r.search_batch_raw(qs)
         oe, oc = o.search_multiple_bytes(qs)
         assert counts == oc.tolist() and sorted(ents) == sorted(oe)
+    # the unchanged drop-in call: every visible device without being told (src/lib.rs:205-207)
+    for var in ('PSS_DEVICES', 'PSS_DEVICE', 'LOCAL_RANK'):
+        os.environ.pop(var, None)
+    with pysubstringsearch.Reader(idx) as r:
+        assert r.devices == list(range(_gpus())) and len(r.devices) >= 2
+        ents, counts = r.search_batch_raw(qs)
+        assert counts == oc.tolist() and sorted(ents) == sorted(oe)

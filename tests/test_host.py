@@ -387,3 +387,29 @@ def test_host_logic_under_sanitizers(tmp_path):
     assert 'AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
     assert f'{len(tests)} passed' in r.stdout, r.stdout[-500:]
 
+
+
+def test_default_device_list(monkeypatch):
+    """pss_default_devices: what `Reader(path)` / `Writer(path)` use when no device is named -- PSS_DEVICES=all|list
+    first, else the pin of a launcher (PSS_DEVICE / LOCAL_RANK), else every visible device (the reference's search
+    fans over every core without being asked: src/lib.rs:205-207)."""
+    import pysubstringsearch_amd as P
+    for var in ('PSS_DEVICES', 'PSS_DEVICE', 'LOCAL_RANK'):
+        monkeypatch.delenv(var, raising=False)
+    n = P.device_count()
+    assert P.default_devices() == (list(range(n)) if n else [0])
+    monkeypatch.setenv('LOCAL_RANK', '3')
+    assert P.default_devices() == [3 % n if n else 3]
+    monkeypatch.setenv('PSS_DEVICE', '1')
+    assert P.default_devices() == [1 % n if n else 1]              # PSS_DEVICE before LOCAL_RANK
+    monkeypatch.setenv('PSS_DEVICES', '0,0,0')
+    assert P.default_devices() == [0, 0, 0]                         # the list wins; an ordinal may repeat
+    monkeypatch.setenv('PSS_DEVICES', 'all')
+    assert P.default_devices() == (list(range(n)) if n else [0])
+    monkeypatch.setenv('PSS_DEVICES', '0,x')                        # malformed: as if unset (every visible device)
+    assert P.default_devices() == (list(range(n)) if n else [0])
+    arr = (ctypes.c_int32 * 2)()
+    from pysubstringsearch_amd import _ffi
+    monkeypatch.setenv('PSS_DEVICES', '0,0,0')
+    assert _ffi.lib.pss_default_devices(arr, 2) == 2                # never more than the caller's capacity
+    assert _ffi.lib.pss_default_devices(None, 4) == 0

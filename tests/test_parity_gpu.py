@@ -492,6 +492,53 @@ def test_multi_device_reader_in_one_process(tmp_path, oracle):
         pysubstringsearch.Reader(p, devices=[])
     with pytest.raises(ValueError):
         pysubstringsearch.Reader(p, devices=[0], device=0)
+
+
+def test_unchanged_call_uses_the_default_device_list(tmp_path, oracle, monkeypatch):
+    """`Reader(path)` / `Writer(path)` exactly as a user of the reference writes them: with PSS_DEVICES set (or more
+    than one GPU visible) they fan out over the device list without a `devices=` argument -- the reference's search
+    uses every core without being asked (src/lib.rs:205-207).  PSS_DEVICES=0,0,0: three parts on the one GPU of the box."""
+    from tests.util import gen_corpus
+    src = tmp_path / 'c.txt'
+    src.write_bytes(gen_corpus(1, 1 << 19).tobytes())
+    for var in ('PSS_DEVICE', 'LOCAL_RANK'):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv('PSS_DEVICES', '0')
+    p1 = str(tmp_path / 'one.idx')
+    w = pysubstringsearch.Writer(p1, 1 << 16)
+    assert w.devices == [0]
+    w.add_entries_from_file_lines(str(src))
+    w.close()
+    monkeypatch.setenv('PSS_DEVICES', '0,0,0')
+    p3 = str(tmp_path / 'three.idx')
+    w = pysubstringsearch.Writer(p3, 1 << 16)                       # the reference's positional call
+    assert w.devices == [0, 0, 0]
+    w.add_entries_from_file_lines(str(src))
+    w.close()
+    assert open(p1, 'rb').read() == open(p3, 'rb').read()
+    o = oracle.OracleReader(p1)
+    text = src.read_bytes()
+    rng = np.random.default_rng(2)
+    qs = ['', 'e', 'zzzzzz'] + [text[s:s + int(rng.integers(1, 12))].decode() for s in rng.integers(0, len(text) - 20, 400)]
+    qs = [q for q in qs if '\n' not in q]
+    r = pysubstringsearch.Reader(p3)
+    assert r.devices == [0, 0, 0]
+    for q in qs[:40]:
+        assert sorted(r.search(q)) == sorted(o.search(q))
+    got = r.search_multiple(qs)
+    assert sorted(got) == sorted(o.search_multiple(qs))
+    r.close()
+    monkeypatch.setenv('LOCAL_RANK', '0')                           # a launcher's pin does not override PSS_DEVICES ...
+    r = pysubstringsearch.Reader(p3)
+    assert r.devices == [0, 0, 0]
+    r.close()
+    monkeypatch.delenv('PSS_DEVICES')                               # ... but decides when PSS_DEVICES is unset
+    r = pysubstringsearch.Reader(p3)
+    assert r.devices == [0]
+    r.close()
+    r = pysubstringsearch.Reader(p3, device=0)                      # explicit arguments always win
+    assert r.devices == [0]
+    r.close()
     with pytest.raises(FileNotFoundError):
         pysubstringsearch.Reader(str(tmp_path / 'missing.idx'), devices=[0, 0])
 
