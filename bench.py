@@ -321,17 +321,29 @@ def run_chunk(args, D):
     dev = D.local_rank
     nq = args.queries or 10000
 
-    host = np.empty(n, dtype=np.uint8)
-    _ffi.check(lib.pss_gen_corpus(KINDS[args.corpus], host.ctypes.data, n, rank))
-    dT = torch.from_numpy(host).cuda()
+    # The timed steps ROTATE over distinct chunks of the corpus (round 4): a Writer never builds the same chunk twice,
+    # and a build that follows a build of the same kind of text runs under the remembered plan (alphabet + choice of
+    # sort, pss_sa_stats.plan_hint) -- what chunks 2..N of a corpus see.  Rotating keeps that honest: nothing about a
+    # chunk's CONTENT can be remembered from step to step.  The build without any plan (a first chunk) is timed below
+    # and reported beside it (`value_cold`).
+    ROT = max(1, min(3, int(os.environ.get('PSS_BENCH_ROTATE', '3'))))
+    chunk_ids = [(rank + k * world) % 15 for k in range(ROT)]
+    hosts, dTs, qsets = [], [], []
+    for ci in chunk_ids:
+        hk = np.empty(n, dtype=np.uint8)
+        _ffi.check(lib.pss_gen_corpus(KINDS[args.corpus], hk.ctypes.data, n, ci))
+        hosts.append(hk)
+        dTs.append(torch.from_numpy(hk).cuda())
     dSA = torch.empty(n, dtype=torch.int32, device='cuda')
-    if world > 1:
-        box = [make_queries(host, nq, args.qlen) if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        queries = box[0]
-    else:
-        queries = make_queries(host, nq, args.qlen)
+    for k in range(ROT):
+        if world > 1:
+            box = [make_queries(hosts[k], nq, args.qlen) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            qsets.append(box[0])
+        else:
+            qsets.append(make_queries(hosts[k], nq, args.qlen))
     torch.cuda.synchronize()
+    cur = {'k': 0}
 
     st = _ffi.SaStats()
     last = {}
@@ -340,6 +352,8 @@ def run_chunk(args, D):
     reader = Reader._from_handle(h)   # device-resident index of this rank, refreshed every step
 
     def step(flags=0):
+        k = cur['k'] = (cur['k'] + 1) % ROT
+        dT, queries = dTs[k], qsets[k]
         t0 = time.perf_counter()
         _ffi.check(lib.pss_sa_build_device(dT.data_ptr(), dSA.data_ptr(), n, dev, flags, ctypes.byref(st)))
         t1 = time.perf_counter()
@@ -372,8 +386,9 @@ def run_chunk(args, D):
     build_s, search_s, total_s = D.max_over_ranks([build_s, search_s, total_s])
 
     # the suffix array the last timed step left in dSA: is it the reference's?
+    host, dT, queries = hosts[cur['k']], dTs[cur['k']], qsets[cur['k']]
     host_sa = dSA.cpu().numpy() if world == 1 else None
-    verified, how = verify_sa(dSA, host, args.corpus, rank, load_big_goldens(), want_sha=(world == 1), host_sa=host_sa)
+    verified, how = verify_sa(dSA, host, args.corpus, chunk_ids[cur['k']], load_big_goldens(), want_sha=(world == 1), host_sa=host_sa)
     verified = D.all_true(verified)
 
     # ... and are the results of the query leg the reference's?  A sample of the batch (sampled and random queries alike)
@@ -568,11 +583,41 @@ def run_chunk(args, D):
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline_chunk(host, queries, args.cpu_sample_logn)
+        value = None if verified is False else round(world * n * args.steps / build_s / 1e9, 4)
+        value_cold = None if verified is False else round(world * n / sized_ms / 1e6, 4)
+
+        def pick(obj, *path):
+            for k in path:
+                if obj is None:
+                    return None
+                obj = obj[k] if not isinstance(obj, list) else next((x for x in obj if x.get('corpus') == k), None)
+            return obj
         out = {
             'metric': METRIC,
             # a build whose suffix array is not the reference's has no throughput worth reporting
-            'value': None if verified is False else round(world * n * args.steps / build_s / 1e9, 4),
+            'value': value,
             'unit': 'GB/s',
+            # the figures a reader of the line needs first, flat (the legs below carry the detail; corpus15 / e2e are
+            # filled in by the legs that run after this one)
+            'summary': {
+                'index_build_gbs_warm': value, 'index_build_gbs_cold': value_cold,
+                'build_ms_warm': round(build_s / args.steps * 1e3, 3), 'build_ms_first_chunk': round(sized_ms, 3),
+                'distinct_chunks_in_timed_loop': ROT,
+                'dominant_kernel': None if roof is None else roof['kernel'], 'roofline_frac': None if roof is None else roof['frac'],
+                'build_roofline_frac': build_roof['frac'],
+                'queries_per_sec_1chunk': round(len(queries) * args.steps / search_s, 1),
+                'cpu_libsais_gbs': pick(cpu, 'value'),
+                'words_build_ms': pick(secondary, 'build_ms'),
+                'dup_blocks_build_ms': pick(adversarial, 'dup_blocks', 'build_ms'),
+                'mixed_build_ms': pick(adversarial, 'mixed', 'build_ms'),
+                'runs_build_ms': pick(adversarial, 'runs', 'build_ms'),
+                'periodic_build_ms': pick(adversarial, 'periodic', 'build_ms'),
+                'repeat_line_build_ms': pick(adversarial, 'repeat_line', 'build_ms'),
+            },
+            'value_cold': value_cold,
+            'value_is_warm': 'steady state of a Writer: %d distinct chunks rotate through the timed loop, every build after '
+                             'the first runs under the remembered plan (alphabet + choice of sort); value_cold = a build with '
+                             'no plan at all (first chunk of a corpus)' % ROT,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(total_s / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -606,7 +651,7 @@ def run_chunk(args, D):
     else:
         out = None
     reader.close()
-    del dT, dSA
+    del dT, dTs, dSA
     return (1 if verified is False else 0), out
 
 
@@ -824,7 +869,8 @@ def launch_ranks(n: int) -> int:
     import threading
     fw = threading.Thread(target=forward, daemon=True)
     fw.start()
-    rc, live = 0, set(range(n))
+    rc, live, killed = 0, set(range(n)), set()
+    codes = {}
     while live:
         time.sleep(0.2)
         for r in sorted(live):
@@ -832,11 +878,19 @@ def launch_ranks(n: int) -> int:
             if code is None:
                 continue
             live.discard(r)
+            codes[r] = code
             if code != 0:
                 rc = rc or code
                 for q in live:      # exactly the processes started above
-                    procs[q].terminate()
+                    if q not in killed:
+                        procs[q].terminate()
+                        killed.add(q)
     fw.join(timeout=10)
+    # Rank 0 prints the line.  When it ended by itself, its code is the verdict on that line (a rank that failed in the
+    # configs[2]/[3] leg leaves with 1 so that its peers are stopped at once; rank 0 then still prints the configs[1]
+    # result it has and leaves with THAT result's code).
+    if 0 not in killed and 0 in codes:
+        return codes[0]
     return rc
 
 
@@ -862,11 +916,43 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(args.gpus))      # nothing has touched a GPU yet (torch is not even imported)
+    leg = {'corpus15': False, 'bail': None}
     if int(os.environ.get('WORLD_SIZE', '1')) > 1:
         try:                                            # (a leftover of an earlier job on this port)
             os.remove(os.path.join('/tmp', 'pss_bench_abort_%s' % os.environ.get('MASTER_PORT', '0')))
         except OSError:
             pass
+        # SIGTERM is what torchrun and launch_ranks send to every rank when one dies.  Blocking it (pthread_sigmask) is not
+        # enough: a runtime thread that unblocks it takes the signal with the default action and the process is gone
+        # before rank 0 has printed the line it already has (seen on the GPU box).  A handler changes the disposition for
+        # the whole process, whichever thread the signal lands on, and CPython's C-level handler writes the signal number
+        # to the wake-up descriptor at once -- even while the main thread sits inside a collective and runs no Python
+        # code.  The watcher thread blocks on the other end of that pipe.  Set up HERE, before torch is imported.
+        import signal
+        import threading
+        term_r, term_w = os.pipe()
+        os.set_blocking(term_w, False)
+        signal.signal(signal.SIGTERM, lambda *_: None)
+        signal.set_wakeup_fd(term_w, warn_on_full_buffer=False)
+
+        def watch_term():
+            while True:
+                try:
+                    if not os.read(term_r, 1):
+                        return
+                except OSError:
+                    return
+                # A peer can fail in the corpus15 leg while this rank is still on its way there (assembling its configs[1]
+                # result): give the main thread a moment to reach the leg, where the line it has can be printed.  A rank
+                # that is stuck in a collective of configs[1] itself never gets there and leaves empty-handed.
+                for _ in range(300):
+                    if leg['corpus15'] and leg['bail'] is not None:
+                        leg['bail']('terminated by the launcher during the corpus15 leg (another rank failed)')
+                    if leg.get('past'):
+                        break
+                    time.sleep(0.1)
+                os._exit(143)
+        threading.Thread(target=watch_term, daemon=True).start()
     D = Dist(args)
     if args.config == 'chunk':
         rc, out = run_chunk(args, D)
@@ -884,7 +970,12 @@ def main():
             # thread: the main thread may be stuck inside a collective, where no Python signal handler would ever run.
             flag = os.path.join('/tmp', 'pss_bench_abort_%s' % os.environ.get('MASTER_PORT', '0'))
 
+            import threading
+            bail_once = threading.Lock()
+
             def bail(reason, tell=True):
+                if not bail_once.acquire(blocking=False):     # (the watcher and the main thread at once: one line)
+                    time.sleep(3600)
                 if tell and D.world > 1:                      # the other ranks of this node: stop waiting for me
                     try:
                         with open(flag, 'w') as f:
@@ -894,19 +985,19 @@ def main():
                 if out is not None:
                     out['corpus15'] = {'error': reason}
                     print(json.dumps(out), flush=True)
-                os._exit(rc)
+                # rank 0 leaves with the code of the line it printed; every other rank with 1: a launcher sees a failed
+                # rank and stops the others at once instead of leaving that to the flag file alone
+                os._exit(rc if D.rank == 0 else (rc or 1))
             done = None
             if D.world > 1:
-                import signal
-                import threading
                 done = threading.Event()
-                signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})
+                leg['bail'] = bail
+                leg['corpus15'] = True
                 limit = time.time() + float(os.environ.get('PSS_BENCH_CORPUS15_TIMEOUT', '900'))
 
                 def watch():
                     while not done.is_set():
-                        if signal.sigtimedwait({signal.SIGTERM}, 0.5) is not None:
-                            bail('terminated by the launcher during the corpus15 leg (another rank failed)')
+                        time.sleep(0.25)
                         if os.path.exists(flag):
                             try:
                                 why = open(flag).read()[:300]
@@ -926,13 +1017,25 @@ def main():
                 bail(f'{type(e).__name__}: {e}'[:300])
             if done is not None:
                 done.set()
-                signal.pthread_sigmask(signal.SIG_UNBLOCK, {signal.SIGTERM})
+                leg['corpus15'] = False
+                leg['past'] = True
             args.queries = q0
             rc = rc or rc2
             if out is not None and out2 is not None:
                 out['corpus15'] = {k: out2[k] for k in out2 if k not in ('metric', 'higher_is_better', 'vs_baseline', 'data')}
                 if out2['value'] is None:
                     out['value'] = None
+                c_cpu = out2.get('cpu_baseline') or {}
+                lat = out2.get('single_query_us') or {}
+                out['summary'].update({
+                    'corpus15_list_api_queries_per_sec': out2.get('value'),
+                    'corpus15_packed_api_queries_per_sec': out2.get('packed_queries_per_sec'),
+                    'corpus15_cpu_ram_queries_per_sec': c_cpu.get('value'), 'corpus15_cpu_threads': c_cpu.get('cores'),
+                    'corpus15_cpu_disk_queries_per_sec': c_cpu.get('disk_queries_per_sec'),
+                    'corpus15_single_query_us': lat.get('median'),
+                    'corpus15_single_query_us_low_latency': (lat.get('low_latency_mode') or {}).get('median'),
+                    'corpus15_verified': out2.get('verified'),
+                })
     else:
         rc, out = run_corpus(args, D)
     if out is not None:

@@ -900,7 +900,16 @@ int reader_alloc_chunk(pss_reader *r, uint32_t n, ChunkDesc *out, pss_reader::Me
     bool want_hbm = true;
     if (const char *ev = getenv("PSS_READER_HBM_BUDGET"))
         want_hbm = used + m.hbm_bytes + sa_bytes + sk_bytes <= strtoull(ev, nullptr, 0);
-    if (want_hbm) {
+    // (second attempt: the grow-only workspace of the builder on this device -- up to 80 bytes per byte of the largest
+    // chunk it has built, the sample sort's element buffers alone 32 -- goes back before a suffix array settles for the
+    // host tier; the next build allocates what it needs again)
+    for (int attempt = 0; want_hbm && attempt < 2 && !m.sa; ++attempt) {
+        if (attempt == 1) {
+            std::lock_guard<std::recursive_mutex> lk(r->ctx->mu);
+            r->ctx->stop_resident();
+            for (auto &sl : r->ctx->slot) sl.release();
+            r->ctx->small_hdr_ready = nullptr;
+        }
         e = hipMalloc(&m.sa, sa_bytes + sk_bytes);
         if (e == hipSuccess) {
             size_t free_b = 0, total_b = 0;

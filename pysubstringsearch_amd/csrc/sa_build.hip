@@ -2501,8 +2501,18 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     if (!msd_done && ties && knobs.ss != 0 && (knobs.ss == 1 || (n >= (1u << 24) && !forced_chars && knobs.key_chars == 0)) &&
         ss_sample_count(n) != 0) {
         const u32 S = ss_sample_count(n);
-        PSS_TRY(ctx->slot[S_SSA].reserve((size_t)n * 16 + 256));
-        PSS_TRY(ctx->slot[S_SSB].reserve((size_t)n * 16 + 256));
+        // The two element buffers (16 n bytes each: 17 GB at n = 2^29) are the largest allocation of the build.  Where HBM
+        // is short -- a Reader resident on the same device -- the sort DECLINES instead of failing the build: the LSD
+        // passes below need nothing beyond the buffers every build has.
+        bool ss_room = ctx->slot[S_SSA].reserve((size_t)n * 16 + 256) == PSS_OK && ctx->slot[S_SSB].reserve((size_t)n * 16 + 256) == PSS_OK;
+        if (!ss_room) {
+            (void)hipGetLastError();
+            ctx->slot[S_SSA].release();
+            ctx->slot[S_SSB].release();
+            set_error("%s", "");
+            st.ss_declined_nomem = 1;
+        }
+        if (ss_room) {
         PSS_TRY(ctx->slot[S_GRP2].reserve((size_t)n * 4));
         SsBuffers sb;
         sb.A[0] = ctx->slot[S_SSA].p;
@@ -2544,6 +2554,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
             cur = final_buf;
             ss.launches = 4;
             ss.elems = 4ull * n;
+        }
         }
     }
     if (hint && !msd_done) {
