@@ -309,6 +309,86 @@ class Dist:
             self.dist.destroy_process_group()
 
 
+# --------------------------------------------------------------------------------- file API --
+
+def run_e2e(args):
+    """What a user of `Writer` / `Reader` sees: a text file of `--e2e-chunks` chunks goes through
+    Writer.add_entries_from_file_lines into an .idx file (ingest, upload, suffix-array build, download, record write --
+    src/lib.rs:67-124), then Reader opens it (src/lib.rs:162-199: here text AND suffix arrays become resident).  Wall
+    clock around the calls, files in the page cache of PSS_BENCH_E2E_DIR (default: the system's temp directory).  The
+    records of the first and the last chunk are checked against libsais' sha256 (tests/golden/sa_big.json)."""
+    import hashlib
+    import shutil
+    import tempfile
+    import pysubstringsearch
+    from pysubstringsearch_amd import _ffi
+    n = 1 << args.logn
+    chunks = args.e2e_chunks
+    where = os.environ.get('PSS_BENCH_E2E_DIR') or tempfile.gettempdir()
+    d = tempfile.mkdtemp(prefix='pss_e2e_', dir=where)
+    try:
+        src, idx = os.path.join(d, 'corpus.txt'), os.path.join(d, 'out.idx')
+        with open(src, 'wb') as f:
+            for c in range(chunks):
+                buf = np.empty(n, dtype=np.uint8)
+                _ffi.check(_ffi.lib.pss_gen_corpus(KINDS[args.corpus], buf.ctypes.data, n, c))
+                f.write(buf.data)
+        del buf
+        best = None
+        for rep in range(2):                 # the first pass also grows the workspaces and pins the staging rings
+            if os.path.exists(idx):
+                os.remove(idx)
+            t0 = time.perf_counter()
+            w = pysubstringsearch.Writer(idx, n)
+            w.add_entries_from_file_lines(src)
+            w.finalize()
+            w.close()
+            t1 = time.perf_counter()
+            r = pysubstringsearch.Reader(idx)
+            t2 = time.perf_counter()
+            nchunks, devices = r.num_chunks, list(r.devices)
+            r.close()
+            if best is None or t1 - t0 < best[0]:
+                best = (t1 - t0, t2 - t1)
+        sz = os.path.getsize(idx)
+        # the file itself: lengths of every record, libsais' sha256 for the first and the last chunk
+        gold = load_big_goldens()
+        ok, checked = sz == chunks * (8 + 5 * n), []
+        with open(idx, 'rb') as f:
+            for c in range(chunks):
+                at = c * (8 + 5 * n)
+                f.seek(at)
+                if int.from_bytes(f.read(4), 'little') != n:
+                    ok = False
+                f.seek(at + 4 + n)
+                if int.from_bytes(f.read(4), 'little') != (4 * n) & 0xffffffff:
+                    ok = False
+                g = gold.get((args.corpus, c, n))
+                if g is not None and c in (0, chunks - 1):
+                    f.seek(at + 4)
+                    ht = hashlib.sha256(f.read(n)).hexdigest()
+                    f.seek(at + 8 + n)
+                    h = hashlib.sha256()
+                    left = 4 * n
+                    while left:
+                        b = f.read(min(left, 1 << 26))
+                        h.update(b)
+                        left -= len(b)
+                    ok = ok and ht == g['text_sha256'] and h.hexdigest() == g['sa_sha256']
+                    checked.append(c)
+        return {'chunks': chunks, 'chunk_bytes': n, 'dir': where, 'text_bytes': chunks * n, 'idx_bytes': sz,
+                'writer_seconds': round(best[0], 3), 'writer_text_gbs': round(chunks * n / best[0] / 1e9, 3),
+                'writer_idx_gbs': round(sz / best[0] / 1e9, 2),
+                'reader_open_seconds': round(best[1], 3), 'reader_open_idx_gbs': round(sz / best[1] / 1e9, 2),
+                'reader_chunks': nchunks, 'devices': devices,
+                'verified': bool(ok), 'verified_by': f'record lengths of every chunk; text and suffix-array sha256 of chunks {checked} '
+                                                     'against libsais (tests/golden/sa_big.json)',
+                'what': 'wall clock of Writer(path, chunk).add_entries_from_file_lines(text file) + finalize + close, then of '
+                        'Reader(path); best of 2; both files in the page cache'}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 # ----------------------------------------------------------------------------- configs[1] --
 
 def run_chunk(args, D):
@@ -913,6 +993,8 @@ def main():
     ap.add_argument('--no-disk-baseline', action='store_true')
     ap.add_argument('--no-corpus15', action='store_true', help='chunk config: skip the configs[2]/[3] leg of the line')
     ap.add_argument('--corpus15-queries', type=int, default=100000)
+    ap.add_argument('--no-e2e', action='store_true', help='chunk config: skip the file-API leg (Writer -> .idx -> Reader)')
+    ap.add_argument('--e2e-chunks', type=int, default=4)
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(args.gpus))      # nothing has touched a GPU yet (torch is not even imported)
@@ -956,6 +1038,19 @@ def main():
     D = Dist(args)
     if args.config == 'chunk':
         rc, out = run_chunk(args, D)
+        if D.world == 1 and not args.no_e2e and out is not None:
+            import torch
+            torch.cuda.empty_cache()
+            try:
+                e2e = run_e2e(args)
+            except Exception as e:      # noqa: BLE001   (a full temp directory must not cost the line its headline)
+                e2e = {'error': f'{type(e).__name__}: {e}'[:300]}
+            out['e2e'] = e2e
+            out['summary'].update({'e2e_writer_text_gbs': e2e.get('writer_text_gbs'), 'e2e_writer_idx_gbs': e2e.get('writer_idx_gbs'),
+                                   'e2e_reader_open_idx_gbs': e2e.get('reader_open_idx_gbs'), 'e2e_verified': e2e.get('verified')})
+            if e2e.get('verified') is False:
+                out['value'] = None
+                rc = rc or 1
         if not args.no_corpus15:
             # BASELINE configs[2] / [3] in the same line: the 7.5 GB corpus (chunk c on rank c mod N), one batch of 100 000
             # queries of 4..32 bytes, at most 3 timed steps; the CPU path (one thread per chunk; RAM and the reference's

@@ -1,6 +1,11 @@
 // capi.cpp -- the extern "C" surface declared in include/pss.h: container
 // writer / reader (the .idx chunk-record format of reference src/lib.rs:105-124
 // and 162-199) around the device suffix-array builder and the device search.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/vfs.h>
+#include <unistd.h>
+
 #include <cerrno>
 #include <chrono>
 #include <condition_variable>
@@ -250,12 +255,16 @@ struct WDevice {
     int device = 0;
     DevBuf sa[2];                 // suffix arrays in HBM: one being written out, one being built
     hipStream_t io_stream = nullptr;
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipEvent_t ev[8] = {};        // one per staging piece of the record thread (kWPieces)
     std::thread builder;
 };
 
+constexpr int kWPieces = 8;       // pinned staging pieces of the record thread (DeviceCtx::kIoPiece bytes each)
+
 struct pss_writer {
-    FILE *fp = nullptr;
+    int fd = -1;                  // the index file: records are written with pwrite at offsets known in advance
+    int64_t pos = 0;              // where the next record starts
+    bool no_mmap = true;          // records through pwrite (false: through a shared mapping -- see write_record)
     uint8_t *buf = nullptr;
     size_t len = 0;
     size_t limit = 0;    // the reference's Vec capacity (src/lib.rs:62), see reserve()
@@ -275,7 +284,7 @@ struct pss_writer {
     size_t inflight_text = 0;            // bytes of host text owned by jobs that are queued, building or being written
     size_t text_budget = (size_t)8 << 30;   // ... bounded by this (PSS_WRITER_HOST_BUDGET), not only by 2 G jobs
     std::thread record_thread;
-    void *stage[2] = {nullptr, nullptr};                    // pinned staging of the record thread
+    void *stage[kWPieces] = {};                             // pinned staging of the record thread
 };
 
 namespace {
@@ -338,58 +347,142 @@ void put_u32le(uint8_t *p, uint32_t v)
     p[3] = (uint8_t)(v >> 24);
 }
 
-// Streams `bytes` of device memory to fp: the D2H copy of piece i+1 (pinned
-// staging, the owning device's copy stream) runs while piece i is written to the file.
-int download_to_file(pss_writer *w, WDevice &d, const void *src, size_t bytes)
+int pwrite_all(int fd, const void *buf, size_t len, int64_t off)
 {
-    const size_t piece = DeviceCtx::kStage;
-    const size_t pieces = (bytes + piece - 1) / piece;
-    auto issue = [&](size_t i) -> int {
-        const size_t off = i * piece, k = std::min(piece, bytes - off);
-        PSS_HIP(hipMemcpyAsync(w->stage[i & 1], static_cast<const uint8_t *>(src) + off, k, hipMemcpyDeviceToHost,
-                               d.io_stream));
-        PSS_HIP(hipEventRecord(d.ev[i & 1], d.io_stream));
-        return PSS_OK;
-    };
-    if (pieces) PSS_TRY(issue(0));
-    for (size_t i = 0; i < pieces; ++i) {
-        PSS_HIP(hipEventSynchronize(d.ev[i & 1]));
-        if (i + 1 < pieces) PSS_TRY(issue(i + 1));
-        const size_t off = i * piece, k = std::min(piece, bytes - off);
-        errno = 0;
-        if (fwrite(w->stage[i & 1], 1, k, w->fp) != k) return io_error("write");
+    const uint8_t *p = static_cast<const uint8_t *>(buf);
+    size_t at = 0;
+    while (at < len) {
+        const ssize_t k = pwrite(fd, p + at, len - at, (off_t)(off + (int64_t)at));
+        if (k < 0) {
+            if (errno == EINTR) continue;
+            return io_error("write");
+        }
+        at += (size_t)k;
     }
     return PSS_OK;
 }
 
-// One chunk record: u32le len | data | u32le 4n | n x i32le  (src/lib.rs:112-119)
+// Streams `bytes` of device memory to the file at `off`: D2H copies into a ring of pinned pieces on the owning device's
+// copy stream, every piece handed to the I/O pool (pwrite at its own offset) as soon as it has landed -- the copy of
+// piece i + 1 runs while pieces <= i are being written by several threads.
+int download_to_file(pss_writer *w, WDevice &d, const void *src, size_t bytes, int64_t off, IoPool::Batch *batch, uint8_t *map)
+{
+    const size_t piece = DeviceCtx::kIoPiece;
+    const size_t pieces = (bytes + piece - 1) / piece;
+    IoPool &pool = IoPool::get();
+    std::atomic<int> done[kWPieces];
+    for (auto &x : done) x.store(1);
+    static const bool drop = getenv("PSS_EXPERIMENT_NO_FILE") != nullptr;     // measurement only: the copies without the file
+    auto put = [&](size_t i) {          // piece i has landed in its staging buffer: to the pool
+        const size_t o = i * piece, k = std::min(piece, bytes - o);
+        if (drop) return;
+        if (map) pool.submit_copy(batch, map + o, w->stage[i % kWPieces], k, &done[i % kWPieces]);      // map: where `off` is mapped
+        else pool.submit(batch, w->fd, true, w->stage[i % kWPieces], k, off + (int64_t)o, &done[i % kWPieces]);
+    };
+    auto copies = [&]() -> int {
+        for (size_t i = 0; i < pieces; ++i) {
+            const int slot = (int)(i % kWPieces);
+            if (i >= (size_t)kWPieces) IoPool::wait_flag(batch, &done[slot]);  // the write of piece i - kWPieces is through
+            const size_t o = i * piece, k = std::min(piece, bytes - o);
+            PSS_HIP(hipMemcpyAsync(w->stage[slot], static_cast<const uint8_t *>(src) + o, k, hipMemcpyDeviceToHost, d.io_stream));
+            PSS_HIP(hipEventRecord(d.ev[slot], d.io_stream));
+            if (i >= 1) {
+                PSS_HIP(hipEventSynchronize(d.ev[(i - 1) % kWPieces]));
+                put(i - 1);
+            }
+        }
+        if (pieces) {
+            PSS_HIP(hipEventSynchronize(d.ev[(pieces - 1) % kWPieces]));
+            put(pieces - 1);
+        }
+        return PSS_OK;
+    };
+    const int rc = copies();
+    const int err = IoPool::wait_all(batch);     // always: the pool's pieces point at `done` and at the staging ring
+    if (rc != PSS_OK) return rc;
+    if (err) {
+        errno = err;
+        return io_error("write");
+    }
+    return PSS_OK;
+}
+
+// One chunk record: u32le len | data | u32le 4n | n x i32le  (src/lib.rs:112-119), at w->pos.
 int write_record(pss_writer *w, const WJob &job)
 {
     uint8_t hdr[8];
     const size_t hl = w->version == 2 ? 8 : 4;
     const size_t n = job.n;
+    const size_t sa_bytes = n < 2 ? 4 * n : n * 4;
+    const int64_t at = w->pos;
+    const int64_t total = (int64_t)(2 * hl + n + sa_bytes);
+    w->pos += total;                    // whatever happens below, no later record may land here
     errno = 0;
+    // On tmpfs large records go into the file through a shared MAPPING of their range: the blocks are reserved first
+    // (fallocate: a full file system is reported here, not as a SIGBUS later), then the threads of the pool copy into the
+    // mapping and their page faults allocate the pages in parallel.  Elsewhere (and where fallocate or mmap is refused)
+    // the pieces are pwritten: write(2) holds the inode's lock exclusively, so the threads take turns at 11 - 14 GB/s on
+    // this box whatever their number -- the ceiling of ONE index file in the page cache (profiles/r04_pagecache_micro.txt).
+    uint8_t *map = nullptr, *map_base = nullptr;
+    size_t map_len = 0;
+#ifdef __linux__
+    if (total >= (1 << 20) && !w->no_mmap && fallocate(w->fd, 0, (off_t)at, (off_t)total) == 0) {
+        const int64_t pg = (int64_t)sysconf(_SC_PAGESIZE);
+        const int64_t lo = at & ~(pg - 1);
+        map_len = (size_t)(at + total - lo);
+        void *m = mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, w->fd, (off_t)lo);
+        if (m != MAP_FAILED) {
+            map_base = static_cast<uint8_t *>(m);
+            map = map_base + (at - lo);
+        }
+    }
+    errno = 0;
+#endif
+    struct Unmap {
+        uint8_t *p;
+        size_t len;
+        ~Unmap() { if (p) (void)munmap(p, len); }
+    } unmap{map_base, map_len};
+    IoPool::Batch batch;
+    IoPool &pool = IoPool::get();
     if (w->version == 2) put_u64le(hdr, (uint64_t)n);
     else put_u32le(hdr, (uint32_t)n);
+    if (map) memcpy(map, hdr, hl);
+    else PSS_TRY(pwrite_all(w->fd, hdr, hl, at));
     {
-        Phase ph("record: write text");
-        if (fwrite(hdr, 1, hl, w->fp) != hl) return io_error("write");
-        if (fwrite(job.text, 1, n, w->fp) != n) return io_error("write");
+        Phase ph("record: text -> pool");
+        const size_t piece = DeviceCtx::kIoPiece;
+        for (size_t o = 0; o < n; o += piece) {
+            if (map) pool.submit_copy(&batch, map + hl + o, job.text + o, std::min(piece, n - o));
+            else pool.submit(&batch, w->fd, true, job.text + o, std::min(piece, n - o), at + (int64_t)hl + (int64_t)o);
+        }
     }
     if (w->version == 2) put_u64le(hdr, (uint64_t)n * 4);
     else put_u32le(hdr, (uint32_t)(n * 4));   // wraps like `as u32` at n >= 2^30 (lib.rs:116)
-    if (fwrite(hdr, 1, hl, w->fp) != hl) return io_error("write");
-    if (n < 2) {                               // libsais.c:6603-6607: n == 1 -> SA[0] = 0, no device involved
+    int rc = PSS_OK;
+    if (map) memcpy(map + hl + n, hdr, hl);
+    else rc = pwrite_all(w->fd, hdr, hl, at + (int64_t)hl + (int64_t)n);
+    const int64_t sa_at = at + (int64_t)(2 * hl + n);
+    if (rc == PSS_OK && n == 1) {              // libsais.c:6603-6607: n == 1 -> SA[0] = 0, no device involved
         const uint8_t zero[4] = {0, 0, 0, 0};
-        if (fwrite(zero, 1, 4, w->fp) != 4) return io_error("write");
-        return PSS_OK;
+        rc = pwrite_all(w->fd, zero, 4, sa_at);
     }
-    // x86-64 / little-endian host: int32 in memory == i32le on disk (lib.rs:117-119)
-    Phase ph("record: SA -> file");
-    const size_t G = w->devs.size();
-    WDevice &d = w->devs[job.seq % G];
-    PSS_HIP(hipSetDevice(d.device));
-    return download_to_file(w, d, d.sa[(job.seq / G) & 1].p, n * 4);
+    if (rc == PSS_OK && n >= 2) {
+        // x86-64 / little-endian host: int32 in memory == i32le on disk (lib.rs:117-119)
+        Phase ph("record: SA -> file");
+        const size_t G = w->devs.size();
+        WDevice &d = w->devs[job.seq % G];
+        rc = guarded([&]() -> int {
+            PSS_HIP(hipSetDevice(d.device));
+            return download_to_file(w, d, d.sa[(job.seq / G) & 1].p, n * 4, sa_at, &batch, map ? map + 2 * hl + n : nullptr);
+        });
+    }
+    const int err = IoPool::wait_all(&batch);      // the text pieces (and, after a failure above, whatever was in flight)
+    if (rc == PSS_OK && err) {
+        errno = err;
+        rc = io_error("write");
+    }
+    return rc;
 }
 
 void w_fail(pss_writer *w, int rc)      // with w->mu held
@@ -491,12 +584,12 @@ int io_wait(pss_writer *w)
 int pipe_start(pss_writer *w)
 {
     if (w->started) return PSS_OK;
-    for (int i = 0; i < 2; ++i)
-        if (!w->stage[i]) PSS_HIP(hipHostMalloc(&w->stage[i], DeviceCtx::kStage, hipHostMallocPortable));
+    for (int i = 0; i < kWPieces; ++i)
+        if (!w->stage[i]) PSS_HIP(hipHostMalloc(&w->stage[i], DeviceCtx::kIoPiece, hipHostMallocPortable));
     for (auto &d : w->devs) {
         PSS_HIP(hipSetDevice(d.device));
         if (!d.io_stream) PSS_HIP(hipStreamCreateWithFlags(&d.io_stream, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < kWPieces; ++i)
             if (!d.ev[i]) PSS_HIP(hipEventCreateWithFlags(&d.ev[i], hipEventDisableTiming));
     }
     // Lanes on different ordinals must really be different devices: their contexts (workspace, streams) and their
@@ -541,12 +634,12 @@ void pipe_stop(pss_writer *w)
     for (auto &d : w->devs) {
         bool touched = d.io_stream || d.sa[0].p || d.sa[1].p;
         if (touched) (void)hipSetDevice(d.device);
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < kWPieces; ++i)
             if (d.ev[i]) (void)hipEventDestroy(d.ev[i]);
         if (d.io_stream) (void)hipStreamDestroy(d.io_stream);
         for (auto &b : d.sa) b.release();
     }
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < kWPieces; ++i)
         if (w->stage[i]) (void)hipHostFree(w->stage[i]);
     for (auto &t : w->free_text) free(t.first);
     w->free_text.clear();
@@ -630,19 +723,31 @@ extern "C" int pss_writer_open_multi(const char *path, int64_t max_chunk_len, co
             return PSS_EINVAL;
         }
         errno = 0;
-        FILE *fp = fopen(path, "wb");   // File::create truncates, lib.rs:55
-        if (!fp) return io_error(path);
+        const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);   // File::create truncates, lib.rs:55
+        if (fd < 0) return io_error(path);
+        int64_t pos = 0;
         if (format_version == 2) {
             uint8_t hdr[kHeaderV2] = {};
             memcpy(hdr, kMagicV2, 8);
-            if (fwrite(hdr, 1, kHeaderV2, fp) != kHeaderV2) {
+            if (pwrite(fd, hdr, kHeaderV2, 0) != (ssize_t)kHeaderV2) {
                 const int rc = io_error(path);
-                fclose(fp);
+                close(fd);
                 return rc;
             }
+            pos = (int64_t)kHeaderV2;
         }
         pss_writer *w = new pss_writer();
-        w->fp = fp;
+        w->fd = fd;
+        w->pos = pos;
+        // Which way large records go into the page cache is a property of the file system (tests/tools/pagecache_micro.c
+        // on the GPU box, 16 threads, one file): tmpfs takes 18.6 GB/s through a shared mapping and 5.8 through pwrite;
+        // overlayfs / ext4 take 11 - 14 GB/s through pwrite -- the inode's lock lets one thread copy at a time -- and
+        // 2 - 7 through a mapping.  PSS_WRITER_MMAP=0|1 overrides.
+        {
+            struct statfs sf;
+            w->no_mmap = !(fstatfs(fd, &sf) == 0 && (unsigned long)sf.f_type == 0x01021994ul /* TMPFS_MAGIC */);
+            if (const char *e = getenv("PSS_WRITER_MMAP")) w->no_mmap = atoi(e) == 0;
+        }
         w->limit = max_chunk_len < 0 ? (size_t)512 * 1024 * 1024 : (size_t)max_chunk_len;   // lib.rs:57
         w->devs.resize((size_t)n_devices);
         for (int i = 0; i < n_devices; ++i) w->devs[(size_t)i].device = devices[i];
@@ -687,11 +792,30 @@ extern "C" int pss_writer_add_file_lines(pss_writer *w, const char *path)
         if (!w || !path) return PSS_EINVAL;
         Phase ph_all("add_file_lines total");
         errno = 0;
-        FILE *in = fopen(path, "rb");
-        if (!in) return io_error(path);
+        const int in = open(path, O_RDONLY | O_CLOEXEC);
+        if (in < 0) return io_error(path);
+        struct CloseIn {
+            int fd;
+            ~CloseIn() { close(fd); }
+        } close_in{in};
         std::vector<uint8_t> line;                       // carry: the unterminated tail of the previous block
-        std::vector<uint8_t> block((size_t)4 << 20);
+        std::vector<uint8_t> block((size_t)4 << 20), aside;
         int rc = PSS_OK;
+        // read(2) until `want` bytes or the end of the file
+        auto rd = [&](uint8_t *dst, size_t want, size_t *got) -> int {
+            size_t at = 0;
+            while (at < want) {
+                const ssize_t k = read(in, dst + at, want - at);
+                if (k < 0) {
+                    if (errno == EINTR) continue;
+                    return io_error(path);
+                }
+                if (k == 0) break;
+                at += (size_t)k;
+            }
+            *got = at;
+            return PSS_OK;
+        };
         auto deliver = [&](const uint8_t *p, size_t l, bool terminated) -> int {
             if (terminated && l && p[l - 1] == '\r') --l;
             if (w->len + l + 1 > w->limit) PSS_TRY(w_dump(w));   // lib.rs:75-77
@@ -725,40 +849,66 @@ extern "C" int pss_writer_add_file_lines(pss_writer *w, const char *path)
             }
             return PSS_OK;
         };
-        for (;;) {
-            const size_t got = fread(block.data(), 1, block.size(), in);
-            if (got == 0) break;
+        // one block of the file, wherever it was read to
+        auto process = [&](const uint8_t *blk, size_t got) -> int {
             size_t p = 0;
             if (!line.empty()) {   // finish the carried line first
-                const uint8_t *nl = static_cast<const uint8_t *>(memchr(block.data(), '\n', got));
-                const size_t e = nl ? (size_t)(nl - block.data()) : got;
-                line.insert(line.end(), block.begin(), block.begin() + e);
-                if (!nl) continue;
-                rc = deliver(line.data(), line.size(), true);
+                const uint8_t *nl = static_cast<const uint8_t *>(memchr(blk, '\n', got));
+                const size_t e = nl ? (size_t)(nl - blk) : got;
+                line.insert(line.end(), blk, blk + e);
+                if (!nl) return PSS_OK;
+                PSS_TRY(deliver(line.data(), line.size(), true));
                 line.clear();
                 p = e + 1;
-                if (rc != PSS_OK) break;
             }
-            const void *last = p < got ? memrchr(block.data() + p, '\n', got - p) : nullptr;
-            const size_t whole_end = last ? (size_t)(static_cast<const uint8_t *>(last) - block.data()) + 1 : p;
+            const void *last = p < got ? memrchr(blk + p, '\n', got - p) : nullptr;
+            const size_t whole_end = last ? (size_t)(static_cast<const uint8_t *>(last) - blk) + 1 : p;
             if (whole_end > p) {
-                if (memchr(block.data() + p, '\r', whole_end - p) == nullptr) {
-                    rc = bulk(block.data() + p, whole_end - p);
+                if (memchr(blk + p, '\r', whole_end - p) == nullptr) {
+                    PSS_TRY(bulk(blk + p, whole_end - p));
                 } else {
-                    while (p < whole_end && rc == PSS_OK) {
-                        const uint8_t *nl = static_cast<const uint8_t *>(memchr(block.data() + p, '\n', whole_end - p));
-                        const size_t e = (size_t)(nl - block.data());
-                        rc = deliver(block.data() + p, e - p, true);
+                    while (p < whole_end) {
+                        const uint8_t *nl = static_cast<const uint8_t *>(memchr(blk + p, '\n', whole_end - p));
+                        const size_t e = (size_t)(nl - blk);
+                        PSS_TRY(deliver(blk + p, e - p, true));
                         p = e + 1;
                     }
                 }
-                if (rc != PSS_OK) break;
             }
-            line.insert(line.end(), block.begin() + whole_end, block.begin() + got);
+            line.insert(line.end(), blk + whole_end, blk + got);
+            return PSS_OK;
+        };
+        for (;;) {
+            const size_t room = w->limit > w->len ? w->limit - w->len : 0;
+            size_t got = 0;
+            if (line.empty() && room >= ((size_t)1 << 20)) {
+                // The file is read STRAIGHT into the chunk being filled (round 4: one copy of every byte instead of two).
+                // Whatever is read fits the chunk, so its whole lines are exactly what the per-line rule would have
+                // appended; the unterminated tail is carried over as always.  A block with a '\r' in it is set aside
+                // and goes line by line.
+                const size_t want = std::min(room, (size_t)32 << 20);
+                rc = w_reserve(w, want);
+                if (rc != PSS_OK) break;
+                uint8_t *q = w->buf + w->len;
+                rc = rd(q, want, &got);
+                if (rc != PSS_OK || got == 0) break;
+                if (memchr(q, '\r', got) == nullptr) {
+                    const void *last = memrchr(q, '\n', got);
+                    const size_t whole = last ? (size_t)(static_cast<const uint8_t *>(last) - q) + 1 : 0;
+                    line.assign(q + whole, q + got);
+                    w->len += whole;
+                    continue;
+                }
+                aside.assign(q, q + got);
+                rc = process(aside.data(), got);
+            } else {
+                rc = rd(block.data(), block.size(), &got);
+                if (rc != PSS_OK || got == 0) break;
+                rc = process(block.data(), got);
+            }
+            if (rc != PSS_OK) break;
         }
-        if (rc == PSS_OK && ferror(in)) rc = io_error(path);
         if (rc == PSS_OK && !line.empty()) rc = deliver(line.data(), line.size(), false);
-        fclose(in);
         return rc;
     });
 }
@@ -774,8 +924,7 @@ extern "C" int pss_writer_finalize(pss_writer *w)
         if (!w) return PSS_EINVAL;
         if (w->len) PSS_TRY(w_dump(w));   // lib.rs:129-131
         PSS_TRY(io_wait(w));              // the record in flight reaches the file before the flush
-        errno = 0;
-        if (fflush(w->fp) != 0) return io_error("flush");   // lib.rs:132
+        // (lib.rs:132 flushes the BufWriter: here every record went to the file with pwrite, nothing is buffered)
         return PSS_OK;
     });
 }
@@ -792,7 +941,7 @@ extern "C" int pss_writer_close(pss_writer *w)
         const std::string msg = rc != PSS_OK ? last_error() : std::string();
         pipe_stop(w);
         errno = 0;
-        if (fclose(w->fp) != 0 && rc == PSS_OK) rc = io_error("close");
+        if (close(w->fd) != 0 && rc == PSS_OK) rc = io_error("close");
         else if (rc != PSS_OK) {
             set_error("%s", msg.c_str());
             errno = e;
@@ -1024,30 +1173,73 @@ void reader_free(pss_reader *r)
     delete r;
 }
 
-// Reads `bytes` from fp into device memory: fread of piece i+1 (into the other
-// pinned staging buffer) overlaps the H2D copy of piece i on the copy stream.
+// Reads `bytes` from fp's current position into host memory with the I/O pool (pieces of 16 MiB, several threads).
+int read_file_parallel(FILE *fp, void *dst, size_t bytes)
+{
+    const int fd = fileno(fp);
+    const int64_t base = (int64_t)ftello(fp);
+    const size_t piece = DeviceCtx::kIoPiece;
+    IoPool::Batch batch;
+    for (size_t o = 0; o < bytes; o += piece)
+        IoPool::get().submit(&batch, fd, false, static_cast<uint8_t *>(dst) + o, std::min(piece, bytes - o), base + (int64_t)o);
+    const int err = IoPool::wait_all(&batch);
+    if (err) {
+        set_error("failed to fill whole buffer (truncated index file)");   // UnexpectedEof
+        return PSS_EFORMAT;
+    }
+    if (fseeko(fp, (off_t)(base + (int64_t)bytes), SEEK_SET) != 0) return io_error("seek");
+    return PSS_OK;
+}
+
+// Reads `bytes` from fp's current position into device memory: the threads of the I/O pool pread pieces into a ring of
+// pinned buffers (up to kIoPieces reads in flight), the copy stream uploads every piece as soon as it has arrived --
+// reading, uploading and the page-cache copies of several pieces overlap (round 3: one thread's fread, then the copy).
 int upload_from_file(pss_reader *r, FILE *fp, void *dst, size_t bytes)
 {
     DeviceCtx *ctx = r->ctx;
-    PSS_TRY(ctx->ensure_staging());
-    const size_t piece = DeviceCtx::kStage;
-    size_t done = 0, i = 0;
-    while (done < bytes) {
-        const size_t k = std::min(piece, bytes - done);
-        const int b = (int)(i & 1);
-        if (i >= 2) PSS_HIP(hipEventSynchronize(ctx->stage_ev[b]));   // staging buffer b is free again
-        if (fread(ctx->stage[b], 1, k, fp) != k) {
-            (void)hipStreamSynchronize(ctx->copy_stream);
-            set_error("failed to fill whole buffer (truncated index file)");   // UnexpectedEof
-            return PSS_EFORMAT;
+    PSS_TRY(ctx->ensure_io_ring());
+    const int fd = fileno(fp);
+    const int64_t base = (int64_t)ftello(fp);
+    const size_t piece = DeviceCtx::kIoPiece;
+    constexpr int S = DeviceCtx::kIoPieces;
+    const size_t pieces = (bytes + piece - 1) / piece;
+    IoPool::Batch batch;
+    IoPool &pool = IoPool::get();
+    std::atomic<int> done[S];
+    for (auto &x : done) x.store(1);
+    size_t next = 0;
+    bool short_read = false;
+    auto body = [&]() -> int {
+        for (size_t i = 0; i < pieces; ++i) {
+            while (next < pieces && next < i + (size_t)S) {
+                const int slot = (int)(next % S);
+                if (next >= (size_t)S) PSS_HIP(hipEventSynchronize(ctx->io_ev[slot]));   // the upload of piece next - S is through
+                const size_t o = next * piece;
+                pool.submit(&batch, fd, false, ctx->io_ring[slot], std::min(piece, bytes - o), base + (int64_t)o, &done[slot]);
+                ++next;
+            }
+            const int slot = (int)(i % S);
+            IoPool::wait_flag(&batch, &done[slot]);
+            {
+                std::lock_guard<std::mutex> lk(batch.mu);
+                if (batch.err) { short_read = true; return PSS_OK; }
+            }
+            const size_t o = i * piece, k = std::min(piece, bytes - o);
+            PSS_HIP(hipMemcpyAsync(static_cast<uint8_t *>(dst) + o, ctx->io_ring[slot], k, hipMemcpyHostToDevice, ctx->copy_stream));
+            PSS_HIP(hipEventRecord(ctx->io_ev[slot], ctx->copy_stream));
         }
-        PSS_HIP(hipMemcpyAsync(static_cast<uint8_t *>(dst) + done, ctx->stage[b], k, hipMemcpyHostToDevice,
-                               ctx->copy_stream));
-        PSS_HIP(hipEventRecord(ctx->stage_ev[b], ctx->copy_stream));
-        done += k;
-        ++i;
+        return PSS_OK;
+    };
+    const int rc = body();
+    const int err = IoPool::wait_all(&batch);          // always: the pool's pieces point at `done` and at the ring
+    const hipError_t he = hipStreamSynchronize(ctx->copy_stream);
+    if (rc != PSS_OK) return rc;
+    if (err || short_read) {
+        set_error("failed to fill whole buffer (truncated index file)");   // UnexpectedEof
+        return PSS_EFORMAT;
     }
-    PSS_HIP(hipStreamSynchronize(ctx->copy_stream));
+    PSS_HIP(he);
+    if (fseeko(fp, (off_t)(base + (int64_t)bytes), SEEK_SET) != 0) return io_error("seek");
     return PSS_OK;
 }
 
@@ -1183,10 +1375,7 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
             if (bytes_read + 2 * hl + dlen + sa_bytes_file > flen) { set_error("%s", kTrunc); rc = PSS_EFORMAT; break; }
             if (mine && dlen) {
                 if (cm.sa_host) {      // host tier: the file is read straight into the pinned buffer
-                    if (fread(cm.sa, 1, (size_t)sa_bytes_file, fp) != (size_t)sa_bytes_file) {
-                        set_error("%s", kTrunc);
-                        rc = PSS_EFORMAT;
-                    }
+                    rc = read_file_parallel(fp, cm.sa, (size_t)sa_bytes_file);
                 } else {
                     rc = upload_from_file(r, fp, cm.sa, (size_t)sa_bytes_file);
                 }

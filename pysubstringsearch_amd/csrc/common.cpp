@@ -1,6 +1,10 @@
 // common.cpp -- error state and per-device contexts.
 #include "common.h"
 
+#include <algorithm>
+#include <cerrno>
+#include <unistd.h>
+
 #include <mutex>
 #include <vector>
 
@@ -56,6 +60,120 @@ int DeviceCtx::ensure_staging()
         PSS_HIP(hipEventCreateWithFlags(&stage_ev[i], hipEventDisableTiming));
     }
     return PSS_OK;
+}
+
+int DeviceCtx::ensure_io_ring()
+{
+    PSS_TRY(ensure_staging());
+    if (io_ring[0]) return PSS_OK;
+    for (int i = 0; i < kIoPieces; ++i) {
+        PSS_HIP(hipHostMalloc(&io_ring[i], kIoPiece, hipHostMallocPortable));
+        PSS_HIP(hipEventCreateWithFlags(&io_ev[i], hipEventDisableTiming));
+    }
+    return PSS_OK;
+}
+
+IoPool &IoPool::get()
+{
+    static IoPool pool;
+    return pool;
+}
+
+IoPool::IoPool()
+{
+    int k = 0;
+    if (const char *e = getenv("PSS_IO_THREADS")) k = atoi(e);
+    if (k <= 0) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        k = (int)std::min<unsigned>(16u, std::max<unsigned>(8u, hw / 8));
+    }
+    if (k > 64) k = 64;
+    for (int i = 0; i < k; ++i) workers_.emplace_back([this] { run(); });
+}
+
+IoPool::~IoPool()
+{
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto &t : workers_)
+        if (t.joinable()) t.join();
+}
+
+void IoPool::submit(Batch *b, int fd, bool write, void *buf, size_t len, int64_t off, std::atomic<int> *done)
+{
+    {
+        std::lock_guard<std::mutex> lk(b->mu);
+        b->submitted += 1;
+    }
+    if (done) done->store(0, std::memory_order_relaxed);
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        q_.push_back(Task{b, fd, write, buf, len, off, done});
+    }
+    cv_.notify_one();
+}
+
+void IoPool::submit_copy(Batch *b, void *dst, const void *src, size_t len, std::atomic<int> *done)
+{
+    submit(b, -2, true, dst, len, (int64_t)reinterpret_cast<intptr_t>(src), done);
+}
+
+void IoPool::run()
+{
+    for (;;) {
+        Task t;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+            if (q_.empty()) return;
+            t = q_.front();
+            q_.pop_front();
+        }
+        int err = 0;
+        size_t at = 0;
+        uint8_t *p = static_cast<uint8_t *>(t.buf);
+        if (t.fd == -2) {
+            memcpy(t.buf, reinterpret_cast<const void *>((intptr_t)t.off), t.len);
+            at = t.len;
+        }
+        while (at < t.len) {
+            const ssize_t k = t.write ? pwrite(t.fd, p + at, t.len - at, (off_t)(t.off + (int64_t)at))
+                                      : pread(t.fd, p + at, t.len - at, (off_t)(t.off + (int64_t)at));
+            if (k < 0) {
+                if (errno == EINTR) continue;
+                err = errno ? errno : EIO;
+                break;
+            }
+            if (k == 0) {               // end of file inside the piece: a truncated index (or a full disk)
+                err = t.write ? ENOSPC : ENODATA;
+                break;
+            }
+            at += (size_t)k;
+        }
+        {
+            std::lock_guard<std::mutex> lk(t.b->mu);
+            if (err && !t.b->err) t.b->err = err;
+            t.b->finished += 1;
+            if (t.done) t.done->store(1, std::memory_order_release);
+        }
+        t.b->cv.notify_all();
+    }
+}
+
+int IoPool::wait_all(Batch *b)
+{
+    std::unique_lock<std::mutex> lk(b->mu);
+    b->cv.wait(lk, [&] { return b->finished == b->submitted; });
+    return b->err;
+}
+
+void IoPool::wait_flag(Batch *b, std::atomic<int> *done)
+{
+    std::unique_lock<std::mutex> lk(b->mu);
+    b->cv.wait(lk, [&] { return done->load(std::memory_order_acquire) != 0; });
 }
 
 int DeviceCtx::ensure_search_stage()

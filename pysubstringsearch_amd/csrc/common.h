@@ -8,8 +8,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/pss.h"
 
@@ -146,6 +151,56 @@ struct DeviceCtx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     int ensure_staging();
+    // Ring of pinned pieces for the parallel file path of the reader (IoPool threads pread into them, the copy stream
+    // uploads them): kIoPieces x kIoPiece bytes, allocated on first use.
+    static constexpr size_t kIoPiece = (size_t)16 << 20;
+    static constexpr int kIoPieces = 12;
+    void *io_ring[kIoPieces] = {};
+    hipEvent_t io_ev[kIoPieces] = {};
+    int ensure_io_ring();
+};
+
+// A few threads that pread / pwrite disjoint pieces of one file (round 4).  A chunk record is 2.7 GB at the default chunk
+// size: one thread copying it into (out of) the page cache moves 3 - 6 GB/s, which was the whole end-to-end time of the
+// Writer and of Reader::new.  Record offsets are known in advance (8 + 5 n bytes per chunk, src/lib.rs:112-119), so the
+// pieces of one record can be written in any order by any thread -- the file that results is byte-identical.
+class IoPool {
+public:
+    struct Batch {                       // completion state of the pieces one caller has submitted
+        std::mutex mu;
+        std::condition_variable cv;
+        size_t submitted = 0, finished = 0;
+        int err = 0;                     // first errno (EIO for a short read)
+    };
+    static IoPool &get();                // process-wide, threads started on first use (PSS_IO_THREADS, default 8 .. 16)
+    // One piece: the whole of [off, off + len) of fd to / from buf.  *done (optional) is set to 1 when the piece is through.
+    void submit(Batch *b, int fd, bool write, void *buf, size_t len, int64_t off, std::atomic<int> *done = nullptr);
+    // One piece of a plain copy (fd == -2): len bytes from src to dst -- dst a shared mapping of the file: page-cache
+    // pages are then allocated by the page faults of several threads at once, where write(2) on one file holds the
+    // inode's lock exclusively and lets one thread copy at a time.
+    void submit_copy(Batch *b, void *dst, const void *src, size_t len, std::atomic<int> *done = nullptr);
+    static int wait_all(Batch *b);       // every piece submitted so far: 0 or the first errno
+    static void wait_flag(Batch *b, std::atomic<int> *done);
+    int threads() const { return (int)workers_.size(); }
+    ~IoPool();
+
+private:
+    IoPool();
+    struct Task {
+        Batch *b;
+        int fd;
+        bool write;
+        void *buf;
+        size_t len;
+        int64_t off;
+        std::atomic<int> *done;
+    };
+    void run();
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<Task> q_;
+    bool stop_ = false;
+    std::vector<std::thread> workers_;
 };
 
 // Validates `device`, makes it current, returns its context (created lazily).
