@@ -236,6 +236,16 @@ int pss_reader_open(const char *path, int32_t device, int32_t shard_index, int32
  * ("virtual devices": the parts then take turns on that GPU).  pss_reader_search_batch / count_batch / residency /
  * evict / promote work on such a reader; the device-resident result and the chunk hand-off calls do not. */
 int pss_reader_open_multi(const char *path, const int32_t *devices, int32_t n_devices, pss_reader **out);
+
+/* Residency manager ("LRU when index > HBM"; the reference keeps every suffix array on disk,
+ * src/lib.rs:179-189).  A reader whose suffix arrays do not all fit the HBM budget keeps a decayed per-chunk count of the
+ * hits its batches find and, between batches, lets the hottest suffix array of the host tier change places with the
+ * coldest one in HBM when it is more than twice as hot (at most one exchange per batch).  On by default
+ * (PSS_READER_AUTO_RESIDENCY=0 or on = 0: off); pss_reader_evict_chunk / promote_chunk remain as explicit overrides.
+ * pss_reader_chunk_tiers: tiers[c] = 0 (suffix array of chunk c in HBM) or 1 (pinned host memory), for the first `cap`
+ * chunks; *auto_moves = exchanges / promotions the manager has made so far. */
+int pss_reader_set_auto_residency(pss_reader *r, int32_t on);
+int pss_reader_chunk_tiers(const pss_reader *r, uint8_t *tiers, uint64_t cap, uint64_t *auto_moves);
 /* Residency control: move the suffix array of resident chunk `index` (file order) out of HBM into
  * pinned host memory, where the kernels read it over PCIe (evict), or back (promote; PSS_ENOMEM when HBM has no
  * room).  Text and key samples stay in HBM.  No-ops when the chunk already is where it is asked to be. */

@@ -260,6 +260,26 @@ class Reader:
         _ffi.check(_lib.pss_reader_residency(self._handle(), ctypes.byref(hbm), ctypes.byref(host), ctypes.byref(nhost)))
         return {'hbm_bytes': hbm.value, 'host_bytes': host.value, 'host_chunks': nhost.value}
 
+    @property
+    def chunk_tiers(self) -> typing.List[str]:
+        """Extension: where the suffix array of every chunk lives right now -- 'hbm' or 'host' (pinned memory)."""
+        n = self.num_chunks
+        buf = (ctypes.c_uint8 * max(n, 1))()
+        _ffi.check(_lib.pss_reader_chunk_tiers(self._handle(), buf, n, None))
+        return ['host' if buf[i] else 'hbm' for i in range(n)]
+
+    @property
+    def residency_moves(self) -> int:
+        """Extension: exchanges / promotions the residency manager has made on its own (pss_reader_set_auto_residency)."""
+        moves = ctypes.c_uint64()
+        _ffi.check(_lib.pss_reader_chunk_tiers(self._handle(), None, 0, ctypes.byref(moves)))
+        return moves.value
+
+    def set_auto_residency(self, on: bool = True) -> None:
+        """Extension: between batches the hottest suffix array of the host tier changes places with
+        the coldest one in HBM (include/pss.h).  On by default; ``evict`` / ``promote`` override by hand."""
+        _ffi.check(_lib.pss_reader_set_auto_residency(self._handle(), 1 if on else 0))
+
     def evict(self, chunk: int) -> None:
         """Extension: move the suffix array of resident chunk ``chunk`` out of HBM into pinned host
         memory (searches keep working, the kernels read it over PCIe); ``promote`` brings it back."""

@@ -173,6 +173,8 @@ def _load() -> ctypes.CDLL:
         'pss_writer_chunk_limit': (u64, [vp]),
         'pss_reader_open': (ctypes.c_int, [cp, i32, i32, i32, pvp]),
         'pss_reader_open_multi': (ctypes.c_int, [cp, ctypes.POINTER(i32), i32, pvp]),
+        'pss_reader_set_auto_residency': (ctypes.c_int, [vp, i32]),
+        'pss_reader_chunk_tiers': (ctypes.c_int, [vp, vp, u64, ctypes.POINTER(u64)]),
         'pss_reader_evict_chunk': (ctypes.c_int, [vp, u64]),
         'pss_reader_promote_chunk': (ctypes.c_int, [vp, u64]),
         'pss_reader_set_low_latency': (ctypes.c_int, [vp, i32]),

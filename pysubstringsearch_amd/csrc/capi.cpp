@@ -975,6 +975,14 @@ struct pss_reader {
     size_t d_descs_cap = 0;
     bool dirty = true;
     bool low_latency = false;            // single queries through the resident kernel (pss_reader_set_low_latency)
+    // Residency manager ("LRU when index > HBM").  A reader with suffix arrays on the host tier keeps,
+    // per chunk, a decayed count of the hits its batches found there and the number of the last batch that touched it;
+    // between batches the hottest host-tier suffix array changes places with the coldest one in HBM when it is more than
+    // twice as hot (one exchange per batch; PSS_READER_AUTO_RESIDENCY=0: never -- evict / promote stay as overrides).
+    std::vector<uint64_t> heat, last_touch, batch_hits;
+    std::vector<uint8_t> manual;         // chunks the caller placed by hand (evict / promote): the manager leaves them alone
+    uint64_t batch_seq = 0, auto_moves = 0;
+    bool auto_residency = getenv("PSS_READER_AUTO_RESIDENCY") == nullptr || atoi(getenv("PSS_READER_AUTO_RESIDENCY")) != 0;
     pss_search_stats last{};
     // A reader over several devices (pss_reader_open_multi) is a front for one reader per device -- part k holds the
     // chunks c with c % G == k on devices[k] -- each with a worker thread that answers the batch for its chunks; the
@@ -1024,6 +1032,9 @@ void reader_free_mem(pss_reader::Mem &m)
 
 // Text (zero padded) and suffix array of one chunk; the key-sample table (search.h) lives behind
 // the suffix array in the same allocation (or on its own in HBM when the suffix array is on the host).
+uint64_t *reader_hits_buffer(pss_reader *r);
+void reader_note_batch(pss_reader *r);
+
 int reader_alloc_chunk(pss_reader *r, uint32_t n, ChunkDesc *out, pss_reader::Mem *mem)
 {
     PSS_HIP(hipSetDevice(r->device));
@@ -1127,9 +1138,12 @@ void part_run(pss_reader::Part *p)      // the job in p's mailbox, on p's reader
         rc = PSS_EDEVICE;
     }
     if (rc == PSS_OK) rc = reader_sync_descs(r);
-    if (rc == PSS_OK)
+    if (rc == PSS_OK) {
+        uint64_t *hits = reader_hits_buffer(r);
         rc = search_batch_device(r->ctx, r->d_descs, (uint32_t)r->chunks.size(), p->qbytes, p->qoffsets, p->nq, &p->res, &r->last,
-                                 (SearchMode)p->mode);
+                                 (SearchMode)p->mode, false, hits);
+        if (rc == PSS_OK && hits) reader_note_batch(r);
+    }
     if (rc != PSS_OK) p->err = last_error();
     p->rc = rc;
 }
@@ -1658,12 +1672,82 @@ int reader_move_sa(pss_reader *r, uint64_t index, bool to_host)
     return reader_sync_descs(r);
 }
 
+// ---- residency manager ----------------------------------------------------------------------------------------
+bool reader_hbm_room(pss_reader *r, size_t bytes)
+{
+    if (const char *ev = getenv("PSS_READER_HBM_BUDGET")) {
+        uint64_t used = 0;
+        for (const auto &x : r->mem) used += x.hbm_bytes;
+        return used + bytes <= strtoull(ev, nullptr, 0);
+    }
+    size_t free_b = 0, total_b = 0;
+    return hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= bytes + kHbmReserve;
+}
+
+uint64_t *reader_hits_buffer(pss_reader *r)
+{
+    if (!r->auto_residency) return nullptr;
+    bool host = false;
+    for (size_t c = 0; c < r->mem.size(); ++c) host = host || (r->mem[c].sa_host && !(c < r->manual.size() && r->manual[c]));
+    if (!host) return nullptr;          // everything (the manager may move) lives in HBM: nothing to decide, nothing to measure
+    r->batch_hits.assign(r->chunks.size(), 0);
+    return r->batch_hits.data();
+}
+
+// After a batch whose per-chunk hits are in r->batch_hits: decay, then at most one exchange.  Failures to move are not
+// failures of the search: the tiers stay as they are.
+void reader_note_batch(pss_reader *r)
+{
+    const size_t nc = r->chunks.size();
+    if (r->batch_hits.size() != nc || nc == 0) return;
+    r->heat.resize(nc, 0);
+    r->last_touch.resize(nc, 0);
+    r->batch_seq += 1;
+    for (size_t c = 0; c < nc; ++c) {
+        r->heat[c] = r->heat[c] / 2 + r->batch_hits[c];
+        if (r->batch_hits[c]) r->last_touch[c] = r->batch_seq;
+    }
+    r->batch_hits.clear();
+    size_t hot = nc, cold = nc;
+    for (size_t c = 0; c < nc; ++c) {
+        if (r->chunks[c].n == 0 || (c < r->manual.size() && r->manual[c])) continue;
+        if (r->mem[c].sa_host) {
+            if (hot == nc || r->heat[c] > r->heat[hot]) hot = c;
+        } else if (cold == nc || r->heat[c] < r->heat[cold] ||
+                   (r->heat[c] == r->heat[cold] && r->last_touch[c] < r->last_touch[cold])) {
+            cold = c;
+        }
+    }
+    if (hot == nc || r->heat[hot] < 16) return;
+    const size_t need = round_up((size_t)r->chunks[hot].n * 4 + 16, 8) +
+                        (r->chunks[hot].skeys ? sample_count(r->chunks[hot].n, r->chunks[hot].shift) * 8 : 0);
+    const std::string keep = last_error();
+    if (reader_hbm_room(r, need)) {
+        if (reader_move_sa(r, hot, false) == PSS_OK) r->auto_moves += 1;
+    } else if (cold != nc && r->heat[hot] > 2 * r->heat[cold]) {
+        if (reader_move_sa(r, cold, true) == PSS_OK) {
+            if (reader_move_sa(r, hot, false) == PSS_OK) r->auto_moves += 1;
+            else (void)reader_move_sa(r, cold, false);       // no room after all: back as it was
+        }
+    }
+    set_error("%s", keep.c_str());
+}
+
 int reader_move_any(pss_reader *r, uint64_t index, bool to_host)
 {
     if (!r) return PSS_EINVAL;
-    if (r->parts.empty()) return reader_move_sa(r, index, to_host);
-    const uint64_t G = r->parts.size();      // chunk c of the file lives in part c % G at position c / G
-    return reader_move_sa(r->parts[index % G]->reader, index / G, to_host);
+    pss_reader *x = r;
+    uint64_t at = index;
+    if (!r->parts.empty()) {
+        const uint64_t G = r->parts.size();  // chunk c of the file lives in part c % G at position c / G
+        x = r->parts[index % G]->reader;
+        at = index / G;
+    }
+    PSS_TRY(reader_move_sa(x, at, to_host));
+    std::lock_guard<std::recursive_mutex> lk(x->ctx->mu);
+    x->manual.resize(x->chunks.size(), 0);
+    x->manual[at] = 1;                       // placed by hand: the residency manager leaves it where it is
+    return PSS_OK;
 }
 
 }  // namespace
@@ -1675,6 +1759,40 @@ extern "C" int pss_reader_evict_chunk(pss_reader *r, uint64_t index)
 extern "C" int pss_reader_promote_chunk(pss_reader *r, uint64_t index)
 {
     return guarded([&]() -> int { return reader_move_any(r, index, false); });
+}
+
+extern "C" int pss_reader_set_auto_residency(pss_reader *r, int32_t on)
+{
+    if (!r) return PSS_EINVAL;
+    r->auto_residency = on != 0;
+    r->manual.clear();                       // (switching the manager on again hands every chunk back to it)
+    for (pss_reader::Part *p : r->parts) {
+        p->reader->auto_residency = on != 0;
+        p->reader->manual.clear();
+    }
+    return PSS_OK;
+}
+
+extern "C" int pss_reader_chunk_tiers(const pss_reader *r, uint8_t *tiers, uint64_t cap, uint64_t *auto_moves)
+{
+    if (!r) return PSS_EINVAL;
+    uint64_t moves = r->auto_moves;
+    if (r->parts.empty()) {
+        for (size_t c = 0; c < r->mem.size() && c < cap; ++c)
+            if (tiers) tiers[c] = r->mem[c].sa_host ? 1 : 0;
+    } else {
+        const uint64_t G = r->parts.size();      // chunk c of the file lives in part c % G at position c / G
+        for (uint64_t g = 0; g < G; ++g) {
+            const pss_reader *x = r->parts[g]->reader;
+            moves += x->auto_moves;
+            for (size_t k = 0; k < x->mem.size(); ++k) {
+                const uint64_t c = (uint64_t)k * G + g;
+                if (tiers && c < cap) tiers[c] = x->mem[k].sa_host ? 1 : 0;
+            }
+        }
+    }
+    if (auto_moves) *auto_moves = moves;
+    return PSS_OK;
 }
 
 extern "C" uint64_t pss_reader_num_chunks(const pss_reader *r)
@@ -1727,8 +1845,10 @@ extern "C" int pss_reader_search_batch(pss_reader *r, const uint8_t *qbytes, con
         const uint32_t nc = (uint32_t)r->chunks.size();
         PSS_TRY(reader_sync_descs(r));
         pss_result *res = new pss_result();
+        uint64_t *hits = reader_hits_buffer(r);
         const int rc = search_batch_device(r->ctx, r->d_descs, nc, qbytes, qoffsets, nq, &res->r, &r->last, SEARCH_FULL,
-                                           r->low_latency);
+                                           r->low_latency, hits);
+        if (rc == PSS_OK && hits) reader_note_batch(r);
         if (rc != PSS_OK) {
             pss_result_free(res);
             return rc;
@@ -1782,7 +1902,9 @@ extern "C" int pss_reader_count_batch(pss_reader *r, const uint8_t *qbytes, cons
         const uint32_t nc = (uint32_t)r->chunks.size();
         PSS_TRY(reader_sync_descs(r));
         pss_result res;
-        const int rc = search_batch_device(r->ctx, r->d_descs, nc, qbytes, qoffsets, nq, &res.r, &r->last, SEARCH_COUNTS);
+        uint64_t *hits = reader_hits_buffer(r);
+        const int rc = search_batch_device(r->ctx, r->d_descs, nc, qbytes, qoffsets, nq, &res.r, &r->last, SEARCH_COUNTS, false, hits);
+        if (rc == PSS_OK && hits) reader_note_batch(r);
         if (rc == PSS_OK && nq) memcpy(counts, res.r.qcount, (size_t)nq * sizeof(uint64_t));
         res.r.release();
         return rc;

@@ -50,9 +50,12 @@ enum SearchMode {
     SEARCH_DEVICE = 2,   // packed result left on the device (multi-GPU gather over RCCL takes it from there)
 };
 
+// chunk_hits (optional, nc entries): how much of the batch's work landed on every chunk -- suffix-array hits per chunk on
+// the multi-kernel paths, entries per chunk on the fused small-batch path.  The reader's residency manager feeds on it
+// (capi.cpp); it costs one small kernel and a stream synchronisation, so readers whose chunks all live in HBM pass nullptr.
 int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, uint32_t nc, const uint8_t *qbytes,
                         const uint64_t *qoffsets, uint32_t nq, HostResult *res, pss_search_stats *st,
-                        SearchMode mode = SEARCH_FULL, bool low_latency = false);
+                        SearchMode mode = SEARCH_FULL, bool low_latency = false, uint64_t *chunk_hits = nullptr);
 
 // Merge of `world` packed results of the same nq queries, all resident on ctx's device, into one (query-major,
 // rank-major inside a query -- pss_merge_packed's order) on the same device.  starts[r] = entry starts (no closing

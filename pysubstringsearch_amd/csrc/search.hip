@@ -1317,7 +1317,7 @@ __global__ __launch_bounds__(256) void query_counts_kernel(u32 nc, u32 nq, const
 // same time), header of the resident kernel
 constexpr size_t SM_ARENA_RHDR = 64 + (size_t)SM_BYTE_CAP + 64;
 constexpr size_t SM_ARENA_BYTES = SM_ARENA_RHDR + 64;
-enum SSlot { Q_BYTES = 10, Q_OFF, Q_LO, Q_CNT, Q_HITOFF, Q_START, Q_LEN, Q_EIDX, Q_BOFF, Q_ENTOFF, Q_OUT, Q_SMALL, Q_QCOUNT, Q_ARENA = 28 };
+enum SSlot { Q_BYTES = 10, Q_OFF, Q_LO, Q_CNT, Q_HITOFF, Q_START, Q_LEN, Q_EIDX, Q_BOFF, Q_ENTOFF, Q_OUT, Q_SMALL, Q_QCOUNT, Q_ARENA = 28, Q_HEAT = 46 };
 
 void HostResult::release()
 {
@@ -1354,7 +1354,7 @@ static int alloc_result(HostResult *res, u64 E, u64 B, bool allow_pinned)
 // The packed result of one small-path launch from what the kernel left in the pinned arena (records, entry table,
 // the first SM_BYTE_PREFIX result bytes) and, beyond that prefix, in the device arena.
 static int small_collect(DeviceCtx *ctx, const u8 *h_arena, const u8 *d_bytes, u64 nrec, u32 spread, u32 nc, HostResult *res,
-                         pss_search_stats *st)
+                         pss_search_stats *st, uint64_t *chunk_hits = nullptr)
 {
     const SearchKnobs &knobs = search_knobs();
     hipStream_t s = ctx->stream;
@@ -1386,6 +1386,7 @@ static int small_collect(DeviceCtx *ctx, const u8 *h_arena, const u8 *d_bytes, u
     for (u64 ri = 0; ri < nrec; ++ri) {       // pairs in (query, chunk) order, sub-blocks in interval order
         const SmallRecord r = h_rec[ri];
         res->qcount[(ri / spread) / nc] += r.ent_count;
+        if (chunk_hits) chunk_hits[(ri / spread) % nc] += r.ent_count;
         if (r.ent_count == 0) continue;
         // the entries of one record are packed back to back in the arena: one copy for all of them
         const u64 first = b_out;
@@ -1495,9 +1496,26 @@ static int resident_query(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, con
     return PSS_OK;
 }
 
-int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const uint8_t *qbytes,
-                        const uint64_t *qoffsets, uint32_t nq, HostResult *res, pss_search_stats *st, SearchMode mode, bool low_latency)
+// Suffix-array hits of the batch per chunk (pair p = query p / nc on chunk p % nc): one workgroup per chunk.
+__global__ __launch_bounds__(256) void chunk_hits_kernel(const u32 *cnt, u64 nq, u32 nc, u64 *out)
 {
+    __shared__ u64 s_w[256 / kWave];
+    const u32 c = blockIdx.x;
+    u64 acc = 0;
+    for (u64 q = threadIdx.x; q < nq; q += 256) acc += cnt[q * nc + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane_id() == 0) s_w[wave_id()] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[c] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const uint8_t *qbytes,
+                        const uint64_t *qoffsets, uint32_t nq, HostResult *res, pss_search_stats *st, SearchMode mode, bool low_latency,
+                        uint64_t *chunk_hits)
+{
+    if (chunk_hits)
+        for (u32 c = 0; c < nc; ++c) chunk_hits[c] = 0;
     const bool counts_only = mode == SEARCH_COUNTS;
     const bool device_only = mode == SEARCH_DEVICE;
     const SearchKnobs &knobs = search_knobs();
@@ -1607,7 +1625,7 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
         if (timed) PSS_HIP(hipEventRecord(e2, s));
         PSS_HIP(hipStreamSynchronize(s));
         if (!*h_overflow) {
-            PSS_TRY(small_collect(ctx, h_arena, d_bytes, nvq * spread, spread, nc, res, st));
+            PSS_TRY(small_collect(ctx, h_arena, d_bytes, nvq * spread, spread, nc, res, st, chunk_hits));
             float ms = 0.f;
             if (timed) PSS_HIP(hipEventElapsedTime(&ms, e0, e2));
             st->ms_device = ms;
@@ -1649,6 +1667,15 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
         hipLaunchKernelGGL(search_interval_kernel, dim3((u32)((nvq + waves_per_block - 1) / waves_per_block)), dim3(256),
                            0, s, d_chunks, nc, d_q, d_qoff, nvq, d_lo, d_cnt);
     PSS_HIP(hipEventRecord(e1, s));
+    if (chunk_hits && nc <= 4096) {
+        // (a reader with suffix arrays on the host tier: where did this batch's hits land?  One small kernel over the
+        // pair counts and a wait -- next to probes over PCIe, nothing)
+        PSS_TRY(ctx->slot[Q_HEAT].reserve((size_t)nc * 8));
+        u64 *d_heat = ctx->slot[Q_HEAT].as<u64>();
+        hipLaunchKernelGGL(chunk_hits_kernel, dim3(nc), dim3(256), 0, s, d_cnt, (u64)nq, nc, d_heat);
+        PSS_HIP(hipMemcpyAsync(chunk_hits, d_heat, (size_t)nc * 8, hipMemcpyDeviceToHost, s));
+        PSS_HIP(hipStreamSynchronize(s));
+    }
     if (nvq <= MID_MAX && !counts_only && !knobs.no_mid_pipeline) {
         // ---- mid pipeline: totals stay on the device, one wait for them, one for the result ----
         const u64 byte_cap = (u64)16 << 20;

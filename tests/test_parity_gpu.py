@@ -581,6 +581,67 @@ def test_evict_and_promote_chunks(tmp_path, oracle):
                 r.evict(10 ** 6)
 
 
+def test_residency_manager_converges_on_the_hot_chunks(tmp_path, oracle, monkeypatch):
+    """SURVEY 8(f) row 2, "LRU when index > HBM": six chunks, an HBM budget for the suffix arrays of two.  Batches whose
+    hits land on two chunks of the host tier make the manager exchange them with the cold ones in HBM, one per batch;
+    when the hot set changes, residency follows.  Results equal the oracle's throughout; chunks placed by hand stay put."""
+    from tests.util import gen_corpus
+    src = tmp_path / 'c.txt'
+    n = 1 << 16
+    src.write_bytes(b''.join(gen_corpus(0, n, c).tobytes() for c in range(6)))
+    p = str(tmp_path / 'c.idx')
+    w = pysubstringsearch.Writer(p, n)
+    w.add_entries_from_file_lines(str(src))
+    w.close()
+    text = src.read_bytes()
+    o = oracle.OracleReader(p)
+    rng = np.random.default_rng(9)
+
+    def batch_on(chunks, k=1500):
+        qs = []
+        while len(qs) < k:
+            c = int(rng.choice(chunks))
+            s = c * n + int(rng.integers(0, n - 20))
+            q = text[s:s + 10]
+            if b'\n' not in q:
+                qs.append(q)
+        return qs
+
+    def check(r, qs):
+        ents, counts = r.search_batch_raw(qs)
+        oe, oc = o.search_multiple_bytes(qs)
+        assert counts == oc.tolist() and sorted(ents) == sorted(oe)
+
+    monkeypatch.setenv('PSS_READER_HBM_BUDGET', str(6 * (n + 128) + 2 * (n * 4 + 4096) + 1024))
+    with pysubstringsearch.Reader(p) as r:
+        assert r.num_chunks == 6 and r.chunk_tiers == ['hbm', 'hbm', 'host', 'host', 'host', 'host']
+        for _ in range(6):
+            check(r, batch_on([4, 5]))
+        assert r.chunk_tiers == ['host', 'host', 'host', 'host', 'hbm', 'hbm'] and r.residency_moves >= 2
+        moves = r.residency_moves
+        for _ in range(3):                                  # nothing hotter outside HBM: nothing moves
+            check(r, batch_on([4, 5]))
+        assert r.residency_moves == moves
+        for _ in range(8):                                  # the hot set changes: residency follows
+            check(r, batch_on([1, 2]))
+        assert r.chunk_tiers == ['host', 'hbm', 'hbm', 'host', 'host', 'host']
+        for q in batch_on([0], 40):                         # single queries (fused path) count too
+            check(r, [q])
+        r.evict(1)                                          # placed by hand: stays, however hot
+        for _ in range(4):
+            check(r, batch_on([1], 1200))
+        assert r.chunk_tiers[1] == 'host'
+        r.set_auto_residency(False)
+        tiers = r.chunk_tiers
+        for _ in range(3):
+            check(r, batch_on([3]))
+        assert r.chunk_tiers == tiers
+    with pysubstringsearch.Reader(p, devices=[0, 0]) as r:  # through a multi-device reader: every part manages its own chunks
+        for _ in range(6):
+            check(r, batch_on([4, 5]))
+        assert r.residency_moves >= 1
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize('chunk', [1 << 16, 1 << 20])
 def test_low_latency_mode_matches_the_launch_path(tmp_path, oracle, monkeypatch, chunk):
