@@ -309,6 +309,166 @@ class Dist:
             self.dist.destroy_process_group()
 
 
+# ------------------------------------------------------------------------- N GPUs, one process --
+
+def run_inproc(args):
+    """`--inproc`: the N-GPU line without torch.distributed and without RCCL -- ONE process, one host thread per device
+    (ctypes releases the GIL inside the library, so the N builds and searches really run side by side).  Weak scaling
+    like the ranks route: device r builds its own rotating chunks of the corpus and answers the query batch against its
+    resident chunk; `value` = text bytes of all devices / the slowest device's build time.  Then the two handles a user
+    of the drop-in API gets on a multi-GPU node -- Writer(devices=...) and Reader(devices=...) (pss_writer_open_multi /
+    pss_reader_open_multi: chunk c on device c mod N, what the reference does with rayon inside one process,
+    src/lib.rs:205-207) -- are taken through a small index and compared with the one-device handles.  A second,
+    independent route to an N-GPU number: bench.py falls back to it by itself when the ranks route prints no line."""
+    import threading
+    import torch
+    import pysubstringsearch
+    from pysubstringsearch_amd import Reader, _ffi
+    lib = _ffi.lib
+    N = args.gpus
+    n = 1 << args.logn
+    nq = args.queries or 10000
+    visible = torch.cuda.device_count()
+    devs = [r % max(visible, 1) for r in range(N)]          # fewer devices than N (test boxes): they take turns
+    gold = load_big_goldens()
+    ROT = 3
+    state = [None] * N
+    errors = []
+    start = threading.Barrier(N + 1)
+    stop = threading.Barrier(N + 1)
+
+    def work(r):
+        try:
+            dev = devs[r]
+            torch.cuda.set_device(dev)
+            ids = [(r + k * N) % 15 for k in range(ROT)]
+            hosts, dTs, qsets = [], [], []
+            for ci in ids:
+                hk = np.empty(n, dtype=np.uint8)
+                _ffi.check(lib.pss_gen_corpus(KINDS[args.corpus], hk.ctypes.data, n, ci))
+                hosts.append(hk)
+                dTs.append(torch.from_numpy(hk).to(f'cuda:{dev}'))
+                qsets.append(make_queries(hk, nq, args.qlen))
+            dSA = torch.empty(n, dtype=torch.int32, device=f'cuda:{dev}')
+            h = ctypes.c_void_p()
+            _ffi.check(lib.pss_reader_create(dev, ctypes.byref(h)))
+            reader = Reader._from_handle(h)
+            st = _ffi.SaStats()
+            k = 0
+            tb = ts = 0.0
+
+            def step():
+                nonlocal k, tb, ts
+                k = (k + 1) % ROT
+                t0 = time.perf_counter()
+                _ffi.check(lib.pss_sa_build_device(dTs[k].data_ptr(), dSA.data_ptr(), n, dev, 0, ctypes.byref(st)))
+                t1 = time.perf_counter()
+                _ffi.check(lib.pss_reader_set_chunk_device(h, 0, dTs[k].data_ptr(), dSA.data_ptr(), n))
+                t2 = time.perf_counter()
+                ents, _ = reader.search_batch_raw(qsets[k])
+                t3 = time.perf_counter()
+                return t1 - t0, t3 - t2, len(ents)
+            for _ in range(args.warmup):
+                step()
+            torch.cuda.synchronize(dev)
+            start.wait()
+            entries = 0
+            for _ in range(args.steps):
+                b, q, entries = step()
+                tb += b
+                ts += q
+            torch.cuda.synchronize(dev)
+            stop.wait()
+            ok, how = verify_sa(dSA, hosts[k], args.corpus, ids[k], gold, want_sha=False)
+            state[r] = {'build_s': tb, 'search_s': ts, 'verified': ok, 'how': how, 'entries': entries, 'device': dev,
+                        'ms_total': st.ms_total}
+            reader.close()
+        except Exception as e:      # noqa: BLE001
+            errors.append(f'device thread {r}: {type(e).__name__}: {e}')
+            for b in (start, stop):
+                try:
+                    b.abort()
+                except Exception:   # noqa: BLE001
+                    pass
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(N)]
+    for t in threads:
+        t.start()
+    try:
+        start.wait()
+        t_begin = time.perf_counter()
+        stop.wait()
+        total_s = time.perf_counter() - t_begin
+    except threading.BrokenBarrierError:
+        total_s = float('nan')
+    for t in threads:
+        t.join()
+    if errors or any(x is None for x in state):
+        return 1, {'metric': METRIC, 'value': None, 'unit': 'GB/s', 'n_gpus': N, 'route': 'inproc', 'error': '; '.join(errors)[:600]}
+    build_s = max(x['build_s'] for x in state)
+    search_s = max(x['search_s'] for x in state)
+    verified = False if any(x['verified'] is False for x in state) else (None if any(x['verified'] is None for x in state) else True)
+
+    # the multi-device handles of the drop-in API on a small index: same bytes, same results as the one-device handles
+    handles = None
+    try:
+        import shutil
+        import tempfile
+        d = tempfile.mkdtemp(prefix='pss_inproc_')
+        try:
+            cn = 1 << min(args.logn, 22)
+            src = os.path.join(d, 'c.txt')
+            with open(src, 'wb') as f:
+                for c in range(2 * N + 1):
+                    buf = np.empty(cn, dtype=np.uint8)
+                    _ffi.check(lib.pss_gen_corpus(KINDS[args.corpus], buf.ctypes.data, cn, c))
+                    f.write(buf.data)
+            one, many = os.path.join(d, 'one.idx'), os.path.join(d, 'many.idx')
+            w = pysubstringsearch.Writer(one, cn, device=devs[0])
+            w.add_entries_from_file_lines(src)
+            w.close()
+            t0 = time.perf_counter()
+            w = pysubstringsearch.Writer(many, cn, devices=devs)
+            w.add_entries_from_file_lines(src)
+            w.close()
+            t_w = time.perf_counter() - t0
+            same_bytes = open(one, 'rb').read() == open(many, 'rb').read()
+            qs = make_queries(np.fromfile(src, dtype=np.uint8, count=cn), 3000, args.qlen)
+            with pysubstringsearch.Reader(one, device=devs[0]) as r1, pysubstringsearch.Reader(many, devices=devs) as rn:
+                e1, c1 = r1.search_batch_raw(qs)
+                t0 = time.perf_counter()
+                en, cn_ = rn.search_batch_raw(qs)
+                t_r = time.perf_counter() - t0
+                same_results = list(c1) == list(cn_) and sorted(e1) == sorted(en)
+            handles = {'devices': devs, 'chunks': 2 * N + 1, 'chunk_bytes': cn, 'writer_same_bytes_as_one_device': bool(same_bytes),
+                       'reader_same_results_as_one_device': bool(same_results), 'writer_seconds': round(t_w, 3),
+                       'reader_batch_seconds': round(t_r, 4)}
+            if not (same_bytes and same_results):
+                verified = False
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    except Exception as e:      # noqa: BLE001
+        handles = {'error': f'{type(e).__name__}: {e}'[:300]}
+    value = None if verified is False else round(N * n * args.steps / build_s / 1e9, 4)
+    out = {
+        'metric': METRIC, 'value': value, 'unit': 'GB/s', 'n_gpus': N, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(total_s / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'u64', 'data': 'synthetic', 'route': 'inproc', 'verified': verified,
+        'verified_by': state[0]['how'],
+        'config': {'workload': f'configs[1] on {N} GPUs inside ONE process (one host thread per device, no torch.distributed, no RCCL): '
+                               f'one {n >> 20} MiB synthetic `{args.corpus}` chunk per GPU, suffix-array build + {nq} '
+                               f'{args.qlen}-byte queries against the device\'s own chunk',
+                   'corpus': args.corpus, 'chunk_bytes': n, 'queries': nq, 'query_len': args.qlen,
+                   'devices': devs, 'visible_devices': visible,
+                   'value_is': 'index-build GB/s (text bytes of all devices / the slowest device\'s build time, inputs resident in HBM)'},
+        'summary': {'index_build_gbs_warm': value, 'per_device_build_ms': [round(x['build_s'] / args.steps * 1e3, 3) for x in state],
+                    'queries_per_sec_all_devices': round(N * nq * args.steps / search_s, 1), 'route': 'inproc'},
+        'build_ms': round(build_s / args.steps * 1e3, 3), 'search_ms': round(search_s / args.steps * 1e3, 3),
+        'per_device': state, 'multi_device_handles': handles,
+    }
+    return (1 if verified is False else 0), out
+
+
 # --------------------------------------------------------------------------------- file API --
 
 def run_e2e(args):
@@ -921,7 +1081,7 @@ def run_corpus(args, D, steps=None, warmup=None):
     return rc, out
 
 
-def launch_ranks(n: int) -> int:
+def launch_ranks(n: int, printed=None) -> int:
     """`python3 bench.py --gpus N` without a launcher: this process never touches a GPU; it starts N fresh copies of
     itself, one per GPU, with the torch.distributed environment of a one-node job (rendezvous on 127.0.0.1), lets
     rank 0's stdout through (the one JSON line) and returns the worst exit code.  A rank that dies takes the others
@@ -945,6 +1105,8 @@ def launch_ranks(n: int) -> int:
         for line in procs[0].stdout:
             (sys.stdout if line.startswith('{') else sys.stderr).write(line)
             sys.stdout.flush()
+            if printed is not None and line.startswith('{'):
+                printed.append(1)
 
     import threading
     fw = threading.Thread(target=forward, daemon=True)
@@ -995,9 +1157,22 @@ def main():
     ap.add_argument('--corpus15-queries', type=int, default=100000)
     ap.add_argument('--no-e2e', action='store_true', help='chunk config: skip the file-API leg (Writer -> .idx -> Reader)')
     ap.add_argument('--e2e-chunks', type=int, default=4)
+    ap.add_argument('--inproc', action='store_true',
+                    help='N GPUs inside ONE process (a host thread per device; no torch.distributed, no RCCL)')
     args = ap.parse_args()
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        sys.exit(launch_ranks(args.gpus))      # nothing has touched a GPU yet (torch is not even imported)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and not args.inproc:
+        printed = []
+        rc = launch_ranks(args.gpus, printed)      # nothing has touched a GPU yet (torch is not even imported)
+        if printed or os.environ.get('PSS_BENCH_NO_INPROC_FALLBACK'):
+            sys.exit(rc)
+        # The ranks route (one process per GPU, RCCL) printed no line: the same N GPUs inside this one process instead --
+        # a second, independent route to the number (its line says `route: inproc`).
+        sys.stderr.write('bench.py: the ranks route printed no line (exit code %d); falling back to --inproc\n' % rc)
+        args.inproc = True
+    if args.inproc and 'WORLD_SIZE' not in os.environ:
+        rc, out = run_inproc(args)
+        print(json.dumps(out), flush=True)
+        sys.exit(rc)
     leg = {'corpus15': False, 'bail': None}
     if int(os.environ.get('WORLD_SIZE', '1')) > 1:
         try:                                            # (a leftover of an earlier job on this port)

@@ -108,3 +108,40 @@ def test_bench_two_ranks_under_torchrun():
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     _check_two_ranks(_last_json(r.stdout))
+
+
+def _gpus() -> int:
+    import torch
+    return torch.cuda.device_count()       # (does not initialise the GPUs)
+
+
+def test_bench_inproc_route():
+    """`--inproc`: N GPUs inside one process, a host thread per device, no torch.distributed (on the one-GPU test box the
+    two "devices" take turns on GPU 0).  The line carries the weak-scaling build figure, the per-device times and the
+    check of the multi-device Writer / Reader handles against the one-device ones."""
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'PSS_BENCH_BACKEND'):
+        env.pop(k, None)
+    cmd = [sys.executable, 'bench.py', '--gpus', '2', '--inproc', '--steps', '2', '--warmup', '1', '--logn', '22', '--queries', '500']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d['route'] == 'inproc' and d['n_gpus'] == 2 and d['value'] > 0 and d['verified'] is True
+    assert len(d['per_device']) == 2 and all(x['verified'] is True for x in d['per_device'])
+    h = d['multi_device_handles']
+    assert h['writer_same_bytes_as_one_device'] is True and h['reader_same_results_as_one_device'] is True
+
+
+def test_bench_falls_back_to_inproc_when_the_ranks_route_prints_nothing():
+    """On a one-GPU box `python bench.py --gpus 2` over RCCL cannot start its second rank: no line from the ranks route,
+    so the same command answers through the in-process route instead of leaving the driver without a number."""
+    if _gpus() >= 2:
+        pytest.skip('the ranks route works here')
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'PSS_BENCH_BACKEND'):
+        env.pop(k, None)
+    cmd = [sys.executable, 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--logn', '22', '--queries', '500',
+           '--no-corpus15']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    d = _last_json(r.stdout)
+    assert d['route'] == 'inproc' and d['n_gpus'] == 2 and d['value'] > 0, r.stderr[-2000:]
