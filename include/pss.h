@@ -136,7 +136,10 @@ typedef struct pss_sa_stats {
                                   the same kind of text (same byte values, same size class) with the MSD sort and this
                                   build went straight to it (PSS_NO_PLAN_CACHE=1: never); 2: ... and recoded the text with
                                   the remembered alphabet inside the sort's first pass, without an alphabet pass of its
-                                  own (the pass checks that every byte has a code; PSS_NO_PLAN_FRONT=1: never) */
+                                  own (the pass checks that every byte has a code; PSS_NO_PLAN_FRONT=1: never); 3: no
+                                  plan, but the chunk's own symbol counts are close to uniform (sum p^2 < 0.035: log lines,
+                                  identifiers -- not natural language) and it went to the MSD sort the same way, without
+                                  recode pass and sizing sample */
     /* anchor round (ties that outlive the text rounds -- duplicated stretches of text -- are resolved by ONE round
      * keyed by the ranks of a content-defined sample of positions, the anchors, instead of log2(repeat length) rank
      * rounds over the whole text; anchor_impl.h) */
@@ -172,8 +175,12 @@ int32_t pss_sa_build(const uint8_t *T, int32_t *SA, int32_t n, int32_t device);
 
 /* Same, with T and SA already resident in the HBM of `device` (T must be
  * readable for n bytes, SA writable for n int32).  `flags` bit 0 = profile
- * mode (per-pass HIP events, fills ms_sort).  This is the timed region of
- * bench.py: inputs resident, no PCIe. */
+ * mode (per-pass HIP events, fills ms_sort); bit 1 = build without any plan
+ * shortcut (internal: restarts); bit 2 = no shortcut from the symbol counts of a
+ * first chunk (internal: restarts); bit 3 = forget what earlier builds on this
+ * device left behind first (a COLD build: what the first chunk of a corpus sees;
+ * bench.py's value_cold).  This is the timed region of bench.py: inputs resident,
+ * no PCIe. */
 int32_t pss_sa_build_device(const void *d_T, void *d_SA, int32_t n, int32_t device,
                             uint32_t flags, pss_sa_stats *stats);
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -89,11 +90,28 @@ struct ResidentMailbox {
         volatile uint32_t seq_b;
     } post;
     uint8_t query[256 + 64];         // queries of more than sizeof(Post::bytes) bytes
-    volatile uint32_t done_seq;      // kernel -> host: sequence number of the last query answered
+    // kernel -> host, ONE 8-byte system-scope store: the sequence number of the last query answered (low word) and the
+    // checksum of the query bytes the workgroups worked on (high word, xor over them) -- a torn read of the posted line
+    // shows there
+    volatile uint64_t done_seq_echo;
     volatile uint32_t exited;        //                 1: the kernel has left (lease over, or told to)
     volatile uint32_t closing;       //                 1: the kernel is about to leave and looks once more
-    volatile uint32_t pad2[13];
+    volatile uint32_t pad2[12];
 };
+static_assert(offsetof(ResidentMailbox, done_seq_echo) % 8 == 0, "one aligned 8-byte store");
+// Checksum of a posted query (FNV-1a over the zero-padded 8-byte words and the length): what the host expects in `echo`
+// from ONE workgroup; an even number of workgroups cancels to 0, an odd number leaves it.
+static inline uint32_t resident_query_checksum(const uint8_t *q, uint32_t plen)
+{
+    uint32_t h = 0x811C9DC5u ^ plen;
+    for (uint32_t i = 0; i < plen; i += 8) {
+        uint64_t w = 0;
+        for (uint32_t k = 0; k < 8 && i + k < plen; ++k) w |= (uint64_t)q[i + k] << (8 * k);
+        h = (h ^ (uint32_t)w) * 0x01000193u;
+        h = (h ^ (uint32_t)(w >> 32)) * 0x01000193u;
+    }
+    return h;
+}
 static_assert(sizeof(ResidentMailbox::Post) == 64, "the posted line is one cache line");
 constexpr uint32_t kResidentStop = 0xffffffffu;
 
@@ -130,7 +148,7 @@ struct DeviceCtx {
         uint32_t nc = 0, spread = 0;
         void *d_arena = nullptr;
         uint32_t seq = 0;
-        uint64_t launches = 0, served = 0;
+        uint64_t launches = 0, served = 0, torn = 0;
         void post(const uint8_t *q, uint32_t plen);      // next sequence number, query (or kResidentStop) into the mailbox
     } resident;
     static constexpr size_t kResidentMailboxOff = 24576;   // inside the first 32 KiB of the arena (search.hip, SM_OFF_*)

@@ -862,7 +862,10 @@ __global__ __launch_bounds__(MSD_BLOCK) void msd_local_sort_kernel(const u64 *in
 // counting the smaller ones -- neighbouring lanes sit in the same bin, so those LDS reads are broadcasts.
 // A tile with a bin above LS_KMAX elements (many equal or nearly equal keys) is handed to the general
 // kernel instead.
-constexpr int LS_BIN_BITS = 12;
+#ifndef PSS_LS_BIN_BITS
+#define PSS_LS_BIN_BITS 12
+#endif
+constexpr int LS_BIN_BITS = PSS_LS_BIN_BITS;
 constexpr u32 LS_BINS = 1u << LS_BIN_BITS;          // 16-bit counters, two per LDS word (a tile has < 8192 elements)
 constexpr u32 LS_WORDS = LS_BINS / 2;
 constexpr u32 LS_KMAX = 64;
@@ -972,12 +975,14 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
             scr[MSD_WAVES + 3] = 0;
         }
         {
-            // exclusive scan over the 4096 bins in place: four adjacent words = eight bins per thread
-            u32 c[8];
+            // exclusive scan over the bins in place: LS_WPT adjacent words = 2 LS_WPT bins per thread (four words at 4096 bins)
+            constexpr int LS_WPT = LS_WORDS / MSD_BLOCK;
+            static_assert(LS_WPT * MSD_BLOCK == (int)LS_WORDS && LS_WPT >= 1, "bins split evenly over the threads");
+            u32 c[2 * LS_WPT];
             u32 sum = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const u32 wv = hist[4 * tid + j];
+            for (int j = 0; j < LS_WPT; ++j) {
+                const u32 wv = hist[LS_WPT * tid + j];
                 c[2 * j] = wv & 0xffffu;
                 c[2 * j + 1] = wv >> 16;
                 sum += c[2 * j] + c[2 * j + 1];
@@ -988,9 +993,9 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
             u32 ex = incl - sum;
             for (int w = 0; w < wave_id(); ++w) ex += scr[w];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < LS_WPT; ++j) {
                 const u32 lo = ex, hi = ex + c[2 * j];
-                hist[4 * tid + j] = hist2[4 * tid + j] = lo | (hi << 16);
+                hist[LS_WPT * tid + j] = hist2[LS_WPT * tid + j] = lo | (hi << 16);
                 ex = hi + c[2 * j + 1];
             }
         }

@@ -2226,6 +2226,10 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     }
     const u32 n = (u32)n_in;
     const bool profile = flags & 1u;
+    if (flags & 8u) {                // a cold build: nothing of earlier builds on this device is used
+        ctx->plan_path = 0;
+        flags &= ~8u;                // (a restart of THIS build keeps what it has learnt)
+    }
     const Knobs knobs = Knobs::read();
     hipStream_t s = ctx->stream;
     if (n < 2) {
@@ -2373,7 +2377,24 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     }
     int kmax = 64 / b;
     if (kmax > 16) kmax = 16;
-    int key_chars = fronted ? kmax : choose_key_chars(h_small + 256, n, b, kmax);
+    // A first chunk (no plan yet) whose symbols are close to uniform -- log lines, identifiers, hex, base64: sum p^2 below
+    // 0.035; natural language sits at 0.065 and above -- goes to the MSD sort the way a planned chunk does: the sort's
+    // first histogram pass recodes the raw text with the table just built, no recode pass, no sizing sample (0.4 ms and a
+    // host round trip: what the sample would say is what the symbol counts say already).  The sort's exact bucket check
+    // still decides; a decline starts the build over along the long road (flags bit 2), at the price of the passes made.
+    bool fresh = false;
+    if (!fronted && plain && !knobs.no_front && (flags & 4u) == 0 && n >= (1u << 24) && sigma >= 2 && sigma < 256 &&
+        (reinterpret_cast<uintptr_t>(T) & 15u) == 0) {
+        double tot = 0, c2 = 0;
+        for (int c = 0; c < 256; ++c) tot += h_small[256 + c];
+        for (int c = 0; c < 256 && tot > 0; ++c) {
+            const double pr = h_small[256 + c] / tot;
+            c2 += pr * pr;
+        }
+        fresh = tot > 0 && c2 < 0.035;
+    }
+    const bool front_any = fronted || fresh;
+    int key_chars = front_any ? kmax : choose_key_chars(h_small + 256, n, b, kmax);
     const bool forced_chars = knobs.key_chars >= 1 && knobs.key_chars <= kmax;
     if (forced_chars) key_chars = knobs.key_chars;
     st.sigma = sigma;
@@ -2382,7 +2403,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     memcpy(h_small + 1024, lut, 256);
     PSS_HIP(hipMemcpyAsync(d_lut, h_small + 1024, 256, hipMemcpyHostToDevice, s));
     u32 *d_bad = d_counters + 44;
-    if (fronted) {
+    if (front_any) {
         // the codes are made by the sort (below); their padding past n and the flag for a byte without a code
         const size_t tail0 = (size_t)n & ~(size_t)15;
         PSS_HIP(hipMemsetAsync(codes + tail0, 0, n_pad - tail0, s));
@@ -2404,10 +2425,10 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     for (int c = 0; c < 256; ++c)
         if (plus_one || lut[c]) present_bits[c >> 5] |= 1u << (c & 31);
     int hint = 0;
-    if (fronted) hint = 1;
+    if (front_any) hint = 1;
     else if (plain && n >= (1u << 24) && ctx->plan_path && ctx->plan_logn == logn && memcmp(ctx->plan_present, present_bits, 32) == 0)
         hint = ctx->plan_path;
-    st.plan_hint = (uint64_t)(fronted ? 2 : hint);
+    st.plan_hint = (uint64_t)(fronted ? 2 : (fresh ? 3 : hint));
     if (hint) {
         sampled = true;
         msd_screen_ok = hint == 1;
@@ -2462,12 +2483,13 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
             act.st_idx = reinterpret_cast<u32 *>(K[0]) + n;
             const MsdFront front{T, d_lut, d_bad};
             PSS_TRY(msd_suffix_sort(ctx, &mk, n, kb, K, SA, ctx->slot[S_P0].p, h_small, profile, &ms, &accepted,
-                                    knobs.no_msd_fuse ? nullptr : &act, fronted ? &front : nullptr));
-            if (fronted && !accepted) {
+                                    knobs.no_msd_fuse ? nullptr : &act, front_any ? &front : nullptr));
+            if (front_any && !accepted) {
                 // the plan did not hold for this text (a byte outside the remembered alphabet, a crowded bucket): all
                 // over again without it -- the alphabet pass, the run-length and periodic-text checks, the sample
+                // (a first chunk taken on its symbol counts alone: the same, with that shortcut switched off)
                 ctx->plan_path = 0;
-                return sa_build_device(ctx, d_T, d_SA, n_in, flags, stats);
+                return sa_build_device(ctx, d_T, d_SA, n_in, fresh ? (flags | 4u) : flags, stats);
             }
             msd_fused = accepted && !knobs.no_msd_fuse;
             msd_active = act.count;
@@ -2491,9 +2513,9 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
             }
         }
     }
-    if (fronted && !msd_done) {              // (the sort was not even tried: nothing has made the codes)
+    if (front_any && !msd_done) {            // (the sort was not even tried: nothing has made the codes)
         ctx->plan_path = 0;
-        return sa_build_device(ctx, d_T, d_SA, n_in, flags, stats);
+        return sa_build_device(ctx, d_T, d_SA, n_in, fresh ? (flags | 4u) : flags, stats);
     }
     // Natural text (some 20-bit prefix holds far more suffixes than a tile, and a 64-bit key leaves most suffixes tied
     // anyway): sample sort over 16-byte [key | index] elements (ss_sort_impl.h) -- splitters from a sorted sample cut the

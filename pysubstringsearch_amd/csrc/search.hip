@@ -783,6 +783,7 @@ constexpr u32 SM_MAX_PLEN = 256;       // longest query the path takes (kept in 
 struct SmallHeader {   // device memory; all zero between launches (the last wave to finish resets it)
     u32 ent_cursor, byte_cursor, done;
     u32 leave;          // resident kernel: its first workgroup tells the others to leave
+    u32 echo;           // resident kernel: xor of the workgroups' query checksums (ResidentMailbox::echo)
 };
 struct SmallRecord {
     u32 ent_start, ent_count;
@@ -1191,7 +1192,9 @@ __global__ __launch_bounds__(SM_BLOCK) void search_resident_kernel(const ChunkDe
                     seq = seq_a;
                     break;
                 }
-                if ((spin & 7u) != 7u) continue;
+                // (the lease is looked at every eighth poll -- and at once when the query just answered ran past it: a host
+                // posting back to back would otherwise never let the idle polls, hence the clock, come round)
+                if ((spin & 7u) != 7u && !(first && spin == 0 && t_last - t_start > life_ticks)) continue;
                 if (first) {
                     const u64 now = wall_clock64();
                     if (now - t_last > idle_ticks || now - t_start > life_ticks) {
@@ -1242,6 +1245,15 @@ __global__ __launch_bounds__(SM_BLOCK) void search_resident_kernel(const ChunkDe
         seen = seq;
         if (tid >= plen && tid < SM_MAX_PLEN + 32) s_pat[tid] = 0;     // zero padding behind the query
         __syncthreads();
+        u32 ck = 0;
+        if (tid == 0) {             // what did THIS workgroup read off the posted line?  (resident_query_checksum, common.h)
+            ck = 0x811C9DC5u ^ plen;
+            for (u32 i = 0; i < plen; i += 8) {
+                const u64 wv = *reinterpret_cast<const u64 *>(s_pat + i);
+                ck = (ck ^ (u32)wv) * 0x01000193u;
+                ck = (ck ^ (u32)(wv >> 32)) * 0x01000193u;
+            }
+        }
         const bool wrote = block_pair(ch, s_pat, plen, sub, blockIdx.x, spread, hdr, h_overflow, rec, ent, bytes, hbytes,
                                       nc * spread == 1);
         stores_done();
@@ -1250,14 +1262,18 @@ __global__ __launch_bounds__(SM_BLOCK) void search_resident_kernel(const ChunkDe
         // result bytes are ordinary stores and stay there otherwise) -- a write-back per wave costs 4 us, one per
         // workgroup ~1, a workgroup without entries none (its record went out as a system-scope store)
         if (wrote && tid < kWave) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        if (tid == 0 && nc * spread != 1) __hip_atomic_fetch_xor(&hdr->echo, ck, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0 && (nc * spread == 1 || atomicAdd(&hdr->done, 1u) == nc * spread - 1)) {
             if (nc * spread != 1) {          // (a workgroup on its own never moves the cursors)
+                ck = __hip_atomic_load(&hdr->echo, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                 dev_store(&hdr->ent_cursor, 0u);
                 dev_store(&hdr->byte_cursor, 0u);
                 dev_store(&hdr->done, 0u);
+                dev_store(&hdr->echo, 0u);
                 stores_done();
             }
-            sys_store(&mb->done_seq, seq);
+            __hip_atomic_store(const_cast<u64 *>(&mb->done_seq_echo), (u64)seq | ((u64)ck << 32), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
         }
         t_last = wall_clock64();
     }
@@ -1275,6 +1291,7 @@ __global__ __launch_bounds__(SM_BLOCK) void search_resident_kernel(const ChunkDe
             dev_store(&hdr->byte_cursor, 0u);
             dev_store(&hdr->done, 0u);
             dev_store(&hdr->leave, 0u);
+            dev_store(&hdr->echo, 0u);
             stores_done();
             sys_store(&mb->exited, 1u);
         }
@@ -1317,6 +1334,10 @@ __global__ __launch_bounds__(256) void query_counts_kernel(u32 nc, u32 nq, const
 // same time), header of the resident kernel
 constexpr size_t SM_ARENA_RHDR = 64 + (size_t)SM_BYTE_CAP + 64;
 constexpr size_t SM_ARENA_BYTES = SM_ARENA_RHDR + 64;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "search.hip is written for gfx950 (MI355X): the fused search kernels keep ~72 KiB of LDS per workgroup (160 KiB per CU there; gfx90a / gfx942 stop at 64 KiB)"
+#endif
+
 enum SSlot { Q_BYTES = 10, Q_OFF, Q_LO, Q_CNT, Q_HITOFF, Q_START, Q_LEN, Q_EIDX, Q_BOFF, Q_ENTOFF, Q_OUT, Q_SMALL, Q_QCOUNT, Q_ARENA = 28, Q_HEAT = 46 };
 
 void HostResult::release()
@@ -1462,14 +1483,17 @@ static int resident_query(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, con
         R.post(q, plen);
         const u32 seq = R.seq;
         bool answered = false;
+        u64 done_pair = 0;
         const auto t0 = std::chrono::steady_clock::now();
         for (u32 spins = 0;; ++spins) {
-            if (__atomic_load_n(&mb->done_seq, __ATOMIC_ACQUIRE) == seq) {
+            done_pair = __atomic_load_n(&mb->done_seq_echo, __ATOMIC_ACQUIRE);
+            if ((u32)done_pair == seq) {
                 answered = true;
                 break;
             }
             if (__atomic_load_n(&mb->exited, __ATOMIC_ACQUIRE)) {
-                answered = __atomic_load_n(&mb->done_seq, __ATOMIC_ACQUIRE) == seq;   // (written before `exited`)
+                done_pair = __atomic_load_n(&mb->done_seq_echo, __ATOMIC_ACQUIRE);   // (written before `exited`)
+                answered = (u32)done_pair == seq;
                 break;
             }
             __builtin_ia32_pause();
@@ -1481,6 +1505,14 @@ static int resident_query(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, con
             }
         }
         if (answered) {
+            // Did every workgroup work on the bytes that were posted?  (The two sequence numbers at the ends of the line
+            // guard a read that the fabric splits in halves; a finer split could leave a stale word in the middle.)
+            const u32 one = resident_query_checksum(q, plen);
+            const u32 want = (nc * spread) % 2 ? one : 0u;
+            if ((u32)(done_pair >> 32) != want) {
+                ++R.torn;
+                return PSS_OK;                   // not served: the launch path answers this query
+            }
             // (no HIP events on this path: the time from the post to the answer as the host saw it)
             st->ms_device = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_post).count();
             st->ms_interval = st->ms_device;
@@ -1895,6 +1927,22 @@ __global__ __launch_bounds__(256) void merge_counts_kernel(MergeArgs a, u64 *out
     }
 }
 
+// What arrives over RCCL is data from another process: before anything is copied by its offsets, every rank's counts must
+// add up to its number of entries and its entry starts must ascend inside its bytes -- what pss_merge_packed checks on the
+// host.  *bad = 1 otherwise (the copy kernel would read and write out of bounds).
+__global__ __launch_bounds__(256) void merge_validate_kernel(MergeArgs a, u32 *bad)
+{
+    const u64 t0 = (u64)blockIdx.x * blockDim.x + threadIdx.x, step = (u64)gridDim.x * blockDim.x;
+    for (u32 r = 0; r < a.world; ++r) {
+        const MergeRank &m = a.r[r];
+        if (t0 == 0 && m.ebase[a.nq] != m.E) *bad = 1;
+        for (u64 e = t0; e < m.E; e += step) {
+            const u64 s0 = m.starts[e], s1 = e + 1 < m.E ? m.starts[e + 1] : m.B;
+            if (s0 > s1 || s1 > m.B) *bad = 1;
+        }
+    }
+}
+
 // one wavefront per (query, rank) segment: its entries' offsets, then its bytes
 __global__ __launch_bounds__(256) void merge_copy_kernel(MergeArgs a, const u64 *qbase /* [nq + 1] entries before query q */,
                                                            const u64 *sbase /* [nq * world + 1] bytes before segment */, u64 *out_offsets,
@@ -1932,6 +1980,15 @@ int merge_packed_device(DeviceCtx *ctx, u32 world, u64 nq, const void *const *d_
         B += num_bytes[r];
     }
     u64 *out_counts = static_cast<u64 *>(d_out_counts), *out_offsets = static_cast<u64 *>(d_out_offsets);
+    if (!out_counts || !out_offsets || (B && !d_out_bytes)) {
+        set_error("pss_merge_packed_device: null output buffer");
+        return PSS_EINVAL;
+    }
+    for (u32 r = 0; r < world; ++r)
+        if ((nq && !d_counts[r]) || (num_entries[r] && !d_starts[r]) || (num_bytes[r] && !d_bytes[r])) {
+            set_error("pss_merge_packed_device: null buffer of rank %u", r);
+            return PSS_EINVAL;
+        }
     if (nq == 0) {
         PSS_HIP(hipMemsetAsync(out_offsets, 0, 8, s));
         PSS_HIP(hipStreamSynchronize(s));
@@ -1958,6 +2015,20 @@ int merge_packed_device(DeviceCtx *ctx, u32 world, u64 nq, const void *const *d_
         PSS_TRY(device_excl_scan(ctx, InCounts{a.r[r].counts}, nq, partial, d_total, eb));
     }
     u64 *qbase = scr + (size_t)world * (nq + 1), *sbase = qbase + (nq + 1);
+    {
+        u32 *d_bad = reinterpret_cast<u32 *>(d_total + 4);
+        u32 *h_bad = static_cast<u32 *>(ctx->pinned);
+        PSS_HIP(hipMemsetAsync(d_bad, 0, 4, s));
+        const u32 gv = (u32)std::min<u64>((E + 255) / 256 + 1, (u64)ctx->num_cus * 8);
+        hipLaunchKernelGGL(merge_validate_kernel, dim3(gv), dim3(256), 0, s, a, d_bad);
+        PSS_HIP(hipMemcpyAsync(h_bad, d_bad, 4, hipMemcpyDeviceToHost, s));
+        PSS_HIP(hipStreamSynchronize(s));
+        if (*h_bad) {
+            set_error("pss_merge_packed_device: a rank's counts do not add up to its entries, or its entry starts do not ascend "
+                      "inside its bytes");
+            return PSS_EINVAL;
+        }
+    }
     const u32 grid = (u32)std::min<u64>((nq + 255) / 256, (u64)ctx->num_cus * 8);
     hipLaunchKernelGGL(merge_counts_kernel, dim3(grid), dim3(256), 0, s, a, out_counts);
     PSS_TRY(device_excl_scan(ctx, InCounts{out_counts}, nq, partial, d_total, qbase));

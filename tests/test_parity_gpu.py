@@ -935,6 +935,16 @@ def test_device_merge_equals_host_merge():
         hb, ho, hc = pdist.merge_packed_starts(per_rank_host) if nq else (np.zeros(0, np.uint8), np.zeros(1, np.int64), np.zeros(0, np.int64))
         db, do, dc = pdist.merge_on_device(per_rank_dev, nq)
         assert np.array_equal(dc, hc) and np.array_equal(do, ho) and np.array_equal(db, hb), (world, nq)
+    # What arrives from another process is checked before anything is copied by its offsets: counts that do not add up to
+    # the rank's entries, entry starts that do not ascend or leave the rank's bytes -> ValueError, as on the host.
+    blob = torch.arange(100, dtype=torch.uint8).cuda()
+    good = (blob, torch.tensor([0, 10, 50], dtype=torch.int64).cuda(), torch.tensor([1, 2, 0], dtype=torch.int64).cuda())
+    pdist.merge_on_device([good], 3)
+    for bad in ((blob, torch.tensor([0, 60, 50], dtype=torch.int64).cuda(), good[2]),            # starts descend
+                (blob, torch.tensor([0, 10, 500], dtype=torch.int64).cuda(), good[2]),           # a start beyond the bytes
+                (blob, good[1], torch.tensor([1, 1, 0], dtype=torch.int64).cuda())):             # counts != entries
+        with pytest.raises(ValueError):
+            pdist.merge_on_device([good, bad], 3)
 
 
 def test_single_query_over_many_chunks_with_thousands_of_hits(tmp_path, oracle):

@@ -165,7 +165,7 @@ def test_radix_sort_pairs_stable(n, bits):
 
 # ---- hybrid MSD initial sort (msd_sort.hip) ----
 
-def _sa_device(host, stats=None):
+def _sa_device(host, stats=None, flags=0):
     import ctypes
     import torch
     from pysubstringsearch_amd import _ffi
@@ -173,7 +173,7 @@ def _sa_device(host, stats=None):
     dT = torch.from_numpy(host).cuda()
     dSA = torch.empty(n, dtype=torch.int32, device='cuda')
     st = _ffi.SaStats()
-    _ffi.check(_ffi.lib.pss_sa_build_device(dT.data_ptr(), dSA.data_ptr(), n, 0, 0, ctypes.byref(st)))
+    _ffi.check(_ffi.lib.pss_sa_build_device(dT.data_ptr(), dSA.data_ptr(), n, 0, flags, ctypes.byref(st)))
     if stats is not None:
         stats.update(st.as_dict())
     return dSA.cpu().numpy()
@@ -304,7 +304,10 @@ def test_initial_sort_plan_is_reused_and_checked(oracle, monkeypatch, front):
     n = 1 << 24
     lines = gen_corpus(0, n)
     want = hashlib.sha256(oracle.sa(lines).tobytes()).hexdigest()
-    _sa_device(lines, {})
+    st = {}
+    _sa_device(lines, st, flags=8)       # (flags bit 3: a cold build, whatever earlier tests left on the device)
+    # a first chunk whose symbols are close to uniform goes to the MSD sort on its symbol counts alone (plan_hint 3)
+    assert (st['plan_hint'], st['msd']) == (3 if front else 0, 1)
     st = {}
     sa = _sa_device(lines, st)
     assert (st['plan_hint'], st['msd']) == (2 if front else 1, 1)
@@ -325,7 +328,7 @@ def test_initial_sort_plan_is_reused_and_checked(oracle, monkeypatch, front):
         assert 126 not in np.unique(lines)
         st = {}
         sa = _sa_device(odd, st)
-        assert (st['plan_hint'], st['msd']) == (0, 1)
+        assert (st['plan_hint'], st['msd']) == (3, 1)           # (rebuilt without the plan: a first chunk again)
         assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(odd).tobytes()).hexdigest()
         # ... which is the plan now; the old text is over a subset of that alphabet and takes the larger table
         st = {}
@@ -349,7 +352,7 @@ def test_initial_sort_plan_is_reused_and_checked(oracle, monkeypatch, front):
     assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(crowded).tobytes()).hexdigest()
     st = {}
     _sa_device(lines, st)
-    assert (st['plan_hint'], st['msd']) == (0, 1)             # the refusal cleared the plan
+    assert (st['plan_hint'], st['msd']) == (3 if front else 0, 1)      # the refusal cleared the plan
     _sa_device(lines, {})
     monkeypatch.setenv('PSS_NO_PLAN_CACHE', '1')              # (the build reads its switches on every call)
     st = {}
