@@ -342,6 +342,22 @@ typedef struct pss_device_result {
 int pss_reader_search_batch_device(pss_reader *r, const uint8_t *qbytes, const uint64_t *qoffsets,
                                    uint32_t nq, pss_device_result *out);
 /*
+ * Gather of per-rank packed results over RCCL, torch-free (one process per GPU; src/lib.rs:205-207, 280-284 is what it
+ * replaces: rayon tasks appending to one Vec under a mutex).  pss_comm_unique_id: 128 bytes (an ncclUniqueId) made by ONE
+ * rank and shipped to the others by any means; pss_comm_init: every rank, same id, its rank and its device (collective).
+ * pss_gather_packed_rccl: every rank of the communicator calls it with the pss_device_result of ITS chunks for the same
+ * queries (pss_reader_search_batch_device); rank dst receives the others' buffers device to device (one grouped
+ * ncclSend / ncclRecv batch), merges on its GPU (query-major, rank-major inside a query) and gets the packed result in
+ * *out (pss_result_*); the other ranks get *out = NULL.  The RCCL entry points are looked up at run time in the librccl
+ * the process has loaded (PSS_RCCL_LIB names another): libpss.so does not link it.
+ */
+typedef struct pss_comm pss_comm;
+int pss_comm_unique_id(uint8_t *id128);
+int pss_comm_init(const uint8_t *id128, int32_t world, int32_t rank, int32_t device, pss_comm **out);
+int pss_comm_destroy(pss_comm *c);
+int pss_gather_packed_rccl(pss_comm *c, const pss_device_result *mine, int32_t dst, pss_result **out);
+
+/*
  * Host merge of `world` packed results of the same nq queries (one per rank, each query-major) into one:
  * query-major, rank-major inside a query -- the cross-chunk concatenation of src/lib.rs:280-286 across
  * ranks.  counts[r] = u64[nq], offsets[r] = u64[num_entries[r]] entry starts, bytes[r] = num_bytes[r]

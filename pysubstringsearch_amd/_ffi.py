@@ -189,6 +189,10 @@ def _load() -> ctypes.CDLL:
         'pss_reader_search_batch_device': (ctypes.c_int, [vp, vp, vp, u32, ctypes.POINTER(DeviceResult)]),
         'pss_merge_packed': (ctypes.c_int, [u32, u64, vp, vp, vp, vp, vp, vp, vp, vp]),
         'pss_merge_packed_device': (ctypes.c_int, [i32, u32, u64, vp, vp, vp, vp, vp, vp, vp, vp]),
+        'pss_comm_unique_id': (ctypes.c_int, [vp]),
+        'pss_comm_init': (ctypes.c_int, [vp, i32, i32, i32, pvp]),
+        'pss_comm_destroy': (ctypes.c_int, [vp]),
+        'pss_gather_packed_rccl': (ctypes.c_int, [vp, ctypes.POINTER(DeviceResult), i32, pvp]),
         'pss_reload_env': (ctypes.c_int, []),
         'pss_reader_last_stats': (ctypes.c_int, [vp, ctypes.POINTER(SearchStats)]),
         'pss_reader_close': (ctypes.c_int, [vp]),

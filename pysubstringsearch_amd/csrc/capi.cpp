@@ -1,6 +1,7 @@
 // capi.cpp -- the extern "C" surface declared in include/pss.h: container
 // writer / reader (the .idx chunk-record format of reference src/lib.rs:105-124
 // and 162-199) around the device suffix-array builder and the device search.
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/vfs.h>
@@ -2007,6 +2008,243 @@ extern "C" int pss_merge_packed_device(int32_t device, uint32_t world, uint64_t 
         std::lock_guard<std::recursive_mutex> lk(ctx->mu);
         return merge_packed_device(ctx, world, nq, d_counts, d_starts, d_bytes, num_entries, num_bytes, d_out_counts, d_out_offsets,
                                    d_out_bytes);
+    });
+}
+
+// ---- gather of per-rank packed results over RCCL, inside the C ABI (round 4) -------------------------------------
+// One process per GPU (north_star: "RCCL over xGMI only to gather / dedupe result strings"): every rank has answered the
+// batch for its own chunks and holds a pss_device_result in HBM; the collecting rank receives the others' three buffers
+// device to device (one grouped ncclSend / ncclRecv batch, exact sizes, nothing padded), merges them on its GPU
+// (merge_packed_device) and brings ONE result down.  No torch: the RCCL entry points are looked up in whatever librccl
+// the process has loaded (dlopen: the library is not a link-time dependency of libpss.so), the communicator is built
+// from a 128-byte id that the caller ships to every rank by any means (a file, MPI, a torch.distributed broadcast).
+namespace {
+
+typedef struct { char internal[128]; } pss_nccl_id;      // ncclUniqueId
+typedef void *pss_nccl_comm;
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(pss_nccl_id *) = nullptr;
+    int (*CommInitRank)(pss_nccl_comm *, int, pss_nccl_id, int) = nullptr;
+    int (*CommDestroy)(pss_nccl_comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, pss_nccl_comm, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, pss_nccl_comm, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, pss_nccl_comm, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+constexpr int kNcclUint8 = 1, kNcclUint64 = 5;            // ncclUint8, ncclUint64 (rccl.h)
+
+RcclApi &rccl()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {getenv("PSS_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char *nm : names) {
+            if (!nm || !*nm) continue;
+            api.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);               // the copy the process already has (torch's), if any
+            if (!api.lib) api.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) return;
+        auto sym = [&](const char *n) { return dlsym(api.lib, n); };
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+        api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+        api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+        api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+        api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+        api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.GroupStart && api.GroupEnd && api.Send && api.Recv &&
+                 api.AllGather;
+    });
+    return api;
+}
+
+int rccl_check(int rc, const char *what)
+{
+    if (rc == 0) return PSS_OK;
+    RcclApi &a = rccl();
+    set_error("%s failed: %s", what, a.GetErrorString ? a.GetErrorString(rc) : "RCCL error");
+    return PSS_EDEVICE;
+}
+#define PSS_RCCL(expr) PSS_TRY(rccl_check((expr), #expr))
+
+constexpr int G_RECV = 47;      // DeviceCtx slot of the receive / merge buffers of the gather
+
+}  // namespace
+
+struct pss_comm {
+    pss_nccl_comm comm = nullptr;
+    int32_t world = 0, rank = 0, device = 0;
+};
+
+extern "C" int pss_comm_unique_id(uint8_t *id128)
+{
+    return guarded([&]() -> int {
+        if (!id128) return PSS_EINVAL;
+        RcclApi &a = rccl();
+        if (!a.ok) {
+            set_error("no usable librccl in this process (PSS_RCCL_LIB names one)");
+            return PSS_EDEVICE;
+        }
+        pss_nccl_id id;
+        PSS_RCCL(a.GetUniqueId(&id));
+        memcpy(id128, id.internal, 128);
+        return PSS_OK;
+    });
+}
+
+extern "C" int pss_comm_init(const uint8_t *id128, int32_t world, int32_t rank, int32_t device, pss_comm **out)
+{
+    return guarded([&]() -> int {
+        if (!id128 || !out || world < 1 || world > 16 || rank < 0 || rank >= world) {
+            set_error("pss_comm_init: bad arguments (1 .. 16 ranks)");
+            return PSS_EINVAL;
+        }
+        RcclApi &a = rccl();
+        if (!a.ok) {
+            set_error("no usable librccl in this process (PSS_RCCL_LIB names one)");
+            return PSS_EDEVICE;
+        }
+        DeviceCtx *ctx;
+        PSS_TRY(get_ctx(device, &ctx));
+        PSS_HIP(hipSetDevice(device));
+        pss_nccl_id id;
+        memcpy(id.internal, id128, 128);
+        pss_comm *c = new pss_comm();
+        c->world = world;
+        c->rank = rank;
+        c->device = device;
+        const int rc = rccl_check(a.CommInitRank(&c->comm, world, id, rank), "ncclCommInitRank");
+        if (rc != PSS_OK) {
+            delete c;
+            return rc;
+        }
+        *out = c;
+        return PSS_OK;
+    });
+}
+
+extern "C" int pss_comm_destroy(pss_comm *c)
+{
+    return guarded([&]() -> int {
+        if (!c) return PSS_OK;
+        if (c->comm) (void)rccl().CommDestroy(c->comm);
+        delete c;
+        return PSS_OK;
+    });
+}
+
+extern "C" int pss_gather_packed_rccl(pss_comm *c, const pss_device_result *mine, int32_t dst, pss_result **out)
+{
+    return guarded([&]() -> int {
+        if (!c || !mine || dst < 0 || dst >= c->world || (c->rank == dst && !out)) {
+            set_error("pss_gather_packed_rccl: bad arguments");
+            return PSS_EINVAL;
+        }
+        if (out) *out = nullptr;
+        RcclApi &a = rccl();
+        DeviceCtx *ctx;
+        PSS_TRY(get_ctx(c->device, &ctx));
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+        PSS_HIP(hipSetDevice(c->device));
+        hipStream_t s = ctx->stream;
+        const uint32_t W = (uint32_t)c->world;
+        const uint64_t nq = mine->num_queries;
+        // 1. who sends how much: (entries, bytes, queries) of every rank
+        PSS_TRY(ctx->slot[G_RECV].reserve(4096 + (size_t)W * 64));
+        uint64_t *d_sz = ctx->slot[G_RECV].as<uint64_t>();
+        uint64_t *h_sz = static_cast<uint64_t *>(ctx->pinned);
+        h_sz[0] = mine->num_entries;
+        h_sz[1] = mine->num_bytes;
+        h_sz[2] = nq;
+        h_sz[3] = 0;
+        PSS_HIP(hipMemcpyAsync(d_sz, h_sz, 32, hipMemcpyHostToDevice, s));
+        PSS_RCCL(a.AllGather(d_sz, d_sz + 8, 4, kNcclUint64, c->comm, s));
+        PSS_HIP(hipMemcpyAsync(h_sz + 8, d_sz + 8, (size_t)W * 32, hipMemcpyDeviceToHost, s));
+        PSS_HIP(hipStreamSynchronize(s));
+        std::vector<uint64_t> E(W), B(W);
+        uint64_t Et = 0, Bt = 0;
+        for (uint32_t r = 0; r < W; ++r) {
+            E[r] = h_sz[8 + 4 * r];
+            B[r] = h_sz[8 + 4 * r + 1];
+            if (h_sz[8 + 4 * r + 2] != nq) {
+                set_error("pss_gather_packed_rccl: rank %u answered %llu queries, this rank %llu", r,
+                          (unsigned long long)h_sz[8 + 4 * r + 2], (unsigned long long)nq);
+                return PSS_EINVAL;
+            }
+            Et += E[r];
+            Bt += B[r];
+        }
+        if ((uint32_t)c->rank != (uint32_t)dst) {
+            // 2a. a contributing rank: its three buffers go to dst as they are
+            PSS_RCCL(a.GroupStart());
+            if (nq) PSS_RCCL(a.Send(mine->d_counts, nq, kNcclUint64, dst, c->comm, s));
+            if (mine->num_entries) PSS_RCCL(a.Send(mine->d_offsets, mine->num_entries, kNcclUint64, dst, c->comm, s));
+            if (mine->num_bytes) PSS_RCCL(a.Send(mine->d_bytes, mine->num_bytes, kNcclUint8, dst, c->comm, s));
+            PSS_RCCL(a.GroupEnd());
+            PSS_HIP(hipStreamSynchronize(s));
+            return PSS_OK;
+        }
+        // 2b. the collecting rank: exact-size receive buffers, then the merge outputs, in one reservation
+        size_t need = 4096 + (size_t)W * 64;
+        std::vector<size_t> off_c(W), off_s(W), off_b(W);
+        for (uint32_t r = 0; r < W; ++r) {
+            if (r == (uint32_t)dst) continue;
+            off_c[r] = need; need += round_up((size_t)nq * 8 + 8, 256);
+            off_s[r] = need; need += round_up((size_t)E[r] * 8 + 8, 256);
+            off_b[r] = need; need += round_up((size_t)B[r] + 8, 256);
+        }
+        const size_t o_cnt = need; need += round_up((size_t)nq * 8 + 8, 256);
+        const size_t o_off = need; need += round_up((size_t)(Et + 1) * 8, 256);
+        const size_t o_byt = need; need += round_up((size_t)Bt + 8, 256);
+        PSS_TRY(ctx->slot[G_RECV].reserve(need));
+        uint8_t *base = ctx->slot[G_RECV].as<uint8_t>();
+        std::vector<const void *> pc(W), ps(W), pb(W);
+        PSS_RCCL(a.GroupStart());
+        for (uint32_t r = 0; r < W; ++r) {
+            if (r == (uint32_t)dst) {
+                pc[r] = mine->d_counts;
+                ps[r] = mine->d_offsets;
+                pb[r] = mine->d_bytes;
+                continue;
+            }
+            pc[r] = base + off_c[r];
+            ps[r] = base + off_s[r];
+            pb[r] = base + off_b[r];
+            if (nq) PSS_RCCL(a.Recv(base + off_c[r], nq, kNcclUint64, (int)r, c->comm, s));
+            if (E[r]) PSS_RCCL(a.Recv(base + off_s[r], E[r], kNcclUint64, (int)r, c->comm, s));
+            if (B[r]) PSS_RCCL(a.Recv(base + off_b[r], B[r], kNcclUint8, (int)r, c->comm, s));
+        }
+        PSS_RCCL(a.GroupEnd());
+        PSS_HIP(hipStreamSynchronize(s));
+        // 3. merge on the device (query-major, rank-major inside a query), one result down
+        PSS_TRY(merge_packed_device(ctx, W, nq, pc.data(), ps.data(), pb.data(), E.data(), B.data(), base + o_cnt, base + o_off,
+                                    base + o_byt));
+        pss_result *res = new pss_result();
+        res->r.nq = nq;
+        res->r.n_entries = Et;
+        res->r.n_bytes = Bt;
+        res->r.qcount = static_cast<uint64_t *>(calloc(nq ? nq : 1, 8));
+        res->r.offsets = static_cast<uint64_t *>(malloc((size_t)(Et + 1) * 8));
+        res->r.bytes = static_cast<uint8_t *>(malloc(Bt ? Bt : 1));
+        if (!res->r.qcount || !res->r.offsets || !res->r.bytes) {
+            pss_result_free(res);
+            set_error("host allocation of the gathered result failed");
+            return PSS_ENOMEM;
+        }
+        if (nq) PSS_HIP(hipMemcpyAsync(res->r.qcount, base + o_cnt, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
+        PSS_HIP(hipMemcpyAsync(res->r.offsets, base + o_off, (size_t)(Et + 1) * 8, hipMemcpyDeviceToHost, s));
+        if (Bt) PSS_HIP(hipMemcpyAsync(res->r.bytes, base + o_byt, Bt, hipMemcpyDeviceToHost, s));
+        PSS_HIP(hipStreamSynchronize(s));
+        *out = res;
+        return PSS_OK;
     });
 }
 

@@ -295,3 +295,62 @@ class ShardedReader:
 
     def search(self, substring: str, dst: int = 0):
         return self.search_multiple([substring], dst)
+
+
+class EngineComm:
+    """The engine's own RCCL communicator (include/pss.h, pss_comm_*): built from a 128-byte id that rank 0 makes and
+    ``share`` hands to every rank -- ``share(id_bytes_or_None) -> id_bytes`` is any broadcast the caller has (a
+    ``torch.distributed`` broadcast over gloo, MPI, a file).  With it the gather of per-rank results happens INSIDE the C
+    ABI (``pss_gather_packed_rccl``: grouped ncclSend / ncclRecv on the device results, device-side merge), no torch
+    tensor in the path: what a C or Rust host of the library calls."""
+
+    def __init__(self, rank: int, world: int, device: int, share):
+        import ctypes
+        from . import _ffi
+        buf = (ctypes.c_uint8 * 128)()
+        if rank == 0:
+            _ffi.check(_ffi.lib.pss_comm_unique_id(buf))
+        raw = share(bytes(buf) if rank == 0 else None)
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(raw)
+        self._h = ctypes.c_void_p()
+        self.rank, self.world, self.device = rank, world, device
+        _ffi.check(_ffi.lib.pss_comm_init(buf, world, rank, device, ctypes.byref(self._h)))
+
+    def gather(self, reader, patterns: typing.Sequence[bytes], dst: int = 0):
+        """Collective: every rank searches its own chunks (``reader``: a single-device Reader) and rank ``dst`` gets
+        (blob uint8, offsets int64[E + 1], counts int64[nq]) as numpy arrays, the others None."""
+        import ctypes
+        from . import _ffi
+        nq = len(patterns)
+        blob = b''.join(patterns)
+        offs = np.zeros(nq + 1, dtype=np.uint64)
+        if nq:
+            np.cumsum(np.fromiter(map(len, patterns), dtype=np.uint64, count=nq), out=offs[1:])
+        dr = _ffi.DeviceResult()
+        _ffi.check(_ffi.lib.pss_reader_search_batch_device(reader._handle(), blob, offs.ctypes.data, nq, ctypes.byref(dr)))
+        res = ctypes.c_void_p()
+        _ffi.check(_ffi.lib.pss_gather_packed_rccl(self._h, ctypes.byref(dr), dst, ctypes.byref(res)))
+        if self.rank != dst:
+            return None
+        try:
+            n = _ffi.lib.pss_result_num_entries(res)
+            counts = np.ctypeslib.as_array(_ffi.lib.pss_result_query_counts(res), shape=(max(nq, 1),))[:nq].astype(np.int64)
+            offsets = np.ctypeslib.as_array(_ffi.lib.pss_result_offsets(res), shape=(n + 1,)).astype(np.int64)
+            nbytes = int(offsets[n])
+            data = (np.ctypeslib.as_array(_ffi.lib.pss_result_bytes(res), shape=(max(nbytes, 1),))[:nbytes].copy()
+                    if nbytes else np.zeros(0, dtype=np.uint8))
+            return data, offsets, counts
+        finally:
+            _ffi.lib.pss_result_free(res)
+
+    def close(self) -> None:
+        from . import _ffi
+        if self._h:
+            h, self._h = self._h, None
+            _ffi.lib.pss_comm_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001
+            pass

@@ -28,6 +28,21 @@ def main():
             res[name] = {'counts': [int(c) for c in got[1]], 'entries': [e.decode('latin-1') for e in got[0]]}
         else:
             assert got is None
+    # the same gather INSIDE the C ABI (pss_gather_packed_rccl: the engine's own communicator, no torch tensor in the path);
+    # the 128-byte id travels over the process group that is already up
+    def share(raw):
+        box = [raw]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+    comm = pdist.EngineComm(rank, world, rank, share)
+    for name, batch in (('one', qs[:1]), ('few', qs[:40]), ('all', qs)):
+        got = comm.gather(r.local, batch, dst=0)
+        if rank == 0:
+            ents = pdist.packed_to_list(got[0], got[1])
+            res['cabi_' + name] = {'counts': [int(c) for c in got[2]], 'entries': [e.decode('latin-1') for e in ents]}
+        else:
+            assert got is None
+    comm.close()
     # the multi-device Writer with two distinct ordinals: same bytes as the single-device file
     if rank == 0:
         w = Writer(idx + '.multi', 1 << 16, devices=[0, 1])

@@ -56,6 +56,8 @@ def test_rccl_gather_and_multi_device_handles(tmp_path, oracle):
         for c in oc.tolist():
             assert sorted(got[name]['entries'][pos:pos + c]) == sorted(e.decode('latin-1') for e in oe[pos:pos + c])
             pos += c
+        assert got['cabi_' + name]['counts'] == oc.tolist(), name                     # the gather inside the C ABI
+        assert sorted(got['cabi_' + name]['entries']) == sorted(e.decode('latin-1') for e in oe)
     assert got['multi_writer_identical'] is True
     # and the single-process reader over the two real devices
     with pysubstringsearch.Reader(idx, devices=[0, 1]) as r:

@@ -966,3 +966,30 @@ def test_single_query_over_many_chunks_with_thousands_of_hits(tmp_path, oracle):
             assert len(got) == len(exp) and sorted(got) == sorted(exp), q
         assert max(o.search_multiple_bytes([b'e'])[1]) > 33 * 1025 / 2
 
+
+
+def test_rccl_gather_inside_the_c_abi_single_rank(tmp_path, oracle):
+    """pss_comm_* / pss_gather_packed_rccl with a communicator of ONE rank (all a one-GPU box can form): the RCCL entry
+    points are found in the process, the communicator comes up, the collecting rank's own device result goes through the
+    device-side merge and comes back equal to the oracle's.  The two-rank exchange runs in tests/test_dist_gpu.py."""
+    from tests.util import gen_corpus
+    from pysubstringsearch_amd import dist as pdist
+    src = tmp_path / 'c.txt'
+    src.write_bytes(gen_corpus(0, 1 << 18).tobytes())
+    p = str(tmp_path / 'c.idx')
+    w = pysubstringsearch.Writer(p, 1 << 16)
+    w.add_entries_from_file_lines(str(src))
+    w.close()
+    text = src.read_bytes()
+    rng = np.random.default_rng(3)
+    qs = [b'', b'e', b'zzzzzz'] + [text[s:s + int(rng.integers(1, 12))] for s in rng.integers(0, len(text) - 20, 2000)]
+    o = oracle.OracleReader(p)
+    comm = pdist.EngineComm(0, 1, 0, lambda raw: raw)
+    with pysubstringsearch.Reader(p, device=0) as r:
+        for batch in (qs[:1], qs[:40], qs, []):
+            data, offsets, counts = comm.gather(r, batch, dst=0)
+            oe, oc = o.search_multiple_bytes(batch) if batch else ([], np.zeros(0, np.int64))
+            assert counts.tolist() == list(oc)
+            got = pdist.packed_to_list(data, offsets)
+            assert sorted(got) == sorted(oe)
+    comm.close()
