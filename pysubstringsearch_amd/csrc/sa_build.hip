@@ -1726,7 +1726,8 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
         }
         if (round == 0 && mode == M_DENSE && subset) h = 1;           // (no text round was needed: the elements are symbols already)
         if (round == 0 && mode == M_DENSE && (subset || rank_only)) PSS_TRY(snapshot_symbols());
-        if (h >= (u64)n) {
+        // (subset mode counts h in SYMBOLS of the text while its text rounds run, in elements afterwards)
+        if (h >= (subset && mode == M_TEXT ? (u64)text_n : (u64)n)) {
             set_error("sa_build: %u suffixes unresolved at h=%llu >= n (internal error)", m_next,
                       (unsigned long long)h);
             return PSS_EDEVICE;

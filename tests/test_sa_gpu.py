@@ -630,3 +630,22 @@ def test_anchor_round_is_chosen_for_long_repeats_only(oracle):
         _ffi.check(_ffi.lib.pss_sa_build_device(dT.data_ptr(), dSA.data_ptr(), n, 0, 0, ctypes.byref(st)))
         assert int(st.anchor) == want and st.anchor_left == 0, (kind, n, st.anchor)
         assert (dSA.cpu().numpy() == oracle.sa(t)).all()
+
+
+def test_anchor_round_on_a_text_with_fewer_anchors_than_symbols_per_key(oracle, monkeypatch):
+    """Regression (tests/tools/fuzz.py, seed 4512): 891 bytes over two symbols with PSS_ANCHOR=1 -- the anchors' own sort
+    (subset mode) counts h in symbols of the text while its text rounds run, and a few dozen anchors are fewer than the 32
+    symbols of one key: the "h >= n" guard compared symbols with elements and refused the build."""
+    import os
+    monkeypatch.setenv('PSS_ANCHOR', '1')
+    monkeypatch.setenv('PSS_MODE', 'text')
+    monkeypatch.setenv('PSS_PERIOD', '0')
+    t = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'regress_anchor_tiny_subset.npy'))
+    assert (sa_gpu(t) == oracle.sa(t)).all()
+    rng = np.random.default_rng(4)
+    for n in (70, 200, 900, 3000):          # tiny texts full of repeats, narrow alphabets
+        for alpha in (2, 3):
+            blk = rng.integers(0, alpha, max(8, n // 5), dtype=np.uint8) + 190
+            t = np.resize(blk, n).copy()
+            t[rng.integers(0, n, 3)] = 190
+            assert (sa_gpu(t) == oracle.sa(t)).all(), (n, alpha)

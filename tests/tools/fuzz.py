@@ -82,7 +82,8 @@ def build(path, entries, limit, W):
 
 
 KNOBS = ('PSS_MODE', 'PSS_KEY_CHARS', 'PSS_KEY_DROP', 'PSS_TEXT_ROUNDS', 'PSS_NO_TIES_PASS', 'PSS_NO_SMALL_PATH', 'PSS_MSD',
-         'PSS_MSD_NO_FUSE', 'PSS_MSD_SLOW_LOCAL', 'PSS_NO_PINNED_RESULTS', 'PSS_NO_MID_TIER', 'PSS_RLE', 'PSS_RLE_SORT', 'PSS_PERIOD')
+         'PSS_MSD_NO_FUSE', 'PSS_MSD_SLOW_LOCAL', 'PSS_NO_PINNED_RESULTS', 'PSS_NO_MID_TIER', 'PSS_RLE', 'PSS_RLE_SORT', 'PSS_PERIOD', 'PSS_ANCHOR', 'PSS_ANCHOR_OMEGA',
+         'PSS_COUNT_SORT', 'PSS_NO_PROBE', 'PSS_DEVICES', 'PSS_WRITER_MMAP', 'PSS_IO_THREADS')
 
 
 def random_knobs(rng):
@@ -121,6 +122,18 @@ def random_knobs(rng):
             os.environ['PSS_RLE_SORT'] = '1'                     # ... with the radix-sort expansion
     if rng.random() < 0.3:
         os.environ['PSS_PERIOD'] = '0'                           # never the closed form for one repeated word
+    if rng.random() < 0.6:                                       # round 4: the anchor round forced on / off, narrow windows
+        os.environ['PSS_ANCHOR'] = rng.choice(['0', '1', '1'])
+        if rng.random() < 0.5:
+            os.environ['PSS_ANCHOR_OMEGA'] = str(rng.choice([9, 12, 17, 33]))
+        if rng.random() < 0.3:
+            os.environ['PSS_NO_PROBE'] = '1'
+    if rng.random() < 0.3:
+        os.environ['PSS_COUNT_SORT'] = '1'                       # rank rounds: counting instead of the segmented merge sort
+    if rng.random() < 0.3:
+        os.environ['PSS_DEVICES'] = rng.choice(['0', '0,0', '0,0,0', 'all'])      # the default device list of Writer / Reader
+    if rng.random() < 0.3:
+        os.environ['PSS_WRITER_MMAP'] = rng.choice(['0', '1'])   # records through a shared mapping / pwrite
     _ffi.lib.pss_reload_env()
 
 
