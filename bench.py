@@ -1030,12 +1030,27 @@ def run_corpus(args, D, steps=None, warmup=None):
         ms_dev = stats['ms_device']
         # No fraction of the HBM peak is claimed for the search: SURVEY's 58-probe model is not what this implementation
         # moves (key samples + 64-ary steps), and its traffic has not been measured with PMC counters.
-        roof = {'bound': 'hbm', 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None, 'traffic': None,
+        # Traffic of the batch's kernels by PMC (profiles/pmc_search_corpus15.json, tests/tools/pmc_search.sh: separate
+        # FETCH_SIZE / WRITE_SIZE runs of this workload at N = 1; raw request bytes -- the gather kernels read 64-byte sectors,
+        # for which the x 2 of streaming reads does not apply) over the device time measured in THIS run.
+        traffic = achieved = None
+        pmcs = os.path.join(ROOT, 'profiles', 'pmc_search_corpus15.json')
+        if os.path.exists(pmcs) and world == 1 and chunks == 15 and args.logn == 29 and len(queries) == 100000:
+            try:
+                traffic = json.load(open(pmcs)).get('total_bytes_raw')
+                achieved = round(traffic / ms_dev / 1e6, 1) if traffic and ms_dev else None
+            except Exception:
+                traffic = achieved = None
+        roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': None if achieved is None else round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                'traffic_source': None if traffic is None else 'profiles/pmc_search_corpus15.json (committed PMC runs of this workload; '
+                                  'raw FETCH_SIZE + WRITE_SIZE of the batch kernels, not measured in this run)',
                 'kernel': 'search pipeline of one batch on rank 0 (interval search, entry recovery, emit)',
                 'ms_device': round(ms_dev, 3), 'ms_interval': round(stats['ms_interval'], 3),
                 'survey_model_bytes': int(a_query),
                 'note': 'latency / transaction bound by construction (SURVEY 8(d)): graded on queries/s against the CPU path; '
-                        'no roofline fraction claimed (bytes of the SURVEY model are not the bytes this search moves)'}
+                        'achieved = measured fabric bytes of the batch kernels / device time of the batch (the bytes of the SURVEY '
+                        'model -- 58 dependent probes -- are not the bytes this search moves)'}
         qps = len(queries) * steps / total_s
         out = {
             'metric': METRIC, 'value': None if verified is False else round(qps, 1), 'unit': 'queries/s',

@@ -1,0 +1,56 @@
+#!/bin/bash
+# Everything profiles/ holds for a round, in one call on the GPU box (about 25 minutes):
+#   tests/tools/round_evidence.sh r04        -> gpurun_out/ev/*  (summaries only; copy what is to be kept into profiles/)
+tag=${1:-r04}
+root=$GRAFT_REPO_ROOT; [ -z "$root" ] && root=$(pwd)
+ev=$root/gpurun_out/ev; mkdir -p $ev
+cd $root
+# 1. the GPU suite
+timeout 1200 python -m pytest tests -q -m gpu > $ev/${tag}_pytest_gpu.log 2>&1
+tail -3 $ev/${tag}_pytest_gpu.log
+# 2. the driver's command
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $ev/${tag}_bench_default.json 2> $ev/bench_default.err
+# 3. kernel stats under rocprofv3
+cd /tmp && export TMPDIR=/tmp; cd $root
+PSS_BENCH_NO_SECONDARY=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ev/prof_bench -o t -- python3 bench.py --no-cpu-baseline --no-corpus15 --no-e2e > $ev/${tag}_bench_under_rocprof.json 2>/dev/null
+cp $ev/prof_bench/t_kernel_stats.csv $ev/${tag}_bench_kernel_stats.csv
+for spec in lines:12 words:5 dup_blocks:3 mixed:3; do
+  c=${spec%%:*}; k=${spec#*:}
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ev/prof_$c -o t -- python3 tests/tools/sa_perf.py $c 29 $k > $ev/prof_$c.log 2>&1
+  cp $ev/prof_$c/t_kernel_stats.csv $ev/${tag}_sa_build_${c}_kernel_stats.csv
+  python tests/tools/timeline.py $ev/prof_$c/t_kernel_trace.csv 400 > $ev/${tag}_timeline_$c.txt 2>&1
+done
+# 4. HBM traffic by PMC (separate FETCH_SIZE / WRITE_SIZE passes)
+mkdir -p $ev/json
+for spec in lines:3 words:2 dup_blocks:2 mixed:2; do
+  c=${spec%%:*}; k=${spec#*:}
+  timeout 900 tests/tools/pmc_traffic.sh $ev/pmc_$c $c $k > /dev/null 2>&1
+  python tests/tools/pmc_traffic_json.py $ev/pmc_$c $k $ev/json $c > $ev/pmc_$c.ratios.txt 2>&1
+done
+timeout 600 tests/tools/pmc_requests.sh $ev/pmcreq_words words 1 > /dev/null 2>&1
+python tests/tools/pmc_requests_json.py $ev/pmcreq_words $ev/json/pmc_requests_words.json 1 > $ev/pmc_requests_words.txt 2>&1
+timeout 1500 tests/tools/pmc_search.sh $ev/pmc_search > /dev/null 2>&1
+msd=$(python - <<P
+import json
+try:
+    d = json.loads(open('$ev/${tag}_bench_default.json').read().strip().splitlines()[-1])
+    print(d['corpus15']['ms_device'])
+except Exception:
+    print('')
+P
+)
+python tests/tools/pmc_search_json.py $ev/pmc_search $ev/json/pmc_search_corpus15.json $msd > $ev/pmc_search.txt 2>&1
+# 5. the file API
+python tests/tools/e2e_file.py 29 4 multi dir=/tmp check > $ev/${tag}_e2e_file_4x512MiB.txt 2>&1
+python tests/tools/e2e_file.py 29 4 dir=/dev/shm >> $ev/${tag}_e2e_file_4x512MiB.txt 2>&1
+python tests/tools/e2e_file.py 29 15 dir=/tmp > $ev/${tag}_e2e_file_15x512MiB.txt 2>&1
+# 6. single-query latency against the number of results
+python tests/tools/latency_hits.py 29 1 > $ev/lat1.txt 2>&1; tail -1 $ev/lat1.txt > $ev/${tag}_latency_vs_results_1chunk.json
+python tests/tools/latency_hits.py 29 1 resident > $ev/lat1r.txt 2>&1; tail -1 $ev/lat1r.txt > $ev/${tag}_latency_vs_results_1chunk_low_latency.json
+python tests/tools/latency_hits.py 29 15 > $ev/lat15.txt 2>&1; tail -1 $ev/lat15.txt > $ev/${tag}_latency_vs_results_15chunks.json
+python tests/tools/latency_hits.py 29 15 resident > $ev/lat15r.txt 2>&1; tail -1 $ev/lat15r.txt > $ev/${tag}_latency_vs_results_15chunks_low_latency.json
+# 7. fuzzing of the final code
+(echo "# tests/tools/fuzz.py 300; FUZZ_BIG=1 fuzz.py 300; fuzz_search.py 200; anchor_check.py 150"; timeout 500 python tests/tools/fuzz.py 300 7001 2>&1 | tail -1; FUZZ_BIG=1 timeout 500 python tests/tools/fuzz.py 300 7002 2>&1 | tail -1; timeout 700 python tests/tools/fuzz_search.py 200 7003 2>&1 | tail -1; timeout 300 python tests/tools/anchor_check.py 150 7004 2>&1 | tail -1) > $ev/${tag}_fuzz.txt 2>&1
+# keep the summaries only
+rm -rf $ev/prof_* $ev/pmc_lines $ev/pmc_words $ev/pmc_dup_blocks $ev/pmc_mixed $ev/pmcreq_words $ev/pmc_search
+ls -la $ev $ev/json
