@@ -623,6 +623,8 @@ def run_chunk(args, D):
     D.sync_all()
     total_s = time.perf_counter() - t_begin
     sa_stats = st.as_dict()
+    per_rank_build_ms = [round(x / args.steps * 1e3, 3) for x in D.gather_floats(build_s)]        # (collective: every rank)
+    per_rank_search_ms = [round(x / args.steps * 1e3, 3) for x in D.gather_floats(search_s)]
     build_s, search_s, total_s = D.max_over_ranks([build_s, search_s, total_s])
 
     # the suffix array the last timed step left in dSA: is it the reference's?
@@ -874,6 +876,8 @@ def run_chunk(args, D):
             'build_ms': round(build_s / args.steps * 1e3, 3),
             'build_ms_first_chunk': round(sized_ms, 3), 'plan_hint': int(sa_stats.get('plan_hint', 0)), 'plan_hint_first_chunk': cold_hint,
             'search_ms': round(search_s / args.steps * 1e3, 3),
+            'per_rank_build_ms': per_rank_build_ms, 'per_rank_search_ms': per_rank_search_ms,
+            'ranks': world, 'gather': None if world == 1 else f'{D.backend} (torch.distributed P2P, device-side merge on rank 0)',
             'entries_per_batch': last.get('entries'),
             'search_stats': last.get('search_stats'),
             'sa_stats': {k: sa_stats[k] for k in ('sigma', 'code_bits', 'key_chars', 'initial_passes', 'rounds',

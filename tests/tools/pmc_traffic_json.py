@@ -25,13 +25,20 @@ ALGO = {   # algorithmic bytes per element of the kernels of the initial sort (D
     'ss_digits1_kernel': 3, 'ss_scatter_kernel<true>': 19, 'ss_digits2_kernel': 18, 'ss_scatter_kernel<false>': 34,
     'ss_local_kernel': 20,
 }
+# Kernels whose reads are GATHERS (one 64-byte request per element: a random 4-byte rank, 32 bytes of text at a random
+# offset): for them FETCH_SIZE is what it says.  Calibrated in round 4 with the request counters themselves
+# (profiles/pmc_requests_words.json: text_keys makes 0.99 read requests per element, all of them counted at 64 B -- at
+# 128 B each the kernel would have moved 6.7 TB/s, above what the chip sustains for streaming; ss_local, which streams
+# 16 B per lane, makes one request per 128 B).  Every other kernel reads wide and coalesced: FETCH x 2 (guide, "HBM").
+GATHER = ('text_keys_kernel', 'rank_keys_kernel', 'subset_keys_kernel', 'gather_names_kernel', 'build_keys_kernel',
+          'probe_repeats_kernel', 'sample_keys_kernel', 'ss_sample_kernel')
 n = 1 << 29
 kernels, total = {}, 0.0
 for name, cs in agg.items():
     short = name.replace('void ', '').replace('pss::', '').split('(')[0]
     fk, wk = cs.get('FETCH_SIZE', []), cs.get('WRITE_SIZE', [])
     launches = max(len(fk), len(wk)) / builds
-    f_b = sum(fk) / builds * 1024 * 2
+    f_b = sum(fk) / builds * 1024 * (1 if short.split('<')[0] in GATHER else 2)
     w_b = sum(wk) / builds * 1024
     total += f_b + w_b
     per = (f_b + w_b) / max(launches, 1)
@@ -43,7 +50,8 @@ for name, cs in agg.items():
     kernels[short] = e
 src = ('tests/tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) around default-config '
        f'pss_sa_build_device calls on the {corpus} corpus, n = 2^29')
-corr = 'bytes = FETCH_SIZE_KB * 1024 * 2 (gfx950 counts 64 B per 128-B request) + WRITE_SIZE_KB * 1024'
+corr = ('bytes = FETCH_SIZE_KB * 1024 * 2 (gfx950 counts 64 B per 128-B request of a wide coalesced read) + WRITE_SIZE_KB * 1024; '
+        'x 1 instead of x 2 for the gather kernels (' + ', '.join(GATHER) + '): their requests are 64 bytes, see profiles/pmc_requests_words.json')
 big = {k: v for k, v in kernels.items() if v['bytes_per_launch'] * v['launches_per_build'] > 50e6}
 if corpus == 'lines':
     json.dump({'source': src, 'correction': corr, 'kernels': big}, open(f'{out}/pmc_traffic.json', 'w'), indent=1)
