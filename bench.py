@@ -1222,17 +1222,96 @@ def main():
                 # A peer can fail in the corpus15 leg while this rank is still on its way there (assembling its configs[1]
                 # result): give the main thread a moment to reach the leg, where the line it has can be printed.  A rank
                 # that is stuck in a collective of configs[1] itself never gets there and leaves empty-handed.
+                if leg.get('fallback'):
+                    continue                # rank 0 is producing the line through the in-process route: the line comes first
                 for _ in range(300):
+                    if leg.get('fallback'):
+                        break
                     if leg['corpus15'] and leg['bail'] is not None:
                         leg['bail']('terminated by the launcher during the corpus15 leg (another rank failed)')
                     if leg.get('past'):
                         break
                     time.sleep(0.1)
+                if leg.get('fallback'):
+                    continue
                 os._exit(143)
         threading.Thread(target=watch_term, daemon=True).start()
-    D = Dist(args)
+    # The ranks route has never met real peers (the builder's boxes have one GPU).  If its configs[1] leg does not finish --
+    # RCCL does not come up, a collective hangs, a rank dies with an exception -- the N-GPU number is still wanted: rank 0
+    # then runs the SAME workload through the in-process route (a fresh process: this one may be stuck inside a
+    # collective) over all the devices and prints that line (`route: inproc`, with the reason); the other ranks just leave.
+    ranks_abort = os.path.join('/tmp', 'pss_bench_ranks_abort_%s' % os.environ.get('MASTER_PORT', '0'))
+    chunk_done = None
+
+    def ranks_fallback(reason):
+        rank = int(os.environ.get('RANK', '0'))
+        try:
+            with open(ranks_abort, 'a') as f:
+                f.write(f'rank {rank}: {reason}\n')
+        except OSError:
+            pass
+        if rank != 0:
+            os._exit(0)                 # (0: a launcher that sees a failed rank tears rank 0 down with it)
+        leg['fallback'] = True          # (SIGTERM is ignored from here on: the line comes first)
+        time.sleep(3.0)                 # the others leave their GPUs
+        import subprocess
+        env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR',
+                                                                 'MASTER_PORT', 'GROUP_RANK', 'ROLE_RANK', 'TORCHELASTIC_RUN_ID')}
+        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(args.gpus), '--inproc', '--steps', str(args.steps),
+               '--warmup', str(args.warmup), '--logn', str(args.logn), '--corpus', args.corpus, '--qlen', str(args.qlen)]
+        if args.queries:
+            cmd += ['--queries', str(args.queries)]
+        code, line = 1, None
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+            code = r.returncode
+            line = next((ln for ln in r.stdout.splitlines() if ln.startswith('{')), None)
+        except Exception as e:      # noqa: BLE001
+            reason += f'; the in-process route failed too: {type(e).__name__}: {e}'
+        if line:
+            try:
+                d = json.loads(line)
+                d['fallback_reason'] = f'the ranks route (one process per GPU, {os.environ.get("PSS_BENCH_BACKEND", "nccl")}) did not finish: ' + reason[:400]
+                line = json.dumps(d)
+            except Exception:       # noqa: BLE001
+                pass
+            print(line, flush=True)
+        else:
+            print(json.dumps({'metric': METRIC, 'value': None, 'unit': 'GB/s', 'n_gpus': args.gpus, 'error': reason[:600]}), flush=True)
+        os._exit(code)
+
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 and args.config == 'chunk' and not os.environ.get('PSS_BENCH_NO_INPROC_FALLBACK'):
+        try:
+            os.remove(ranks_abort)
+        except OSError:
+            pass
+        chunk_done = threading.Event()
+        limit = float(os.environ.get('PSS_BENCH_RANKS_TIMEOUT', '600'))
+
+        def watch_ranks():
+            t0 = time.time()
+            while not chunk_done.is_set():
+                time.sleep(0.5)
+                if os.path.exists(ranks_abort) and not chunk_done.is_set():
+                    ranks_fallback('another rank gave up')
+                if time.time() - t0 > limit and not chunk_done.is_set():
+                    ranks_fallback(f'configs[1] not finished after {limit:.0f} s')
+        threading.Thread(target=watch_ranks, daemon=True).start()
+    try:
+        D = Dist(args)
+        if args.config == 'chunk':
+            if os.environ.get('PSS_BENCH_HANG_RANK') == os.environ.get('RANK', '0'):      # test hook: this rank never gets there
+                time.sleep(3600)
+            rc, out = run_chunk(args, D)
+    except Exception as e:      # noqa: BLE001
+        if chunk_done is None:
+            raise
+        import traceback
+        traceback.print_exc()
+        ranks_fallback(f'{type(e).__name__}: {e}'[:300])
+    if chunk_done is not None:
+        chunk_done.set()
     if args.config == 'chunk':
-        rc, out = run_chunk(args, D)
         if D.world == 1 and not args.no_e2e and out is not None:
             import torch
             torch.cuda.empty_cache()

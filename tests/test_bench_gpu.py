@@ -145,3 +145,18 @@ def test_bench_falls_back_to_inproc_when_the_ranks_route_prints_nothing():
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     d = _last_json(r.stdout)
     assert d['route'] == 'inproc' and d['n_gpus'] == 2 and d['value'] > 0, r.stderr[-2000:]
+
+
+def test_bench_ranks_route_that_hangs_falls_back_on_rank_0():
+    """The ranks route (one process per GPU) has never met real peers: when its configs[1] leg does not finish (test hook:
+    rank 1 never arrives, rank 0 waits in the first collective), rank 0 runs the same workload through the in-process
+    route in a fresh process and prints THAT line, with the reason; the other ranks leave quietly."""
+    env = dict(os.environ, PSS_BENCH_BACKEND='gloo', PSS_BENCH_HANG_RANK='1', PSS_BENCH_RANKS_TIMEOUT='25')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--logn', '22', '--queries', '500',
+           '--no-corpus15']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    d = _last_json(r.stdout)
+    assert d['route'] == 'inproc' and d['n_gpus'] == 2 and d['value'] > 0 and d['verified'] is True, r.stderr[-2000:]
+    assert 'did not finish' in d['fallback_reason']
