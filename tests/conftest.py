@@ -8,6 +8,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The suite's expectations (HBM budgets, residency, which context holds what) are written for ONE device; handles
+# opened without a device argument use every visible GPU by default (pss_default_devices), so the session pins the
+# default list to device 0.  The tests of the default list itself (test_default_device_list,
+# test_unchanged_call_uses_the_default_device_list, tests/test_dist_gpu.py) set or unset the variable themselves.
+os.environ.setdefault('PSS_DEVICES', '0')
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
     # a fresh checkout has no built artefacts (they are git-ignored): build them once
