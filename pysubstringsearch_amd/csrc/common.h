@@ -124,7 +124,7 @@ struct DeviceCtx {
     int device = -1;
     hipStream_t stream = nullptr;
     int num_cus = 256;
-    static constexpr int kSlots = 48;
+    static constexpr int kSlots = 56;
     DevBuf slot[kSlots];
     static constexpr size_t kPinnedBytes = (size_t)640 << 10;   // 64 KiB of counters / small tables / query staging, 64 KiB of
                                                                 // result bytes, 512 KiB of entry records (search.hip, SM_OFF_*)
@@ -159,9 +159,12 @@ struct DeviceCtx {
     // would only say so again (sa_build.hip; a wrong guess is caught by the sorts' own exact checks and costs one restart).
     uint32_t plan_present[8] = {};
     uint32_t plan_logn = 0;
-    int plan_path = 0;                   // 0 none, 1 hybrid MSD
+    int plan_path = 0;                   // 0 none, 1 hybrid MSD, 2 sample sort
     uint8_t plan_lut[256] = {};          // ... and its byte -> code table (the next build recodes with it inside the sort)
     uint32_t plan_sigma = 0;
+    // ... 2: it took the sample sort, whose sorted sample (slot S_SSPLAN of sa_build.hip) cuts the next chunk of that
+    // exact size and alphabet too
+    uint32_t ss_plan_n = 0, ss_plan_radix = 0;
     // Two pinned staging buffers + a copy stream: file <-> HBM transfers are
     // double-buffered so the PCIe copy of piece i overlaps the file I/O of piece i+1.
     static constexpr size_t kStage = (size_t)64 << 20;

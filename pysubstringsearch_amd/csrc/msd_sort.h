@@ -61,6 +61,11 @@ struct SsBuffers {
     uint64_t *K[2];        // >= S entries each: scratch of the sample's sort
     uint32_t *V[2];
     void *sort_work;       // radix_sort_workspace_bytes()
+    // The plan of the sample sort (round 4): the SORTED sample of the previous chunk of the same corpus cuts this chunk
+    // as well as a sample of its own would -- bucket sizes follow the same distribution either way (the noise is in the
+    // four sample members per bucket, not in which chunk they came from) -- and any splitters give the exact result.
+    const void *sample_in = nullptr;     // use these S sorted sample elements, draw and sort none
+    void *sample_keep = nullptr;         // a copy of the sorted sample goes here (16 S bytes)
 };
 // Sample members drawn for n suffixes (0: the path does not take texts of this size).
 uint32_t ss_sample_count(uint32_t n);

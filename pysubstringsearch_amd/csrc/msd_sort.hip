@@ -1465,6 +1465,9 @@ int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t radix, uint32_
     E16 *E0 = static_cast<E16 *>(buf.E0), *E = static_cast<E16 *>(buf.E);
     PSS_TRY(mark());                                                                       // [0]
     // ---- the sample, sorted as 128-bit numbers ----
+    if (buf.sample_in) {
+        E = const_cast<E16 *>(static_cast<const E16 *>(buf.sample_in));      // (read only from here on)
+    } else {
     hipLaunchKernelGGL(ss_sample_kernel, dim3((S + 255) / 256), dim3(256), 0, s, tx, S, E0, buf.K[0], buf.V[0]);
     if (S <= 8192) {
         // (small texts, tests: the device sort's one-workgroup path is not stable, which the second of the chained sorts needs)
@@ -1484,6 +1487,8 @@ int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t radix, uint32_
         const int hi_bits = std::min(64, std::max(1, g.key_bits + g.ib - 64));
         PSS_TRY(radix_sort_pairs(ctx, K, V, S, hi_bits, 0xffu, nullptr, d1, buf.sort_work, &d2, false, &ss1));
         hipLaunchKernelGGL(ss_gather_elems_kernel, dim3((S + 255) / 256), dim3(256), 0, s, E0, (const u32 *)V[d2], S, E);
+    }
+    if (buf.sample_keep) PSS_HIP(hipMemcpyAsync(buf.sample_keep, E, (size_t)S * 16, hipMemcpyDeviceToDevice, s));
     }
     PSS_TRY(mark());                                                                       // [1]
 

@@ -1417,7 +1417,7 @@ static void rerank_geometry(u32 m, RerankArgs &a)
     a.num_ranges = (a.num_tiles + a.tiles_per_range - 1) / a.tiles_per_range;
 }
 
-enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK, S_GRP2 = 26, S_BIG = 27, S_SCR = 29, S_SSA = 30, S_SSB = 31, S_ANC = 32 /* .. 38: one per level */, S_X0 = 39 /* .. 45 */ };      // (10 .. 23, 28: search.hip; 24, 25: capi.cpp)
+enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK, S_GRP2 = 26, S_BIG = 27, S_SCR = 29, S_SSA = 30, S_SSB = 31, S_ANC = 32 /* .. 38: one per level */, S_X0 = 39 /* .. 45 */, S_SSPLAN = 48 };      // (10 .. 23, 28: search.hip; 24, 25: capi.cpp)
 
 // Initial key width.  Model the text as i.i.d. with per-symbol collision
 // probability c = sum p_i^2 (from the sampled counts): two suffixes agree on k
@@ -2546,7 +2546,12 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         sb.K[0] = K[0]; sb.K[1] = K[1];
         sb.V[0] = v_scratch; sb.V[1] = (final_buf == 0) ? V[1] : V[0];     // (never the caller's SA buffer)
         sb.sort_work = work;
-        (void)S;
+        // the plan: the previous chunk of this corpus (same size, same alphabet) left its sorted sample behind
+        const u32 radix = plus_one ? 257u : sigma + 1u;
+        const bool planned = hint == 2 && ctx->ss_plan_n == n && ctx->ss_plan_radix == radix && ctx->slot[S_SSPLAN].p != nullptr;
+        if (planned) sb.sample_in = ctx->slot[S_SSPLAN].p;
+        else if (plain && ctx->slot[S_SSPLAN].reserve((size_t)S * 16) == PSS_OK) sb.sample_keep = ctx->slot[S_SSPLAN].p;
+        ctx->ss_plan_n = 0;                                                // (valid again once this sort has been accepted)
         MsdActive act;
         act.pos = ctx->slot[S_P1].as<u32>();
         act.idx = (final_buf == 0) ? V[1] : V[0];
@@ -2577,6 +2582,11 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
             cur = final_buf;
             ss.launches = 4;
             ss.elems = 4ull * n;
+            if (sb.sample_in || sb.sample_keep) {
+                ctx->ss_plan_n = n;
+                ctx->ss_plan_radix = radix;
+            }
+            st.ss_planned = sb.sample_in ? 1 : 0;
         }
         }
     }
@@ -2586,7 +2596,9 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         return sa_build_device(ctx, d_T, d_SA, n_in, flags, stats);
     }
     if (plain && n >= (1u << 24) && !fronted) {
-        ctx->plan_path = st.msd ? 1 : 0;      // only the sort whose own exact check can refuse a text is taken unsampled
+        // (the MSD sort's own exact check can refuse a text; the sample sort takes any text, and a bucket beyond a tile --
+        // with remembered splitters as unlikely as with fresh ones -- declines: both start over without the plan)
+        ctx->plan_path = st.msd ? 1 : (st.ss && ctx->ss_plan_n == n ? 2 : 0);
         ctx->plan_logn = logn;
         memcpy(ctx->plan_present, present_bits, 32);
         memcpy(ctx->plan_lut, lut, 256);
