@@ -157,6 +157,9 @@ typedef struct pss_sa_stats {
     uint64_t anchor_levels;    /* anchor levels stacked: 1 = anchors of the text; 2 = anchors of the string of their names, ... */
     uint64_t probe_pairs;      /* before the first text round: neighbours of the active list sampled from one group ... */
     uint64_t probe_same;       /* ... and those that share 48 more symbols (most of them: the ties are repeats, no text round) */
+    uint64_t periodic_rounds;  /* rank rounds (of any anchor level) in which large groups took the periodic key: members of a run of
+                                  period p <= h ordered by how far the period goes on and how it breaks, not by ISA[i + h] */
+    uint64_t periodic_members; /* ... and the members of those groups, summed over the rounds */
     uint64_t ss_planned;       /* 1: the sample sort cut this chunk with the sorted sample of the previous chunk of the same
                                   size and alphabet (no sample of its own, no sizing sample: plan_hint = 1 with ss = 1) */
     uint64_t ss_declined_nomem; /* 1: no room in HBM for the sample sort's two 16 n-byte element buffers -- the build went on

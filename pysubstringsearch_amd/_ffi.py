@@ -82,6 +82,8 @@ class SaStats(ctypes.Structure):
         ('anchor_levels', ctypes.c_uint64),
         ('probe_pairs', ctypes.c_uint64),
         ('probe_same', ctypes.c_uint64),
+        ('periodic_rounds', ctypes.c_uint64),
+        ('periodic_members', ctypes.c_uint64),
         ('ss_planned', ctypes.c_uint64),
         ('ss_declined_nomem', ctypes.c_uint64),
         ('anchor_ms', ctypes.c_double),

@@ -1297,6 +1297,245 @@ __global__ __launch_bounds__(256) void big_writeback_kernel(const u32 *order, co
     }
 }
 
+// ---- periodic runs inside a rank round (round 4) ----------------------------------------------------------------
+// Prefix doubling resolves a run of period p and length L in log2(L / h) rounds, every one of them over nearly all of
+// the run: at depth h the suffixes of one phase form one group, their keys ISA[i + h] are the (equal) ranks of another
+// phase, and only those within 2 h of the run's end come apart.  The order inside such a group is known without
+// looking further than the end of the run, though.  Let the group's common h-prefix have period p <= h, and let
+// l(i) >= h be how far that period goes on from member i (T[i + x] = T[i + x - p] for p <= x < l(i), not at x = l(i)).
+// Members i, j with l(i) < l(j) agree on l(i) symbols -- both continue the same prefix periodically -- and then i has
+// its break symbol T[i + l(i)] where j has the periodic one, T[i + l(i) - p]: i < j iff the break symbol is the smaller
+// (type L; the end of the string is the smallest symbol), whatever l(j) is.  So the group is ordered by
+//     ( type L: 0, l ascending | type G: 1, l descending ),  then the rank of the suffix at the break, i + l(i),
+// and members that tie on all three share l + h >= 2 h symbols: a valid doubling round, finer than it need be.
+// The members of a run are found from their positions: i and i + p (p <= h) in one group means T[i .. i + p + h) has
+// period p, so in position order the members of a run are a chain of steps p, and l(i) = l(z) + z - i for the chain's
+// last member z, whose l(z) < h + p comes from at most p symbol comparisons.  A group takes the periodic key when its
+// steps <= h all equal one p and at least half of its members have such a step; every other group keeps ISA[i + h].
+// Only the groups beyond the LDS sorts (> 3072 members) are looked at: shorter runs need a dozen rounds at most.
+struct PerSyms {
+    const u32 *names;     // the symbols of an integer string, or
+    const u8 *codes;      // the codes of the text
+    u32 n;
+};
+__device__ __forceinline__ long long per_sym(const PerSyms &y, u64 i)
+{
+    if (i >= y.n) return -1;
+    return y.names ? (long long)y.names[i] : (long long)y.codes[i];
+}
+
+__global__ __launch_bounds__(256) void per_pack_kernel(const u32 *bt, const u32 *bgid, const u32 *idx, u32 nbig, int idx_bits,
+                                                         u64 *pk, u32 *pv)
+{
+    for (u32 e = blockIdx.x * blockDim.x + threadIdx.x; e < nbig; e += gridDim.x * blockDim.x) {
+        pk[e] = ((u64)bgid[e] << idx_bits) | (u64)idx[bt[e]];
+        pv[e] = e;
+    }
+}
+
+// step[r] = distance to the next member of the same group in position order (0: none); pmin[g] = smallest step <= h;
+// gsize[g] = members.  The list is sorted by group and every wave walks a contiguous piece of it, keeping the tallies
+// of the group it is in and handing them over when the group changes: a handful of atomics per wave, not one per row
+// (1.1 M atomics on seven addresses cost 23 ms at 18 M members).
+__device__ __forceinline__ u32 per_wave_min(u32 v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = min(v, (u32)__shfl_xor((int)v, o));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void per_steps_kernel(const u64 *pk, u32 nbig, int idx_bits, u32 h, u32 *step, u32 *pmin,
+                                                          u32 *gsize)
+{
+    const u64 mask = (1ull << idx_bits) - 1;
+    const u32 waves = gridDim.x * (blockDim.x / kWave), wid = blockIdx.x * (blockDim.x / kWave) + wave_id();
+    const u32 nrow = (nbig + kWave - 1) / kWave, per = (nrow + waves - 1) / waves;
+    const u32 row0 = min(nrow, wid * per), row1 = min(nrow, row0 + per);
+    u32 cg = 0xffffffffu, csize = 0, cmin = 0xffffffffu;
+    auto flush = [&]() {
+        if (cg != 0xffffffffu && lane_id() == 0) {
+            atomicAdd(&gsize[cg], csize);
+            if (cmin != 0xffffffffu) atomicMin(&pmin[cg], cmin);
+        }
+    };
+    for (u32 row = row0; row < row1; ++row) {
+        const u32 r = row * kWave + lane_id();
+        const bool valid = r < nbig;
+        u32 g = 0xffffffffu, d = 0;
+        if (valid) {
+            const u64 a = pk[r];
+            g = (u32)(a >> idx_bits);
+            if (r + 1 < nbig) {
+                const u64 c = pk[r + 1];
+                if ((u32)(c >> idx_bits) == g) d = (u32)((c & mask) - (a & mask));
+            }
+            step[r] = d;
+        }
+        u64 todo = __ballot(valid);
+        while (todo) {
+            const int first = __ffsll((unsigned long long)todo) - 1;
+            const u32 g0 = __shfl(g, first);
+            const bool in = valid && g == g0;
+            const u64 same = __ballot(in);
+            const u32 mn = per_wave_min((in && d != 0 && d <= h) ? d : 0xffffffffu);
+            if (g0 != cg) {
+                flush();
+                cg = g0;
+                csize = 0;
+                cmin = 0xffffffffu;
+            }
+            csize += (u32)__popcll(same);
+            cmin = min(cmin, mn);
+            todo &= ~same;
+        }
+    }
+    flush();
+}
+
+// links[g] = members whose step is pmin[g]; bad[g] = some step <= h is another one; out[1] += members whose step
+// equals their successor's (a run whose period the depth has not reached yet shows up like that), out[2] = the smallest such step.
+__global__ __launch_bounds__(256) void per_check_kernel(const u64 *pk, const u32 *step, u32 nbig, int idx_bits, u32 h,
+                                                          const u32 *pmin, u32 *links, u32 *bad, u32 *out)
+{
+    const u32 waves = gridDim.x * (blockDim.x / kWave), wid = blockIdx.x * (blockDim.x / kWave) + wave_id();
+    const u32 nrow = (nbig + kWave - 1) / kWave, per = (nrow + waves - 1) / waves;
+    const u32 row0 = min(nrow, wid * per), row1 = min(nrow, row0 + per);
+    u32 cg = 0xffffffffu, clinks = 0, cbad = 0, carith = 0, cstep = 0xffffffffu;
+    auto flush = [&]() {
+        if (cg != 0xffffffffu && lane_id() == 0) {
+            if (clinks) atomicAdd(&links[cg], clinks);
+            if (cbad) atomicOr(&bad[cg], 1u);
+        }
+    };
+    for (u32 row = row0; row < row1; ++row) {
+        const u32 r = row * kWave + lane_id();
+        const bool valid = r < nbig;
+        u32 g = 0xffffffffu, d = 0;
+        bool link = false, wrong = false, arith = false;
+        if (valid) {
+            g = (u32)(pk[r] >> idx_bits);
+            d = step[r];
+            const u32 p = pmin[g];
+            link = d != 0 && d == p;
+            wrong = d != 0 && d <= h && d != p;
+            arith = d != 0 && r + 1 < nbig && step[r + 1] == d;
+        }
+        carith += (u32)__popcll(__ballot(arith));
+        cstep = min(cstep, per_wave_min(arith ? d : 0xffffffffu));
+        u64 todo = __ballot(valid);
+        while (todo) {
+            const int first = __ffsll((unsigned long long)todo) - 1;
+            const u32 g0 = __shfl(g, first);
+            const u64 same = __ballot(valid && g == g0);
+            const u64 bl = __ballot(link && g == g0), bw = __ballot(wrong && g == g0);
+            if (g0 != cg) {
+                flush();
+                cg = g0;
+                clinks = 0;
+                cbad = 0;
+            }
+            clinks += (u32)__popcll(bl);
+            cbad |= bw ? 1u : 0u;
+            todo &= ~same;
+        }
+    }
+    flush();
+    if (lane_id() == 0 && carith) {
+        atomicAdd(&out[1], carith);
+        atomicMin(&out[2], cstep);      // the shortest step that repeats: no period below it can show up later
+    }
+}
+
+constexpr u32 PER_MAX_PERIOD = 1u << 16;
+// pg[g] = the period the group's key is made with, or 0: the group keeps the plain key.  out[0] += members of periodic groups.
+__global__ __launch_bounds__(256) void per_decide_kernel(const u32 *pmin, const u32 *gsize, const u32 *links, const u32 *bad,
+                                                           u32 ngroups, u32 *pg, u32 *out)
+{
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 mine = 0;
+    if (g < ngroups) {
+        const u32 p = pmin[g];
+        const bool yes = p != 0xffffffffu && p <= PER_MAX_PERIOD && !bad[g] && (u64)links[g] * 2 >= (u64)gsize[g];
+        pg[g] = yes ? p : 0u;
+        if (yes) mine = gsize[g];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mine += (u32)__shfl_xor((int)mine, o);
+    if (lane_id() == 0 && mine) atomicAdd(&out[0], mine);
+}
+
+// flag[r] = member r ends a chain of a periodic group (no successor at the group's step)
+__global__ __launch_bounds__(256) void per_flag_kernel(const u64 *pk, const u32 *step, u32 nbig, int idx_bits, const u32 *pg,
+                                                         u32 *flag)
+{
+    for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < nbig; r += gridDim.x * blockDim.x) {
+        const u32 p = pg[(u32)(pk[r] >> idx_bits)];
+        flag[r] = (p != 0 && step[r] != p) ? 1u : 0u;
+    }
+}
+
+// One wave per chain end z (the c[r]-th): l(z) by comparing symbols from h on (fewer than p of them hold), the type of the
+// break, the rank of the suffix at the break.
+__global__ __launch_bounds__(256) void per_ends_kernel(const u64 *pk, const u32 *flag, const u64 *c, u32 nbig, int idx_bits,
+                                                         const u32 *pg, u32 h, PerSyms y, const u32 *ISA, u32 *epos, u32 *eell,
+                                                         u64 *etail)
+{
+    const u64 mask = (1ull << idx_bits) - 1;
+    const u32 lane = lane_id();
+    const u32 waves = gridDim.x * (blockDim.x / kWave);
+    const u32 nrow = (nbig + kWave - 1) / kWave;
+    for (u32 row = blockIdx.x * (blockDim.x / kWave) + wave_id(); row < nrow; row += waves) {
+        const u32 r = row * kWave + lane;
+        const bool mine = r < nbig && flag[r];
+        u64 todo = __ballot(mine);
+        while (todo) {
+            const int src = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const u32 rr = row * kWave + (u32)src;
+            const u64 a = pk[rr];
+            const u32 z = (u32)(a & mask), p = pg[(u32)(a >> idx_bits)];
+            const u64 lim = (u64)y.n - z;      // (l(z) < h + p when the groups are the classes of depth h; they may be finer)
+            u64 ell = lim;
+            for (u64 x0 = h; x0 < lim; x0 += kWave) {
+                const u64 x = x0 + lane;
+                const bool differs = x < lim && per_sym(y, z + x) != per_sym(y, z + x - p);
+                const u64 bd = __ballot(differs);
+                if (bd) { ell = x0 + (u64)(__ffsll((unsigned long long)bd) - 1); break; }
+            }
+            if ((int)lane == src) {
+                const u64 k = c[rr];
+                const long long brk = per_sym(y, (u64)z + ell), per = per_sym(y, (u64)z + ell - p);
+                const u64 type = brk < per ? 0ull : 1ull;
+                const u64 rank = ((u64)z + ell < y.n) ? (u64)ISA[(u64)z + ell] : 0ull;
+                epos[k] = z;
+                eell[k] = (u32)ell;
+                etail[k] = (type << 63) | rank;
+            }
+        }
+    }
+}
+
+// The key of every member of a periodic group: ( type | l or its complement | rank at the break ), into the list of the
+// large groups and into the key plane of the round (the write-back and the regrouping read it there).
+__global__ __launch_bounds__(256) void per_keys_kernel(const u64 *pk, const u32 *pv, const u64 *c, u32 nbig, int idx_bits,
+                                                         const u32 *pg, const u32 *epos, const u32 *eell, const u64 *etail,
+                                                         const u32 *bt, u64 *bkey, u64 *slot_key)
+{
+    const u64 mask = (1ull << idx_bits) - 1;
+    for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < nbig; r += gridDim.x * blockDim.x) {
+        const u64 a = pk[r];
+        if (pg[(u32)(a >> idx_bits)] == 0) continue;
+        const u64 k = c[r];                       // chain ends before r = the ordinal of the end of r's chain
+        const u64 ell = (u64)(epos[k] - (u32)(a & mask)) + eell[k];
+        const u64 t = etail[k];
+        const u64 field = (t >> 63) ? (0x7fffffffull - ell) : ell;
+        const u64 key = (t & (1ull << 63)) | (field << 32) | (t & 0xffffffffull);
+        const u32 e = pv[r];
+        bkey[e] = key;
+        slot_key[bt[e]] = key;
+    }
+}
+
 __global__ __launch_bounds__(256) void iota_kernel(u32 *v, u32 n)
 {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1417,7 +1656,7 @@ static void rerank_geometry(u32 m, RerankArgs &a)
     a.num_ranges = (a.num_tiles + a.tiles_per_range - 1) / a.tiles_per_range;
 }
 
-enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK, S_GRP2 = 26, S_BIG = 27, S_SCR = 29, S_SSA = 30, S_SSB = 31, S_ANC = 32 /* .. 38: one per level */, S_X0 = 39 /* .. 45 */, S_SSPLAN = 48 };      // (10 .. 23, 28: search.hip; 24, 25: capi.cpp)
+enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK, S_GRP2 = 26, S_BIG = 27, S_SCR = 29, S_SSA = 30, S_SSB = 31, S_ANC = 32 /* .. 38: one per level */, S_X0 = 39 /* .. 45 */, S_SSPLAN = 48, S_PER = 49 };      // (10 .. 23, 28: search.hip; 24, 25: capi.cpp)
 
 // Initial key width.  Model the text as i.i.d. with per-symbol collision
 // probability c = sum p_i^2 (from the sampled counts): two suffixes agree on k
@@ -1472,6 +1711,7 @@ struct Knobs {
     int anchor_omega = 0;       // PSS_ANCHOR_OMEGA  force the window of the minimizers (0 = as wide as the known common prefix allows)
     bool no_probe = false;      // PSS_NO_PROBE   always a text round before the anchor round (no sampling of the ties)
     bool count_sort = false;    // PSS_COUNT_SORT  rank rounds: groups ranked by counting (group_sort_kernel) instead of the merge sort
+    bool no_periodic = false;   // PSS_PERIODIC=0  rank rounds: no periodic keys for the large groups (per_*_kernel)
     bool timing = false;        // PSS_TIMING     per-round trace on stderr
     static Knobs read()
     {
@@ -1498,6 +1738,7 @@ struct Knobs {
         if (const char *e = getenv("PSS_ANCHOR_OMEGA")) k.anchor_omega = atoi(e);
         k.no_probe = getenv("PSS_NO_PROBE") != nullptr;
         k.count_sort = getenv("PSS_COUNT_SORT") != nullptr;
+        { const char *e = getenv("PSS_PERIODIC"); k.no_periodic = e && atoi(e) == 0; }
         k.timing = getenv("PSS_TIMING") != nullptr;
         return k;
     }
@@ -1655,11 +1896,17 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
     // Integer strings (rank rounds only): the ranks the first round leaves ARE the string, up to renaming -- kept for the
     // minimizers of an anchor level on top of this one (anchor_impl.h), should the rounds reach depth 32 with much left tied.
     u32 *X0 = nullptr;
+    const u32 *Xsym = nullptr;   // the same snapshot for the periodic keys of the rank rounds (per_*_kernel), never given up
+    bool last_per = false;       // the last rank round met periodic runs among its large groups, or chains that will be
+    u64 per_wait_h = 0;          // ... and the depth from which their period can be seen
     auto snapshot_symbols = [&]() -> int {
-        if (knobs.anchor == 0 || io.level >= 6 || n < (knobs.anchor == 1 ? 64u : (1u << 20))) return PSS_OK;
+        const bool for_levels = !(knobs.anchor == 0 || io.level >= 6 || n < (knobs.anchor == 1 ? 64u : (1u << 20)));
+        if (!for_levels && (knobs.no_periodic || io.level >= 6 || n <= 3072u)) return PSS_OK;
         PSS_TRY(ctx->slot[S_X0 + io.level].reserve((size_t)n * 4));
-        X0 = ctx->slot[S_X0 + io.level].as<u32>();
-        PSS_HIP(hipMemcpyAsync(X0, ISA, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        u32 *snap = ctx->slot[S_X0 + io.level].as<u32>();
+        PSS_HIP(hipMemcpyAsync(snap, ISA, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        if (for_levels) X0 = snap;
+        Xsym = snap;
         return PSS_OK;
     };
     for (int round = 0;; ++round) {
@@ -1818,13 +2065,75 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
                                d_off_heads, d_bt, BK[0], d_bgid);
             PSS_HIP(hipStreamSynchronize(s));
             const u32 nbig_groups = h_small[0];
+            int gid_bits = 1;
+            while ((1ull << gid_bits) < (u64)nbig_groups) ++gid_bits;
+            int big_key_bits = use_text ? kt * b : rank_bits;
+            last_per = false;
+            const bool per_syms = (subset || rank_only) ? Xsym != nullptr : codes != nullptr;
+            if (per_wait_h > h && nbig >= 2) last_per = true;      // (chains seen, their period still ahead of the depth)
+            if (!use_text && !key_of_suffix && !knobs.no_periodic && per_syms && nbig >= 2 && h < (1ull << 31) && h >= per_wait_h) {
+                // periodic runs among the large groups: their members get the key that orders them at once (per_*_kernel)
+                int idx_bits = 1;
+                while ((1ull << idx_bits) < (u64)n) ++idx_bits;
+                const size_t g4 = round_up((size_t)nbig_groups * 4, 64), e4 = round_up((size_t)nbig * 4, 64), e8 = round_up((size_t)nbig * 8 + 8, 64);
+                if (ctx->slot[S_PER].reserve(e8 + e4 + e4 + e4 + e8 + e4 + e4 + e8 + 5 * g4 + 256) == PSS_OK) {
+                    u8 *pb = ctx->slot[S_PER].as<u8>();
+                    size_t po = 0;
+                    auto pcarve = [&](size_t bytes) { u8 *q = pb + po; po += bytes; return q; };
+                    u64 *PK[2] = {reinterpret_cast<u64 *>(pcarve(e8)), BK[1]};
+                    u32 *PV[2] = {reinterpret_cast<u32 *>(pcarve(e4)), BV[1]};
+                    u32 *d_step = reinterpret_cast<u32 *>(pcarve(e4)), *d_flag = reinterpret_cast<u32 *>(pcarve(e4));
+                    u64 *d_c = reinterpret_cast<u64 *>(pcarve(e8));
+                    u32 *d_epos = reinterpret_cast<u32 *>(pcarve(e4)), *d_eell = reinterpret_cast<u32 *>(pcarve(e4));
+                    u64 *d_etail = reinterpret_cast<u64 *>(pcarve(e8));
+                    u32 *d_pmin = reinterpret_cast<u32 *>(pcarve(g4));
+                    u32 *d_gsize = reinterpret_cast<u32 *>(pcarve(4 * g4 + 256));        // gsize, links, bad, pg, out: zeroed together
+                    u32 *d_links = d_gsize + g4 / 4, *d_bad = d_links + g4 / 4, *d_pg = d_bad + g4 / 4, *d_out = d_pg + g4 / 4;
+                    const u32 pgrid = std::min<u32>((nbig + 255) / 256, (u32)ctx->num_cus * 16);
+                    const u32 wgrid = std::min<u32>((nbig + 255) / 256, (u32)ctx->num_cus * 4);      // (waves that walk contiguous pieces)
+                    PSS_HIP(hipMemsetAsync(d_pmin, 0xff, g4, s));
+                    PSS_HIP(hipMemsetAsync(d_gsize, 0, 4 * g4 + 256, s));
+                    PSS_HIP(hipMemsetAsync(d_out + 2, 0xff, 4, s));
+                    hipLaunchKernelGGL(per_pack_kernel, dim3(pgrid), dim3(256), 0, s, d_bt, d_bgid, V[src], nbig, idx_bits, PK[0], PV[0]);
+                    int dp = 0;
+                    SortStats sp;
+                    PSS_TRY(radix_sort_pairs(ctx, PK, PV, nbig, gid_bits + idx_bits, 0xffffffffu, nullptr, 0, work, &dp, false, &sp));
+                    hipLaunchKernelGGL(per_steps_kernel, dim3(wgrid), dim3(256), 0, s, PK[dp], nbig, idx_bits, h32, d_step, d_pmin, d_gsize);
+                    hipLaunchKernelGGL(per_check_kernel, dim3(wgrid), dim3(256), 0, s, PK[dp], d_step, nbig, idx_bits, h32, d_pmin,
+                                       d_links, d_bad, d_out);
+                    hipLaunchKernelGGL(per_decide_kernel, dim3((nbig_groups + 255) / 256), dim3(256), 0, s, d_pmin, d_gsize, d_links,
+                                       d_bad, nbig_groups, d_pg, d_out);
+                    PSS_HIP(hipMemcpyAsync(h_small, d_out, 12, hipMemcpyDeviceToHost, s));
+                    PSS_HIP(hipStreamSynchronize(s));
+                    const u32 per_members = h_small[0], arith = h_small[1];
+                    // most of the list in chains whose step the depth has not reached: nothing to find before it has
+                    per_wait_h = (per_members == 0 && (u64)arith * 2 >= (u64)nbig && h_small[2] != 0xffffffffu) ? h_small[2] : 0;
+                    if (knobs.timing)
+                        fprintf(stderr, "[pss] rank round: h=%llu large-group members=%u in periodic groups=%u, equal steps=%u\n",
+                                (unsigned long long)h, nbig, per_members, arith);
+                    last_per = per_members != 0 || (u64)arith * 4 >= (u64)nbig;
+                    if (per_members) {
+                        const PerSyms y{(subset || rank_only) ? Xsym : nullptr, (subset || rank_only) ? nullptr : codes, n};
+                        hipLaunchKernelGGL(per_flag_kernel, dim3(pgrid), dim3(256), 0, s, PK[dp], d_step, nbig, idx_bits, d_pg, d_flag);
+                        PSS_TRY(device_excl_scan(ctx, InU32{d_flag}, nbig, d_partial, d_total, d_c));
+                        hipLaunchKernelGGL(per_ends_kernel, dim3(pgrid), dim3(256), 0, s, PK[dp], d_flag, d_c, nbig, idx_bits, d_pg, h32,
+                                           y, ISA, d_epos, d_eell, d_etail);
+                        hipLaunchKernelGGL(per_keys_kernel, dim3(pgrid), dim3(256), 0, s, PK[dp], PV[dp], d_c, nbig, idx_bits, d_pg, d_epos,
+                                           d_eell, d_etail, d_bt, BK[0], K[src]);
+                        big_key_bits = 64;
+                        st.periodic_rounds += 1;
+                        st.periodic_members += per_members;
+                    }
+                    st.round_passes += (u32)sp.launches;
+                } else {
+                    (void)hipGetLastError();
+                    set_error("%s", "");
+                }
+            }
             hipLaunchKernelGGL(iota_kernel, dim3((nbig + 255) / 256), dim3(256), 0, s, BV[0], nbig);
             SortStats s1, s2;
             int d1 = 0, d2 = 0;
-            PSS_TRY(radix_sort_pairs(ctx, BK, BV, nbig, use_text ? kt * b : rank_bits, 0xffffffffu, nullptr, 0, work, &d1,
-                                     profile, &s1));
-            int gid_bits = 1;
-            while ((1ull << gid_bits) < (u64)nbig_groups) ++gid_bits;
+            PSS_TRY(radix_sort_pairs(ctx, BK, BV, nbig, big_key_bits, 0xffffffffu, nullptr, 0, work, &d1, profile, &s1));
             hipLaunchKernelGGL(gather_gid_kernel, dim3((nbig + 255) / 256), dim3(256), 0, s, BV[d1], d_bgid, nbig,
                                nbig <= 4096u, BK[d1]);
             if (nbig_groups > 1)
@@ -1934,7 +2243,7 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
         if (mode == M_DENSE && global_above == 0) {
             bool bail = false;
             PSS_TRY(local_round(false, &bail));
-            if (last_big_frac > 0.5) global_above = m / 2;
+            if (last_big_frac > 0.5 && !last_per) global_above = m / 2;      // (periodic runs: the local rounds know a shortcut)
             keyed_grp = false;
             cur = src ^ 1;
             st.rounds += 1;
@@ -2153,6 +2462,8 @@ static int anchor_rank_keys(DeviceCtx *ctx, const Knobs &knobs, const RoundsIO &
     st.anchor_rounds += sub.rounds - sub.text_rounds + sub.anchor_rounds;
     st.anchor_sum_active += sub.sum_active + sub.anchor_sum_active;
     st.anchor_left += sub.anchor_left;
+    st.periodic_rounds += sub.periodic_rounds;
+    st.periodic_members += sub.periodic_members;
     st.anchor_levels = std::max<uint64_t>(st.anchor_levels, 1 + sub.anchor_levels);
     hipLaunchKernelGGL(isa_from_sa_kernel, dim3(gk), dim3(256), 0, s, A_sa, m, A_rank);
     hipLaunchKernelGGL(anc_walk_kernel<true>, dim3(grid), dim3(256), 0, s, d_dist, n, d_tile_off, num_tiles, (u32 *)nullptr,

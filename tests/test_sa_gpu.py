@@ -674,6 +674,61 @@ def test_anchor_round_is_chosen_for_long_repeats_only(oracle):
         assert (dSA.cpu().numpy() == oracle.sa(t)).all()
 
 
+def _periodic_stretch_cases():
+    """Texts whose large tied groups are the phases of periodic runs: several runs of one word -- equal lengths among
+    them (ties on type and extent: the rank at the break decides), breaks above and below the periodic symbol, one run
+    that ends with the text, runs of another word with the same first symbols -- inside random text."""
+    rng = np.random.default_rng(12)
+    out = []
+    for alpha, word_len, run_lens, n in ((4, 3, (30000, 30000, 12000, 47000), 300000), (26, 7, (50000, 20000, 20000), 250000),
+                                         (2, 5, (40000, 25000, 40000), 200000), (200, 60, (90000, 90000), 400000),
+                                         (3, 1, (20000, 20000, 35000), 150000), (39, 12, (80000,), 200000)):
+        t = rng.integers(0, alpha, n, dtype=np.uint8) + (97 if alpha <= 26 else 0)
+        word = t[:word_len].copy()
+        at = 1000
+        for k, L in enumerate(run_lens):
+            t[at:at + L] = np.resize(np.roll(word, -k), L)
+            # the symbol that breaks the period: once below, once above the periodic one, then whatever the text holds
+            if k < 2:
+                per = int(t[at + L - word_len])
+                t[at + L] = per - 1 if (k == 0 and per > int(t.min())) else min(255, per + 1)
+            at += L + int(rng.integers(1, 5000))
+        tail = min(n // 6, 25000)
+        t[n - tail:] = np.resize(word, tail)                       # periodic up to the end of the text
+        other = word.copy()
+        other[-1] = word[-1] + 1 if word[-1] < 255 else word[-1] - 1
+        t[at:at + 9000] = np.resize(other, 9000)                   # another word with the same first symbols
+        out.append(np.ascontiguousarray(t))
+    return out
+
+
+@pytest.mark.parametrize('anchor', ['0', '1'])
+def test_periodic_runs_inside_rank_rounds(oracle, monkeypatch, anchor):
+    """Rank rounds (of the text with PSS_ANCHOR=0, of the anchors' names with 1): large groups whose members are the
+    phases of periodic runs take the key (type of the break, how far the period goes on, rank at the break) and come
+    apart in that one round (`periodic_rounds`, `periodic_members`) -- libsais' order, the same as with PSS_PERIODIC=0,
+    which takes log2(run / depth) rounds over them."""
+    monkeypatch.setenv('PSS_ANCHOR', anchor)
+    monkeypatch.setenv('PSS_PERIOD', '0')      # (no closed form for a text that starts periodic: the rounds are under test)
+    monkeypatch.setenv('PSS_RLE', '0')
+    took = 0
+    for t in _periodic_stretch_cases():
+        want = oracle.sa(t)
+        st = {}
+        got = _sa_device(t, st)
+        assert (got == want).all()
+        assert st['anchor_left'] == 0
+        took += int(st['periodic_rounds'] > 0)
+        monkeypatch.setenv('PSS_PERIODIC', '0')
+        st0 = {}
+        got0 = _sa_device(t, st0)
+        monkeypatch.delenv('PSS_PERIODIC')
+        assert (got0 == want).all() and st0['periodic_rounds'] == 0
+        if st['periodic_rounds'] and anchor == '0':
+            assert st['rounds'] <= st0['rounds']
+    assert took >= 4
+
+
 def test_anchor_round_on_a_text_with_fewer_anchors_than_symbols_per_key(oracle, monkeypatch):
     """Regression (tests/tools/fuzz.py, seed 4512): 891 bytes over two symbols with PSS_ANCHOR=1 -- the anchors' own sort
     (subset mode) counts h in symbols of the text while its text rounds run, and a few dozen anchors are fewer than the 32

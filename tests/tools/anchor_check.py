@@ -43,7 +43,7 @@ def build(t, **env):
 
 def make_case(rng: random.Random):
     nrng = np.random.default_rng(rng.randrange(1 << 30))
-    kind = rng.randrange(7)
+    kind = rng.randrange(9)
     alpha = rng.choice([2, 3, 4, 26, 39, 200, 256])
     n = rng.choice([3000, 20000, 70000, 300000, 1 << 20])
     base = nrng.integers(0, alpha, n, dtype=np.uint8)
@@ -91,6 +91,23 @@ def make_case(rng: random.Random):
             t[s:s + rng.randrange(20, 600)] = t[s]
         half = n // 2
         t[half:half + n // 4] = t[:n // 4]
+    elif kind in (7, 8):   # several runs of one word (equal lengths among them, one up to the end of the text), other words too
+        t = base.copy()
+        words = [base[s:s + rng.choice([1, 2, 3, 4, 7, 12, 60, 200])].copy() for s in (0, 300, 900)]
+        lens = [rng.choice([5000, 20000, 70000]) for _ in range(3)]
+        at = 0
+        for r in range(rng.randrange(2, 9)):
+            w = words[rng.randrange(1 if kind == 7 else 3)]
+            L = min(lens[rng.randrange(3)], n // 10)
+            at += rng.randrange(1, max(2, n // 10))
+            if at + L > n:
+                break
+            ph = rng.randrange(w.size)
+            t[at:at + L] = np.resize(np.roll(w, -ph), L)
+            at += L
+        if rng.random() < 0.4:
+            L = min(n // 8, 30000)
+            t[n - L:] = np.resize(words[0], L)
     else:               # natural-text-like corpus with a repetitive middle
         t = np.empty(n, dtype=np.uint8)
         _ffi.check(_ffi.lib.pss_gen_corpus(6, t.ctypes.data, n, rng.randrange(4)))
@@ -118,7 +135,8 @@ def main():
         print(f'case {c}: kind={kind} alpha={alpha} n={t.size} omega={omega} ok={ok} ok0={ok0} anchor={st["anchor"]} '
               f'w={st["anchor_w"]} om={st["anchor_omega"]} depth={st["anchor_depth"]} anchors={st["anchor_count"]} '
               f'active={st["anchor_active"]} left={st["anchor_left"]} arounds={st["anchor_text_rounds"]}+{st["anchor_rounds"]} lv={st["anchor_levels"]} '
-              f'rounds={st["rounds"]} vs {st0["rounds"]} ms={st["ms_total"]:.2f} vs {st0["ms_total"]:.2f}{flag}', flush=True)
+              f'rounds={st["rounds"]} vs {st0["rounds"]} per={st["periodic_rounds"]}/{st["periodic_members"]} vs {st0["periodic_rounds"]}/{st0["periodic_members"]} '
+              f'ms={st["ms_total"]:.2f} vs {st0["ms_total"]:.2f}{flag}', flush=True)
     print(f'{cases} cases, {took} took the anchor round, {bad} bad')
     sys.exit(1 if bad else 0)
 

@@ -83,7 +83,7 @@ def build(path, entries, limit, W):
 
 KNOBS = ('PSS_MODE', 'PSS_KEY_CHARS', 'PSS_KEY_DROP', 'PSS_TEXT_ROUNDS', 'PSS_NO_TIES_PASS', 'PSS_NO_SMALL_PATH', 'PSS_MSD',
          'PSS_MSD_NO_FUSE', 'PSS_MSD_SLOW_LOCAL', 'PSS_NO_PINNED_RESULTS', 'PSS_NO_MID_TIER', 'PSS_RLE', 'PSS_RLE_SORT', 'PSS_PERIOD', 'PSS_ANCHOR', 'PSS_ANCHOR_OMEGA',
-         'PSS_COUNT_SORT', 'PSS_NO_PROBE', 'PSS_DEVICES', 'PSS_WRITER_MMAP', 'PSS_IO_THREADS')
+         'PSS_COUNT_SORT', 'PSS_NO_PROBE', 'PSS_PERIODIC', 'PSS_DEVICES', 'PSS_WRITER_MMAP', 'PSS_IO_THREADS')
 
 
 def random_knobs(rng):
@@ -130,6 +130,8 @@ def random_knobs(rng):
             os.environ['PSS_NO_PROBE'] = '1'
     if rng.random() < 0.3:
         os.environ['PSS_COUNT_SORT'] = '1'                       # rank rounds: counting instead of the segmented merge sort
+    if rng.random() < 0.2:
+        os.environ['PSS_PERIODIC'] = '0'                         # rank rounds: no periodic keys for the large groups
     if rng.random() < 0.3:
         os.environ['PSS_DEVICES'] = rng.choice(['0', '0,0', '0,0,0', 'all'])      # the default device list of Writer / Reader
     if rng.random() < 0.3:
