@@ -165,6 +165,8 @@ typedef struct pss_sa_stats {
     uint64_t ss_declined_nomem; /* 1: no room in HBM for the sample sort's two 16 n-byte element buffers -- the build went on
                                   with the LSD passes instead of failing */
     double anchor_ms;          /* device time of the anchors' selection and sort */
+    double ms_restarts;        /* part of ms_total: attempts given up (a remembered plan, or the shortcut of a first chunk, that
+                                  this text did not fit -- the build started over without it) */
 } pss_sa_stats;
 
 /*

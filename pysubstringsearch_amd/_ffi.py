@@ -87,6 +87,7 @@ class SaStats(ctypes.Structure):
         ('ss_planned', ctypes.c_uint64),
         ('ss_declined_nomem', ctypes.c_uint64),
         ('anchor_ms', ctypes.c_double),
+        ('ms_restarts', ctypes.c_double),
     ]
 
     def as_dict(self):

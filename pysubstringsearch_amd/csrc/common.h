@@ -165,6 +165,8 @@ struct DeviceCtx {
     // ... 2: it took the sample sort, whose sorted sample (slot S_SSPLAN of sa_build.hip) cuts the next chunk of that
     // exact size and alphabet too
     uint32_t ss_plan_n = 0, ss_plan_radix = 0;
+    double restart_ms = 0.0;             // device time of the attempts the running build gave up (sa_build.hip, start_over)
+    int restart_depth = 0;
     // Two pinned staging buffers + a copy stream: file <-> HBM transfers are
     // double-buffered so the PCIe copy of piece i overlaps the file I/O of piece i+1.
     static constexpr size_t kStage = (size_t)64 << 20;

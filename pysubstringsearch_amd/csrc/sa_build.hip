@@ -2587,6 +2587,19 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     PSS_HIP(hipEventCreate(&timer.ev1));
     PSS_HIP(hipEventCreate(&timer.ev_mid));
     PSS_HIP(hipEventRecord(timer.ev0, s));
+    // A build that starts over (a plan that did not hold) reports the time of the attempts it gave up as well.
+    if (ctx->restart_depth == 0) ctx->restart_ms = 0.0;
+    auto start_over = [&](uint32_t new_flags) -> int {
+        PSS_HIP(hipEventRecord(timer.ev1, s));
+        PSS_HIP(hipStreamSynchronize(s));
+        float gone = 0.f;
+        PSS_HIP(hipEventElapsedTime(&gone, timer.ev0, timer.ev1));
+        ctx->restart_ms += gone;
+        ctx->restart_depth += 1;
+        const int rc = sa_build_device(ctx, d_T, d_SA, n_in, new_flags, stats);
+        ctx->restart_depth -= 1;
+        return rc;
+    };
 
     // ---- 0. alphabet ----
     const int grid_stream = ctx->num_cus * 8;
@@ -2635,7 +2648,8 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
             PSS_HIP(hipStreamSynchronize(s));
             float ms = 0.f;
             PSS_HIP(hipEventElapsedTime(&ms, timer.ev0, timer.ev1));
-            st.ms_total = ms;
+            st.ms_total = ms + ctx->restart_ms;
+            st.ms_restarts = ctx->restart_ms;
             if (stats) *stats = st;
             return PSS_OK;
         }
@@ -2662,7 +2676,8 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
                     PSS_HIP(hipStreamSynchronize(s));
                     float ms = 0.f;
                     PSS_HIP(hipEventElapsedTime(&ms, timer.ev0, timer.ev1));
-                    st.ms_total = ms;
+                    st.ms_total = ms + ctx->restart_ms;
+            st.ms_restarts = ctx->restart_ms;
                     if (stats) *stats = st;
                     return PSS_OK;
                 }
@@ -2801,7 +2816,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
                 // over again without it -- the alphabet pass, the run-length and periodic-text checks, the sample
                 // (a first chunk taken on its symbol counts alone: the same, with that shortcut switched off)
                 ctx->plan_path = 0;
-                return sa_build_device(ctx, d_T, d_SA, n_in, fresh ? (flags | 4u) : flags, stats);
+                return start_over(fresh ? (flags | 4u) : flags);
             }
             msd_fused = accepted && !knobs.no_msd_fuse;
             msd_active = act.count;
@@ -2827,7 +2842,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     }
     if (front_any && !msd_done) {            // (the sort was not even tried: nothing has made the codes)
         ctx->plan_path = 0;
-        return sa_build_device(ctx, d_T, d_SA, n_in, fresh ? (flags | 4u) : flags, stats);
+        return start_over(fresh ? (flags | 4u) : flags);
     }
     // Natural text (some 20-bit prefix holds far more suffixes than a tile, and a 64-bit key leaves most suffixes tied
     // anyway): sample sort over 16-byte [key | index] elements (ss_sort_impl.h) -- splitters from a sorted sample cut the
@@ -2904,7 +2919,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     if (hint && !msd_done) {
         // Neither the remembered sort nor the sample sort took this text: forget the plan and size the key the long way.
         ctx->plan_path = 0;
-        return sa_build_device(ctx, d_T, d_SA, n_in, flags, stats);
+        return start_over(flags);
     }
     if (plain && n >= (1u << 24) && !fronted) {
         // (the MSD sort's own exact check can refuse a text; the sample sort takes any text, and a bucket beyond a tile --
@@ -2947,7 +2962,8 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     PSS_HIP(hipStreamSynchronize(s));
     float ms = 0.f;
     PSS_HIP(hipEventElapsedTime(&ms, timer.ev0, timer.ev1));
-    st.ms_total = ms;
+    st.ms_total = ms + ctx->restart_ms;
+            st.ms_restarts = ctx->restart_ms;
     PSS_HIP(hipEventElapsedTime(&ms, timer.ev0, timer.ev_mid));
     st.ms_initial = ms;
     st.ms_sort = ss.ms;
