@@ -88,6 +88,30 @@ __device__ __forceinline__ int cmp_suffix(const u8 *text, u32 n, u32 s, const u8
 {
     return cmp_suffix(text, n, s, pat, plen, load_u64_unaligned(pat));
 }
+// The same with the suffix's first 8 bytes already fetched (a0 = load_text8(text + s)): two probes of one lane can have
+// their loads in flight together.
+__device__ __forceinline__ int cmp_suffix_a0(const u8 *text, u32 n, u32 s, const u8 *pat, u32 plen, u64 pat0, u64 a0)
+{
+    const u32 avail = n - s;
+    const u32 L = plen < avail ? plen : avail;
+    u32 i = 0;
+    while (i < L) {
+        u64 a = i ? load_text8(text + s + i) : a0;
+        u64 b = i ? load_u64_unaligned(pat + i) : pat0;
+        const u32 rem = L - i;
+        if (rem < 8) {
+            const u64 mask = (1ull << (8 * rem)) - 1ull;
+            a &= mask;
+            b &= mask;
+        }
+        if (a != b) {
+            const int sh = __builtin_ctzll(a ^ b) & ~7;
+            return ((a >> sh) & 0xffu) < ((b >> sh) & 0xffu) ? -1 : 1;
+        }
+        i += 8;
+    }
+    return (L == plen) ? 0 : -1;
+}
 
 // First index in [lo, hi) whose suffix is NOT before the bound; wave-cooperative.
 // upper == false: suffixes < pattern are "before"; upper == true: suffixes that
@@ -155,6 +179,19 @@ __device__ __forceinline__ void wave_bounds(const u8 *text, u32 n, const u32 *sa
         }
         // the bounds part: L in (p[kl - 1], p[kl]], U in (p[ku - 1], p[ku]]
         const u32 l_hi = (u32)__shfl((int)p, (int)kl), u_lo = (u32)__shfl((int)p, (int)ku - 1) + 1;
+        if (l_hi - l_lo <= kWave && u_hi - u_lo <= kWave) {
+            // both gaps fit a wave (they do whenever the window came from the key samples): one round trip for the two
+            // of them -- every lane fetches a suffix of each gap before it looks at either (round 4: a query with hits
+            // paid the second chain of loads, ~1 us)
+            const bool inl = lane < l_hi - l_lo, inu = lane < u_hi - u_lo;
+            const u32 sl = inl ? sa[l_lo + lane] : 0u, su = inu ? sa[u_lo + lane] : 0u;
+            const u64 tl = inl ? load_text8(text + sl) : 0ull, tu = inu ? load_text8(text + su) : 0ull;
+            const int cl = inl ? cmp_suffix_a0(text, n, sl, pat, plen, pat0, tl) : 1;
+            const int cu = inu ? cmp_suffix_a0(text, n, su, pat, plen, pat0, tu) : 1;
+            L = l_lo + (u32)__popcll(__ballot(cl < 0));
+            U = u_lo + (u32)__popcll(__ballot(cu <= 0));
+            return;
+        }
         L = wave_bound(text, n, sa, pat, plen, l_lo, l_hi, false);
         U = wave_bound(text, n, sa, pat, plen, u_lo, u_hi, true);
         return;
@@ -936,11 +973,18 @@ __device__ __forceinline__ void put_record(SmallRecord *rec, u32 ent_start, u32 
 }
 __device__ __forceinline__ void put_flag(u32 *flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
+// (Diagnostic build, -DPSS_TRACE_RESIDENT: thread 0 stamps the device clock at the phase borders of a resident query and
+// the kernel leaves the stamps in the mailbox's padding; tests/tools/latency_trace.py prints them.)
+#ifdef PSS_TRACE_RESIDENT
+#define PSS_TR(tr, i) do { if ((tr) && threadIdx.x == 0) (tr)[i] = (u32)wall_clock64(); } while (0)
+#else
+#define PSS_TR(tr, i) do { } while (0)
+#endif
 // Returns true when the workgroup wrote entries (entry table and result bytes, ordinary stores) that also goes to pinned host memory (they are
 // only in the device arena then).
 __device__ __forceinline__ bool block_pair(const ChunkDesc ch, const u8 *s_pat /* LDS, zero padded, visible */, u32 plen, u32 sub,
                                            u32 ri, u32 spread, SmallHeader *hdr, u32 *h_overflow, SmallRecord *rec,
-                                           SmallEntry *ent, u8 *bytes, u8 *hbytes, bool alone = false)
+                                           SmallEntry *ent, u8 *bytes, u8 *hbytes, bool alone = false, u32 *tr = nullptr)
 {
     // alone: this workgroup is the whole launch (the resident kernel of a one-chunk reader) -- its entries start at 0 without
     // a trip to the cursors, and a result of a few entries goes to the pinned prefix as system-scope stores and nowhere
@@ -972,6 +1016,7 @@ __device__ __forceinline__ bool block_pair(const ChunkDesc ch, const u8 *s_pat /
         }
     }
     __syncthreads();
+    PSS_TR(tr, 1);
     const u32 total = s_cnt;
     const u32 first = sub * SM_BLOCK_MAX_HITS;                 // this workgroup's slice of the interval
     const u32 L = s_L + first;
@@ -1015,6 +1060,7 @@ __device__ __forceinline__ bool block_pair(const ChunkDesc ch, const u8 *s_pat /
             }
         }
         __syncthreads();
+        PSS_TR(tr, 2);
         // entries / bytes before each thread's run of consecutive hits (suffix-array order)
         const u32 per = (cnt + SM_BLOCK - 1) / SM_BLOCK;
         const u32 j0 = min(tid * per, cnt), j1 = min(j0 + per, cnt);
@@ -1051,16 +1097,99 @@ __device__ __forceinline__ bool block_pair(const ChunkDesc ch, const u8 *s_pat /
             else put_record(rec + ri, e0, n_ent);
         }
         __syncthreads();
+        PSS_TR(tr, 3);
         const u32 e0 = s_e0, b0 = s_b0;
         if (e0 + n_ent <= SM_ENT_CAP && b0 + n_bytes <= SM_BYTE_CAP) {
             // (only a few entries: every system-scope store is a transaction of its own on the bus -- 10 KiB of result
             // took 260 us that way, 24 through L2 and one write-back)
             const bool direct = alone && n_bytes <= 512 && n_ent <= 16;
-            wrote = n_ent != 0 && !direct;
             // pass 2: pack.  When the workgroup's bytes fit the LDS stage, entries are assembled there (unaligned
             // pieces, byte tails) and leave as one run of aligned 16-byte stores per destination; else entry by entry.
             const bool staged = n_bytes <= SM_STAGE_BYTES - 16;
             const u32 skew = b0 & 15u;                          // keeps stage and destinations 16-byte congruent
+            const bool pinned_all = b0 + n_bytes <= SM_BYTE_PREFIX;
+            // Round 4: by OUTPUT pieces.  One entry per thread meant one chain of loads per entry -- the longest of a few
+            // hundred sets the pace, 5.6 us for 241 entries -- and a second trip through LDS.  Here the entries only leave
+            // their (offset, source, length) in LDS and mark the 16-byte pieces of the output whose first byte is theirs;
+            // then every thread builds whole pieces: its owner's bytes from the text with one unaligned 16-byte load, the
+            // next entries' if the piece runs on, and stores them aligned -- one round of loads whatever the lengths.  A
+            // workgroup on its own whose bytes fit the pinned prefix writes nothing to the device arena: the host reads the
+            // pinned copy only.
+            const bool coop = staged && !direct && n_ent != 0;
+            const bool arena_too = !(alone && pinned_all);
+            wrote = n_ent != 0 && !direct;       // (ordinary stores, to the arena or to pinned memory alike, wait in L2 for the write-back)
+            if (coop) {
+                static_assert(SM_STAGE_BYTES >= 3 * 4 * SM_BLOCK_MAX_HITS + 2 * (SM_STAGE_BYTES / 16 + 2), "tables in the stage");
+                u32 *t_off = reinterpret_cast<u32 *>(s_stage), *t_src = t_off + SM_BLOCK_MAX_HITS, *t_len = t_src + SM_BLOCK_MAX_HITS;
+                u16 *t_owner = reinterpret_cast<u16 *>(t_len + SM_BLOCK_MAX_HITS);
+                u32 k = e_before, off = b_before;                // entry ordinal / byte offset inside this workgroup's result
+                for (u32 j = j0; j < j1; ++j) {
+                    const u32 ll = s_ll[j];
+                    if (ll == kSkip) continue;
+                    ent[e0 + k] = SmallEntry{b0 + off, ll};
+                    t_off[k] = off;
+                    t_src[k] = s_ls[j];
+                    t_len[k] = ll;
+                    // pieces whose first valid byte lies in [off, off + ll): piece t starts at byte 16 t - skew (piece 0 at 0)
+                    if (ll) {
+                        const u32 t0 = off == 0 ? 0u : (off + skew + 15u) / 16u, t1 = (off + ll - 1u + skew) / 16u;
+                        for (u32 t = t0; t <= t1; ++t) t_owner[t] = (u16)k;
+                    }
+                    ++k;
+                    off += ll;
+                }
+                __syncthreads();
+                PSS_TR(tr, 4);
+                const u32 end = skew + n_bytes, pieces = (end + 15u) / 16u;
+                u8 *d0 = bytes + (b0 - skew), *d1 = hbytes + (b0 - skew);
+                for (u32 t = tid; t < pieces; t += SM_BLOCK) {
+                    const u32 pstart = 16u * t;                                   // in stage coordinates (byte x of the result at skew + x)
+                    u32 cur = max(pstart, skew) - skew;                           // result byte the piece starts with
+                    const u32 stop = min(pstart + 16u, end) - skew;
+                    u32 kk = t_owner[t];
+                    u64 lo = 0, hi = 0;
+                    // 16 bytes of the text from byte `within` of entry k on (readable past the end of the text)
+                    auto load16 = [&](u32 k, u32 within, u64 &x0, u64 &x1) {
+                        const uintptr_t a = (uintptr_t)(ch.text + t_src[k] + within);
+                        const uint4 *q = reinterpret_cast<const uint4 *>(a & ~(uintptr_t)15);
+                        const uint4 v0 = q[0], v1 = q[1];
+                        const u64 w0 = (u64)v0.x | ((u64)v0.y << 32), w1 = (u64)v0.z | ((u64)v0.w << 32);
+                        const u64 w2 = (u64)v1.x | ((u64)v1.y << 32), w3 = (u64)v1.z | ((u64)v1.w << 32);
+                        const bool up = (a & 8) != 0;
+                        const u32 s8 = (u32)(a & 7) * 8;
+                        const u64 l0 = up ? w1 : w0, l1 = up ? w2 : w1, l2 = up ? w3 : w2;
+                        x0 = s8 ? (l0 >> s8) | (l1 << (64 - s8)) : l0;
+                        x1 = s8 ? (l1 >> s8) | (l2 << (64 - s8)) : l1;
+                    };
+                    while (cur < stop) {
+                        while (t_off[kk] + t_len[kk] <= cur) ++kk;                // (empty entries, and the ones this piece has used up)
+                        const u32 within = cur - t_off[kk];
+                        const u32 take = min(stop - cur, t_len[kk] - within);
+                        u64 x0, x1;
+                        load16(kk, within, x0, x1);
+                        // keep `take` bytes, move them to byte (cur + skew - pstart) of the piece
+                        if (take < 8) { x0 &= (1ull << (8 * take)) - 1ull; x1 = 0; }
+                        else if (take < 16) x1 &= take == 8 ? 0ull : (1ull << (8 * (take - 8))) - 1ull;
+                        const u32 sh = (cur + skew - pstart) * 8u;
+                        if (sh == 0) { lo |= x0; hi |= x1; }
+                        else if (sh < 64) { lo |= x0 << sh; hi |= (x1 << sh) | (x0 >> (64 - sh)); }
+                        else { hi |= x0 << (sh - 64); }
+                        cur += take;
+                    }
+                    if (pstart >= skew && pstart + 16u <= end) {
+                        const uint4 v = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+                        if (arena_too) *reinterpret_cast<uint4 *>(d0 + pstart) = v;
+                        if (pinned_all) *reinterpret_cast<uint4 *>(d1 + pstart) = v;
+                    } else {
+                        for (u32 b = max(pstart, skew); b < min(pstart + 16u, end); ++b) {
+                            const u32 i = b - pstart;
+                            const u8 x = (u8)(i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8)));
+                            if (arena_too) d0[b] = x;
+                            if (pinned_all) d1[b] = x;
+                        }
+                    }
+                }
+            } else {
             u32 e = e0 + e_before, o = b0 + b_before;
             for (u32 j = j0; j < j1; ++j) {
                 const u32 ll = s_ll[j];
@@ -1074,6 +1203,7 @@ __device__ __forceinline__ bool block_pair(const ChunkDesc ch, const u8 *s_pat /
             }
             if (staged) {
                 __syncthreads();
+                PSS_TR(tr, 4);
                 const u32 end = skew + n_bytes;                  // stage bytes [skew, end) -> arena bytes [b0, b0 + n_bytes)
                 u8 *d0 = bytes + (b0 - skew), *d1 = hbytes + (b0 - skew);
                 const bool pinned_too = b0 + n_bytes <= SM_BYTE_PREFIX;   // (else the host takes everything from the device arena)
@@ -1098,6 +1228,7 @@ __device__ __forceinline__ bool block_pair(const ChunkDesc ch, const u8 *s_pat /
                         }
                     }
                 }
+            }
             }
         }
     }
@@ -1254,14 +1385,30 @@ __global__ __launch_bounds__(SM_BLOCK) void search_resident_kernel(const ChunkDe
                 ck = (ck ^ (u32)(wv >> 32)) * 0x01000193u;
             }
         }
+#ifdef PSS_TRACE_RESIDENT
+        __shared__ u32 s_tr[8];
+        u32 *tr = blockIdx.x == 0 ? s_tr : nullptr;
+#else
+        u32 *tr = nullptr;
+#endif
+        PSS_TR(tr, 0);
         const bool wrote = block_pair(ch, s_pat, plen, sub, blockIdx.x, spread, hdr, h_overflow, rec, ent, bytes, hbytes,
-                                      nc * spread == 1);
+                                      nc * spread == 1, tr);
+        PSS_TR(tr, 5);
         stores_done();
         __syncthreads();
+        PSS_TR(tr, 6);
         // every wave's stores have reached L2; one wave writes the workgroup's XCD L2 back (the entry table and the
         // result bytes are ordinary stores and stay there otherwise) -- a write-back per wave costs 4 us, one per
         // workgroup ~1, a workgroup without entries none (its record went out as a system-scope store)
         if (wrote && tid < kWave) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+#ifdef PSS_TRACE_RESIDENT
+        if (tr && tid == 0) {
+            tr[7] = (u32)wall_clock64();
+            for (int i = 0; i < 8; ++i) sys_store(&mb->pad2[i], tr[i]);
+            stores_done();
+        }
+#endif
         if (tid == 0 && nc * spread != 1) __hip_atomic_fetch_xor(&hdr->echo, ck, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0 && (nc * spread == 1 || atomicAdd(&hdr->done, 1u) == nc * spread - 1)) {
             if (nc * spread != 1) {          // (a workgroup on its own never moves the cursors)
@@ -1516,6 +1663,14 @@ static int resident_query(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, con
             // (no HIP events on this path: the time from the post to the answer as the host saw it)
             st->ms_device = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_post).count();
             st->ms_interval = st->ms_device;
+#ifdef PSS_TRACE_RESIDENT
+            if (getenv("PSS_TRACE_RESIDENT")) {
+                u32 t[8];
+                for (int i = 0; i < 8; ++i) t[i] = mb->pad2[i];
+                fprintf(stderr, "[pss] resident trace (10 ns ticks): host %.1f us | interval %u, bounds %u, sums %u, pack %u, copy %u, drain %u, fence %u\n",
+                        st->ms_device * 1e3, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6]);
+            }
+#endif
             ++R.served;
             if (*h_overflow) return PSS_OK;      // too many hits for this path: the launch path and its fallbacks take it
             PSS_TRY(small_collect(ctx, h_arena, arena + 64, (u64)nc * spread, spread, nc, res, st));
