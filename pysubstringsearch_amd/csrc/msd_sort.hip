@@ -1538,6 +1538,22 @@ int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t radix, uint32_
         stats->samples = S;
         stats->key_chars = g.kc;
     }
+    if (maxb > SS_MAX_BUCKET && getenv("PSS_SS_DEBUG")) {
+        // diagnostic: where did the crowded bucket come from?  (first-level bucket sizes, the largest joint buckets)
+        std::vector<u32> hj1(MSD_BINS + 1), hj((size_t)nbk + 1);
+        (void)hipMemcpy(hj1.data(), J1, (MSD_BINS + 1) * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hj.data(), J, ((size_t)nbk + 1) * 4, hipMemcpyDeviceToHost);
+        u32 m1 = 0, a1 = 0;
+        for (u32 i = 0; i < g.B1; ++i) { const u32 c = hj1[i + 1] - hj1[i]; if (c > m1) { m1 = c; a1 = i; } }
+        fprintf(stderr, "[pss] ss declined: n=%u S=%u B1=%u B2=%u kc=%d ib=%d | largest first-level bucket %u (#%u, average %u) | joint buckets above the cap:", n, S,
+                g.B1, g.B2, g.kc, g.ib, m1, a1, n / g.B1);
+        int shown = 0;
+        for (u64 i = 0; i < nbk && shown < 12; ++i) {
+            const u32 c = hj[i + 1] - hj[i];
+            if (c > SS_MAX_BUCKET) { fprintf(stderr, " #%llu:%u@%u", (unsigned long long)i, c, hj[i]); ++shown; }
+        }
+        fprintf(stderr, "\n");
+    }
     if (maxb > SS_MAX_BUCKET) return PSS_OK;      // (a sampling accident, probability ~1e-10 per bucket: the caller falls back)
     hipLaunchKernelGGL(ss_scatter_kernel<false>, dim3((u32)max_ranges2), dim3(SS_SBLOCK), 0, s, a);
     PSS_TRY(mark());                                                                       // [3]

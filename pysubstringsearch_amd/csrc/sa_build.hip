@@ -1710,6 +1710,7 @@ struct Knobs {
                                 //                whole text instead), 1: whenever ties outlive them, unset: texts of >= 2^20 bytes
     int anchor_omega = 0;       // PSS_ANCHOR_OMEGA  force the window of the minimizers (0 = as wide as the known common prefix allows)
     bool no_probe = false;      // PSS_NO_PROBE   always a text round before the anchor round (no sampling of the ties)
+    int probe_skip_pct = 50;    // PSS_PROBE_SKIP_PCT  no text rounds when more than this share of the sampled tied pairs are repeats
     bool count_sort = false;    // PSS_COUNT_SORT  rank rounds: groups ranked by counting (group_sort_kernel) instead of the merge sort
     bool no_periodic = false;   // PSS_PERIODIC=0  rank rounds: no periodic keys for the large groups (per_*_kernel)
     bool timing = false;        // PSS_TIMING     per-round trace on stderr
@@ -1737,6 +1738,7 @@ struct Knobs {
         if (const char *e = getenv("PSS_ANCHOR")) k.anchor = atoi(e);
         if (const char *e = getenv("PSS_ANCHOR_OMEGA")) k.anchor_omega = atoi(e);
         k.no_probe = getenv("PSS_NO_PROBE") != nullptr;
+        if (const char *e = getenv("PSS_PROBE_SKIP_PCT")) k.probe_skip_pct = atoi(e);
         k.count_sort = getenv("PSS_COUNT_SORT") != nullptr;
         { const char *e = getenv("PSS_PERIODIC"); k.no_periodic = e && atoi(e) == 0; }
         k.timing = getenv("PSS_TIMING") != nullptr;
@@ -2167,7 +2169,7 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
                 PSS_HIP(hipStreamSynchronize(s));
                 st.probe_pairs = h_small[0];
                 st.probe_same = h_small[1];
-                skip_text = h_small[0] >= 64 && (u64)h_small[1] * 2 > (u64)h_small[0];
+                skip_text = h_small[0] >= 64 && (u64)h_small[1] * 100 > (u64)h_small[0] * (u64)knobs.probe_skip_pct;
                 if (knobs.timing) fprintf(stderr, "[pss] probe: %u of %u sampled pairs share 48 more symbols%s\n", h_small[1], h_small[0], skip_text ? ": no text rounds" : "");
             }
             if (anchored) {

@@ -206,12 +206,15 @@ __global__ __launch_bounds__(256) void ss_sample_kernel(SsText t, u32 S, E16 *E0
 {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
-    const u32 stride = t.n / S;
+    // one sample from every stratum [i n / S, (i + 1) n / S): the strata cover the WHOLE text (round 4: with a stride of
+    // floor(n / S) the last n mod S positions -- 1.3 MB of a 412 MB chunk of real files -- were never sampled, a run of
+    // 18 432 equal bytes there made one bucket of 18 432 elements and the sort declined)
+    const u64 s0 = (u64)i * t.n / S, s1 = (u64)(i + 1) * t.n / S;
     u64 x = ((u64)i + 1) * 0x9E3779B97F4A7C15ull;
     x ^= x >> 29;
     x *= 0xBF58476D1CE4E5B9ull;
     x ^= x >> 32;
-    const u32 pos = i * stride + (u32)(x % stride);
+    const u32 pos = (u32)(s0 + x % (s1 - s0));
     u64 q[5];
     ss_stream_at<5>(t.codes, pos, q);      // 40 bytes >= SS_MAX_CHARS
     E16 e[1];

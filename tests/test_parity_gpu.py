@@ -274,6 +274,53 @@ def test_file_ingest_fuzz(tmp_path, oracle, seed):
         assert open(p, 'rb').read() == open(q, 'rb').read(), (seed, limit)
 
 
+def test_real_files_through_the_file_api(tmp_path, oracle):
+    """Real files (tests/tools/real_text.py: Python sources and headers found on the machine, bytes above 127, CRLF files,
+    tabs, empty lines) through Writer.add_entries_from_file_lines -> .idx -> Reader: the container is byte-identical with
+    the oracle's, and substrings sampled from the files -- and some that are not there -- return the oracle's entries."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('real_text', os.path.join(os.path.dirname(__file__), 'tools', 'real_text.py'))
+    rt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rt)
+    raw = rt.collect(5 << 20)
+    if len(raw) < (2 << 20):
+        pytest.skip('not enough text files on this machine')
+    src = tmp_path / 'real.txt'
+    src.write_bytes(raw)
+    p, q = str(tmp_path / 'g.idx'), str(tmp_path / 'o.idx')
+    limit = 1 << 20
+    w = pysubstringsearch.Writer(p, limit)
+    w.add_entries_from_file_lines(str(src))
+    w.close()
+    oracle.use_reference_sa(oracle.have_reference())
+    ow = oracle.OracleWriter(q, limit)
+    ow.add_entries_from_file_lines(str(src))
+    ow.close()
+    oracle.use_reference_sa(False)
+    assert open(p, 'rb').read() == open(q, 'rb').read()
+    rng = np.random.default_rng(3)
+    qs = []
+    for s0, k in zip(rng.integers(0, len(raw) - 64, 150), rng.integers(2, 40, 150)):
+        cand = raw[int(s0):int(s0) + int(k)]
+        if b'\n' not in cand and b'\r' not in cand:
+            qs.append(cand)
+    qs += [b'import ', b'    return', b'zq#zq#zq', b'\xc3\xa9', b'Copyright']
+    o = oracle.OracleReader(p)
+    oe, oc = o.search_multiple_bytes(qs)
+    with pysubstringsearch.Reader(p) as r:
+        ents, counts = r.search_batch_raw(qs)
+        assert counts == [int(c) for c in oc]
+        a = b = 0
+        for cg, ce in zip(counts, oc):
+            assert sorted(ents[a:a + cg]) == sorted(oe[b:b + int(ce)])
+            a += cg
+            b += int(ce)
+        for i in (0, 5, len(qs) - 5, len(qs) - 1):
+            one, c1 = r.search_batch_raw([qs[i]])
+            assert c1 == [counts[i]]
+
+
 def test_packed_result_api(tmp_path, oracle):
     entries = ['alpha beta', 'beta gamma', 'gamma', 'alphabet', '']
     p = str(tmp_path / 'p.idx')

@@ -403,6 +403,42 @@ def test_sample_sort_plan_is_reused_across_chunks(oracle, monkeypatch):
     assert (st['plan_hint'], st['ss'], st['ss_planned']) == (0, 1, 0)
 
 
+def test_sample_sort_samples_the_whole_text(oracle):
+    """Regression (tests/tools/real_text.py, 412 MB of real source files): the sample took one position from every
+    stride of floor(n / S) bytes, so the last n mod S positions of a text whose length is no multiple of the sample size
+    were never sampled; a run of equal bytes there -- 18 432 of them in that chunk -- has equal keys and consecutive
+    indices, landed in one bucket beyond a tile, and the sample sort declined (the build fell back to the LSD passes
+    with keys of 8 symbols instead of 12: 168 ms instead of 132).  The strata now cover the text to its last byte."""
+    n = (1 << 24) + 70000                     # S = 131 072: floor(n / S) = 128 leaves the last 70 000 bytes out
+    t = gen_corpus(1, n)
+    t[n - 50000:n - 20000] = ord('q')         # a run longer than 7 tiles where no sample used to fall
+    st = {}
+    sa = _sa_device(t, st, flags=8)
+    assert st['ss'] == 1 and st['ss_max_bucket'] <= 4088, (st['ss'], st['ss_max_bucket'])
+    assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(t).tobytes()).hexdigest()
+
+
+def test_real_files_chunk(oracle):
+    """Real files instead of generated text: 20 MB of the Python sources, headers and documentation found on the
+    machine, in sorted path order (tests/tools/real_text.py) -- licence headers copied hundreds of times, rules of
+    dashes, indentation runs, bytes above 127, 200-odd byte values.  The suffix array is libsais'; the build takes the
+    sample sort, a text round and the anchor round, like the 412 MB chunk of profiles/r04_real_files.txt."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('real_text', os.path.join(os.path.dirname(__file__), 'tools', 'real_text.py'))
+    rt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rt)
+    raw = rt.collect(20 << 20)
+    if len(raw) < (17 << 20):
+        pytest.skip('not enough text files on this machine')
+    t = np.frombuffer(raw, dtype=np.uint8).copy()
+    t[-1] = 10
+    st = {}
+    sa = _sa_device(t, st, flags=8)
+    assert st['ss'] == 1
+    assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(t).tobytes()).hexdigest()
+
+
 # ---- texts that repeat one word (rle_build.hip, periodic prefix) ----
 
 def _periodic(word, n, tail=b''):
