@@ -1500,6 +1500,7 @@ int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t radix, uint32_
     a.B2 = g.B2;
     a.spb = S / g.B1;
     a.st2 = g.os;
+    a.zl = (u32)std::max(0, std::min(64 - SS_CELL_BITS, 128 - g.key_bits - g.ib));
     const u32 num_tiles = (u32)(((u64)n + SS_DTILE1 - 1) / SS_DTILE1);
     a.tiles_per_range1 = (num_tiles + MSD_G1_RANGES - 1) / MSD_G1_RANGES;
     a.num_ranges1 = (num_tiles + a.tiles_per_range1 - 1) / a.tiles_per_range1;

@@ -1710,6 +1710,7 @@ struct Knobs {
                                 //                whole text instead), 1: whenever ties outlive them, unset: texts of >= 2^20 bytes
     int anchor_omega = 0;       // PSS_ANCHOR_OMEGA  force the window of the minimizers (0 = as wide as the known common prefix allows)
     bool no_probe = false;      // PSS_NO_PROBE   always a text round before the anchor round (no sampling of the ties)
+    int anchor_min_omega = 11;  // PSS_ANCHOR_MIN_OMEGA  narrowest window the anchor round accepts by itself
     int probe_skip_pct = 50;    // PSS_PROBE_SKIP_PCT  no text rounds when more than this share of the sampled tied pairs are repeats
     bool count_sort = false;    // PSS_COUNT_SORT  rank rounds: groups ranked by counting (group_sort_kernel) instead of the merge sort
     bool no_periodic = false;   // PSS_PERIODIC=0  rank rounds: no periodic keys for the large groups (per_*_kernel)
@@ -1739,6 +1740,7 @@ struct Knobs {
         if (const char *e = getenv("PSS_ANCHOR_OMEGA")) k.anchor_omega = atoi(e);
         k.no_probe = getenv("PSS_NO_PROBE") != nullptr;
         if (const char *e = getenv("PSS_PROBE_SKIP_PCT")) k.probe_skip_pct = atoi(e);
+        if (const char *e = getenv("PSS_ANCHOR_MIN_OMEGA")) k.anchor_min_omega = std::max(2, atoi(e));
         k.count_sort = getenv("PSS_COUNT_SORT") != nullptr;
         { const char *e = getenv("PSS_PERIODIC"); k.no_periodic = e && atoi(e) == 0; }
         k.timing = getenv("PSS_TIMING") != nullptr;
@@ -2158,7 +2160,7 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
             bool bail = true;
             const bool anchors_on = !subset && knobs.anchor != 0 && (knobs.anchor == 1 || n >= (1u << 20));
             bool skip_text = false;
-            if (anchors_on && !anchored && text_rounds == 0 && !knobs.no_probe && m >= 4096 && (u64)m * 16 >= (u64)n && h >= 14) {
+            if (anchors_on && !anchored && text_rounds == 0 && !knobs.no_probe && m >= 4096 && (u64)m * 16 >= (u64)n && h >= (u64)knobs.anchor_min_omega + 3) {
                 // are these ties repeats (see probe_repeats_kernel)?  Then no text round will resolve them.
                 u32 *d_probe = d_counters + 48;
                 PSS_HIP(hipMemsetAsync(d_probe, 0, 8, s));
@@ -2355,7 +2357,7 @@ static int anchor_rank_keys(DeviceCtx *ctx, const Knobs &knobs, const RoundsIO &
     }
     if (knobs.anchor_omega > 0) omega64 = std::min<u64>(omega64, (u64)knobs.anchor_omega);
     const u32 omega = (u32)std::min<u64>(omega64, 64);       // wider windows: fewer anchors, but names of 2 omega + w - 1 symbols
-    if (omega < (forced ? 2u : 11u) || n < 64 || outer.level >= 6) return PSS_OK;
+    if (omega < (forced ? 2u : (u32)knobs.anchor_min_omega) || n < 64 || outer.level >= 6) return PSS_OK;
     const u32 num_tiles = (n + ANC_TILE - 1) / ANC_TILE;
     const size_t n16 = round_up((size_t)n, 16) + 16;
     const u32 m_cap = n / 5 + 64;
