@@ -83,7 +83,7 @@ def build(path, entries, limit, W):
 
 KNOBS = ('PSS_MODE', 'PSS_KEY_CHARS', 'PSS_KEY_DROP', 'PSS_TEXT_ROUNDS', 'PSS_NO_TIES_PASS', 'PSS_NO_SMALL_PATH', 'PSS_MSD',
          'PSS_MSD_NO_FUSE', 'PSS_MSD_SLOW_LOCAL', 'PSS_NO_PINNED_RESULTS', 'PSS_NO_MID_TIER', 'PSS_RLE', 'PSS_RLE_SORT', 'PSS_PERIOD', 'PSS_ANCHOR', 'PSS_ANCHOR_OMEGA',
-         'PSS_COUNT_SORT', 'PSS_NO_PROBE', 'PSS_PERIODIC', 'PSS_DEVICES', 'PSS_WRITER_MMAP', 'PSS_IO_THREADS')
+         'PSS_COUNT_SORT', 'PSS_NO_PROBE', 'PSS_PERIODIC', 'PSS_PROBE_SKIP_PCT', 'PSS_ANCHOR_MIN_OMEGA', 'PSS_DEVICES', 'PSS_WRITER_MMAP', 'PSS_IO_THREADS')
 
 
 def random_knobs(rng):
@@ -128,6 +128,10 @@ def random_knobs(rng):
             os.environ['PSS_ANCHOR_OMEGA'] = str(rng.choice([9, 12, 17, 33]))
         if rng.random() < 0.3:
             os.environ['PSS_NO_PROBE'] = '1'
+        if rng.random() < 0.3:
+            os.environ['PSS_PROBE_SKIP_PCT'] = rng.choice(['0', '20', '90'])      # when the probe sends the ties straight to the anchors
+        if rng.random() < 0.3:
+            os.environ['PSS_ANCHOR_MIN_OMEGA'] = rng.choice(['3', '7', '9'])      # narrowest window taken without PSS_ANCHOR=1
     if rng.random() < 0.3:
         os.environ['PSS_COUNT_SORT'] = '1'                       # rank rounds: counting instead of the segmented merge sort
     if rng.random() < 0.2:
