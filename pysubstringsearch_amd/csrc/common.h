@@ -164,7 +164,10 @@ struct DeviceCtx {
     uint32_t plan_sigma = 0;
     // ... 2: it took the sample sort, whose sorted sample (slot S_SSPLAN of sa_build.hip) cuts the next chunk of that
     // exact size and alphabet too
-    uint32_t ss_plan_n = 0, ss_plan_radix = 0;
+    uint64_t ss_plan_tag = 0;            // ss_geometry_tag() of the text the sample came from (0: none)
+    uint32_t ss_plan_radix = 0;
+    bool ss_refused_note = false;        // (the running build started over because the plan's sample was refused)
+    uint32_t ss_plan_skip = 0, ss_plan_backoff = 0;      // builds that go by before the plan is tried again after a refusal
     double restart_ms = 0.0;             // device time of the attempts the running build gave up (sa_build.hip, start_over)
     int restart_depth = 0;
     // Two pinned staging buffers + a copy stream: file <-> HBM transfers are

@@ -72,6 +72,7 @@ uint32_t ss_sample_count(uint32_t n);
 // Symbols a 16-byte element carries next to the index of one of n suffixes when the text has radix - 1 distinct bytes
 // (the key is a base-radix number, code 0 = past the end of the text).
 int ss_key_chars(uint32_t n, uint32_t radix);
+uint64_t ss_geometry_tag(uint32_t n, uint32_t radix);
 // Same contract as suffix_sort_flags / msd_suffix_sort without `active` (bit 31 of sa_out[i] = "same key as my
 // predecessor"); the key is the first ss_key_chars() symbols.  `work`: msd_workspace_bytes(n).
 int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t radix, uint32_t n, const SsBuffers &buf, uint32_t *sa_out,

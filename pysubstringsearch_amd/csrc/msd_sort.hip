@@ -1405,6 +1405,14 @@ uint32_t ss_sample_count(uint32_t n)
     SsGeometry g;
     return ss_geometry(n, 257, &g) ? g.S : 0u;
 }
+// Everything about the sort that depends on n and the alphabet, in one number (0: the sort does not take this text): two
+// texts with the same tag can be cut by the same sorted sample (sa_build.hip, the plan of the sample sort).
+uint64_t ss_geometry_tag(uint32_t n, uint32_t radix)
+{
+    SsGeometry g;
+    if (!ss_geometry(n, radix, &g)) return 0;
+    return ((uint64_t)g.S << 32) | ((uint64_t)g.B1 << 20) | ((uint64_t)g.B2 << 8) | ((uint64_t)g.ib << 2) | (uint64_t)(g.os == 8) | ((uint64_t)g.kc << 58);
+}
 int ss_key_chars(uint32_t n, uint32_t radix)
 {
     SsGeometry g;

@@ -2544,6 +2544,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     const bool profile = flags & 1u;
     if (flags & 8u) {                // a cold build: nothing of earlier builds on this device is used
         ctx->plan_path = 0;
+        ctx->ss_plan_skip = ctx->ss_plan_backoff = 0;
         flags &= ~8u;                // (a restart of THIS build keeps what it has learnt)
     }
     const Knobs knobs = Knobs::read();
@@ -2592,7 +2593,10 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     PSS_HIP(hipEventCreate(&timer.ev_mid));
     PSS_HIP(hipEventRecord(timer.ev0, s));
     // A build that starts over (a plan that did not hold) reports the time of the attempts it gave up as well.
-    if (ctx->restart_depth == 0) ctx->restart_ms = 0.0;
+    if (ctx->restart_depth == 0) {
+        ctx->restart_ms = 0.0;
+        ctx->ss_refused_note = false;
+    }
     auto start_over = [&](uint32_t new_flags) -> int {
         PSS_HIP(hipEventRecord(timer.ev1, s));
         PSS_HIP(hipStreamSynchronize(s));
@@ -2878,10 +2882,13 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         sb.sort_work = work;
         // the plan: the previous chunk of this corpus (same size, same alphabet) left its sorted sample behind
         const u32 radix = plus_one ? 257u : sigma + 1u;
-        const bool planned = hint == 2 && ctx->ss_plan_n == n && ctx->ss_plan_radix == radix && ctx->slot[S_SSPLAN].p != nullptr;
+        // (the same sample size, bucket counts, index bits and symbols per key: chunks of one Writer differ by an entry or two)
+        const u64 tag = ss_geometry_tag(n, radix);
+        const bool planned = hint == 2 && tag != 0 && ctx->ss_plan_tag == tag && ctx->ss_plan_radix == radix && ctx->slot[S_SSPLAN].p != nullptr &&
+                             ctx->ss_plan_skip == 0;
         if (planned) sb.sample_in = ctx->slot[S_SSPLAN].p;
         else if (plain && ctx->slot[S_SSPLAN].reserve((size_t)S * 16) == PSS_OK) sb.sample_keep = ctx->slot[S_SSPLAN].p;
-        ctx->ss_plan_n = 0;                                                // (valid again once this sort has been accepted)
+        ctx->ss_plan_tag = 0;                                              // (valid again once this sort has been accepted)
         MsdActive act;
         act.pos = ctx->slot[S_P1].as<u32>();
         act.idx = (final_buf == 0) ? V[1] : V[0];
@@ -2893,6 +2900,19 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         bool accepted = false;
         PSS_TRY(ss_suffix_sort(ctx, &sk, plus_one ? 257u : sigma + 1u, n, sb, SA, ctx->slot[S_P0].p, h_small, profile, &sst, &accepted,
                                &act));
+        if (planned && !accepted) {
+            // The previous chunk's splitters left a bucket beyond a tile (real files: millions of suffixes with one key --
+            // blanks -- sit where the files put them, not where the last chunk had them).  The build starts over without the
+            // plan, and the next chunks do not try it again at once: 1, 3, 7, ... builds go by first.
+            ctx->ss_plan_backoff = std::min(63u, 2 * ctx->ss_plan_backoff + 1);
+            ctx->ss_plan_skip = ctx->ss_plan_backoff;
+            ctx->ss_refused_note = true;
+            ctx->plan_path = 0;               // all over again without the plan: this may not be natural text at all
+            return start_over(flags);
+        } else if (accepted) {
+            if (planned) ctx->ss_plan_backoff = 0;
+            else if (hint == 2 && ctx->ss_plan_skip) --ctx->ss_plan_skip;      // (a chunk that went by without trying)
+        }
         st.ss_buckets = sst.buckets;
         st.ss_max_bucket = sst.max_bucket;
         st.ss_samples = sst.samples;
@@ -2913,7 +2933,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
             ss.launches = 4;
             ss.elems = 4ull * n;
             if (sb.sample_in || sb.sample_keep) {
-                ctx->ss_plan_n = n;
+                ctx->ss_plan_tag = tag;
                 ctx->ss_plan_radix = radix;
             }
             st.ss_planned = sb.sample_in ? 1 : 0;
@@ -2928,7 +2948,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     if (plain && n >= (1u << 24) && !fronted) {
         // (the MSD sort's own exact check can refuse a text; the sample sort takes any text, and a bucket beyond a tile --
         // with remembered splitters as unlikely as with fresh ones -- declines: both start over without the plan)
-        ctx->plan_path = st.msd ? 1 : (st.ss && ctx->ss_plan_n == n ? 2 : 0);
+        ctx->plan_path = st.msd ? 1 : (st.ss && ctx->ss_plan_tag != 0 ? 2 : 0);
         ctx->plan_logn = logn;
         memcpy(ctx->plan_present, present_bits, 32);
         memcpy(ctx->plan_lut, lut, 256);
@@ -2966,6 +2986,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     PSS_HIP(hipStreamSynchronize(s));
     float ms = 0.f;
     PSS_HIP(hipEventElapsedTime(&ms, timer.ev0, timer.ev1));
+    st.ss_plan_refused = ctx->ss_refused_note ? 1 : 0;
     st.ms_total = ms + ctx->restart_ms;
             st.ms_restarts = ctx->restart_ms;
     PSS_HIP(hipEventElapsedTime(&ms, timer.ev0, timer.ev_mid));

@@ -362,44 +362,61 @@ def test_initial_sort_plan_is_reused_and_checked(oracle, monkeypatch, front):
 
 
 def test_sample_sort_plan_is_reused_across_chunks(oracle, monkeypatch):
-    """Natural text: the sorted sample of one chunk cuts the next chunk of the corpus (same size, same alphabet) -- no
-    sizing sample, no sample of its own (ss_planned = 1) -- and the suffix array is libsais' all the same: any splitters
-    give the exact result, the previous chunk's only have to keep the buckets inside a tile, which the exact bucket
-    check confirms on every build.  A chunk of another size, a cold build (flags bit 3) and PSS_NO_PLAN_CACHE=1 draw
-    their own sample; a text of another distribution over the same bytes whose buckets outgrow a tile starts over."""
-    n = 1 << 24
+    """Natural text: the sorted sample of one chunk cuts the next chunks of the corpus (same sample size, bucket counts,
+    index bits and alphabet -- the chunks of one Writer differ by an entry or two in length) -- no sizing sample, no sample
+    of their own (ss_planned = 1) -- and the suffix array is libsais' all the same: any splitters give the exact result,
+    the previous chunk's only have to keep the buckets inside a tile, which the exact bucket check confirms on every
+    build.  A chunk of another size class, a cold build (flags bit 3) and PSS_NO_PLAN_CACHE=1 draw their own sample; a
+    chunk whose equal keys sit where no remembered splitter separates them starts over without the plan
+    (ss_plan_refused) and the plan rests for a build."""
+    n = (1 << 25) - 4096
     a, b_ = gen_corpus(1, n, 0), gen_corpus(1, n, 1)
     assert np.array_equal(np.unique(a), np.unique(b_)) and not np.array_equal(a, b_)
+
+    def check(t, st):
+        sa = _sa_device(t, st)
+        assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(t).tobytes()).hexdigest()
+
     st = {}
     _sa_device(a, st, flags=8)
     assert (st['plan_hint'], st['ss'], st['ss_planned']) == (0, 1, 0)
-    for t in (b_, a, b_):
+    for t in (b_, a):
         st = {}
-        sa = _sa_device(t, st)
+        check(t, st)
         assert (st['plan_hint'], st['ss'], st['ss_planned'], st['msd']) == (2, 1, 1, 0)
-        assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(t).tobytes()).hexdigest()
     # a cold build forgets, and leaves a new plan
     st = {}
     _sa_device(b_, st, flags=8)
     assert (st['plan_hint'], st['ss_planned']) == (0, 0)
+    # a chunk a few entries shorter: the same geometry, the plan holds (splitters whose index lies beyond this chunk's end
+    # are numbers like any other)
+    c = gen_corpus(1, n - 70001, 2)
+    st = {}
+    check(c, st)
+    assert (st['ss'], st['ss_planned'], st['ss_plan_refused']) == (1, 1, 0)
     # another size class: own sample
-    c = gen_corpus(1, (1 << 24) + 4096, 2)
+    c = gen_corpus(1, (1 << 25) + 4096, 2)
     st = {}
-    sa = _sa_device(c, st)
+    check(c, st)
     assert (st['ss'], st['ss_planned']) == (1, 0)
-    assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(c).tobytes()).hexdigest()
-    # the same bytes in sorted order (every bucket of the remembered splitters but a few is empty, one run per byte value):
-    # whatever road the build takes from the plan, the bytes are libsais'
+    # equal keys where no remembered splitter separates them (300 000 times one byte in the middle of the chunk): refused,
+    # the build starts over with a sample of its own; the next chunk does not try the plan at once, the one after does
     _sa_device(a, {}, flags=8)
-    skew = np.sort(a)
-    skew[-1] = a.min()                    # (not one run-length class per symbol only: a last suffix below the rest)
+    odd = a.copy()
+    odd[1 << 23:(1 << 23) + 300000] = a[0]
     st = {}
-    sa = _sa_device(skew, st)
-    assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(skew).tobytes()).hexdigest()
+    check(odd, st)
+    assert (st['ss'], st['ss_planned'], st['ss_plan_refused']) == (1, 0, 1) and st['ms_restarts'] > 0, (st['ss_planned'], st['ss_plan_refused'])
+    st = {}
+    _sa_device(b_, st)
+    assert (st['plan_hint'], st['ss_planned'], st['ss_plan_refused']) == (2, 0, 0)
+    st = {}
+    check(a, st)
+    assert (st['ss_planned'], st['ss_plan_refused']) == (1, 0)
     monkeypatch.setenv('PSS_NO_PLAN_CACHE', '1')
     _sa_device(a, {})
     st = {}
-    sa = _sa_device(b_, st)
+    _sa_device(b_, st)
     assert (st['plan_hint'], st['ss'], st['ss_planned']) == (0, 1, 0)
 
 

@@ -47,7 +47,36 @@ def collect(limit):
     return b''.join(parts)
 
 
+def two_chunks(logn):
+    """The plan of the sample sort on real files: the text in two halves of equal geometry, built one after the other
+    a few times -- is the second half cut by the first half's sample, or refused?"""
+    n = 1 << logn
+    raw = collect(n)
+    half = (len(raw) // 2) & ~0xfff
+    parts = [np.frombuffer(raw[:half], dtype=np.uint8).copy(), np.frombuffer(raw[half:2 * half - 4097], dtype=np.uint8).copy()]
+    for t in parts:
+        t[-1] = 10
+    from oracle import oracle as O
+    want = [hashlib.sha256(O.sa(t).tobytes()).hexdigest() for t in parts]
+    dTs = [torch.from_numpy(t).cuda() for t in parts]
+    dSA = torch.empty(half, dtype=torch.int32, device='cuda')
+    st = _ffi.SaStats()
+    ok = True
+    for r in range(8):
+        k = r % 2
+        nn = parts[k].size
+        _ffi.check(_ffi.lib.pss_sa_build_device(dTs[k].data_ptr(), dSA.data_ptr(), nn, 0, 8 if r == 0 else 0, ctypes.byref(st)))
+        d = st.as_dict()
+        same = hashlib.sha256(dSA[:nn].cpu().numpy().tobytes()).hexdigest() == want[k]
+        ok = ok and same
+        print(f'build {r} (half {k}, {nn} bytes): {st.ms_total:.1f} ms  plan={d["plan_hint"]} ss={d["ss"]} planned={d["ss_planned"]} '
+              f'refused={d["ss_plan_refused"]} max bucket {d["ss_max_bucket"]} equal to libsais: {same}', flush=True)
+    sys.exit(0 if ok else 1)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[2] == 'halves':
+        return two_chunks(int(sys.argv[1]))
     logn = int(sys.argv[1]) if len(sys.argv) > 1 else 26
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     n = 1 << logn
