@@ -162,6 +162,8 @@ typedef struct pss_sa_stats {
     uint64_t periodic_members; /* ... and the members of those groups, summed over the rounds */
     uint64_t ss_planned;       /* 1: the sample sort cut this chunk with the sorted sample of the previous chunk of the same
                                   size and alphabet (no sample of its own, no sizing sample: plan_hint = 1 with ss = 1) */
+    uint64_t dup_screen;       /* first chunk with log-like symbol counts: places among 8192 sampled ones whose 16 bytes occur at an
+                                  earlier sampled place too (>= 8: copies, no shortcut to the MSD sort) */
     uint64_t ss_plan_refused;  /* 1: the previous chunk's sample left a bucket beyond a tile; the build started over
                                   without the plan (the attempt is part of ms_total, ms_restarts), later chunks wait before they try */
     uint64_t ss_declined_nomem; /* 1: no room in HBM for the sample sort's two 16 n-byte element buffers -- the build went on

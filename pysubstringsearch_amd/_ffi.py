@@ -85,6 +85,7 @@ class SaStats(ctypes.Structure):
         ('periodic_rounds', ctypes.c_uint64),
         ('periodic_members', ctypes.c_uint64),
         ('ss_planned', ctypes.c_uint64),
+        ('dup_screen', ctypes.c_uint64),
         ('ss_plan_refused', ctypes.c_uint64),
         ('ss_declined_nomem', ctypes.c_uint64),
         ('anchor_ms', ctypes.c_double),

@@ -50,6 +50,44 @@ namespace pss {
 
 // ---------------------------------------------------------------- alphabet --
 
+// Are there copies in the text?  8192 positions, the 16 bytes at each hashed to 32 bits and put into an LDS table:
+// *dups = positions whose fingerprint was there already.  Random text has none (false matches: 0.008 expected); a text
+// that holds the same megabyte a few hundred times has dozens.  A first chunk whose symbol counts look like log lines is
+// sent to the MSD sort without a sizing sample (below) -- unless this says that the bucket check will refuse it.
+constexpr u32 DUP_SAMPLES = 8192, DUP_SLOTS = 16384;
+__global__ __launch_bounds__(1024) void dup_screen_kernel(const u8 *T, u32 n, u32 *dups)
+{
+    __shared__ u32 table[DUP_SLOTS];
+    for (u32 i = threadIdx.x; i < DUP_SLOTS; i += 1024) table[i] = 0;
+    __syncthreads();
+    u32 mine = 0;
+    if (n >= 64) {
+        const u32 stride = (n - 32) / DUP_SAMPLES;
+        for (u32 k = threadIdx.x; k < DUP_SAMPLES; k += 1024) {
+            u64 x = ((u64)k + 1) * 0x9E3779B97F4A7C15ull;
+            x ^= x >> 29;
+            x *= 0xBF58476D1CE4E5B9ull;
+            x ^= x >> 32;
+            const u32 pos = stride ? k * stride + (u32)(x % stride) : k % (n - 32);
+            const u64 a = load_u64_unaligned(T + pos), b = load_u64_unaligned(T + pos + 8);
+            u64 hsh = (a ^ (b * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull;
+            hsh ^= hsh >> 32;
+            u32 f = (u32)hsh;
+            if (f == 0) f = 1;
+            u32 slot = (f * 2654435761u) >> (32 - 14);
+            static_assert(DUP_SLOTS == (1u << 14), "14-bit slot");
+            for (;;) {
+                const u32 old = atomicCAS(&table[slot], 0u, f);
+                if (old == 0u) break;
+                if (old == f) { ++mine; break; }
+                slot = (slot + 1) & (DUP_SLOTS - 1);
+            }
+        }
+    }
+    const u32 tot = wave_incl_sum(mine);
+    if (lane_id() == kWave - 1 && tot) atomicAdd(dups, tot);
+}
+
 // present[c] = 1 for every byte value that occurs (exact); counts[c] += its
 // occurrences inside a 1/16 sample of the 16-byte vectors (for the entropy
 // estimate that sizes the initial key).
@@ -2630,8 +2668,11 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         PSS_HIP(hipMemsetAsync(d_present, 0, 2048, s));
         PSS_HIP(hipMemsetAsync(d_runs, 0, 4, s));
         hipLaunchKernelGGL(sa_symbols_kernel, dim3(grid_stream), dim3(256), 0, s, T, n, d_present, d_present + 256, d_runs);
+        const bool screen_dups = plain && !knobs.no_front && (flags & 4u) == 0 && n >= (1u << 24);      // (only the shortcut of a first chunk asks)
+        PSS_HIP(hipMemsetAsync(d_runs + 1, 0, 4, s));
+        if (screen_dups) hipLaunchKernelGGL(dup_screen_kernel, dim3(1), dim3(1024), 0, s, T, n, d_runs + 1);
         PSS_HIP(hipMemcpyAsync(h_small, d_present, 2048, hipMemcpyDeviceToHost, s));
-        PSS_HIP(hipMemcpyAsync(h_small + 512, d_runs, 4, hipMemcpyDeviceToHost, s));
+        PSS_HIP(hipMemcpyAsync(h_small + 512, d_runs, 8, hipMemcpyDeviceToHost, s));
         // (the head of the text rides along: does it repeat one word?  -- see below)
         u8 *h_head = static_cast<u8 *>(ctx->pinned) + 32768;         // the search path's query staging; builds and searches take turns
         const u32 head_len = std::min<u32>(n, kPeriodProbe);
@@ -2726,7 +2767,10 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
             const double pr = h_small[256 + c] / tot;
             c2 += pr * pr;
         }
-        fresh = tot > 0 && c2 < 0.035;
+        // ... and no copies among 8192 sampled places (dup_screen_kernel): a text of log lines that repeats itself would be
+        // refused by the sort's bucket check after 3.5 ms of passes
+        fresh = tot > 0 && c2 < 0.035 && h_small[513] < 8;
+        st.dup_screen = h_small[513];
     }
     const bool front_any = fronted || fresh;
     int key_chars = front_any ? kmax : choose_key_chars(h_small + 256, n, b, kmax);
