@@ -767,6 +767,44 @@ def run_chunk(args, D):
                                 'prefix_doubling_verified': d_ok})
             del a_dT
 
+    # Real files instead of generated text (N = 1 only): 32 MiB of the Python sources and C / HIP headers found on this
+    # machine, in sorted path order (tests/tools/real_text.py) -- licence headers copied thousands of times, indentation,
+    # 200-odd byte values; four suffixes in five sit inside copies, so the build goes through the sample sort, a text
+    # round and the anchor round.  Checked against libsais run on the same bytes (verify_sa).
+    real_files = None
+    if world == 1 and args.corpus == 'lines' and not os.environ.get('PSS_BENCH_NO_SECONDARY') and not args.no_real_files:
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location('real_text', os.path.join(ROOT, 'tests', 'tools', 'real_text.py'))
+            rt = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(rt)
+            t_c = time.perf_counter()
+            raw = rt.collect(1 << 25)
+            collect_s = time.perf_counter() - t_c
+            if len(raw) >= (1 << 24):
+                r_host = np.frombuffer(raw, dtype=np.uint8).copy()
+                r_host[-1] = 10
+                rn = int(r_host.size)
+                r_dT = torch.from_numpy(r_host).cuda()
+                r_dSA = dSA[:rn] if rn <= n else torch.empty(rn, dtype=torch.int32, device='cuda')
+                rst = _ffi.SaStats()
+                best = None
+                for i in range(3):
+                    _ffi.check(lib.pss_sa_build_device(r_dT.data_ptr(), r_dSA.data_ptr(), rn, dev, 0, ctypes.byref(rst)))
+                    best = rst.ms_total if best is None else min(best, rst.ms_total)
+                rd = rst.as_dict()
+                r_ok, r_how = verify_sa(r_dSA, r_host, 'real_files', 0, {}, want_sha=True)
+                real_files = {'bytes': rn, 'byte_values': int(len(np.unique(r_host))), 'lines': int((r_host == 10).sum()),
+                              'build_ms': round(best, 3), 'index_build_gbs': round(rn / best / 1e6, 3),
+                              'verified': r_ok, 'verified_by': r_how, 'collect_seconds': round(collect_s, 1),
+                              'initial_sort': 'sample sort' if rd['ss'] else ('hybrid MSD' if rd['msd'] else 'LSD'),
+                              'anchor_round': bool(rd['anchor']), 'anchors': rd['anchor_count'],
+                              'tied_after_initial_sort': rd['sum_active'], 'text_rounds': rd['text_rounds'],
+                              'note': 'a 412 MB chunk of the same files: 131 ms = 3.15 GB/s (profiles/r04_real_files.txt)'}
+                del r_dT, r_dSA
+        except Exception as e:                       # (a machine without such files, or without the tool)
+            real_files = {'error': repr(e)[:200]}
+
     if rank == 0:
         # dominant kernel = the scatter instantiation with the largest summed duration in the profiled
         # build: the passes of the initial sort are fs_scatter_kernel<KIN, KOUT> (key plane bytes in /
@@ -874,6 +912,7 @@ def run_chunk(args, D):
                 'runs_build_ms': pick(adversarial, 'runs', 'build_ms'),
                 'periodic_build_ms': pick(adversarial, 'periodic', 'build_ms'),
                 'repeat_line_build_ms': pick(adversarial, 'repeat_line', 'build_ms'),
+                'real_files_32MiB_build_gbs': pick(real_files, 'index_build_gbs') if real_files and 'error' not in real_files else None,
             },
             'value_cold': value_cold,
             'value_is_warm': 'steady state of a Writer: %d distinct chunks rotate through the timed loop, every build after '
@@ -910,6 +949,7 @@ def run_chunk(args, D):
             'cpu_baseline': cpu,
             'secondary': secondary,
             'adversarial': adversarial,
+            'real_files': real_files,
         }
     else:
         out = None
@@ -1193,6 +1233,7 @@ def main():
     ap.add_argument('--no-disk-baseline', action='store_true')
     ap.add_argument('--no-corpus15', action='store_true', help='chunk config: skip the configs[2]/[3] leg of the line')
     ap.add_argument('--corpus15-queries', type=int, default=100000)
+    ap.add_argument('--no-real-files', action='store_true', help='chunk config: skip the build of real files found on the machine')
     ap.add_argument('--no-e2e', action='store_true', help='chunk config: skip the file-API leg (Writer -> .idx -> Reader)')
     ap.add_argument('--e2e-chunks', type=int, default=4)
     ap.add_argument('--inproc', action='store_true',
