@@ -452,8 +452,8 @@ def test_real_files_chunk(oracle):
     t[-1] = 10
     st = {}
     sa = _sa_device(t, st, flags=8)
-    assert st['ss'] == 1
     assert hashlib.sha256(sa.tobytes()).hexdigest() == hashlib.sha256(oracle.sa(t).tobytes()).hexdigest()
+    assert st['anchor_left'] == 0            # (which sorts the build took depends on the files; on this image: sample sort + anchors)
 
 
 # ---- texts that repeat one word (rle_build.hip, periodic prefix) ----
