@@ -1,0 +1,96 @@
+"""Real files end to end: the machine's source files (tests/tools/real_text.py) through the drop-in API --
+Writer.add_entries_from_file_lines -> .idx -> Reader -> search_multiple -- with a sample of the queries checked against
+the oracle's Reader on the same .idx.
+
+    python tests/tools/real_e2e.py [logn=29] [queries=20000]
+"""
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, '.')
+import pysubstringsearch_amd as pss  # noqa: E402
+
+spec = importlib.util.spec_from_file_location('real_text', os.path.join(os.path.dirname(__file__), 'real_text.py'))
+rt = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(rt)
+
+
+def main():
+    logn = int(sys.argv[1]) if len(sys.argv) > 1 else 29
+    nq = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
+    raw = rt.collect(1 << logn)
+    src, idx = '/tmp/real_e2e.txt', '/tmp/real_e2e.idx'
+    open(src, 'wb').write(raw)
+    out = {'text_bytes': len(raw)}
+    best_w = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        w = pss.Writer(idx)
+        w.add_entries_from_file_lines(src)
+        w.finalize()
+        w.close()
+        dt = time.perf_counter() - t0
+        best_w = dt if best_w is None else min(best_w, dt)
+    out['writer_seconds'] = round(best_w, 3)
+    out['writer_text_gbs'] = round(len(raw) / best_w / 1e9, 3)
+    out['idx_bytes'] = os.path.getsize(idx)
+    t0 = time.perf_counter()
+    r = pss.Reader(idx)
+    out['reader_open_seconds'] = round(time.perf_counter() - t0, 3)
+    rng = np.random.default_rng(5)
+    qs = []
+    while len(qs) < nq // 2:
+        s0, k = int(rng.integers(0, len(raw) - 40)), int(rng.integers(8, 33))      # (4-byte pieces of real code -- four blanks, 'self' --
+        # have millions of hits each: 20 000 of them asked for 94 GB of result, and got MemoryError)
+        c = raw[s0:s0 + k]
+        if b'\n' not in c and b'\r' not in c:
+            qs.append(c)
+    alpha = b'abcdefghijklmnopqrstuvwxyz_ (),=.'
+    for _ in range(nq - len(qs)):
+        qs.append(bytes(alpha[int(i)] for i in rng.integers(0, len(alpha), int(rng.integers(6, 12)))))
+    r.search_batch_packed(qs[:100])
+    best_s, pk = None, None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        pk = r.search_batch_packed(qs)
+        dt = time.perf_counter() - t0
+        best_s = dt if best_s is None else min(best_s, dt)
+    out['queries'] = len(qs)
+    out['entries_returned'] = int(len(pk.offsets) - 1)
+    out['result_bytes'] = int(pk.offsets[-1])
+    out['batch_seconds'] = round(best_s, 4)
+    out['queries_per_sec'] = round(len(qs) / best_s, 1)
+    for q in (b'import ', b'Copyright', b'def __init__', b'zq#zq#'):
+        t0 = time.perf_counter()
+        res = r.search(q.decode())
+        out[f'single {q!r}'] = {'results': len(res), 'ms': round((time.perf_counter() - t0) * 1e3, 2)}
+    # parity on a sample
+    from oracle import oracle as O
+    o = O.OracleReader(idx)
+    pick = list(range(0, len(qs), max(1, len(qs) // 300)))
+    sub = [qs[i] for i in pick]
+    ge, gc = r.search_batch_raw(sub)
+    oe, oc = o.search_multiple_bytes(sub)
+    ok = list(gc) == [int(c) for c in oc]
+    a = b = 0
+    for cg, ce in zip(gc, oc):
+        if not ok:
+            break
+        ok = sorted(ge[a:a + cg]) == sorted(oe[b:b + int(ce)])
+        a += cg
+        b += int(ce)
+    out['sample_equal_to_oracle'] = {'queries': len(sub), 'entries': int(sum(gc)), 'ok': bool(ok)}
+    r.close()
+    print(json.dumps(out))
+    for f in (src, idx):
+        os.remove(f)
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == '__main__':
+    main()
