@@ -158,9 +158,80 @@ extern "C" size_t pss_last_error(char *buf, size_t cap)
     return e.size();
 }
 
+// Buffers a Writer needs again the next time one is opened in this process (round 4): its pinned stages (8 x 16 MiB) and up
+// to three host text buffers of a chunk each.  Allocating, faulting in and unmapping 512 MiB buffers and pinning / unpinning
+// the stages cost a Writer of one chunk 0.25 s at close and 0.1 s on the way -- of 0.7 s in all; a process that writes
+// index after index pays that once.  pss_release_workspace() gives everything back.
+namespace {
+std::mutex g_wcache_mu;
+std::vector<void *> g_stage_cache;                                  // pinned, DeviceCtx::kIoPiece each
+std::vector<std::pair<uint8_t *, size_t>> g_text_cache;             // malloc'ed
+constexpr size_t kTextCacheMax = 3, kTextCacheMaxBytes = (size_t)3 << 30, kStageCacheMax = 16;
+
+void *stage_cache_take()
+{
+    std::lock_guard<std::mutex> lk(g_wcache_mu);
+    if (g_stage_cache.empty()) return nullptr;
+    void *p = g_stage_cache.back();
+    g_stage_cache.pop_back();
+    return p;
+}
+void stage_cache_give(void *p)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_wcache_mu);
+        if (g_stage_cache.size() < kStageCacheMax) {
+            g_stage_cache.push_back(p);
+            return;
+        }
+    }
+    (void)hipHostFree(p);
+}
+// the smallest cached text buffer of at least `need` bytes (nullptr: none)
+uint8_t *text_cache_take(size_t need, size_t *cap)
+{
+    std::lock_guard<std::mutex> lk(g_wcache_mu);
+    int best = -1;
+    for (int i = 0; i < (int)g_text_cache.size(); ++i)
+        if (g_text_cache[i].second >= need && (best < 0 || g_text_cache[i].second < g_text_cache[best].second)) best = i;
+    if (best < 0) return nullptr;
+    uint8_t *p = g_text_cache[best].first;
+    *cap = g_text_cache[best].second;
+    g_text_cache.erase(g_text_cache.begin() + best);
+    return p;
+}
+void text_cache_give(uint8_t *p, size_t cap)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_wcache_mu);
+        size_t held = 0;
+        for (const auto &t : g_text_cache) held += t.second;
+        if (cap >= ((size_t)1 << 20) && g_text_cache.size() < kTextCacheMax && held + cap <= kTextCacheMaxBytes) {
+            g_text_cache.emplace_back(p, cap);
+            return;
+        }
+    }
+    free(p);
+}
+void writer_caches_release()
+{
+    std::vector<void *> st;
+    std::vector<std::pair<uint8_t *, size_t>> tx;
+    {
+        std::lock_guard<std::mutex> lk(g_wcache_mu);
+        st.swap(g_stage_cache);
+        tx.swap(g_text_cache);
+    }
+    for (void *p : st) (void)hipHostFree(p);
+    for (auto &t : tx) free(t.first);
+}
+}  // namespace
+
 extern "C" int pss_release_workspace(void)
 {
     return guarded([&]() -> int {
+        writer_caches_release();
         trim_all();
         return PSS_OK;
     });
@@ -303,6 +374,14 @@ int w_reserve(pss_writer *w, size_t additional)
         w->limit = nc;
     }
     const size_t need = w->len + additional;
+    if (need > w->alloc && w->buf == nullptr && w->len == 0) {
+        // (a buffer an earlier Writer of this process left behind: a whole chunk's worth, its pages already there)
+        size_t cap = 0;
+        if (uint8_t *p = text_cache_take(need, &cap)) {
+            w->buf = p;
+            w->alloc = cap;
+        }
+    }
     if (need > w->alloc) {
         size_t na = w->alloc ? w->alloc : 65536;
         while (na < need) na *= 2;
@@ -586,7 +665,8 @@ int pipe_start(pss_writer *w)
 {
     if (w->started) return PSS_OK;
     for (int i = 0; i < kWPieces; ++i)
-        if (!w->stage[i]) PSS_HIP(hipHostMalloc(&w->stage[i], DeviceCtx::kIoPiece, hipHostMallocPortable));
+        if (!w->stage[i] && !(w->stage[i] = stage_cache_take()))
+            PSS_HIP(hipHostMalloc(&w->stage[i], DeviceCtx::kIoPiece, hipHostMallocPortable));
     for (auto &d : w->devs) {
         PSS_HIP(hipSetDevice(d.device));
         if (!d.io_stream) PSS_HIP(hipStreamCreateWithFlags(&d.io_stream, hipStreamNonBlocking));
@@ -641,8 +721,11 @@ void pipe_stop(pss_writer *w)
         for (auto &b : d.sa) b.release();
     }
     for (int i = 0; i < kWPieces; ++i)
-        if (w->stage[i]) (void)hipHostFree(w->stage[i]);
-    for (auto &t : w->free_text) free(t.first);
+        if (w->stage[i]) {
+            stage_cache_give(w->stage[i]);
+            w->stage[i] = nullptr;
+        }
+    for (auto &t : w->free_text) text_cache_give(t.first, t.second);
     w->free_text.clear();
 }
 
@@ -940,14 +1023,21 @@ extern "C" int pss_writer_close(pss_writer *w)
         if (rc == PSS_OK) rc = rc2;
         const int e = errno;
         const std::string msg = rc != PSS_OK ? last_error() : std::string();
+        const auto tc0 = std::chrono::steady_clock::now();
         pipe_stop(w);
+        const auto tc1 = std::chrono::steady_clock::now();
         errno = 0;
-        if (close(w->fd) != 0 && rc == PSS_OK) rc = io_error("close");
+        const int crc = close(w->fd);
+        if (getenv("PSS_TIMING"))
+            fprintf(stderr, "[pss] writer close: threads and device buffers %.1f ms, close(fd) %.1f ms\n",
+                    std::chrono::duration<double, std::milli>(tc1 - tc0).count(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc1).count());
+        if (crc != 0 && rc == PSS_OK) rc = io_error("close");
         else if (rc != PSS_OK) {
             set_error("%s", msg.c_str());
             errno = e;
         }
-        free(w->buf);
+        text_cache_give(w->buf, w->alloc);
         delete w;
         return rc;
     });
