@@ -62,6 +62,11 @@ int pss_reload_env(void);
  * bytes around for reuse; resident Reader chunks are not touched). */
 int pss_release_workspace(void);
 
+/* sizeof(pss_sa_stats) / sizeof(pss_search_stats) as the library was built: a binding that declares the structs itself
+ * (ctypes, cgo, JNI) compares them with its own before the first call that fills one. */
+uint64_t pss_sa_stats_size(void);
+uint64_t pss_search_stats_size(void);
+
 /* ---- suffix-array builder seam ----------------------------------------- */
 
 /* Per-build statistics (filled when `stats` is non-NULL). */

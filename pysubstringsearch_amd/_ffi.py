@@ -164,6 +164,8 @@ def _load() -> ctypes.CDLL:
         'pss_device_count': (ctypes.c_int, []),
         'pss_default_devices': (i32, [ctypes.POINTER(i32), i32]),
         'pss_release_workspace': (ctypes.c_int, []),
+        'pss_sa_stats_size': (u64, []),
+        'pss_search_stats_size': (u64, []),
         'pss_last_error': (ctypes.c_size_t, [cp, ctypes.c_size_t]),
         'pss_sa_build': (i32, [vp, vp, i32, i32]),
         'pss_sa_build_device': (i32, [vp, vp, i32, i32, u32, ctypes.POINTER(SaStats)]),
@@ -214,6 +216,13 @@ def _load() -> ctypes.CDLL:
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
+    # the stats structs are declared twice (include/pss.h and above): a field added on one side only would let the
+    # library write past the end of the Python object
+    for what, have, want in (('pss_sa_stats', ctypes.sizeof(SaStats), L.pss_sa_stats_size()),
+                             ('pss_search_stats', ctypes.sizeof(SearchStats), L.pss_search_stats_size())):
+        if have != want:
+            raise ImportError(f'{LIB_PATH}: {what} is {want} bytes in the library and {have} in _ffi.py -- rebuild the '
+                              'library (make -C pysubstringsearch_amd/csrc) or update the binding')
     return L
 
 

@@ -237,6 +237,9 @@ extern "C" int pss_release_workspace(void)
     });
 }
 
+extern "C" uint64_t pss_sa_stats_size(void) { return sizeof(pss_sa_stats); }
+extern "C" uint64_t pss_search_stats_size(void) { return sizeof(pss_search_stats); }
+
 // --------------------------------------------------------------- SA builder --
 
 extern "C" int32_t pss_sa_build(const uint8_t *T, int32_t *SA, int32_t n, int32_t device)

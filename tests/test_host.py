@@ -27,6 +27,33 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(lib, n), f'{n} declared in include/pss.h but not exported'
 
 
+def test_stats_structs_are_declared_alike_on_both_sides():
+    """pss_sa_stats / pss_search_stats exist twice -- include/pss.h and the ctypes classes of _ffi.py: same fields in the same
+    order with the same types, and the library reports the size its build had (the binding refuses to load otherwise)."""
+    from pysubstringsearch_amd import _ffi
+    hdr = open(os.path.join(ROOT, 'include', 'pss.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    ctype = {'uint64_t': ctypes.c_uint64, 'uint32_t': ctypes.c_uint32, 'int32_t': ctypes.c_int32, 'double': ctypes.c_double,
+             'float': ctypes.c_float, 'int64_t': ctypes.c_int64}
+    for name, cls in (('pss_sa_stats', _ffi.SaStats), ('pss_search_stats', _ffi.SearchStats)):
+        body = re.search(r'typedef struct(?:\s+\w+)?\s*\{([^}]*)\}\s*' + name + r'\s*;', hdr, flags=re.S).group(1)
+        fields = []
+        for decl in body.split(';'):
+            decl = decl.strip()
+            if not decl:
+                continue
+            m = re.match(r'(\w+)\s+(\w+)(?:\[(\d+)\])?$', decl)
+            assert m, decl
+            t = ctype[m.group(1)]
+            fields.append((m.group(2), t * int(m.group(3)) if m.group(3) else t))
+        have = [(k, t) for k, t in cls._fields_]
+        assert [k for k, _ in fields] == [k for k, _ in have], name
+        for (k, t), (_, u) in zip(fields, have):
+            assert ctypes.sizeof(t) == ctypes.sizeof(u) and (t is u or getattr(t, '_length_', 0) == getattr(u, '_length_', 0)), (name, k)
+    assert _ffi.lib.pss_sa_stats_size() == ctypes.sizeof(_ffi.SaStats)
+    assert _ffi.lib.pss_search_stats_size() == ctypes.sizeof(_ffi.SearchStats)
+
+
 def test_api_signatures_match_reference(pss):
     import pysubstringsearch
     assert pysubstringsearch.Writer is pss.Writer and pysubstringsearch.Reader is pss.Reader
