@@ -67,7 +67,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-KINDS = {'lines': 0, 'words': 1, 'runs': 2, 'periodic': 3, 'repeat_line': 4, 'dup_blocks': 5, 'mixed': 6}
+KINDS = {'lines': 0, 'words': 1, 'runs': 2, 'periodic': 3, 'repeat_line': 4, 'dup_blocks': 5, 'mixed': 6, 'source': 7}
 ALPHA = b'abcdefghijklmnopqrstuvwxyz0123456789 .'
 METRIC = 'queries/sec (batched) + index-build GB/s on 512MB chunk, 1/2/4/8 GPU'
 MASK64 = (1 << 64) - 1
@@ -211,9 +211,13 @@ def cpu_baseline_corpus(texts, sas, queries, sample_queries: int, want_disk: boo
            'sample': f'the first {len(qs)} queries of the batch, one at a time, fanned out over the {nchunks} chunks on '
                      f'{threads} threads (oracle/pss_oracle.c orc_bench_search: rayon par_iter_mut of src/lib.rs:207 restated)'}
     r = O.OracleReader.from_arrays(texts, sas)
-    b = r.bench_search(qs, threads)
+    b = r.bench_search(qs, threads)                       # per-chunk dedupe by a hash set, like lib.rs:262
     out['value'] = round(len(qs) / b['seconds'], 1)
-    out['value_is'] = 'suffix arrays in RAM (kinder than the reference, which probes them on disk)'
+    out['value_is'] = ('suffix arrays in RAM (kinder than the reference, which probes them on disk); per-chunk dedupe by a hash set '
+                       'like the reference\'s AHashSet (src/lib.rs:262)')
+    bs = r.bench_search(qs, threads, dedupe='sort')       # the checker's sorted scratch list (rounds 1-4 timed this one)
+    assert np.array_equal(bs['counts'], b['counts'])
+    out['sort_dedupe_queries_per_sec'] = round(len(qs) / bs['seconds'], 1)
     out['entries_per_query'] = round(b['entries'] / max(len(qs), 1), 2)
     b1 = r.bench_search(qs[:max(len(qs) // 10, 1)], 1)
     out['one_thread_queries_per_sec'] = round(max(len(qs) // 10, 1) / b1['seconds'], 1)

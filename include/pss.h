@@ -410,6 +410,7 @@ void pss_result_free(pss_result *res);
 #define PSS_CORPUS_REPEAT_LINE 4 /* one 40-byte line repeated (period 40, no runs of equal bytes) */
 #define PSS_CORPUS_DUP_BLOCKS 5  /* a 1 MiB block of `lines` text repeated, 16 single-byte edits per copy */
 #define PSS_CORPUS_MIXED 6       /* `words` whose middle third is one 60-byte line repeated, then 64 KiB blocks copied from the first third */
+#define PSS_CORPUS_SOURCE 7      /* source-like text: 200-odd byte values, indentation, licence headers, stretches of lines copied from earlier in the chunk (round 5) */
 /* Fills out[0..n) on the host; deterministic in (kind, n, chunk_index). */
 int pss_gen_corpus(int kind, uint8_t *out, uint64_t n, uint64_t chunk_index);
 

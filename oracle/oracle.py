@@ -76,6 +76,9 @@ def lib() -> ctypes.CDLL:
         L.orc_reader_chunk_data.restype = ctypes.POINTER(ctypes.c_uint8)
         L.orc_reader_chunk_sa.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
         L.orc_reader_chunk_sa.restype = ctypes.POINTER(ctypes.c_int32)
+        L.orc_set_hash_dedupe.argtypes = [ctypes.c_int]
+        L.orc_set_hash_dedupe.restype = None
+        L.orc_get_hash_dedupe.restype = ctypes.c_int
         L.orc_gen_lines.argtypes = [vp, ctypes.c_size_t, ctypes.c_uint64]
         L.orc_gen_lines.restype = None
         _lib = L
@@ -138,6 +141,12 @@ def sa_reference(data) -> np.ndarray:
 def sa(data) -> np.ndarray:
     """Best available oracle SA: libsais when built, else the restatement."""
     return sa_reference(data) if have_reference() else sa_restatement(data)
+
+
+def set_hash_dedupe(on: bool) -> None:
+    """Per-chunk dedupe of the search restatement: hash set (lib.rs:262 as written) or the sorted scratch list the
+    checker has used since round 1.  Same results, same order; tests run both."""
+    lib().orc_set_hash_dedupe(1 if on else 0)
 
 
 def gen_lines(n: int, chunk_index: int = 0) -> np.ndarray:
@@ -233,11 +242,22 @@ class OracleReader:
             _raise(rc, 'from_arrays')
         return r
 
-    def bench_search(self, patterns: typing.Sequence[bytes], threads: int, disk: bool = False) -> dict:
+    def bench_search(self, patterns: typing.Sequence[bytes], threads: int, disk: bool = False, dedupe: str = 'hash') -> dict:
         """The reference-shaped CPU baseline: queries one at a time, each
         fanned out over the chunks on `threads` workers (lib.rs:207), suffix array probed in
         RAM or -- disk=True -- in the index file with lseek + read(8 KiB) per probe
-        (lib.rs:216-217).  Returns seconds, entries, bytes and the per-query counts."""
+        (lib.rs:216-217).  Returns seconds, entries, bytes and the per-query counts.
+        dedupe='hash' (default): the per-chunk dedupe is a hash set, like the reference's AHashSet (lib.rs:262);
+        'sort': the checker's sorted scratch list (O(h log h): slower on high-hit queries, same output)."""
+        assert dedupe in ('hash', 'sort')
+        was = lib().orc_get_hash_dedupe()
+        lib().orc_set_hash_dedupe(1 if dedupe == 'hash' else 0)
+        try:
+            return self._bench_search(patterns, threads, disk, dedupe)
+        finally:
+            lib().orc_set_hash_dedupe(was)
+
+    def _bench_search(self, patterns, threads, disk, dedupe) -> dict:
         blob = b''.join(patterns)
         off = np.zeros(len(patterns) + 1, dtype=np.uint64)
         if patterns:
@@ -250,7 +270,7 @@ class OracleReader:
         if rc:
             _raise(rc, 'bench_search')
         return {'seconds': sec.value, 'entries': ent.value, 'bytes': byt.value, 'counts': counts[:len(patterns)],
-                'threads': min(threads, max(self.num_chunks, 1)), 'disk': bool(disk)}
+                'threads': min(threads, max(self.num_chunks, 1)), 'disk': bool(disk), 'dedupe': dedupe}
 
     @property
     def num_chunks(self) -> int:

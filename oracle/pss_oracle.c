@@ -467,6 +467,12 @@ static int res_push(orc_result *res, const uint8_t *p, size_t l)
     return ORC_OK;
 }
 
+/* 0: first-occurrence filter by a sorted scratch list (the checker's default, kept as written in round 1);
+ * 1: a hash set like the reference's AHashSet (lib.rs:262) -- what orc_bench_search times.  Same output either way. */
+static int g_hash_dedupe = 0;
+void orc_set_hash_dedupe(int on) { g_hash_dedupe = on ? 1 : 0; }
+int orc_get_hash_dedupe(void) { return g_hash_dedupe; }
+
 /* slice `pat` vs suffix `line`: Rust `<[u8]>::cmp` (unsigned, shorter first) */
 static int slice_cmp(const uint8_t *a, size_t al, const uint8_t *b, size_t bl)
 {
@@ -546,8 +552,34 @@ static int search_chunk_src(const orc_chunk *ch, orc_sa_src *src, const uint8_t 
         order[2 * k] = (uint64_t)line_tail;
         order[2 * k + 1] = (uint64_t)line_head;
     }
-    /* first-occurrence filter: sort a copy, then mark */
     free(hits_read);
+    if (g_hash_dedupe) {
+        /* lib.rs:262,274 as written: a hash set of line starts (AHashSet<usize>), insert-or-skip per hit, emission in
+         * SA order of the first hit.  Open addressing, load <= 1/2, a multiplicative hash: O(1) per hit -- the timed
+         * CPU baseline uses this one (the sorted-scratch filter below is O(h log h) and would understate the CPU on
+         * high-hit queries). */
+        size_t cap = 16;
+        while (cap < 2 * nh) cap <<= 1;
+        uint64_t *tab = (uint64_t *)malloc(cap * sizeof(uint64_t));
+        if (!tab) { free(seen); free(order); return ORC_ENOMEM; }
+        memset(tab, 0xff, cap * sizeof(uint64_t));                 /* ~0 = empty (no line starts there) */
+        int rc = ORC_OK;
+        for (size_t k = 0; k < nh && rc == ORC_OK; k++) {
+            const uint64_t key = seen[k];
+            size_t ix = (size_t)((key * 0x9E3779B97F4A7C15ULL) >> 32) & (cap - 1);
+            int fresh = 1;
+            while (tab[ix] != ~0ULL) {
+                if (tab[ix] == key) { fresh = 0; break; }
+                ix = (ix + 1) & (cap - 1);
+            }
+            if (!fresh) continue;
+            tab[ix] = key;
+            rc = res_push(res, ch->data + order[2 * k], (size_t)(order[2 * k + 1] - order[2 * k]));
+        }
+        free(tab); free(seen); free(order);
+        return rc;
+    }
+    /* first-occurrence filter: sort a copy, then mark */
     uint64_t *sorted = (uint64_t *)malloc(nh * sizeof(uint64_t));
     if (!sorted) { free(seen); free(order); return ORC_ENOMEM; }
     memcpy(sorted, seen, nh * sizeof(uint64_t));

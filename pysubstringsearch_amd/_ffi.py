@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get('PSS_LIBPSS') or os.path.join(_HERE, 'libpss.so')   # 
 PSS_OK, PSS_EINVAL, PSS_ENOMEM, PSS_EIO, PSS_ETOOBIG, PSS_EDEVICE, PSS_EFORMAT = 0, -1, -2, -3, -4, -5, -6
 
 CORPUS_LINES, CORPUS_WORDS, CORPUS_RUNS, CORPUS_PERIODIC = 0, 1, 2, 3
-CORPUS_REPEAT_LINE, CORPUS_DUP_BLOCKS, CORPUS_MIXED = 4, 5, 6
+CORPUS_REPEAT_LINE, CORPUS_DUP_BLOCKS, CORPUS_MIXED, CORPUS_SOURCE = 4, 5, 6, 7
 
 
 class SaStats(ctypes.Structure):

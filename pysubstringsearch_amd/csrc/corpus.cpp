@@ -194,6 +194,363 @@ void gen_mixed(uint8_t *out, uint64_t n, uint64_t chunk)
     }
 }
 
+// Source-like text (round 5): what users of the library index most -- program sources, headers, documentation -- and the
+// slowest regime of the builder (repeats of every length, 200-odd byte values, a fifth of the lines starting with blanks).
+// The model, measured against 412 MB of real files (tests/tools/lcp_stats.py prints the same figures for both):
+//   * "files" of 20 .. 3000 lines; most open with one of six licence headers (comment lines, one of them with a year and
+//     a name that differ from file to file), one file in six is a copy of an earlier file with a few lines edited;
+//   * lines: blank / comment / rule (one of "-=*~#" 40 .. 79 times) / import, include / def, class, function head /
+//     statement / table of hexadecimal numbers / string of bytes above 127 / closing line; indentation follows a random
+//     walk over 0 .. 7 levels of four blanks (one file in eight: tabs); identifiers from a 32768-word vocabulary with
+//     the skew of `words`, keywords from a fixed list;
+//   * inside a file, stretches of 2 .. 120 lines are copied from anywhere earlier in the chunk at line granularity
+//     (copies of copies included: the repeat counts come out heavy-tailed), and stretches of 3 .. 40 lines from a pool of
+//     512 boilerplate blocks that is the same for every chunk.
+// Integer-only (xorshift64 as above), one thread.
+struct SourceGen {
+    uint8_t *out;
+    uint64_t n, o = 0;
+    Xs64 g;
+    std::vector<uint8_t> letters;          // vocabulary
+    std::vector<uint32_t> wstart;
+    std::vector<uint64_t> line_start;      // start of every line written so far
+    std::vector<uint64_t> file_start;      // index into line_start of every file's first line
+    std::vector<std::vector<uint8_t>> pool, headers;
+    int depth = 0;
+    bool tabs = false;
+
+    static constexpr uint32_t V = 32768;
+
+    void build_vocabulary()
+    {
+        static const char L1[] = "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ_";
+        static const char L2[] = "abcdefghijklmnopqrstuvwxyzabcdefghijklmnopqrstuvwxyz_0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ";
+        Xs64 v{0x2545F4914F6CDD1DULL ^ 0x5DEECE66DULL};
+        wstart.resize(V + 1);
+        for (uint32_t w = 0; w < V; ++w) {
+            wstart[w] = (uint32_t)letters.size();
+            const uint32_t len = 2 + v.nx() % 11;
+            const uint32_t cap = v.nx() % 8;      // one word in eight starts with a capital / underscore
+            letters.push_back((uint8_t)L1[cap == 0 ? 26 + v.nx() % 27 : v.nx() % 26]);
+            for (uint32_t k = 1; k < len; ++k) letters.push_back((uint8_t)L2[v.nx() % (sizeof(L2) - 1)]);
+        }
+        wstart[V] = (uint32_t)letters.size();
+    }
+
+    // ---- emitters into a byte vector (a line is built first, then written: the pool and the headers use the same code)
+    void put(std::vector<uint8_t> &l, const char *s) { while (*s) l.push_back((uint8_t)*s++); }
+    void word(std::vector<uint8_t> &l, Xs64 &r)
+    {
+        const uint32_t a = r.nx() % V, sh = r.nx() % 15;
+        const uint32_t w = a >> sh;
+        l.insert(l.end(), letters.begin() + wstart[w], letters.begin() + wstart[w + 1]);
+    }
+    void number(std::vector<uint8_t> &l, Xs64 &r)
+    {
+        uint32_t v = r.nx() % 100000u;
+        if (r.nx() % 4 == 0) v %= 10;
+        char buf[16];
+        int k = 0;
+        do { buf[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+        while (k) l.push_back((uint8_t)buf[--k]);
+    }
+    void indent(std::vector<uint8_t> &l, int d)
+    {
+        for (int i = 0; i < d; ++i) {
+            if (tabs) l.push_back('\t');
+            else put(l, "    ");
+        }
+    }
+    void expr(std::vector<uint8_t> &l, Xs64 &r, int budget)
+    {
+        switch (r.nx() % 8) {
+            case 0: number(l, r); break;
+            case 1: {
+                l.push_back('\'');
+                word(l, r);
+                l.push_back('\'');
+                break;
+            }
+            case 2:
+            case 3: {
+                word(l, r);
+                l.push_back('(');
+                const uint32_t args = budget > 0 ? r.nx() % 4 : 0;
+                for (uint32_t a = 0; a < args; ++a) {
+                    if (a) put(l, ", ");
+                    expr(l, r, budget - 1);
+                }
+                l.push_back(')');
+                break;
+            }
+            case 4: {
+                word(l, r);
+                l.push_back('.');
+                word(l, r);
+                break;
+            }
+            case 5: {
+                word(l, r);
+                static const char *ops[] = {" + ", " - ", " * ", " == ", " != ", " < ", " and ", " or ", " | ", " & ", " >> "};
+                put(l, ops[r.nx() % 11]);
+                if (budget > 0) expr(l, r, budget - 1);
+                else number(l, r);
+                break;
+            }
+            case 6: {
+                word(l, r);
+                l.push_back('[');
+                if (budget > 0) expr(l, r, budget - 1);
+                else number(l, r);
+                l.push_back(']');
+                break;
+            }
+            default: word(l, r); break;
+        }
+    }
+    // one line (without the newline); may change the depth
+    void make_line(std::vector<uint8_t> &l, Xs64 &r, int &d)
+    {
+        static const char *kw_open[] = {"if ", "for ", "while ", "elif ", "with ", "switch ", "else if "};
+        static const char *types[] = {"int", "void", "const char *", "uint32_t", "size_t", "bool", "double", "auto", "static int", "unsigned"};
+        const uint32_t k = r.nx() % 100;
+        if (k < 8) return;                                       // blank
+        if (k < 20) {                                            // comment
+            indent(l, d);
+            put(l, r.nx() % 2 ? "# " : "// ");
+            const uint32_t words = 2 + r.nx() % 10;
+            for (uint32_t i = 0; i < words; ++i) {
+                if (i) l.push_back(' ');
+                word(l, r);
+            }
+            if (r.nx() % 3 == 0) l.push_back('.');
+            return;
+        }
+        if (k < 23) {                                            // rule
+            indent(l, d);
+            static const char *lead[] = {"", "# ", "// ", "/* "};
+            put(l, lead[r.nx() % 4]);
+            const uint8_t c = (uint8_t)"-=*~#"[r.nx() % 5];
+            const uint32_t len = 40 + r.nx() % 40;
+            l.insert(l.end(), len, c);
+            return;
+        }
+        if (k < 30) {                                            // import / include
+            switch (r.nx() % 3) {
+                case 0: put(l, "import "); word(l, r); if (r.nx() % 2) { l.push_back('.'); word(l, r); } break;
+                case 1: put(l, "from "); word(l, r); l.push_back('.'); word(l, r); put(l, " import "); word(l, r); break;
+                default: put(l, "#include <"); word(l, r); l.push_back('/'); word(l, r); put(l, ".h>"); break;
+            }
+            return;
+        }
+        if (k < 38) {                                            // def / class / function head: one level deeper
+            indent(l, d);
+            const uint32_t f = r.nx() % 3;
+            if (f == 0) { put(l, "def "); word(l, r); put(l, "(self"); }
+            else if (f == 1) { put(l, "class "); word(l, r); l.push_back('('); word(l, r); }
+            else { put(l, types[r.nx() % 10]); l.push_back(' '); word(l, r); l.push_back('('); put(l, types[r.nx() % 10]); l.push_back(' '); word(l, r); }
+            const uint32_t args = r.nx() % 4;
+            for (uint32_t a = 0; a < args; ++a) {
+                put(l, ", ");
+                if (f == 2) { put(l, types[r.nx() % 10]); l.push_back(' '); }
+                word(l, r);
+                if (f == 0 && r.nx() % 3 == 0) put(l, "=None");
+            }
+            put(l, f == 2 ? ") {" : "):");
+            if (d < 7) ++d;
+            return;
+        }
+        if (k < 46) {                                            // control statement: one level deeper
+            indent(l, d);
+            put(l, kw_open[r.nx() % 7]);
+            expr(l, r, 2);
+            put(l, tabs ? ") {" : ":");
+            if (d < 7) ++d;
+            return;
+        }
+        if (k < 82) {                                            // statement
+            indent(l, d);
+            switch (r.nx() % 6) {
+                case 0: put(l, "return "); expr(l, r, 2); break;
+                case 1: put(l, "self."); word(l, r); put(l, " = "); expr(l, r, 2); break;
+                case 2: expr(l, r, 2); break;
+                default: word(l, r); put(l, " = "); expr(l, r, 2); break;
+            }
+            if (tabs) l.push_back(';');
+            return;
+        }
+        if (k < 86) {                                            // table of numbers
+            indent(l, d);
+            static const char HEX[] = "0123456789abcdef";
+            const uint32_t cnt = 4 + r.nx() % 9;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                put(l, "0x");
+                uint32_t v = r.nx();
+                if (r.nx() % 3 == 0) v &= 0xffu;
+                for (int s = 28; s >= 0; s -= 4) l.push_back((uint8_t)HEX[(v >> s) & 15u]);
+                put(l, i + 1 < cnt ? ", " : ",");
+            }
+            return;
+        }
+        if (k < 89) {                                            // text with bytes above 127
+            indent(l, d);
+            word(l, r);
+            put(l, " = \"");
+            const uint32_t cnt = 4 + r.nx() % 28;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const uint32_t x = r.nx();
+                if (x % 4 == 0) l.push_back(' ');
+                else l.push_back((uint8_t)(0x80u + (x >> 8) % 128u));
+            }
+            l.push_back('"');
+            return;
+        }
+        // closing line: one level up
+        if (d > 0) --d;
+        indent(l, d);
+        static const char *close[] = {"}", "pass", "return", "break", "};", "continue", "#endif", "return None"};
+        put(l, tabs ? "}" : close[r.nx() % 8]);
+    }
+
+    bool full() const { return o >= n; }
+    void write_line(const std::vector<uint8_t> &l)
+    {
+        if (full()) return;
+        line_start.push_back(o);
+        const uint64_t len = std::min<uint64_t>(l.size(), n - o);
+        memcpy(out + o, l.data(), len);
+        o += len;
+        if (o < n) out[o++] = '\n';
+    }
+    void write_lines(const std::vector<uint8_t> &block)   // a block holds whole lines, each with its newline
+    {
+        size_t a = 0;
+        while (a < block.size() && !full()) {
+            size_t e = a;
+            while (block[e] != '\n') ++e;
+            line_start.push_back(o);
+            const uint64_t len = std::min<uint64_t>(e + 1 - a, n - o);
+            memcpy(out + o, block.data() + a, len);
+            o += len;
+            a = e + 1;
+        }
+    }
+    // lines [first, first + count) of what has been written, copied to the end (the source may run into the copy)
+    void copy_lines(uint64_t first, uint64_t count)
+    {
+        const uint64_t have = line_start.size();
+        for (uint64_t i = 0; i < count && first + i + 1 < have && !full(); ++i) {
+            const uint64_t a = line_start[first + i], e = line_start[first + i + 1];
+            line_start.push_back(o);
+            const uint64_t len = std::min<uint64_t>(e - a, n - o);
+            memmove(out + o, out + a, len);
+            o += len;
+        }
+    }
+
+    void build_pools()
+    {
+        Xs64 r{0xA0761D6478BD642FULL};
+        std::vector<uint8_t> l;
+        headers.resize(6);
+        for (auto &h : headers) {
+            const uint32_t lines = 6 + r.nx() % 22;
+            const bool slash = r.nx() % 2;
+            for (uint32_t i = 0; i < lines; ++i) {
+                put(h, slash ? "//" : "#");
+                const uint32_t words = r.nx() % 13;
+                for (uint32_t k = 0; k < words; ++k) { h.push_back(' '); word(h, r); }
+                h.push_back('\n');
+            }
+        }
+        pool.resize(512);
+        for (auto &p : pool) {
+            const uint32_t lines = 3 + r.nx() % 38;
+            int d = (int)(r.nx() % 3);
+            for (uint32_t i = 0; i < lines; ++i) {
+                l.clear();
+                make_line(l, r, d);
+                p.insert(p.end(), l.begin(), l.end());
+                p.push_back('\n');
+            }
+        }
+    }
+
+    void run()
+    {
+        build_vocabulary();
+        build_pools();
+        std::vector<uint8_t> l;
+        while (!full()) {
+            // ---- one file
+            const uint64_t my_first_line = line_start.size();
+            const uint32_t kind = g.nx() % 6;
+            if (kind == 0 && file_start.size() >= 2) {
+                // a copy of an earlier file, a line in sixty-four written anew
+                const uint64_t f = g.nx() % (file_start.size() - 1);
+                const uint64_t a = file_start[f], e = file_start[f + 1];
+                int d = 0;
+                for (uint64_t i = a; i < e && !full(); ++i) {
+                    if (g.nx() % 64 == 0) {
+                        l.clear();
+                        make_line(l, g, d);
+                        write_line(l);
+                    } else copy_lines(i, 1);
+                }
+                file_start.push_back(my_first_line);
+                continue;
+            }
+            tabs = g.nx() % 8 == 0;
+            depth = 0;
+            if (g.nx() % 4 != 0) {
+                const auto &h = headers[g.nx() % 6];
+                l.clear();
+                put(l, h[0] == '/' ? "// Copyright (c) " : "# Copyright (c) ");
+                { uint32_t y = 1990 + g.nx() % 36; char b4[4]; for (int i = 3; i >= 0; --i) { b4[i] = (char)('0' + y % 10); y /= 10; } l.insert(l.end(), b4, b4 + 4); }
+                l.push_back(' ');
+                word(l, g);
+                l.push_back(' ');
+                word(l, g);
+                write_line(l);
+                write_lines(h);
+            }
+            uint32_t body = 20 + g.nx() % 600;
+            if (g.nx() % 8 == 0) body *= 5;
+            for (uint32_t done = 0; done < body && !full();) {
+                const uint32_t ev = g.nx() % 100;
+                if (ev < 30 && line_start.size() > 64) {            // a stretch copied from anywhere earlier in the chunk
+                    uint32_t len = 2 + g.nx() % 30;
+                    if (g.nx() % 4 == 0) len *= 4;
+                    const uint64_t first = (((uint64_t)g.nx() << 32) | g.nx()) % (line_start.size() - 1);
+                    copy_lines(first, len);
+                    done += len;
+                } else if (ev < 42) {                                // boilerplate
+                    write_lines(pool[(g.nx() % 512) >> (g.nx() % 6)]);
+                    done += 20;
+                } else {                                             // 1 .. 12 new lines
+                    const uint32_t fresh = 1 + g.nx() % 12;
+                    for (uint32_t i = 0; i < fresh && !full(); ++i) {
+                        l.clear();
+                        make_line(l, g, depth);
+                        write_line(l);
+                    }
+                    done += fresh;
+                }
+            }
+            file_start.push_back(my_first_line);
+        }
+    }
+};
+
+void gen_source(uint8_t *out, uint64_t n, uint64_t chunk)
+{
+    SourceGen sg;
+    sg.out = out;
+    sg.n = n;
+    sg.g = Xs64{(kSeed ^ 0x8EBC6AF09C88C6E3ULL) + chunk};
+    sg.run();
+}
+
 }  // namespace
 
 extern "C" int pss_gen_corpus(int kind, uint8_t *out, uint64_t n, uint64_t chunk_index)
@@ -207,6 +564,7 @@ extern "C" int pss_gen_corpus(int kind, uint8_t *out, uint64_t n, uint64_t chunk
         case PSS_CORPUS_REPEAT_LINE: gen_repeat_line(out, n, chunk_index); break;
         case PSS_CORPUS_DUP_BLOCKS: gen_dup_blocks(out, n, chunk_index); break;
         case PSS_CORPUS_MIXED: gen_mixed(out, n, chunk_index); break;
+        case PSS_CORPUS_SOURCE: gen_source(out, n, chunk_index); break;
         default: return PSS_EINVAL;
     }
     if (n) out[n - 1] = '\n';

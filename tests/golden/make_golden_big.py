@@ -28,7 +28,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import numpy as np  # noqa: E402
 
-KIND_IDS = {'lines': 0, 'words': 1, 'runs': 2, 'periodic': 3, 'repeat_line': 4, 'dup_blocks': 5, 'mixed': 6}
+KIND_IDS = {'lines': 0, 'words': 1, 'runs': 2, 'periodic': 3, 'repeat_line': 4, 'dup_blocks': 5, 'mixed': 6, 'source': 7}
+
+# Round 5: chunks ABOVE the default size.  The reference accepts any max_chunk_len below 2^30 (src/lib.rs:57,116: the
+# suffix array's byte length is a u32); container format 2 lifts that to 2^31 - 1.  2^30 - 1 is the largest chunk the
+# reference's own format holds, 1.25 GiB one only format 2 can.
+BIG_N = (1 << 30) - 1
+FORMAT2_N = 5 << 28
 
 
 def poly64(sa: np.ndarray) -> int:
@@ -44,10 +50,9 @@ def poly64(sa: np.ndarray) -> int:
 
 
 def one(job):
-    kind, chunk, logn = job
+    kind, chunk, n = job
     from oracle import oracle as O
     from pysubstringsearch_amd import _ffi
-    n = 1 << logn
     t0 = time.time()
     text = np.empty(n, dtype=np.uint8)
     _ffi.check(_ffi.lib.pss_gen_corpus(KIND_IDS[kind], text.ctypes.data, n, chunk))
@@ -72,20 +77,28 @@ def main():
     ap.add_argument('--logn', type=int, default=29)
     ap.add_argument('--lines-chunks', type=int, default=15)
     ap.add_argument('--words-chunks', type=int, default=15)
+    ap.add_argument('--big', action='store_true', help='also the chunks of 2^30 - 1 and 5 * 2^28 bytes')
+    ap.add_argument('--only', default='', help='comma-separated kinds to (re)generate')
     ap.add_argument('--out', default=os.path.join(HERE, 'sa_big.json'))
     args = ap.parse_args()
     from oracle import oracle as O
     assert O.have_reference(), 'needs oracle/_ref/libsais.so (make -C oracle)'
-    jobs = [('lines', 0, args.logn), ('words', 0, args.logn), ('runs', 0, args.logn), ('periodic', 0, args.logn)]
-    jobs += [('lines', c, args.logn) for c in range(1, args.lines_chunks)]
-    jobs += [('words', c, args.logn) for c in range(1, args.words_chunks)]
-    jobs += [('repeat_line', 0, args.logn), ('dup_blocks', 0, args.logn)]      # general repeats (round 3)
-    jobs += [('mixed', 0, args.logn)]                                          # natural text with a repetitive middle (round 4)
+    n0 = 1 << args.logn
+    jobs = [('lines', 0, n0), ('words', 0, n0), ('runs', 0, n0), ('periodic', 0, n0)]
+    jobs += [('lines', c, n0) for c in range(1, args.lines_chunks)]
+    jobs += [('words', c, n0) for c in range(1, args.words_chunks)]
+    jobs += [('repeat_line', 0, n0), ('dup_blocks', 0, n0)]      # general repeats (round 3)
+    jobs += [('mixed', 0, n0)]                                   # natural text with a repetitive middle (round 4)
+    jobs += [('source', 0, n0), ('source', 1, n0)]               # source-like text (round 5)
+    if args.big:                                                 # above the default chunk size (round 5; ~6 GB and 3-4 minutes each)
+        jobs += [('lines', 0, BIG_N), ('words', 0, BIG_N), ('mixed', 0, BIG_N), ('source', 0, BIG_N), ('words', 0, FORMAT2_N)]
     done = {}
     if os.path.exists(args.out):
         for r in json.load(open(args.out))['chunks']:
             done[(r['kind'], r['chunk_index'], r['n'])] = r
-    jobs = [j for j in jobs if (j[0], j[1], 1 << j[2]) not in done]
+    if args.only:
+        jobs = [j for j in jobs if j[0] in args.only.split(',')]
+    jobs = [j for j in jobs if (j[0], j[1], j[2]) not in done]
     with mp.get_context('spawn').Pool(args.workers) as pool:
         for rec in pool.imap_unordered(one, jobs):
             done[(rec['kind'], rec['chunk_index'], rec['n'])] = rec

@@ -153,9 +153,18 @@ def test_thread_per_chunk_baseline_equals_plain_search(oracle, tmp_path):
         qs.append(texts[c][s:s + ln].tobytes())
     ents, counts = r.search_multiple_bytes(qs)
     for threads in (1, 2, 5, 64):
-        b = r.bench_search(qs, threads)
-        assert np.array_equal(b['counts'], counts) and b['entries'] == len(ents) and b['bytes'] == sum(map(len, ents))
-        assert b['threads'] == min(threads, 5) and b['seconds'] > 0
+        for dedupe in ('hash', 'sort'):
+            b = r.bench_search(qs, threads, dedupe=dedupe)
+            assert np.array_equal(b['counts'], counts) and b['entries'] == len(ents) and b['bytes'] == sum(map(len, ents))
+            assert b['threads'] == min(threads, 5) and b['seconds'] > 0 and b['dedupe'] == dedupe
+    # the hash-set dedupe (lib.rs:262 as written: what the timed baseline uses) returns the checker's lists, entry by
+    # entry and in the same order -- SA order of the first hit -- on high-hit queries too
+    try:
+        oracle.set_hash_dedupe(True)
+        e_h, c_h = r.search_multiple_bytes(qs)
+    finally:
+        oracle.set_hash_dedupe(False)
+    assert np.array_equal(c_h, counts) and e_h == ents and int(counts.max()) > 1000
     p = str(tmp_path / 'five.idx')
     with open(p, 'wb') as f:            # chunk records, src/lib.rs:112-119
         for t, s in zip(texts, sas):
