@@ -287,6 +287,19 @@ int pss_reader_promote_chunk(pss_reader *r, uint64_t index);
  * else.  pss_reader_low_latency_stats: kernels started / queries answered by one, per device. */
 int pss_reader_set_low_latency(pss_reader *r, int32_t on);
 int pss_reader_low_latency_stats(const pss_reader *r, uint64_t *launches, uint64_t *served);
+/* Order of the entries INSIDE one chunk's share of a query (round 5).  The reference walks the hits of a chunk in
+ * suffix-array order and pushes an entry when its line start is first seen (src/lib.rs:262-276): a chunk's entries come
+ * out in suffix-array order of their FIRST hit.  The default here (PSS_ORDER_TEXT) keeps the leftmost match of every
+ * entry and lists the entries in suffix-array order of THAT match -- the same multiset (what the reference's tests
+ * compare, tests/test_pysubstringsearch.py:32-37), possibly another order when an entry holds the pattern twice.
+ * PSS_ORDER_SA reproduces the reference's list element by element (chunks in index order; the reference's order between
+ * chunks is whatever its thread pool makes of it, src/lib.rs:207,280).  It takes the general pipeline and one more
+ * sort of the hits: batches pay a few per cent, a single query loses the fused path.  PSS_RESULT_ORDER=sa in the
+ * environment makes it the default of every reader opened afterwards. */
+#define PSS_ORDER_TEXT 0
+#define PSS_ORDER_SA 1
+int pss_reader_set_result_order(pss_reader *r, int32_t order);
+int32_t pss_reader_result_order(const pss_reader *r);
 /* An empty reader on `device`, to be filled with pss_reader_add_chunk_device
  * (Writer -> Reader hand-off through HBM, no file). */
 int pss_reader_create(int32_t device, pss_reader **out);
@@ -372,6 +385,45 @@ int pss_comm_unique_id(uint8_t *id128);
 int pss_comm_init(const uint8_t *id128, int32_t world, int32_t rank, int32_t device, pss_comm **out);
 int pss_comm_destroy(pss_comm *c);
 int pss_gather_packed_rccl(pss_comm *c, const pss_device_result *mine, int32_t dst, pss_result **out);
+/*
+ * Failure behaviour of the gather (round 5).  Every wait for the peers is bounded: PSS_RCCL_TIMEOUT_MS in the
+ * environment (default 60000), pss_comm_set_timeout_ms per communicator; RCCL's asynchronous error state is polled
+ * meanwhile.  When the bound passes, or RCCL reports an error, the communicator is ABORTED (ncclCommAbort), the call
+ * returns PSS_EDEVICE with the reason in pss_last_error, and every later call on that communicator returns PSS_EDEVICE
+ * at once -- readers, builders and other communicators of the process keep working; make a new communicator to go on.
+ * The outcome is collective where it can be: a rank that cannot go through with the exchange (the collecting rank out
+ * of memory, ranks that answered different numbers of queries) says so in a go / no-go word before anybody sends, and
+ * every rank returns an error.  No device context is held while the call waits for a peer.
+ * pss_comm_status: PSS_OK while the communicator is usable, PSS_EDEVICE once it was aborted; counters of completed
+ * gathers and of aborts (either pointer may be NULL).
+ */
+int pss_comm_set_timeout_ms(pss_comm *c, uint32_t ms);
+int pss_comm_status(pss_comm *c, uint64_t *gathers, uint64_t *aborts);
+/*
+ * The collectives library as a table (round 5).  By default libpss looks RCCL up in the process (dlopen of librccl.so,
+ * PSS_RCCL_LIB).  An application that links RCCL itself hands its entry points in -- signatures as in rccl.h, streams
+ * and communicators as void pointers -- and may adopt a communicator it already has (pss_comm_adopt: never destroyed
+ * by pss_comm_destroy, but aborted when a gather times out).  The test-suite uses the same seam to make Send / Recv /
+ * GroupEnd fail and a Recv never complete.  comm_abort, comm_get_async_error, get_error_string, get_unique_id,
+ * comm_init_rank and comm_destroy may be NULL (the last three: pss_comm_adopt only).  NULL restores the lookup;
+ * communicators keep the table they were made with.
+ */
+typedef struct pss_rccl_unique_id { char internal[128]; } pss_rccl_unique_id;      /* ncclUniqueId */
+typedef struct pss_rccl_api {
+    int (*get_unique_id)(pss_rccl_unique_id *id);
+    int (*comm_init_rank)(void **comm, int nranks, pss_rccl_unique_id id, int rank);
+    int (*comm_destroy)(void *comm);
+    int (*comm_abort)(void *comm);
+    int (*comm_get_async_error)(void *comm, int *async_error);
+    int (*group_start)(void);
+    int (*group_end)(void);
+    int (*send)(const void *buf, size_t count, int datatype, int peer, void *comm, void *stream);
+    int (*recv)(void *buf, size_t count, int datatype, int peer, void *comm, void *stream);
+    int (*all_gather)(const void *sendbuf, void *recvbuf, size_t sendcount, int datatype, void *comm, void *stream);
+    const char *(*get_error_string)(int result);
+} pss_rccl_api;
+int pss_rccl_inject(const pss_rccl_api *api);
+int pss_comm_adopt(void *nccl_comm, int32_t world, int32_t rank, int32_t device, pss_comm **out);
 
 /*
  * Host merge of `world` packed results of the same nq queries (one per rank, each query-major) into one:

@@ -205,8 +205,12 @@ class Reader:
         device: typing.Optional[int] = None,
         devices: typing.Optional[typing.Sequence[int]] = None,
         shard: typing.Tuple[int, int] = (0, 1),
+        order: typing.Optional[str] = None,
     ) -> None:
-        """``devices=[0, 1, ...]`` (extension) makes chunk c of the file resident on ``devices[c % len(devices)]`` and
+        """``order='sa'`` (extension): the entries a chunk contributes to a query come in the reference's order --
+        suffix-array order of their first hit, src/lib.rs:262-276 -- so that ``search(s)`` of a one-chunk index equals the
+        reference's list element by element (default ``'text'``: the same multiset, see ``set_result_order``).
+        ``devices=[0, 1, ...]`` (extension) makes chunk c of the file resident on ``devices[c % len(devices)]`` and
         answers every search on all of them at once, inside this process -- no launcher, no ``torch.distributed``: one
         host thread per device, results merged on the host (the reference fans a search over its chunks with rayon,
         src/lib.rs:207).  ``shard=(i, n)`` is the one-process-per-GPU form of the same split (``dist.ShardedReader``)."""
@@ -229,6 +233,8 @@ class Reader:
         else:
             rc = _lib.pss_reader_open(path, devs[0], shard[0], shard[1], ctypes.byref(self._h))
         _ffi.check(rc, index_file_path)
+        if order is not None:
+            self.set_result_order(order)
 
     @property
     def reader(self) -> 'Reader':
@@ -287,6 +293,18 @@ class Reader:
 
     def promote(self, chunk: int) -> None:
         _ffi.check(_lib.pss_reader_promote_chunk(self._handle(), int(chunk)))
+
+    def set_result_order(self, order: str) -> None:
+        """Extension: ``'sa'`` -- the reference's order inside a chunk (suffix-array order of every entry's first hit,
+        src/lib.rs:262-276); ``'text'`` (default) -- suffix-array order of every entry's leftmost match.  The multiset is
+        the same; they differ when an entry holds the pattern more than once.  ``PSS_RESULT_ORDER=sa`` sets the default."""
+        if order not in ('sa', 'text'):
+            raise ValueError("order must be 'sa' or 'text'")
+        _ffi.check(_lib.pss_reader_set_result_order(self._handle(), 1 if order == 'sa' else 0))
+
+    @property
+    def result_order(self) -> str:
+        return 'sa' if _lib.pss_reader_result_order(self._handle()) == 1 else 'text'
 
     def set_low_latency(self, on: bool = True) -> None:
         """Extension: single queries (``search``) through a resident search kernel that waits for them in a pinned

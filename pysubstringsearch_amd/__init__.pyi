@@ -50,8 +50,15 @@ class Reader:
         index_file_path: str,
         *,
         device: typing.Optional[int] = None,
+        devices: typing.Optional[typing.Sequence[int]] = None,
         shard: typing.Tuple[int, int] = (0, 1),
+        order: typing.Optional[str] = None,
     ) -> None: ...
+
+    def set_result_order(self, order: str) -> None: ...
+
+    @property
+    def result_order(self) -> str: ...
 
     @property
     def num_chunks(self) -> int: ...

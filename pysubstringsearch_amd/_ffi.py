@@ -149,6 +149,29 @@ def _preload_hip_runtime() -> None:
             pass
 
 
+class RcclUniqueId(ctypes.Structure):
+    _fields_ = [('internal', ctypes.c_char * 128)]
+
+
+class RcclApiTable(ctypes.Structure):
+    """pss_rccl_api (include/pss.h): the collectives library as a table of entry points -- an application that links
+    RCCL itself hands them in, the tests make them fail."""
+    _vp, _sz, _i = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    GET_UNIQUE_ID = ctypes.CFUNCTYPE(_i, ctypes.POINTER(RcclUniqueId))
+    COMM_INIT_RANK = ctypes.CFUNCTYPE(_i, ctypes.POINTER(_vp), _i, RcclUniqueId, _i)
+    COMM_FN = ctypes.CFUNCTYPE(_i, _vp)
+    ASYNC_ERROR = ctypes.CFUNCTYPE(_i, _vp, ctypes.POINTER(_i))
+    GROUP_FN = ctypes.CFUNCTYPE(_i)
+    SEND = ctypes.CFUNCTYPE(_i, _vp, _sz, _i, _i, _vp, _vp)
+    RECV = ctypes.CFUNCTYPE(_i, _vp, _sz, _i, _i, _vp, _vp)
+    ALL_GATHER = ctypes.CFUNCTYPE(_i, _vp, _vp, _sz, _i, _vp, _vp)
+    ERROR_STRING = ctypes.CFUNCTYPE(ctypes.c_char_p, _i)
+    _fields_ = [('get_unique_id', GET_UNIQUE_ID), ('comm_init_rank', COMM_INIT_RANK), ('comm_destroy', COMM_FN),
+                ('comm_abort', COMM_FN), ('comm_get_async_error', ASYNC_ERROR), ('group_start', GROUP_FN),
+                ('group_end', GROUP_FN), ('send', SEND), ('recv', RECV), ('all_gather', ALL_GATHER),
+                ('get_error_string', ERROR_STRING)]
+
+
 def _load() -> ctypes.CDLL:
     _preload_hip_runtime()
     if not os.path.exists(LIB_PATH):
@@ -186,6 +209,8 @@ def _load() -> ctypes.CDLL:
         'pss_reader_evict_chunk': (ctypes.c_int, [vp, u64]),
         'pss_reader_promote_chunk': (ctypes.c_int, [vp, u64]),
         'pss_reader_set_low_latency': (ctypes.c_int, [vp, i32]),
+        'pss_reader_set_result_order': (ctypes.c_int, [vp, i32]),
+        'pss_reader_result_order': (i32, [vp]),
         'pss_reader_low_latency_stats': (ctypes.c_int, [vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]),
         'pss_reader_create': (ctypes.c_int, [i32, pvp]),
         'pss_reader_add_chunk_device': (ctypes.c_int, [vp, vp, vp, u32]),
@@ -201,6 +226,10 @@ def _load() -> ctypes.CDLL:
         'pss_comm_init': (ctypes.c_int, [vp, i32, i32, i32, pvp]),
         'pss_comm_destroy': (ctypes.c_int, [vp]),
         'pss_gather_packed_rccl': (ctypes.c_int, [vp, ctypes.POINTER(DeviceResult), i32, pvp]),
+        'pss_comm_set_timeout_ms': (ctypes.c_int, [vp, u32]),
+        'pss_comm_status': (ctypes.c_int, [vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]),
+        'pss_rccl_inject': (ctypes.c_int, [ctypes.POINTER(RcclApiTable)]),
+        'pss_comm_adopt': (ctypes.c_int, [vp, i32, i32, i32, pvp]),
         'pss_reload_env': (ctypes.c_int, []),
         'pss_reader_last_stats': (ctypes.c_int, [vp, ctypes.POINTER(SearchStats)]),
         'pss_reader_close': (ctypes.c_int, [vp]),

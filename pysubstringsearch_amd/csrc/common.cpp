@@ -274,10 +274,11 @@ void pinned_pool_trim()
 }
 
 static constexpr int kMaxDevices = 64;
-static DeviceCtx g_ctx[kMaxDevices];
+static DeviceCtx g_ctx[kMaxDevices];        // reader side
+static DeviceCtx g_bctx[kMaxDevices];       // builder side
 static std::mutex g_ctx_mu;
 
-int get_ctx(int device, DeviceCtx **out)
+static int get_ctx_of(DeviceCtx *table, int device, DeviceCtx **out)
 {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -293,7 +294,7 @@ int get_ctx(int device, DeviceCtx **out)
     }
     PSS_HIP(hipSetDevice(device));
     std::lock_guard<std::mutex> lk(g_ctx_mu);
-    DeviceCtx &c = g_ctx[device];
+    DeviceCtx &c = table[device];
     if (c.device < 0) {
         PSS_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
         hipDeviceProp_t prop;
@@ -308,6 +309,9 @@ int get_ctx(int device, DeviceCtx **out)
     *out = &c;
     return PSS_OK;
 }
+
+int get_ctx(int device, DeviceCtx **out) { return get_ctx_of(g_ctx, device, out); }
+int get_build_ctx(int device, DeviceCtx **out) { return get_ctx_of(g_bctx, device, out); }
 
 int DeviceCtx::ensure_resident()
 {
@@ -348,16 +352,18 @@ void DeviceCtx::stop_resident()
 void trim_all()
 {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
-    for (auto &c : g_ctx) {
-        if (c.device < 0) continue;
-        std::lock_guard<std::recursive_mutex> lk2(c.mu);
-        (void)hipSetDevice(c.device);
-        c.stop_resident();               // (it works in one of the slots)
-        for (auto &s : c.slot) s.release();
-        // the fused small-batch path keeps its cursors in one of the slots and only zeroes them when the
-        // arena's address changes: a fresh allocation may come back at the old address with garbage in it
-        c.small_hdr_ready = nullptr;
-    }
+    for (DeviceCtx *table : {g_ctx, g_bctx})
+        for (int d = 0; d < kMaxDevices; ++d) {
+            DeviceCtx &c = table[d];
+            if (c.device < 0) continue;
+            std::lock_guard<std::recursive_mutex> lk2(c.mu);
+            (void)hipSetDevice(c.device);
+            c.stop_resident();               // (it works in one of the slots)
+            for (auto &s : c.slot) s.release();
+            // the fused small-batch path keeps its cursors in one of the slots and only zeroes them when the
+            // arena's address changes: a fresh allocation may come back at the old address with garbage in it
+            c.small_hdr_ready = nullptr;
+        }
     pinned_pool_trim();
 }
 

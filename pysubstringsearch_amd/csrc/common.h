@@ -229,8 +229,14 @@ private:
     std::vector<std::thread> workers_;
 };
 
-// Validates `device`, makes it current, returns its context (created lazily).
+// Validates `device`, makes it current, returns its context (created lazily): the one the READER side works in --
+// resident indexes, searches, gathers, uploads.
 int get_ctx(int device, DeviceCtx **out);
+// The context of the BUILDER side of the same device (pss_sa_build*, the Writer's builder threads): its own lock, stream,
+// pinned scratch and workspace slots (round 5).  With one context per device a Reader waited for a whole build (9 .. 131 ms)
+// whenever a Writer shared its GPU, and a gather over RCCL held up every build; the two sides never touch each other's
+// slots (sa_build.hip 0-9, 26-49; search.hip 10-23, 28, 46, 47, 50-54; the Writer 24, 25), so they need not share a lock.
+int get_build_ctx(int device, DeviceCtx **out);
 // Frees every workspace slot of every context (memory pressure relief).
 void trim_all();
 

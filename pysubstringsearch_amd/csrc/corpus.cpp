@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <cstdlib>
+#include <cstdio>
 #include <thread>
 #include <vector>
 
@@ -220,6 +222,8 @@ struct SourceGen {
     bool tabs = false;
 
     static constexpr uint32_t V = 32768;
+    // tuning (temporary)
+    uint32_t E_FRESH = 480, E_LINE = 910, E_FUNC = 982, E_BLOCK = 990, P_FILECOPY = 12, FILE_EDIT = 300, MAXD = 5, P_RULE = 21;
 
     void build_vocabulary()
     {
@@ -326,7 +330,7 @@ struct SourceGen {
             if (r.nx() % 3 == 0) l.push_back('.');
             return;
         }
-        if (k < 23) {                                            // rule
+        if (k < P_RULE) {                                            // rule
             indent(l, d);
             static const char *lead[] = {"", "# ", "// ", "/* "};
             put(l, lead[r.nx() % 4]);
@@ -357,7 +361,7 @@ struct SourceGen {
                 if (f == 0 && r.nx() % 3 == 0) put(l, "=None");
             }
             put(l, f == 2 ? ") {" : "):");
-            if (d < 7) ++d;
+            if (d < (int)MAXD) ++d;
             return;
         }
         if (k < 46) {                                            // control statement: one level deeper
@@ -365,7 +369,7 @@ struct SourceGen {
             put(l, kw_open[r.nx() % 7]);
             expr(l, r, 2);
             put(l, tabs ? ") {" : ":");
-            if (d < 7) ++d;
+            if (d < (int)MAXD) ++d;
             return;
         }
         if (k < 82) {                                            // statement
@@ -484,14 +488,14 @@ struct SourceGen {
         while (!full()) {
             // ---- one file
             const uint64_t my_first_line = line_start.size();
-            const uint32_t kind = g.nx() % 6;
+            const uint32_t kind = g.nx() % P_FILECOPY;
             if (kind == 0 && file_start.size() >= 2) {
                 // a copy of an earlier file, a line in sixty-four written anew
                 const uint64_t f = g.nx() % (file_start.size() - 1);
                 const uint64_t a = file_start[f], e = file_start[f + 1];
                 int d = 0;
                 for (uint64_t i = a; i < e && !full(); ++i) {
-                    if (g.nx() % 64 == 0) {
+                    if (g.nx() % FILE_EDIT == 0) {
                         l.clear();
                         make_line(l, g, d);
                         write_line(l);
@@ -517,17 +521,22 @@ struct SourceGen {
             uint32_t body = 20 + g.nx() % 600;
             if (g.nx() % 8 == 0) body *= 5;
             for (uint32_t done = 0; done < body && !full();) {
-                const uint32_t ev = g.nx() % 100;
-                if (ev < 30 && line_start.size() > 64) {            // a stretch copied from anywhere earlier in the chunk
-                    uint32_t len = 2 + g.nx() % 30;
-                    if (g.nx() % 4 == 0) len *= 4;
+                const uint32_t ev = g.nx() % 1000;
+                const bool can_copy = line_start.size() > 64;
+                uint32_t len = 0;
+                if (ev >= E_FRESH && can_copy) {
+                    if (ev < E_LINE) len = 1 + g.nx() % 2;                 // a line or two seen before
+                    else if (ev < E_FUNC) len = 3 + g.nx() % 10;           // a function's worth
+                    else if (ev < E_BLOCK) len = 12 + g.nx() % 89;         // a block
+                }
+                if (len) {
                     const uint64_t first = (((uint64_t)g.nx() << 32) | g.nx()) % (line_start.size() - 1);
                     copy_lines(first, len);
                     done += len;
-                } else if (ev < 42) {                                // boilerplate
+                } else if (ev >= E_BLOCK) {                              // boilerplate, the same in every chunk
                     write_lines(pool[(g.nx() % 512) >> (g.nx() % 6)]);
                     done += 20;
-                } else {                                             // 1 .. 12 new lines
+                } else {                                                 // 1 .. 12 new lines
                     const uint32_t fresh = 1 + g.nx() % 12;
                     for (uint32_t i = 0; i < fresh && !full(); ++i) {
                         l.clear();
@@ -548,6 +557,11 @@ void gen_source(uint8_t *out, uint64_t n, uint64_t chunk)
     sg.out = out;
     sg.n = n;
     sg.g = Xs64{(kSeed ^ 0x8EBC6AF09C88C6E3ULL) + chunk};
+    if (const char *e = getenv("SRC_E")) sscanf(e, "%u,%u,%u,%u", &sg.E_FRESH, &sg.E_LINE, &sg.E_FUNC, &sg.E_BLOCK);
+    if (const char *e = getenv("SRC_P_FILECOPY")) sg.P_FILECOPY = atoi(e);
+    if (const char *e = getenv("SRC_FILE_EDIT")) sg.FILE_EDIT = atoi(e);
+    if (const char *e = getenv("SRC_MAXD")) sg.MAXD = atoi(e);
+    if (const char *e = getenv("SRC_P_RULE")) sg.P_RULE = atoi(e);
     sg.run();
 }
 

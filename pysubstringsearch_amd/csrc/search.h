@@ -44,6 +44,10 @@ struct HostResult {
     void release();
 };
 
+// Room for E + 1 offsets and B bytes in `res`: one block of the pinned pool when the result is large (the D2H copy then
+// runs at link speed), else malloc.
+int alloc_host_result(HostResult *res, uint64_t E, uint64_t B, bool allow_pinned);
+
 enum SearchMode {
     SEARCH_FULL = 0,     // packed result on the host
     SEARCH_COUNTS = 1,   // res->qcount only (entries each query would return); no entry is materialised
@@ -55,7 +59,12 @@ enum SearchMode {
 // (capi.cpp); it costs one small kernel and a stream synchronisation, so readers whose chunks all live in HBM pass nullptr.
 int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, uint32_t nc, const uint8_t *qbytes,
                         const uint64_t *qoffsets, uint32_t nq, HostResult *res, pss_search_stats *st,
-                        SearchMode mode = SEARCH_FULL, bool low_latency = false, uint64_t *chunk_hits = nullptr);
+                        SearchMode mode = SEARCH_FULL, bool low_latency = false, uint64_t *chunk_hits = nullptr,
+                        bool sa_order = false);
+// sa_order: the entries of one (query, chunk) pair come out in the reference's order -- suffix-array order of the FIRST hit
+// inside each entry (src/lib.rs:262-276: the hits are walked in suffix-array order and an entry is pushed when its line
+// start is first seen) -- instead of the order of each entry's leftmost match.  Opt-in (pss_reader_set_result_order): it
+// takes the general pipeline and one extra sort of the hits.
 
 // Merge of `world` packed results of the same nq queries, all resident on ctx's device, into one (query-major,
 // rank-major inside a query -- pss_merge_packed's order) on the same device.  starts[r] = entry starts (no closing

@@ -27,6 +27,7 @@
 #include "prims.h"
 #include "scan.h"
 #include "search.h"
+#include "radix_sort.h"
 
 #include <chrono>
 #include <vector>
@@ -1445,6 +1446,39 @@ __global__ __launch_bounds__(SM_BLOCK) void search_resident_kernel(const ChunkDe
     }
 }
 
+// ---- opt-in: the reference's order inside a (query, chunk) pair (pss_reader_set_result_order) -------------------------
+// src/lib.rs:262-276 walks the hits of a chunk in suffix-array order and pushes an entry when its line start is first
+// seen: the entries come out ordered by the suffix-array rank of their FIRST hit.  hit_lines_kernel keeps the LEFTMOST
+// match of an entry instead (that is what it can decide from the text alone), so an entry that holds the pattern
+// twice may come out at another place of the list -- the same multiset, another order.  Here every hit reports its
+// entry, a stable sort of the hits by (pair, line start) brings the hits of one entry together in suffix-array
+// order, and all but the first of each run are dropped; the scans and emit_kernel then run as always.
+__global__ __launch_bounds__(256) void hit_bounds_kernel(const ChunkDesc *chunks, u32 nc, u64 nvq, const u32 *lo, const u64 *hit_off,
+                                                           u64 H, u32 *start_out, u32 *len_out, u64 *key_out, u32 *val_out)
+{
+    for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < H; t += (u64)gridDim.x * blockDim.x) {
+        u64 a = 0, b = nvq;
+        while (b - a > 1) {
+            const u64 mid = a + (b - a) / 2;
+            if (hit_off[mid] <= t) a = mid; else b = mid;
+        }
+        const ChunkDesc ch = chunks[(u32)(a % nc)];
+        const u32 di = ch.sa[lo[a] + (u32)(t - hit_off[a])];
+        u32 ls = 0, ll = 0;
+        entry_bounds(ch, di, ls, ll);
+        start_out[t] = ls;
+        len_out[t] = ll;
+        key_out[t] = (a << 31) | (u64)ls;        // line starts are below 2^31, pairs below 2^33
+        val_out[t] = (u32)t;
+    }
+}
+
+__global__ __launch_bounds__(256) void mark_later_hits_kernel(const u64 *key, const u32 *val, u64 H, u32 *len)
+{
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < H; j += (u64)gridDim.x * blockDim.x)
+        if (j > 0 && key[j] == key[j - 1]) len[val[j]] = kSkip;
+}
+
 __global__ __launch_bounds__(256) void emit_kernel(const ChunkDesc *chunks, u32 nc, u64 nvq, const u64 *hit_off, u64 H,
                                                      const MidState *mid, const u32 *start, const u32 *len,
                                                      const u64 *eidx, const u64 *boff, u64 *ent_off, u8 *out)
@@ -1485,7 +1519,7 @@ constexpr size_t SM_ARENA_BYTES = SM_ARENA_RHDR + 64;
 #error "search.hip is written for gfx950 (MI355X): the fused search kernels keep ~72 KiB of LDS per workgroup (160 KiB per CU there; gfx90a / gfx942 stop at 64 KiB)"
 #endif
 
-enum SSlot { Q_BYTES = 10, Q_OFF, Q_LO, Q_CNT, Q_HITOFF, Q_START, Q_LEN, Q_EIDX, Q_BOFF, Q_ENTOFF, Q_OUT, Q_SMALL, Q_QCOUNT, Q_ARENA = 28, Q_HEAT = 46 };
+enum SSlot { Q_ORD_K0 = 50, Q_ORD_K1, Q_ORD_V0, Q_ORD_V1, Q_ORD_WORK, Q_BYTES = 10, Q_OFF, Q_LO, Q_CNT, Q_HITOFF, Q_START, Q_LEN, Q_EIDX, Q_BOFF, Q_ENTOFF, Q_OUT, Q_SMALL, Q_QCOUNT, Q_ARENA = 28, Q_HEAT = 46 };
 
 void HostResult::release()
 {
@@ -1500,7 +1534,7 @@ void HostResult::release()
 }
 
 // Room for E + 1 offsets and B bytes: one pinned block when the result is large, else malloc.
-static int alloc_result(HostResult *res, u64 E, u64 B, bool allow_pinned)
+int alloc_host_result(HostResult *res, u64 E, u64 B, bool allow_pinned)
 {
     const size_t off_bytes = round_up((size_t)(E + 1) * sizeof(u64), 64);
     if (allow_pinned && off_bytes + B >= ((size_t)8 << 20)) {
@@ -1549,7 +1583,7 @@ static int small_collect(DeviceCtx *ctx, const u8 *h_arena, const u8 *d_bytes, u
         PSS_HIP(hipStreamSynchronize(s));
         h_bytes = dst;
     }
-    PSS_TRY(alloc_result(res, E, B, false));
+    PSS_TRY(alloc_host_result(res, E, B, false));
     u64 e_out = 0, b_out = 0;
     for (u64 ri = 0; ri < nrec; ++ri) {       // pairs in (query, chunk) order, sub-blocks in interval order
         const SmallRecord r = h_rec[ri];
@@ -1699,7 +1733,7 @@ __global__ __launch_bounds__(256) void chunk_hits_kernel(const u32 *cnt, u64 nq,
 
 int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const uint8_t *qbytes,
                         const uint64_t *qoffsets, uint32_t nq, HostResult *res, pss_search_stats *st, SearchMode mode, bool low_latency,
-                        uint64_t *chunk_hits)
+                        uint64_t *chunk_hits, bool sa_order)
 {
     if (chunk_hits)
         for (u32 c = 0; c < nc; ++c) chunk_hits[c] = 0;
@@ -1758,7 +1792,8 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
         memset(stg + qtotal, 0, 32);
         memcpy(stg + 8192, qoffsets, off_bytes);
     }
-    bool small = tiny && nvq <= SM_MAX_VQ && !counts_only && !device_only && !knobs.no_small_path;
+    if (counts_only) sa_order = false;          // (counts do not depend on the order)
+    bool small = tiny && nvq <= SM_MAX_VQ && !counts_only && !device_only && !knobs.no_small_path && !sa_order;
     for (u32 i = 0; small && i < nq; ++i) small = qoffsets[i + 1] - qoffsets[i] <= SM_MAX_PLEN;
     const u64 waves_per_block = 256 / kWave;
     if (small) {
@@ -1863,7 +1898,7 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
         PSS_HIP(hipMemcpyAsync(chunk_hits, d_heat, (size_t)nc * 8, hipMemcpyDeviceToHost, s));
         PSS_HIP(hipStreamSynchronize(s));
     }
-    if (nvq <= MID_MAX && !counts_only && !knobs.no_mid_pipeline) {
+    if (nvq <= MID_MAX && !counts_only && !knobs.no_mid_pipeline && !sa_order) {
         // ---- mid pipeline: totals stay on the device, one wait for them, one for the result ----
         const u64 byte_cap = (u64)16 << 20;
         PSS_TRY(ctx->slot[Q_START].reserve((size_t)MID_MAX * 4));
@@ -1911,7 +1946,7 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
                 st->ms_host = host_ms();
                 return PSS_OK;
             }
-            PSS_TRY(alloc_result(res, E, B, false));
+            PSS_TRY(alloc_host_result(res, E, B, false));
             const size_t need = round_up(E * 8, 64) + round_up(B, 64) + (size_t)nq * 8;
             if (need <= DeviceCtx::kStageR && !knobs.no_search_stage) {
                 // down through pinned staging (three DMA copies, one wait), then plain memcpy
@@ -1963,6 +1998,28 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
         u64 *d_eidx = ctx->slot[Q_EIDX].as<u64>();
         u64 *d_boff = ctx->slot[Q_BOFF].as<u64>();
         const u32 grid = (u32)std::min<u64>((u64)ctx->num_cus * 16, (H + 255) / 256);
+        if (sa_order) {
+            if (H >= (1ull << 32) || nvq >= (1ull << 33)) {
+                set_error("search: %llu hits of %llu (query, chunk) pairs are more than the suffix-array result order takes in one batch",
+                          (unsigned long long)H, (unsigned long long)nvq);
+                return PSS_EINVAL;
+            }
+            PSS_TRY(ctx->slot[Q_ORD_K0].reserve(H * 8));
+            PSS_TRY(ctx->slot[Q_ORD_K1].reserve(H * 8));
+            PSS_TRY(ctx->slot[Q_ORD_V0].reserve(H * 4));
+            PSS_TRY(ctx->slot[Q_ORD_V1].reserve(H * 4));
+            PSS_TRY(ctx->slot[Q_ORD_WORK].reserve(radix_sort_workspace_bytes()));
+            u64 *OK[2] = {ctx->slot[Q_ORD_K0].as<u64>(), ctx->slot[Q_ORD_K1].as<u64>()};
+            u32 *OV[2] = {ctx->slot[Q_ORD_V0].as<u32>(), ctx->slot[Q_ORD_V1].as<u32>()};
+            hipLaunchKernelGGL(hit_bounds_kernel, dim3(grid), dim3(256), 0, s, d_chunks, nc, nvq, d_lo, d_hitoff, H, d_start, d_len,
+                               OK[0], OV[0]);
+            int pair_bits = 1;
+            while ((1ull << pair_bits) < nvq) ++pair_bits;
+            int od = 0;
+            SortStats oss;
+            PSS_TRY(radix_sort_pairs(ctx, OK, OV, (u32)H, 31 + pair_bits, 0xffffffffu, nullptr, 0, ctx->slot[Q_ORD_WORK].p, &od, false, &oss));
+            hipLaunchKernelGGL(mark_later_hits_kernel, dim3(grid), dim3(256), 0, s, OK[od], OV[od], H, d_len);
+        } else
         hipLaunchKernelGGL(hit_lines_kernel, dim3(grid), dim3(256), 0, s, d_chunks, nc, d_q, d_qoff, nvq, d_lo,
                            d_hitoff, H, (const MidState *)nullptr, d_start, d_len);
         PSS_TRY(device_excl_scan(ctx, InKept{d_len}, H, d_partial, d_total, d_eidx));
@@ -2005,7 +2062,7 @@ int search_batch_device(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, const
             res->d_bytes = d_out;
             PSS_HIP(hipStreamSynchronize(s));
         } else {
-            PSS_TRY(alloc_result(res, E, B, !knobs.no_pinned_results));
+            PSS_TRY(alloc_host_result(res, E, B, !knobs.no_pinned_results));
             if (E) PSS_HIP(hipMemcpyAsync(res->offsets, d_entoff, E * 8, hipMemcpyDeviceToHost, s));
             if (B) PSS_HIP(hipMemcpyAsync(res->bytes, d_out, B, hipMemcpyDeviceToHost, s));
             PSS_HIP(hipMemcpyAsync(res->qcount, d_qcount, (size_t)nq * 8, hipMemcpyDeviceToHost, s));

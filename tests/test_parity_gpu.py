@@ -1040,3 +1040,48 @@ def test_rccl_gather_inside_the_c_abi_single_rank(tmp_path, oracle):
             got = pdist.packed_to_list(data, offsets)
             assert sorted(got) == sorted(oe)
     comm.close()
+
+
+@pytest.mark.parametrize('chunk_len', [None, 4096, 300])
+def test_result_order_sa_equals_the_reference_lists(tmp_path, oracle, chunk_len, monkeypatch):
+    """Reader(order='sa') / pss_reader_set_result_order: the entries of a chunk come in the reference's order --
+    suffix-array order of every entry's FIRST hit (src/lib.rs:262-276; the oracle emits exactly that,
+    oracle/pss_oracle.c search_chunk_src) -- so the lists are equal element by element, not just as multisets:
+    one chunk, several chunks (chunks in index order), single queries, batches, the empty pattern, patterns that hold
+    a newline, entries that hold the pattern many times.  The default order is the same multiset."""
+    rng = random.Random(11 if chunk_len is None else chunk_len)
+    entries = ['ten', 'tenten', 'xtenyten', 'ten', 'tententen', 'one', 'onet', 'aaa', 'aaaa', 'aaaaaaaa', '']
+    for _ in range(700):
+        entries.append(''.join(rng.choice('ab') for _ in range(rng.randrange(1, 40))))
+    for _ in range(150):
+        entries.append(' '.join(rng.choice(['ten', 'eleven', 'net', 'tent', 'aa']) for _ in range(rng.randrange(1, 8))))
+    rng.shuffle(entries)
+    p = str(tmp_path / 'o.idx')
+    build(p, entries, chunk_len)
+    o = oracle.OracleReader(p)
+    queries = ['ten', 'a', 'aa', 'ab', 'ba', 'aaa', 'n\nt', 'a\n', '\n', '', 'en t', 'tent', 'zz', 'b', 'abab', 'net ten']
+    differs = 0
+    with pysubstringsearch.Reader(p, order='sa') as r, pysubstringsearch.Reader(p) as d:
+        assert r.result_order == 'sa' and d.result_order == 'text'
+        assert r.num_chunks == o.num_chunks and (chunk_len is None) == (r.num_chunks == 1)
+        for q in queries:
+            want = o.search(q)
+            assert r.search(q) == want, q                      # the reference's list, element by element
+            got_default = d.search(q)
+            assert sorted(got_default) == sorted(want), q
+            differs += got_default != want
+        assert r.search_multiple(queries) == o.search_multiple(queries)
+        big = [q for q in queries for _ in range(40)]              # a batch beyond the fused and mid pipelines' pair counts
+        assert r.search_multiple(big) == o.search_multiple(big)
+        assert r.count_multiple(queries) == [len(o.search(q)) for q in queries]
+        # switching an open reader
+        d.set_result_order('sa')
+        assert d.search('ten') == o.search('ten')
+        d.set_result_order('text')
+        with pytest.raises(ValueError):
+            d.set_result_order('nope')
+    assert differs > 0, 'the corpus was meant to tell the two orders apart'
+    monkeypatch.setenv('PSS_RESULT_ORDER', 'sa')                  # the environment sets the default of new readers
+    with pysubstringsearch.Reader(p) as e:
+        assert e.result_order == 'sa' and e.search('aa') == o.search('aa')
+    o.close()
