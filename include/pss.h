@@ -173,6 +173,8 @@ typedef struct pss_sa_stats {
                                   without the plan (the attempt is part of ms_total, ms_restarts), later chunks wait before they try */
     uint64_t ss_declined_nomem; /* 1: no room in HBM for the sample sort's two 16 n-byte element buffers -- the build went on
                                   with the LSD passes instead of failing */
+    uint64_t anchor_side;      /* 1: the anchors were selected and sorted BESIDE the text round that precedes the anchor round (second
+                                  stream, second host thread: sa_build.hip, SideAnchors); 2: started so, and thrown away */
     double anchor_ms;          /* device time of the anchors' selection and sort */
     double ms_restarts;        /* part of ms_total: attempts given up (a remembered plan, or the shortcut of a first chunk, that
                                   this text did not fit -- the build started over without it) */
@@ -239,6 +241,17 @@ int pss_writer_finalize(pss_writer *w);
 int pss_writer_close(pss_writer *w);
 /* Current chunk limit (Vec capacity in the reference, src/lib.rs:62,75,92,96). */
 uint64_t pss_writer_chunk_limit(const pss_writer *w);
+/* Which way the bytes went (round 5; diagnostics, nothing a caller must look at): records written through a shared
+ * mapping of the index file (tmpfs; PSS_WRITER_MMAP=0|1 overrides, PSS_WRITER_MMAP_MIN = smallest such record, default
+ * 1 MiB) or pwritten; bytes of pss_writer_add_file_lines input read straight into the chunk or through a block buffer
+ * (lines with a '\r', lines that do not fit the chunk any more). */
+typedef struct pss_writer_io {
+    uint64_t records_mapped;
+    uint64_t records_pwritten;
+    uint64_t ingest_direct_bytes;
+    uint64_t ingest_copied_bytes;
+} pss_writer_io;
+int pss_writer_io_stats(pss_writer *w, pss_writer_io *out);
 
 /* ---- Reader (src/lib.rs:146-288; pysubstringsearch/__init__.py:44-73) --- */
 

@@ -118,6 +118,14 @@ class Writer:
             raise ValueError('I/O operation on closed Writer')
         return self._h
 
+    @property
+    def io_stats(self) -> dict:
+        """Extension (diagnostics): records written through a shared mapping / pwritten, file-ingest bytes read straight
+        into the chunk / through a block buffer (include/pss.h, pss_writer_io_stats)."""
+        st = _ffi.WriterIo()
+        _ffi.check(_lib.pss_writer_io_stats(self._handle(), ctypes.byref(st)))
+        return {k: int(getattr(st, k)) for k, _ in st._fields_}
+
     def add_entries_from_file_lines(self, input_file_path: str) -> None:
         _ffi.check(_lib.pss_writer_add_file_lines(self._handle(), _path(input_file_path, 'input_file_path')),
                    input_file_path)

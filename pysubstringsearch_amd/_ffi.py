@@ -88,6 +88,7 @@ class SaStats(ctypes.Structure):
         ('dup_screen', ctypes.c_uint64),
         ('ss_plan_refused', ctypes.c_uint64),
         ('ss_declined_nomem', ctypes.c_uint64),
+        ('anchor_side', ctypes.c_uint64),
         ('anchor_ms', ctypes.c_double),
         ('ms_restarts', ctypes.c_double),
     ]
@@ -144,9 +145,27 @@ def _preload_hip_runtime() -> None:
     cand = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
     if os.path.exists(cand):
         try:
-            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+            global _hip
+            _hip = ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
         except OSError:
             pass
+
+
+_hip = None
+
+
+def hip_runtime() -> ctypes.CDLL:
+    """The HIP runtime this process uses (torch's bundled copy when torch is installed, else the system's): for tools
+    and tests that call the runtime themselves next to the library."""
+    global _hip
+    if _hip is None:
+        _hip = ctypes.CDLL('libamdhip64.so')
+    return _hip
+
+
+class WriterIo(ctypes.Structure):
+    _fields_ = [('records_mapped', ctypes.c_uint64), ('records_pwritten', ctypes.c_uint64),
+                ('ingest_direct_bytes', ctypes.c_uint64), ('ingest_copied_bytes', ctypes.c_uint64)]
 
 
 class RcclUniqueId(ctypes.Structure):
@@ -202,6 +221,7 @@ def _load() -> ctypes.CDLL:
         'pss_writer_finalize': (ctypes.c_int, [vp]),
         'pss_writer_close': (ctypes.c_int, [vp]),
         'pss_writer_chunk_limit': (u64, [vp]),
+        'pss_writer_io_stats': (ctypes.c_int, [vp, ctypes.POINTER(WriterIo)]),
         'pss_reader_open': (ctypes.c_int, [cp, i32, i32, i32, pvp]),
         'pss_reader_open_multi': (ctypes.c_int, [cp, ctypes.POINTER(i32), i32, pvp]),
         'pss_reader_set_auto_residency': (ctypes.c_int, [vp, i32]),

@@ -7,6 +7,7 @@
 #include <sys/vfs.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cerrno>
 #include <chrono>
 #include <condition_variable>
@@ -341,6 +342,11 @@ struct pss_writer {
     int fd = -1;                  // the index file: records are written with pwrite at offsets known in advance
     int64_t pos = 0;              // where the next record starts
     bool no_mmap = true;          // records through pwrite (false: through a shared mapping -- see write_record)
+    int map_fd = -1;              // the same file opened for reading AND writing: a shared mapping needs both (the index file
+                                  // itself is opened like File::create, write-only -- mmap on that fd fails with EACCES)
+    size_t mmap_min = (size_t)1 << 20;     // records below this go through pwrite (PSS_WRITER_MMAP_MIN)
+    std::atomic<uint64_t> records_mapped{0}, records_pwritten{0};      // which way the records went (pss_writer_io_stats)
+    uint64_t ingest_direct = 0, ingest_copied = 0;           // file bytes read straight into the chunk / through a block buffer
     uint8_t *buf = nullptr;
     size_t len = 0;
     size_t limit = 0;    // the reference's Vec capacity (src/lib.rs:62), see reserve()
@@ -510,11 +516,11 @@ int write_record(pss_writer *w, const WJob &job)
     uint8_t *map = nullptr, *map_base = nullptr;
     size_t map_len = 0;
 #ifdef __linux__
-    if (total >= (1 << 20) && !w->no_mmap && fallocate(w->fd, 0, (off_t)at, (off_t)total) == 0) {
+    if ((size_t)total >= w->mmap_min && !w->no_mmap && w->map_fd >= 0 && fallocate(w->fd, 0, (off_t)at, (off_t)total) == 0) {
         const int64_t pg = (int64_t)sysconf(_SC_PAGESIZE);
         const int64_t lo = at & ~(pg - 1);
         map_len = (size_t)(at + total - lo);
-        void *m = mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, w->fd, (off_t)lo);
+        void *m = mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, w->map_fd, (off_t)lo);
         if (m != MAP_FAILED) {
             map_base = static_cast<uint8_t *>(m);
             map = map_base + (at - lo);
@@ -529,6 +535,8 @@ int write_record(pss_writer *w, const WJob &job)
     } unmap{map_base, map_len};
     IoPool::Batch batch;
     IoPool &pool = IoPool::get();
+    if (map) ++w->records_mapped;
+    else ++w->records_pwritten;
     if (w->version == 2) put_u64le(hdr, (uint64_t)n);
     else put_u32le(hdr, (uint32_t)n);
     if (map) memcpy(map, hdr, hl);
@@ -741,6 +749,12 @@ int w_dump(pss_writer *w)
         set_error("chunk of %zu bytes exceeds the 32-bit suffix array", w->len);
         return PSS_EINVAL;
     }
+    if (w->version == 1 && w->len >= ((size_t)1 << 30)) {
+        // the reference writes (4 n) as u32 here and wraps (src/lib.rs:116): a file its own Reader cannot walk.  Refused.
+        set_error("chunk of %zu bytes: the reference container stores the suffix array's byte length in a u32 (src/lib.rs:116), "
+                  "chunks must stay below 2^30 bytes -- format_version 2 holds larger ones", w->len);
+        return PSS_EINVAL;
+    }
     const size_t G = w->devs.size();
     if (w->len >= 2) {
         // no usable device is reported here and now, not by a later call
@@ -835,6 +849,12 @@ extern "C" int pss_writer_open_multi(const char *path, int64_t max_chunk_len, co
             struct statfs sf;
             w->no_mmap = !(fstatfs(fd, &sf) == 0 && (unsigned long)sf.f_type == 0x01021994ul /* TMPFS_MAGIC */);
             if (const char *e = getenv("PSS_WRITER_MMAP")) w->no_mmap = atoi(e) == 0;
+            if (const char *e = getenv("PSS_WRITER_MMAP_MIN")) w->mmap_min = (size_t)strtoull(e, nullptr, 0);
+            if (!w->no_mmap) {
+                w->map_fd = open(path, O_RDWR | O_CLOEXEC);       // (a file this user may not read: records are pwritten)
+                if (w->map_fd < 0) w->no_mmap = true;
+                errno = 0;
+            }
         }
         w->limit = max_chunk_len < 0 ? (size_t)512 * 1024 * 1024 : (size_t)max_chunk_len;   // lib.rs:57
         w->devs.resize((size_t)n_devices);
@@ -966,36 +986,58 @@ extern "C" int pss_writer_add_file_lines(pss_writer *w, const char *path)
             line.insert(line.end(), blk + whole_end, blk + got);
             return PSS_OK;
         };
+        // `pend`: bytes of an unterminated line that sit IN PLACE at w->buf + w->len (the tail of the last direct read).
+        // Round 4 carried that tail over in `line`, and a non-empty `line` sent every later block through the copying
+        // path: the direct read engaged once per file.  The next block is now read right behind the tail, which then
+        // finishes where it lies.
+        size_t pend = 0;
+        size_t direct_block = (size_t)32 << 20, direct_min_room = (size_t)1 << 20;     // tests shrink both: PSS_INGEST_BLOCK, _MIN_ROOM
+        if (const char *e = getenv("PSS_INGEST_BLOCK")) direct_block = std::max<size_t>(16, (size_t)strtoull(e, nullptr, 0));
+        if (const char *e = getenv("PSS_INGEST_MIN_ROOM")) direct_min_room = std::max<size_t>(1, (size_t)strtoull(e, nullptr, 0));
+        auto pend_to_line = [&]() {
+            if (pend) line.assign(w->buf + w->len, w->buf + w->len + pend);
+            pend = 0;
+        };
         for (;;) {
             const size_t room = w->limit > w->len ? w->limit - w->len : 0;
             size_t got = 0;
-            if (line.empty() && room >= ((size_t)1 << 20)) {
+            if (line.empty() && room >= pend + direct_min_room) {
                 // The file is read STRAIGHT into the chunk being filled (round 4: one copy of every byte instead of two).
                 // Whatever is read fits the chunk, so its whole lines are exactly what the per-line rule would have
-                // appended; the unterminated tail is carried over as always.  A block with a '\r' in it is set aside
-                // and goes line by line.
-                const size_t want = std::min(room, (size_t)32 << 20);
-                rc = w_reserve(w, want);
+                // appended; the unterminated tail stays where it is and the next read continues it.  A block with a
+                // '\r' in it is set aside (with the tail) and goes line by line.
+                const size_t want = std::min(room - pend, direct_block);
+                rc = w_reserve(w, pend + want);
                 if (rc != PSS_OK) break;
-                uint8_t *q = w->buf + w->len;
+                uint8_t *q = w->buf + w->len + pend;
                 rc = rd(q, want, &got);
                 if (rc != PSS_OK || got == 0) break;
                 if (memchr(q, '\r', got) == nullptr) {
                     const void *last = memrchr(q, '\n', got);
-                    const size_t whole = last ? (size_t)(static_cast<const uint8_t *>(last) - q) + 1 : 0;
-                    line.assign(q + whole, q + got);
-                    w->len += whole;
+                    if (last) {
+                        const size_t whole = (size_t)(static_cast<const uint8_t *>(last) - (w->buf + w->len)) + 1;
+                        pend = pend + got - whole;
+                        w->len += whole;
+                        w->ingest_direct += whole;
+                    } else {
+                        pend += got;               // a line longer than the block: it goes on
+                    }
                     continue;
                 }
-                aside.assign(q, q + got);
-                rc = process(aside.data(), got);
+                aside.assign(w->buf + w->len, q + got);      // the tail in place and the block behind it
+                pend = 0;
+                w->ingest_copied += aside.size();
+                rc = process(aside.data(), aside.size());
             } else {
+                pend_to_line();
                 rc = rd(block.data(), block.size(), &got);
                 if (rc != PSS_OK || got == 0) break;
+                w->ingest_copied += got;
                 rc = process(block.data(), got);
             }
             if (rc != PSS_OK) break;
         }
+        pend_to_line();
         if (rc == PSS_OK && !line.empty()) rc = deliver(line.data(), line.size(), false);
         return rc;
     });
@@ -1031,6 +1073,7 @@ extern "C" int pss_writer_close(pss_writer *w)
         pipe_stop(w);
         const auto tc1 = std::chrono::steady_clock::now();
         errno = 0;
+        if (w->map_fd >= 0) (void)close(w->map_fd);
         const int crc = close(w->fd);
         if (getenv("PSS_TIMING"))
             fprintf(stderr, "[pss] writer close: threads and device buffers %.1f ms, close(fd) %.1f ms\n",
@@ -1048,6 +1091,16 @@ extern "C" int pss_writer_close(pss_writer *w)
 }
 
 extern "C" uint64_t pss_writer_chunk_limit(const pss_writer *w) { return w ? w->limit : 0; }
+
+extern "C" int pss_writer_io_stats(pss_writer *w, pss_writer_io *out)
+{
+    if (!w || !out) return PSS_EINVAL;
+    out->records_mapped = w->records_mapped.load();
+    out->records_pwritten = w->records_pwritten.load();
+    out->ingest_direct_bytes = w->ingest_direct;
+    out->ingest_copied_bytes = w->ingest_copied;
+    return PSS_OK;
+}
 
 // ------------------------------------------------------------------- Reader --
 
@@ -1173,6 +1226,8 @@ int reader_alloc_chunk(pss_reader *r, uint32_t n, ChunkDesc *out, pss_reader::Me
             if (get_build_ctx(r->device, &bctx) == PSS_OK) {
                 std::lock_guard<std::recursive_mutex> lk(bctx->mu);
                 for (auto &sl : bctx->slot) sl.release();
+                if (bctx->helper)
+                    for (auto &sl : bctx->helper->slot) sl.release();
             }
         }
         e = hipMalloc(&m.sa, sa_bytes + sk_bytes);

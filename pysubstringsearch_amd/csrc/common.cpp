@@ -278,6 +278,20 @@ static DeviceCtx g_ctx[kMaxDevices];        // reader side
 static DeviceCtx g_bctx[kMaxDevices];       // builder side
 static std::mutex g_ctx_mu;
 
+static int init_ctx(DeviceCtx &c, int device)
+{
+    PSS_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    PSS_HIP(hipGetDeviceProperties(&prop, device));
+    c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c.pinned_cap = DeviceCtx::kPinnedBytes;
+    PSS_HIP(hipHostMalloc(&c.pinned, c.pinned_cap, hipHostMallocDefault));
+    PSS_HIP(hipHostGetDevicePointer(&c.pinned_dev, c.pinned, 0));
+    for (hipEvent_t &e : c.search_ev) PSS_HIP(hipEventCreate(&e));
+    c.device = device;
+    return PSS_OK;
+}
+
 static int get_ctx_of(DeviceCtx *table, int device, DeviceCtx **out)
 {
     int count = 0;
@@ -295,18 +309,23 @@ static int get_ctx_of(DeviceCtx *table, int device, DeviceCtx **out)
     PSS_HIP(hipSetDevice(device));
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     DeviceCtx &c = table[device];
-    if (c.device < 0) {
-        PSS_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-        hipDeviceProp_t prop;
-        PSS_HIP(hipGetDeviceProperties(&prop, device));
-        c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        c.pinned_cap = DeviceCtx::kPinnedBytes;
-        PSS_HIP(hipHostMalloc(&c.pinned, c.pinned_cap, hipHostMallocDefault));
-        PSS_HIP(hipHostGetDevicePointer(&c.pinned_dev, c.pinned, 0));
-        for (hipEvent_t &e : c.search_ev) PSS_HIP(hipEventCreate(&e));
-        c.device = device;
-    }
+    if (c.device < 0) PSS_TRY(init_ctx(c, device));
     *out = &c;
+    return PSS_OK;
+}
+
+int get_helper_ctx(DeviceCtx *parent, DeviceCtx **out)
+{
+    if (!parent->helper) {
+        DeviceCtx *h = new DeviceCtx();
+        const int rc = init_ctx(*h, parent->device);
+        if (rc != PSS_OK) {
+            delete h;
+            return rc;
+        }
+        parent->helper = h;
+    }
+    *out = parent->helper;
     return PSS_OK;
 }
 
@@ -360,6 +379,8 @@ void trim_all()
             (void)hipSetDevice(c.device);
             c.stop_resident();               // (it works in one of the slots)
             for (auto &s : c.slot) s.release();
+            if (c.helper)
+                for (auto &s : c.helper->slot) s.release();
             // the fused small-batch path keeps its cursors in one of the slots and only zeroes them when the
             // arena's address changes: a fresh allocation may come back at the old address with garbage in it
             c.small_hdr_ready = nullptr;

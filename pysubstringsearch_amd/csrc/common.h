@@ -184,7 +184,12 @@ struct DeviceCtx {
     void *io_ring[kIoPieces] = {};
     hipEvent_t io_ev[kIoPieces] = {};
     int ensure_io_ring();
+    // A second context on the same device for work the builder runs BESIDE its main line (sa_build.hip: the anchors' own
+    // sort while the text round over the whole list is under way): its own stream, pinned scratch and slots, no lock of
+    // its own -- it belongs to whoever holds this context.  Created on first use (get_helper_ctx).
+    DeviceCtx *helper = nullptr;
 };
+int get_helper_ctx(DeviceCtx *parent, DeviceCtx **out);
 
 // A few threads that pread / pwrite disjoint pieces of one file (round 4).  A chunk record is 2.7 GB at the default chunk
 // size: one thread copying it into (out of) the page cache moves 3 - 6 GB/s, which was the whole end-to-end time of the

@@ -45,6 +45,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <string>
+#include <thread>
 
 namespace pss {
 
@@ -1694,7 +1696,7 @@ static void rerank_geometry(u32 m, RerankArgs &a)
     a.num_ranges = (a.num_tiles + a.tiles_per_range - 1) / a.tiles_per_range;
 }
 
-enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK, S_GRP2 = 26, S_BIG = 27, S_SCR = 29, S_SSA = 30, S_SSB = 31, S_ANC = 32 /* .. 38: one per level */, S_X0 = 39 /* .. 45 */, S_SSPLAN = 48, S_PER = 49 };      // (10 .. 23, 28: search.hip; 24, 25: capi.cpp)
+enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK, S_GRP2 = 26, S_BIG = 27, S_SCR = 29, S_SSA = 30, S_SSB = 31, S_ANC = 32 /* .. 38: one per level */, S_X0 = 39 /* .. 45 */, S_SSPLAN = 48, S_PER = 49, S_ANCW = 55 };      // (10 .. 23, 28: search.hip; 24, 25: capi.cpp)
 
 // Initial key width.  Model the text as i.i.d. with per-symbol collision
 // probability c = sum p_i^2 (from the sampled counts): two suffixes agree on k
@@ -1750,6 +1752,10 @@ struct Knobs {
     bool no_probe = false;      // PSS_NO_PROBE   always a text round before the anchor round (no sampling of the ties)
     int anchor_min_omega = 11;  // PSS_ANCHOR_MIN_OMEGA  narrowest window the anchor round accepts by itself
     int probe_skip_pct = 50;    // PSS_PROBE_SKIP_PCT  no text rounds when more than this share of the sampled tied pairs are repeats
+    int side = -1;              // PSS_ANCHOR_SIDE  0: never sort the anchors beside the text round, 1: whenever a text round precedes the
+                                //                anchor round, unset: texts of >= 2^24 bytes whose sampled ties show copies
+    int side_pct = 8;           // PSS_ANCHOR_SIDE_PCT  ... at least this share of the sampled tied pairs
+    int anchor_cap_div = 5;     // PSS_ANCHOR_CAP_DIV  the anchor round declines when the windows choose more than n / this many anchors
     bool count_sort = false;    // PSS_COUNT_SORT  rank rounds: groups ranked by counting (group_sort_kernel) instead of the merge sort
     bool no_periodic = false;   // PSS_PERIODIC=0  rank rounds: no periodic keys for the large groups (per_*_kernel)
     bool timing = false;        // PSS_TIMING     per-round trace on stderr
@@ -1779,6 +1785,9 @@ struct Knobs {
         k.no_probe = getenv("PSS_NO_PROBE") != nullptr;
         if (const char *e = getenv("PSS_PROBE_SKIP_PCT")) k.probe_skip_pct = atoi(e);
         if (const char *e = getenv("PSS_ANCHOR_MIN_OMEGA")) k.anchor_min_omega = std::max(2, atoi(e));
+        if (const char *e = getenv("PSS_ANCHOR_SIDE")) k.side = atoi(e);
+        if (const char *e = getenv("PSS_ANCHOR_SIDE_PCT")) k.side_pct = atoi(e);
+        if (const char *e = getenv("PSS_ANCHOR_CAP_DIV")) k.anchor_cap_div = std::min(5, std::max(3, atoi(e)));
         k.count_sort = getenv("PSS_COUNT_SORT") != nullptr;
         { const char *e = getenv("PSS_PERIODIC"); k.no_periodic = e && atoi(e) == 0; }
         k.timing = getenv("PSS_TIMING") != nullptr;
@@ -1875,6 +1884,33 @@ struct RoundsIO {
 static int anchor_rank_keys(DeviceCtx *ctx, const Knobs &knobs, const RoundsIO &outer, u64 h, const u32 *syms,
                             const u32 *cur_ranks, u32 *akey, pss_sa_stats &st, bool *ok);
 
+// The anchors' own sort BESIDE the text round (round 5).  Which positions are anchors, their names and the order of the
+// anchor suffixes depend on the text and on the window only -- not on the active list the text round is busy with.  On
+// text with copies in it (source code: 412 MB of real files spent 34 ms in the text round and 50 ms in the anchors'
+// sort, one after the other) the anchors are therefore sorted by a second host thread on a second stream, in a context
+// of its own (DeviceCtx::helper: its stream, pinned scratch and slots), while the main line runs the text round that
+// raises the depth to what the window needs.  Half of the anchors' sort is a long row of small launches (rank rounds over
+// lists of 10^4 .. 10^6 elements on three levels) that leave the device all but empty: they fill the gaps of the other
+// stream instead of standing in line.  The window is fixed in advance (the depth the text round WILL reach); a text round
+// that gives up half-way leaves the depth where it was, and the result of the side line is then thrown away.
+struct SideAnchors {
+    std::thread th;
+    bool started = false, joined = false, ok = false;
+    int rc = PSS_OK;
+    std::string err;
+    u64 h_eff = 0;
+    pss_sa_stats st;
+    u32 *akey = nullptr;
+    void join()
+    {
+        if (started && !joined) {
+            th.join();
+            joined = true;
+        }
+    }
+    ~SideAnchors() { join(); }
+};
+
 static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortStats &ss, pss_sa_stats &st)
 {
     hipStream_t s = ctx->stream;
@@ -1937,6 +1973,7 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
     const u32 grid_all = (u32)grid_stream;
     // Integer strings (rank rounds only): the ranks the first round leaves ARE the string, up to renaming -- kept for the
     // minimizers of an anchor level on top of this one (anchor_impl.h), should the rounds reach depth 32 with much left tied.
+    SideAnchors side;
     u32 *X0 = nullptr;
     const u32 *Xsym = nullptr;   // the same snapshot for the periodic keys of the rank rounds (per_*_kernel), never given up
     bool last_per = false;       // the last rank round met periodic runs among its large groups, or chains that will be
@@ -2198,7 +2235,10 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
             bool bail = true;
             const bool anchors_on = !subset && knobs.anchor != 0 && (knobs.anchor == 1 || n >= (1u << 20));
             bool skip_text = false;
-            if (anchors_on && !anchored && text_rounds == 0 && !knobs.no_probe && m >= 4096 && (u64)m * 16 >= (u64)n && h >= (u64)knobs.anchor_min_omega + 3) {
+            const bool probe_skips = h >= (u64)knobs.anchor_min_omega + 3;       // deep enough for the anchor round to run at once
+            const bool side_on = knobs.side != 0 && !rank_only && (knobs.side == 1 || n >= (1u << 24)) && io.level == 0;
+            bool side_wanted = false;
+            if (anchors_on && !anchored && text_rounds == 0 && !knobs.no_probe && m >= 4096 && (u64)m * 16 >= (u64)n && (probe_skips || side_on)) {
                 // are these ties repeats (see probe_repeats_kernel)?  Then no text round will resolve them.
                 u32 *d_probe = d_counters + 48;
                 PSS_HIP(hipMemsetAsync(d_probe, 0, 8, s));
@@ -2209,8 +2249,58 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
                 PSS_HIP(hipStreamSynchronize(s));
                 st.probe_pairs = h_small[0];
                 st.probe_same = h_small[1];
-                skip_text = h_small[0] >= 64 && (u64)h_small[1] * 100 > (u64)h_small[0] * (u64)knobs.probe_skip_pct;
-                if (knobs.timing) fprintf(stderr, "[pss] probe: %u of %u sampled pairs share 48 more symbols%s\n", h_small[1], h_small[0], skip_text ? ": no text rounds" : "");
+                skip_text = probe_skips && h_small[0] >= 64 && (u64)h_small[1] * 100 > (u64)h_small[0] * (u64)knobs.probe_skip_pct;
+                side_wanted = side_on && !skip_text && h_small[0] >= 64 && (u64)h_small[1] * 100 >= (u64)h_small[0] * (u64)knobs.side_pct;
+                if (knobs.timing) fprintf(stderr, "[pss] probe: %u of %u sampled pairs share 48 more symbols%s\n", h_small[1], h_small[0], skip_text ? ": no text rounds" : (side_wanted ? ": anchors beside the text round" : ""));
+            }
+            if (knobs.side == 1 && side_on && anchors_on && !anchored && text_rounds == 0 && !skip_text) side_wanted = true;
+            if (side_wanted && !side.started && text_rounds < text_rounds_max) {
+                // the depth the coming text round will reach decides the window; the anchors' sort starts now, on the side
+                DeviceCtx *hc = nullptr;
+                const u64 h_eff = h + (u64)kt;
+                const size_t sort_ws = radix_sort_workspace_bytes();
+                int rs = get_helper_ctx(ctx, &hc);
+                if (rs == PSS_OK) rs = hc->slot[S_K0].reserve((size_t)n * 8);
+                if (rs == PSS_OK) rs = hc->slot[S_K1].reserve((size_t)n * 8);
+                if (rs == PSS_OK) rs = hc->slot[S_ISA].reserve((size_t)n * 4 + 64);
+                if (rs == PSS_OK) rs = hc->slot[S_WORK].reserve(sort_ws + 65536);
+                if (rs == PSS_OK) {
+                    u8 *hw = hc->slot[S_WORK].as<u8>();
+                    u8 *hsmall = hw + sort_ws;
+                    RoundsIO o2;
+                    memset(&o2, 0, sizeof o2);
+                    o2.n = n;
+                    o2.K[0] = hc->slot[S_K0].as<u64>();
+                    o2.K[1] = hc->slot[S_K1].as<u64>();
+                    o2.codes = codes;
+                    o2.b = b;
+                    o2.plus_one = plus_one;
+                    o2.work = hw;
+                    o2.d_agg_head = reinterpret_cast<u32 *>(hsmall + 4096);
+                    o2.d_agg_cnt = reinterpret_cast<u32 *>(hsmall + 8192);
+                    o2.d_red = reinterpret_cast<u64 *>(hsmall + 12288);
+                    o2.d_counters = reinterpret_cast<u32 *>(hsmall + 12288 + 64);
+                    o2.h_small = static_cast<u32 *>(hc->pinned);
+                    o2.level = 0;
+                    side.h_eff = h_eff;
+                    side.akey = hc->slot[S_ISA].as<u32>();
+                    memset(&side.st, 0, sizeof side.st);
+                    side.started = true;
+                    const int dev = ctx->device;
+                    SideAnchors *sp = &side;
+                    side.th = std::thread([hc, knobs, o2, h_eff, sp, dev]() {
+                        if (hipSetDevice(dev) != hipSuccess) {
+                            sp->rc = PSS_EDEVICE;
+                            sp->err = "hipSetDevice failed in the anchors' side line";
+                            return;
+                        }
+                        sp->rc = anchor_rank_keys(hc, knobs, o2, h_eff, nullptr, nullptr, sp->akey, sp->st, &sp->ok);
+                        if (sp->rc != PSS_OK) sp->err = last_error();
+                    });
+                } else {
+                    (void)hipGetLastError();      // no room for the side line's buffers: the anchors wait their turn as before
+                    set_error("%s", "");
+                }
             }
             if (anchored) {
                 // cannot happen: the anchor round leaves no ties.  Counted (tests assert zero) and resolved by rank rounds.
@@ -2227,11 +2317,41 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
                 // instead of log2(length of the repeat) rank rounds over the whole text.  The key array takes the place
                 // of the inverse suffix array, which this path never builds.
                 bool ok = false;
-                PSS_TRY(anchor_rank_keys(ctx, knobs, io, h, nullptr, nullptr, ISA, st, &ok));
+                const u32 *akey = ISA;
+                if (side.started) {
+                    side.join();
+                    if (side.rc != PSS_OK) {
+                        set_error("%s", side.err.c_str());
+                        return side.rc;
+                    }
+                    if (side.ok && h >= side.h_eff) {
+                        // sorted beside the text round: its keys are valid for every depth from h_eff on
+                        const pss_sa_stats &t = side.st;
+                        st.anchor = 1;
+                        st.anchor_count = t.anchor_count;
+                        st.anchor_omega = t.anchor_omega;
+                        st.anchor_w = t.anchor_w;
+                        st.anchor_ms += t.anchor_ms;
+                        st.anchor_depth = h;
+                        st.anchor_text_rounds += t.anchor_text_rounds;
+                        st.anchor_rounds += t.anchor_rounds;
+                        st.anchor_sum_active += t.anchor_sum_active;
+                        st.anchor_left += t.anchor_left;
+                        st.periodic_rounds += t.periodic_rounds;
+                        st.periodic_members += t.periodic_members;
+                        st.anchor_levels = std::max<uint64_t>(st.anchor_levels, t.anchor_levels);
+                        st.anchor_side = 1;
+                        akey = side.akey;
+                        ok = true;
+                    } else {
+                        st.anchor_side = 2;      // thrown away: the text round gave up before it reached the window's depth, or the round declined
+                    }
+                }
+                if (!ok) PSS_TRY(anchor_rank_keys(ctx, knobs, io, h, nullptr, nullptr, ISA, st, &ok));
                 if (ok) {
                     st.anchor_active = m;
                     bool b2 = false;
-                    PSS_TRY(local_round(false, &b2, ISA));
+                    PSS_TRY(local_round(false, &b2, akey));
                     anchored = true;
                     keyed_grp = false;
                     cur = src ^ 1;
@@ -2398,7 +2518,8 @@ static int anchor_rank_keys(DeviceCtx *ctx, const Knobs &knobs, const RoundsIO &
     if (omega < (forced ? 2u : (u32)knobs.anchor_min_omega) || n < 64 || outer.level >= 6) return PSS_OK;
     const u32 num_tiles = (n + ANC_TILE - 1) / ANC_TILE;
     const size_t n16 = round_up((size_t)n, 16) + 16;
-    const u32 m_cap = n / 5 + 64;
+    const u32 cap_div = outer.level == 0 ? (u32)knobs.anchor_cap_div : 5u;
+    const u32 m_cap = n / cap_div + 64;
     DevBuf &slot = ctx->slot[S_ANC + outer.level];
     PSS_TRY(slot.reserve(n16 + round_up((size_t)num_tiles * 4, 64) + ((size_t)num_tiles + 2) * 8 + (SC_MAX_BLOCKS + 8) * 8 +
                          (size_t)m_cap * 4 + 1024));
@@ -2436,13 +2557,18 @@ static int anchor_rank_keys(DeviceCtx *ctx, const Knobs &knobs, const RoundsIO &
     if (knobs.timing)
         fprintf(stderr, "[pss] anchors (level %d): n=%u h=%llu omega=%u w=%d anchors=%u (n / %.1f)\n", outer.level, n,
                 (unsigned long long)h, omega, w, m, (double)n / std::max(1u, m));
-    if (m == 0 || m > n / 5) return PSS_OK;
+    if (m == 0 || m > n / cap_div) return PSS_OK;
     hipLaunchKernelGGL(anc_walk_kernel<false>, dim3(grid), dim3(256), 0, s, d_dist, n, d_tile_off, num_tiles, d_Q,
                        (const u32 *)nullptr, (u32 *)nullptr);
     // the anchors' own sort, in the caller's two key buffers
     u8 *b0 = reinterpret_cast<u8 *>(outer.K[0]), *b1 = reinterpret_cast<u8 *>(outer.K[1]);
     const size_t m8 = round_up((size_t)m * 8, 256), m4 = round_up((size_t)m * 4 + 64, 256);
     u64 *AK[2] = {reinterpret_cast<u64 *>(b0), reinterpret_cast<u64 *>(b0 + m8)};
+    if (outer.level == 0 && 9 * m4 > (size_t)n * 8 && 2 * m8 <= (size_t)n * 8) {
+        // more anchors than the caller's second key buffer holds nine arrays of: a slot of their own
+        PSS_TRY(ctx->slot[S_ANCW].reserve(9 * m4));
+        b1 = ctx->slot[S_ANCW].as<u8>();
+    }
     u32 *AV[2] = {reinterpret_cast<u32 *>(b1), reinterpret_cast<u32 *>(b1 + m4)};
     u32 *A_isa = reinterpret_cast<u32 *>(b1 + 2 * m4);
     u32 *AP[2] = {reinterpret_cast<u32 *>(b1 + 3 * m4), reinterpret_cast<u32 *>(b1 + 4 * m4)};
@@ -2450,7 +2576,7 @@ static int anchor_rank_keys(DeviceCtx *ctx, const Knobs &knobs, const RoundsIO &
     u32 *A_grp2 = reinterpret_cast<u32 *>(b1 + 6 * m4);
     u32 *A_sa = reinterpret_cast<u32 *>(b1 + 7 * m4);
     u32 *A_rank = reinterpret_cast<u32 *>(b1 + 8 * m4);
-    if (2 * m8 > (size_t)n * 8 || 9 * m4 > (size_t)n * 8) return PSS_OK;      // (tiny strings)
+    if (2 * m8 > (size_t)n * 8 || (b1 == reinterpret_cast<u8 *>(outer.K[1]) && 9 * m4 > (size_t)n * 8)) return PSS_OK;      // (tiny strings)
     int kt = 64 / outer.b;
     if (kt > 16) kt = 16;
     const u32 gk = (u32)std::min<u64>((u64)ctx->num_cus * 8, ((u64)m + 255) / 256);

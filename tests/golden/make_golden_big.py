@@ -91,7 +91,7 @@ def main():
     jobs += [('mixed', 0, n0)]                                   # natural text with a repetitive middle (round 4)
     jobs += [('source', 0, n0), ('source', 1, n0)]               # source-like text (round 5)
     if args.big:                                                 # above the default chunk size (round 5; ~6 GB and 3-4 minutes each)
-        jobs += [('lines', 0, BIG_N), ('words', 0, BIG_N), ('mixed', 0, BIG_N), ('source', 0, BIG_N), ('words', 0, FORMAT2_N)]
+        jobs += [('lines', 0, BIG_N), ('words', 0, BIG_N), ('mixed', 0, BIG_N), ('runs', 0, BIG_N), ('source', 0, BIG_N), ('words', 0, FORMAT2_N)]
     done = {}
     if os.path.exists(args.out):
         for r in json.load(open(args.out))['chunks']:

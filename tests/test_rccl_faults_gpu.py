@@ -26,7 +26,7 @@ U64 = 5
 
 @pytest.fixture(scope='module')
 def hip():
-    h = ctypes.CDLL('libamdhip64.so')
+    h = _ffi.hip_runtime()
     vp = ctypes.c_void_p
     h.hipMemcpyAsync.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_int, vp]
     h.hipMemsetAsync.argtypes = [vp, ctypes.c_int, ctypes.c_size_t, vp]
@@ -318,15 +318,20 @@ def test_a_gather_does_not_hold_up_a_build_on_the_same_device(hip, two_indexes):
         peer = FakePeer(hip, 0, pt[0], pt[1][:-1], pt[2])
         comm = _adopt(peer, 0, timeout_ms=3000)
         peer.fail = 'hang'
+        n = 1 << 20
+        text = np.empty(n, dtype=np.uint8)
+        _ffi.check(_ffi.lib.pss_gen_corpus(_ffi.CORPUS_WORDS, text.ctypes.data, n, 0))
+        sa = np.empty(n, dtype=np.int32)
+        # (once beforehand: the builder's workspace grows to this size now -- growing frees the old buffers, and hipFree
+        # waits for EVERY stream of the device, a blocked collective included: that is the runtime's rule, not a lock of ours)
+        _ffi.check(_ffi.lib.pss_sa_build(text.ctypes.data, sa.ctypes.data, n, 0))
+        other.search('gamma')
         out = {}
         dr = _device_result(mine, qs)
         th = threading.Thread(target=lambda: out.setdefault('rc', _gather(comm, dr)[0]))
         th.start()
         time.sleep(0.3)                                             # the gather is blocked in its receive by now
-        n = 1 << 20
-        text = np.empty(n, dtype=np.uint8)
-        _ffi.check(_ffi.lib.pss_gen_corpus(_ffi.CORPUS_WORDS, text.ctypes.data, n, 0))
-        sa = np.empty(n, dtype=np.int32)
+        sa[:] = 0
         t0 = time.time()
         _ffi.check(_ffi.lib.pss_sa_build(text.ctypes.data, sa.ctypes.data, n, 0))
         built_in = time.time() - t0

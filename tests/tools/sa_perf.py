@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, '.')
 from pysubstringsearch_amd import _ffi  # noqa: E402
 
-KINDS = {'lines': 0, 'words': 1, 'runs': 2, 'periodic': 3, 'repeat_line': 4, 'dup_blocks': 5, 'mixed': 6}
+KINDS = {'lines': 0, 'words': 1, 'runs': 2, 'periodic': 3, 'repeat_line': 4, 'dup_blocks': 5, 'mixed': 6, 'source': 7}
 
 
 def main():
