@@ -75,6 +75,29 @@ MASK64 = (1 << 64) - 1
 
 # ----------------------------------------------------------------------------- verification --
 
+def evidence(name: str):
+    """A counter file under profiles/ and whether it was measured on THIS tree: (json or None, stamp).  The files carry the
+    content hash of the engine's sources (tests/tools/tree_hash.py); bench.py recomputes it."""
+    p = os.path.join(ROOT, 'profiles', name)
+    if not os.path.exists(p):
+        return None, None
+    try:
+        d = json.load(open(p))
+    except Exception:
+        return None, None
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location('tree_hash', os.path.join(ROOT, 'tests', 'tools', 'tree_hash.py'))
+        th = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(th)
+        now = th.csrc_hash()
+    except Exception:
+        now = None
+    stamp = {'file': 'profiles/' + name, 'measured_on_sources': d.get('csrc_sha256_16'), 'commit': d.get('commit'),
+             'these_sources': now, 'current': bool(now and d.get('csrc_sha256_16') == now)}
+    return d, stamp
+
+
 def load_big_goldens():
     """(kind, chunk_index, n) -> libsais known answers (tests/golden/make_golden_big.py)."""
     p = os.path.join(ROOT, 'tests', 'golden', 'sa_big.json')
@@ -104,7 +127,7 @@ def sa_poly64_numpy(sa: np.ndarray) -> int:
     return acc
 
 
-def verify_sa(d_sa, host_text: np.ndarray, kind: str, chunk_index: int, goldens, want_sha: bool, host_sa=None):
+def verify_sa(d_sa, host_text: np.ndarray, kind: str, chunk_index: int, goldens, want_sha: bool, host_sa=None, live_max: int = 1 << 25):
     """Is the device suffix array libsais' (the reference's) suffix array of this chunk?
     Returns (verified, how): True / False when it could be decided, None when no known answer exists
     for this input and it is too large to run libsais on the spot."""
@@ -118,7 +141,7 @@ def verify_sa(d_sa, host_text: np.ndarray, kind: str, chunk_index: int, goldens,
             ok = hashlib.sha256(sa_np.astype('<i4', copy=False)).hexdigest() == g['sa_sha256']
             how = 'sha256 of the int32 array + positional checksum vs libsais golden (tests/golden/sa_big.json)'
         return bool(ok), how
-    if n <= (1 << 25):
+    if n <= live_max:
         from oracle import oracle as O
         if O.have_reference():
             ref = O.sa_reference(host_text)
@@ -542,7 +565,56 @@ def run_e2e(args):
                         left -= len(b)
                     ok = ok and ht == g['text_sha256'] and h.hexdigest() == g['sa_sha256']
                     checked.append(c)
-        return {'chunks': chunks, 'chunk_bytes': n, 'dir': where, 'text_bytes': chunks * n, 'idx_bytes': sz,
+        # the same text into container format 2 with the suffix arrays striped over eight files of their own
+        # (Writer(..., format_version=2, striped=True), include/pss.h PSS_FORMAT_STRIPED): one file in the page cache is what
+        # bounds the reference container on this box (profiles/r04_pagecache_micro.txt)
+        striped = None
+        try:
+            os.remove(idx)                   # (checked above; the two indexes need not share the disk)
+            sidx = os.path.join(d, 'striped.idx')
+            sbest = None
+            for rep in range(2):
+                for f in [sidx] + [f'{sidx}.sa{j}' for j in range(64)]:
+                    if os.path.exists(f):
+                        os.remove(f)
+                t0 = time.perf_counter()
+                w = pysubstringsearch.Writer(sidx, n, format_version=2, striped=True)
+                w.add_entries_from_file_lines(src)
+                w.finalize()
+                w.close()
+                t1 = time.perf_counter()
+                r = pysubstringsearch.Reader(sidx)
+                t2 = time.perf_counter()
+                s_chunks = r.num_chunks
+                r.close()
+                if sbest is None or t1 - t0 < sbest[0]:
+                    sbest = (t1 - t0, t2 - t1)
+            S, unit = 8, 1 << 24
+            s_ok, s_checked = s_chunks == chunks, []
+            units_per_chunk = (4 * n + unit - 1) // unit
+            for c in (0, chunks - 1):
+                g = gold.get((args.corpus, c, n))
+                if g is None:
+                    continue
+                h = hashlib.sha256()
+                left = 4 * n
+                for u in range(c * units_per_chunk, (c + 1) * units_per_chunk):
+                    with open(f'{sidx}.sa{u % S}', 'rb') as f:
+                        f.seek((u // S) * unit)
+                        b = f.read(min(left, unit))
+                    h.update(b)
+                    left -= len(b)
+                s_ok = s_ok and left == 0 and h.hexdigest() == g['sa_sha256']
+                s_checked.append(c)
+            s_sz = os.path.getsize(sidx) + sum(os.path.getsize(f'{sidx}.sa{j}') for j in range(S))
+            striped = {'writer_seconds': round(sbest[0], 3), 'writer_text_gbs': round(chunks * n / sbest[0] / 1e9, 3),
+                       'writer_idx_gbs': round(s_sz / sbest[0] / 1e9, 2), 'reader_open_seconds': round(sbest[1], 3),
+                       'reader_open_idx_gbs': round(s_sz / sbest[1] / 1e9, 2), 'stripe_files': S, 'bytes': s_sz,
+                       'verified': bool(s_ok), 'verified_by': f'suffix-array sha256 of chunks {s_checked}, read back from the stripe files, '
+                                                              'against libsais (tests/golden/sa_big.json)'}
+        except Exception as e:      # noqa: BLE001
+            striped = {'error': f'{type(e).__name__}: {e}'[:300]}
+        return {'chunks': chunks, 'chunk_bytes': n, 'dir': where, 'text_bytes': chunks * n, 'idx_bytes': sz, 'striped_format_2': striped,
                 'writer_seconds': round(best[0], 3), 'writer_text_gbs': round(chunks * n / best[0] / 1e9, 3),
                 'writer_idx_gbs': round(sz / best[0] / 1e9, 2),
                 'writer_seconds_first': round(first[0], 3), 'writer_text_gbs_first': round(chunks * n / first[0] / 1e9, 3),
@@ -710,19 +782,17 @@ def run_chunk(args, D):
         best = sum(w_ms) / len(w_ms)
         del w_dTs, w_hosts
         wd = wst.as_dict()
-        w_traffic = None
-        wp = os.path.join(ROOT, 'profiles', 'pmc_build_traffic_words.json')
-        if os.path.exists(wp) and args.logn == 29:
-            try:
-                w_traffic = json.load(open(wp)).get('total_bytes')
-            except Exception:
-                w_traffic = None
+        w_traffic, w_stamp = None, None
+        if args.logn == 29:
+            wj, w_stamp = evidence('pmc_build_traffic_words.json')
+            w_traffic = wj.get('total_bytes') if wj else None
         secondary = {'corpus': 'words', 'chunk_bytes': n, 'build_ms': round(best, 3),
                      'build_ms_is': 'mean of 6 builds rotating over 3 distinct chunks, each under the plan its predecessor left',
                      'build_ms_min': round(min(w_ms), 3), 'build_ms_max': round(max(w_ms), 3),
                      'build_ms_cold': round(w_cold, 3), 'planned_builds': w_planned,
                      'index_build_gbs': round(n / best / 1e6, 4), 'verified': w_ok, 'verified_by': w_how,
                      'traffic': w_traffic, 'traffic_gbs': None if not w_traffic else round(w_traffic / best / 1e6, 1),
+                     'traffic_evidence': w_stamp,
                      'initial_sort': ('sample sort over 16-byte [key | index] elements (ss_sort_impl.h)' if wd['ss'] else
                                       'LSD passes with shrinking keys'),
                      'initial_sort_ms': round(wd['ms_initial'], 3),
@@ -735,27 +805,33 @@ def run_chunk(args, D):
     adversarial = None
     if world == 1 and args.corpus == 'lines' and not os.environ.get('PSS_BENCH_NO_SECONDARY'):
         adversarial = []
-        for kind in ('runs', 'periodic', 'repeat_line', 'dup_blocks', 'mixed'):
+        for kind in ('runs', 'periodic', 'repeat_line', 'dup_blocks', 'mixed', 'source'):
             a_host = np.empty(n, dtype=np.uint8)
             _ffi.check(lib.pss_gen_corpus(KINDS[kind], a_host.ctypes.data, n, 0))
             a_dT = torch.from_numpy(a_host).cuda()
             ast = _ffi.SaStats()
             best = None
-            for _ in range(3 if kind in ('runs', 'periodic') else 2):
+            for _ in range(3 if kind in ('runs', 'periodic', 'source') else 2):
                 _ffi.check(lib.pss_sa_build_device(a_dT.data_ptr(), dSA.data_ptr(), n, dev, 0, ctypes.byref(ast)))
                 best = ast.ms_total if best is None else min(best, ast.ms_total)
             ad = ast.as_dict()
             a_ok, a_how = verify_sa(dSA, a_host, kind, 0, load_big_goldens(), want_sha=False)
-            if kind in ('repeat_line', 'dup_blocks', 'mixed'):
-                # repeats that are not runs of one byte: one word repeated (closed form), duplicated blocks and natural
-                # text with a repetitive middle (anchor round: anchor_impl.h)
+            if kind in ('repeat_line', 'dup_blocks', 'mixed', 'source'):
+                # repeats that are not runs of one byte: one word repeated (closed form), duplicated blocks, natural
+                # text with a repetitive middle, source-like text (anchor round: anchor_impl.h)
                 adversarial.append({'corpus': kind, 'chunk_bytes': n, 'build_ms': round(best, 3),
                                     'index_build_gbs': round(n / best / 1e6, 3), 'verified': a_ok, 'verified_by': a_how,
                                     'run_length_path': bool(ad['rle']), 'rounds': ad['rounds'], 'sum_active': ad['sum_active'],
                                     'initial_sort': 'sample sort' if ad['ss'] else ('hybrid MSD' if ad['msd'] else 'LSD'),
                                     'anchor_round': bool(ad['anchor']), 'anchors': ad['anchor_count'],
                                     'anchor_window': ad['anchor_omega'], 'anchor_rank_rounds': ad['anchor_rounds'],
-                                    'anchor_ms': round(ad['anchor_ms'], 2), 'anchor_left_tied': ad['anchor_left']})
+                                    'anchor_ms': round(ad['anchor_ms'], 2), 'anchor_left_tied': ad['anchor_left'],
+                                    'anchors_beside_the_text_round': int(ad['anchor_side']), 'text_rounds': ad['text_rounds']})
+                if kind == 'source':
+                    sj, s_stamp = evidence('pmc_build_traffic_source.json')
+                    if sj and args.logn == 29:
+                        adversarial[-1].update({'traffic': sj.get('total_bytes'), 'traffic_gbs': round(sj['total_bytes'] / best / 1e6, 1),
+                                                'traffic_evidence': s_stamp})
                 del a_dT
                 continue
             os.environ['PSS_RLE'] = '0'
@@ -775,10 +851,10 @@ def run_chunk(args, D):
                                 'prefix_doubling_verified': d_ok})
             del a_dT
 
-    # Real files instead of generated text (N = 1 only): 32 MiB of the Python sources and C / HIP headers found on this
-    # machine, in sorted path order (tests/tools/real_text.py) -- licence headers copied thousands of times, indentation,
-    # 200-odd byte values; four suffixes in five sit inside copies, so the build goes through the sample sort, a text
-    # round and the anchor round.  Checked against libsais run on the same bytes (verify_sa).
+    # Real files instead of generated text (N = 1 only): 256 MiB (--real-files-logn) of the Python sources and C / HIP headers
+    # found on this machine, in sorted path order (tests/tools/real_text.py) -- licence headers copied thousands of times,
+    # indentation, 200-odd byte values; four suffixes in five sit inside copies, so the build goes through the sample
+    # sort, a text round and the anchor round.  Checked against libsais run on the same bytes, here and now.
     real_files = None
     if world == 1 and args.corpus == 'lines' and not os.environ.get('PSS_BENCH_NO_SECONDARY') and not args.no_real_files:
         try:
@@ -787,7 +863,7 @@ def run_chunk(args, D):
             rt = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(rt)
             t_c = time.perf_counter()
-            raw = rt.collect(1 << 25)
+            raw = rt.collect(1 << args.real_files_logn)
             collect_s = time.perf_counter() - t_c
             if len(raw) >= (1 << 24):
                 r_host = np.frombuffer(raw, dtype=np.uint8).copy()
@@ -797,18 +873,27 @@ def run_chunk(args, D):
                 r_dSA = dSA[:rn] if rn <= n else torch.empty(rn, dtype=torch.int32, device='cuda')
                 rst = _ffi.SaStats()
                 best = None
-                for i in range(3):
-                    _ffi.check(lib.pss_sa_build_device(r_dT.data_ptr(), r_dSA.data_ptr(), rn, dev, 0, ctypes.byref(rst)))
-                    best = rst.ms_total if best is None else min(best, rst.ms_total)
+                r_cold = None
+                for i in range(4):
+                    _ffi.check(lib.pss_sa_build_device(r_dT.data_ptr(), r_dSA.data_ptr(), rn, dev, 8 if i == 0 else 0, ctypes.byref(rst)))
+                    if i == 0:
+                        r_cold = rst.ms_total
+                    else:
+                        best = rst.ms_total if best is None else min(best, rst.ms_total)
                 rd = rst.as_dict()
-                r_ok, r_how = verify_sa(r_dSA, r_host, 'real_files', 0, {}, want_sha=True)
+                r_ok, r_how = verify_sa(r_dSA, r_host, 'real_files', 0, {}, want_sha=True, live_max=1 << 29)
+                rj, r_stamp = evidence('pmc_build_traffic_real.json')
                 real_files = {'bytes': rn, 'byte_values': int(len(np.unique(r_host))), 'lines': int((r_host == 10).sum()),
                               'build_ms': round(best, 3), 'index_build_gbs': round(rn / best / 1e6, 3),
                               'verified': r_ok, 'verified_by': r_how, 'collect_seconds': round(collect_s, 1),
                               'initial_sort': 'sample sort' if rd['ss'] else ('hybrid MSD' if rd['msd'] else 'LSD'),
                               'anchor_round': bool(rd['anchor']), 'anchors': rd['anchor_count'],
                               'tied_after_initial_sort': rd['sum_active'], 'text_rounds': rd['text_rounds'],
-                              'note': 'a 412 MB chunk of the same files: 131 ms = 3.15 GB/s (profiles/r04_real_files.txt)'}
+                              'build_ms_cold': round(r_cold, 3), 'anchors_beside_the_text_round': int(rd['anchor_side']),
+                              'anchor_ms': round(rd['anchor_ms'], 2), 'initial_sort_ms': round(rd['ms_initial'], 2),
+                              'a_min_frac': round(5 * rn / best / 1e6 / HBM_PEAK_GBS, 4),
+                              'traffic_per_suffix_committed': None if not rj else rj.get('bytes_per_suffix'),
+                              'traffic_evidence': r_stamp}
                 del r_dT, r_dSA
         except Exception as e:                       # (a machine without such files, or without the tool)
             real_files = {'error': repr(e)[:200]}
@@ -838,18 +923,16 @@ def run_chunk(args, D):
             bytes_per_launch = float(bpe) * elems / launches
             ms_per_launch = ms_sum / launches
             achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9
-            traffic = None
-            pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-            if os.path.exists(pmc) and args.corpus == 'lines' and args.logn == 29:
-                try:
-                    traffic = json.load(open(pmc)).get('kernels', {}).get(kname, {}).get('bytes_per_launch')
-                except Exception:
-                    traffic = None
+            traffic, t_stamp = None, None
+            if args.corpus == 'lines' and args.logn == 29:
+                tj, t_stamp = evidence('pmc_traffic.json')
+                traffic = tj.get('kernels', {}).get(kname, {}).get('bytes_per_launch') if tj else None
             roof = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                     'traffic_source': None if traffic is None else
                     'profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this workload '
                     '(FETCH x 2 on gfx950), committed with the code -- a constant of the build, not measured in this run',
+                    'traffic_evidence': t_stamp,
                     'kernel': kname, 'launches_per_build': launches, 'algorithmic_bytes_per_element': bpe,
                     'ms_per_launch': round(ms_per_launch, 4), 'algorithmic_bytes_per_launch': int(bytes_per_launch)}
         # whole-build roofline: A_min = read T once + write SA once; A_model = what this
@@ -871,13 +954,10 @@ def run_chunk(args, D):
             # MSD initial sort: (1 hist + 1 + 8) + (8 hist + 8 + 8) + (8 + 4) bytes per suffix; the first rerank is fused
             # into the local sort (no pass over the flagged array)
             a_model = 3 * n + 46 * n + 80 * sa_stats['sum_active']
-        measured = None
-        pmcb = os.path.join(ROOT, 'profiles', 'pmc_build_traffic.json')
-        if os.path.exists(pmcb) and args.corpus == 'lines' and args.logn == 29:
-            try:
-                measured = json.load(open(pmcb)).get('total_bytes')
-            except Exception:
-                measured = None
+        measured, m_stamp = None, None
+        if args.corpus == 'lines' and args.logn == 29:
+            mj, m_stamp = evidence('pmc_build_traffic.json')
+            measured = mj.get('total_bytes') if mj else None
         # SURVEY 8(d)'s yardstick (64-bit keys in every pass, P = 8): 5 n + sum over rounds of n_r (32 P + 44)
         a_survey = 5 * n + 300 * (n + sa_stats['sum_active'])
         build_roof = {'a_min_bytes': 5 * n, 'a_model_bytes': int(a_model),
@@ -886,6 +966,7 @@ def run_chunk(args, D):
                       'achieved': round(a_model / build_ms / 1e6, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                       'frac': round(a_model / build_ms / 1e6 / HBM_PEAK_GBS, 4), 'traffic': measured,
                       'traffic_source': None if measured is None else 'profiles/pmc_build_traffic.json (committed PMC runs, not measured in this run)',
+                      'traffic_evidence': m_stamp,
                       'passes': sa_stats['initial_passes'], 'rounds': sa_stats['rounds'], 'sum_active': sa_stats['sum_active']}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -920,7 +1001,9 @@ def run_chunk(args, D):
                 'runs_build_ms': pick(adversarial, 'runs', 'build_ms'),
                 'periodic_build_ms': pick(adversarial, 'periodic', 'build_ms'),
                 'repeat_line_build_ms': pick(adversarial, 'repeat_line', 'build_ms'),
-                'real_files_32MiB_build_gbs': pick(real_files, 'index_build_gbs') if real_files and 'error' not in real_files else None,
+                'source_build_ms': pick(adversarial, 'source', 'build_ms'),
+                'real_files_build_gbs': pick(real_files, 'index_build_gbs') if real_files and 'error' not in real_files else None,
+                'real_files_bytes': pick(real_files, 'bytes') if real_files and 'error' not in real_files else None,
             },
             'value_cold': value_cold,
             'value_is_warm': 'steady state of a Writer: %d distinct chunks rotate through the timed loop, every build after '
@@ -1242,6 +1325,7 @@ def main():
     ap.add_argument('--no-corpus15', action='store_true', help='chunk config: skip the configs[2]/[3] leg of the line')
     ap.add_argument('--corpus15-queries', type=int, default=100000)
     ap.add_argument('--no-real-files', action='store_true', help='chunk config: skip the build of real files found on the machine')
+    ap.add_argument('--real-files-logn', type=int, default=28, help='... and how many bytes of them (2^this) make the chunk')
     ap.add_argument('--no-e2e', action='store_true', help='chunk config: skip the file-API leg (Writer -> .idx -> Reader)')
     ap.add_argument('--e2e-chunks', type=int, default=4)
     ap.add_argument('--inproc', action='store_true',
@@ -1388,6 +1472,8 @@ def main():
                 e2e = {'error': f'{type(e).__name__}: {e}'[:300]}
             out['e2e'] = e2e
             out['summary'].update({'e2e_writer_text_gbs': e2e.get('writer_text_gbs'), 'e2e_writer_idx_gbs': e2e.get('writer_idx_gbs'),
+                                   'e2e_striped_writer_text_gbs': (e2e.get('striped_format_2') or {}).get('writer_text_gbs'),
+                                   'e2e_striped_reader_open_idx_gbs': (e2e.get('striped_format_2') or {}).get('reader_open_idx_gbs'),
                                    'e2e_reader_open_idx_gbs': e2e.get('reader_open_idx_gbs'), 'e2e_verified': e2e.get('verified')})
             if e2e.get('verified') is False:
                 out['value'] = None

@@ -45,9 +45,12 @@ int pss_device_count(void);
  * no device argument) gets; the reference fans out over every core of the machine without being asked (rayon's global
  * pool, src/lib.rs:205-207):
  *   PSS_DEVICES=all | 0,1,...   every visible device / the listed ordinals (one may be listed more than once);
- *   else PSS_DEVICE=k or LOCAL_RANK=k (a launcher runs one process per GPU): device k mod count;
+ *   else (unset, or set to nothing) PSS_DEVICE=k, LOCAL_RANK=k, SLURM_LOCALID=k, OMPI_COMM_WORLD_LOCAL_RANK=k or
+ *        MV2_COMM_WORLD_LOCAL_RANK=k (a launcher runs one process per GPU): device k mod count;
  *   else every visible device.
- * Writes at most cap ordinals to out and returns how many (>= 1). */
+ * Writes at most cap ordinals to out and returns how many (>= 1); -1 (message in pss_last_error) when PSS_DEVICES is set
+ * to something that is neither 'all' nor a list of ordinals below the device count -- handles opened without a device then
+ * fail with PSS_EINVAL instead of spreading over every GPU (round 5: it used to count as unset). */
 int32_t pss_default_devices(int32_t *out, int32_t cap);
 
 /* Copies the calling thread's last error message into buf (NUL-terminated,
@@ -219,7 +222,14 @@ int pss_writer_open(const char *path, int64_t max_chunk_len, int32_t device, pss
  *     u32 at lib.rs:116 limits a chunk to < 1 GiB of text;
  * 2 = "PSSIDX\x02\x00" | u32le flags (0) | u32le reserved (0), then records with 64-bit lengths,
  *     u64le n | text | u64le 4n | n x i32le: chunks of up to 2^31 - 1 bytes (max_chunk_len beyond
- *     that is PSS_EINVAL).  pss_reader_open recognises either format by the magic. */
+ *     that is PSS_EINVAL).  pss_reader_open recognises either format by the magic.
+ * 2 | PSS_FORMAT_STRIPED (round 5) = format 2 with header flags bit 0 set (bits 8..15: S, bits 16..23: log2 of the
+ *     unit, 24): the records hold no suffix arrays (u64le n | text | u64le 4n), the arrays live in S files
+ *     `<path>.sa0` .. `<path>.sa<S-1>` (S = 8; PSS_STRIPES) -- every chunk's array starts a new 16 MiB unit, unit u
+ *     sits in file u mod S at offset (u / S) * 16 MiB -- and are written and read by several threads, a file each:
+ *     one file in the page cache takes 11 - 14 GB/s on the test box whatever the number of writers, a file per
+ *     writer 47 - 97.  The stripe files travel with the index file; pss_reader_open reads the flag. */
+#define PSS_FORMAT_STRIPED 0x100
 int pss_writer_open_format(const char *path, int64_t max_chunk_len, int32_t device, int32_t format_version,
                            pss_writer **out);
 /* The same over several devices ("each GPU builds its chunks; host writes records in chunk

@@ -12,6 +12,7 @@ class Writer:
         device: typing.Optional[int] = None,
         devices: typing.Optional[typing.Sequence[int]] = None,
         format_version: int = 1,
+        striped: bool = False,
     ) -> None: ...
 
     def add_entries_from_file_lines(self, input_file_path: str) -> None: ...

@@ -110,37 +110,40 @@ extern "C" int32_t pss_default_devices(int32_t *out, int32_t cap)
             if (*c < '0' || *c > '9') return false;
         return true;
     };
-    if (const char *e = getenv("PSS_DEVICES")) {
-        if (strcmp(e, "all") != 0 && *e) {
-            // a comma-separated list of ordinals (one may be named more than once: "virtual devices")
-            int32_t k = 0;
-            bool ok = true;
-            const char *c = e;
-            while (ok && *c && k < cap) {
-                char *end = nullptr;
-                const long v = strtol(c, &end, 10);
-                if (end == c || v < 0 || (count > 0 && v >= count)) { ok = false; break; }
-                out[k++] = (int32_t)v;
-                c = end;
-                if (*c == ',') ++c;
-                else if (*c) ok = false;
-            }
-            if (ok && k > 0) return k;
-        }
+    const char *e = getenv("PSS_DEVICES");
+    if (e && *e) {
         if (strcmp(e, "all") == 0) {
             int32_t k = 0;
             for (; k < count && k < cap; ++k) out[k] = k;
-            if (k > 0) return k;
+            if (k == 0) out[k++] = 0;
+            return k;
         }
-        // (anything else: as if unset)
-    } else {
-        for (const char *var : {"PSS_DEVICE", "LOCAL_RANK"}) {       // one process per GPU under a launcher
-            const char *v = getenv(var);
-            if (digits(v)) {
-                const long d = strtol(v, nullptr, 10);
-                out[0] = (int32_t)(count > 0 ? d % count : d);
-                return 1;
-            }
+        // a comma-separated list of ordinals (one may be named more than once: "virtual devices")
+        int32_t k = 0;
+        bool ok = true;
+        const char *c = e;
+        while (ok && *c && k < cap) {
+            char *end = nullptr;
+            const long v = strtol(c, &end, 10);
+            if (end == c || v < 0 || (count > 0 && v >= count)) { ok = false; break; }
+            out[k++] = (int32_t)v;
+            c = end;
+            if (*c == ',') ++c;
+            else if (*c) ok = false;
+        }
+        if (ok && k > 0 && (!*c || k == cap)) return k;       // (a list longer than the caller's room: its first cap ordinals)
+        // A list that does not parse is an ERROR (round 5), not "as if unset": under a launcher every rank would otherwise
+        // open its handles on all visible GPUs at once.
+        set_error("PSS_DEVICES=%s is neither 'all' nor a comma-separated list of device ordinals below %d", e, count);
+        return -1;
+    }
+    // unset (or set to nothing): one process per GPU under a launcher -- ours, torchrun's, Slurm's, Open MPI's, MVAPICH's
+    for (const char *var : {"PSS_DEVICE", "LOCAL_RANK", "SLURM_LOCALID", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK"}) {
+        const char *v = getenv(var);
+        if (digits(v)) {
+            const long d = strtol(v, nullptr, 10);
+            out[0] = (int32_t)(count > 0 ? d % count : d);
+            return 1;
         }
     }
     int32_t k = 0;
@@ -328,6 +331,28 @@ struct WJob {
     enum State { QUEUED, BUILDING, BUILT } state = QUEUED;
 };
 
+// Striped layout of format 2 (opt-in, round 5): header flags bit 0 set, bits 8..15 = S stripe files, bits 16..23 = log2 of
+// the stripe unit.  The records of the index file then hold no suffix array (u64 n | text | u64 4n); the arrays live in
+// `<path>.sa0` .. `<path>.sa<S-1>`: every chunk's array starts a new unit, unit u sits in file u mod S at offset
+// (u / S) * unit.  Why: ONE file in the page cache takes 11 - 14 GB/s on the test box however many threads write it (the
+// inode's lock), a file per writer 47 - 97 GB/s (profiles/r04_pagecache_micro.txt) -- and the suffix arrays are 4/5 of
+// the bytes.  The reference container (and format 2 without the flag) stay as they are.
+constexpr uint32_t kStripedFlag = 1u;
+constexpr int kStripeUnitLog = 24;                     // = DeviceCtx::kIoPiece: one piece of the I/O pool per unit
+static_assert(((size_t)1 << kStripeUnitLog) == DeviceCtx::kIoPiece, "a stripe unit is one piece of the I/O pool");
+struct Stripes {
+    std::vector<int> fd;
+    uint64_t next_unit = 0;                            // first unit of the next chunk's suffix array
+    int S() const { return (int)fd.size(); }
+    void close_all()
+    {
+        for (int f : fd)
+            if (f >= 0) (void)close(f);
+        fd.clear();
+    }
+    static std::string name(const char *path, int j) { return std::string(path) + ".sa" + std::to_string(j); }
+};
+
 struct WDevice {
     int device = 0;
     DevBuf sa[2];                 // suffix arrays in HBM: one being written out, one being built
@@ -342,6 +367,7 @@ struct pss_writer {
     int fd = -1;                  // the index file: records are written with pwrite at offsets known in advance
     int64_t pos = 0;              // where the next record starts
     bool no_mmap = true;          // records through pwrite (false: through a shared mapping -- see write_record)
+    Stripes stripes;              // striped layout: the suffix arrays' files (empty: arrays inline, as in the reference)
     int map_fd = -1;              // the same file opened for reading AND writing: a shared mapping needs both (the index file
                                   // itself is opened like File::create, write-only -- mmap on that fd fails with EACCES)
     size_t mmap_min = (size_t)1 << 20;     // records below this go through pwrite (PSS_WRITER_MMAP_MIN)
@@ -455,7 +481,8 @@ int pwrite_all(int fd, const void *buf, size_t len, int64_t off)
 // Streams `bytes` of device memory to the file at `off`: D2H copies into a ring of pinned pieces on the owning device's
 // copy stream, every piece handed to the I/O pool (pwrite at its own offset) as soon as it has landed -- the copy of
 // piece i + 1 runs while pieces <= i are being written by several threads.
-int download_to_file(pss_writer *w, WDevice &d, const void *src, size_t bytes, int64_t off, IoPool::Batch *batch, uint8_t *map)
+int download_to_file(pss_writer *w, WDevice &d, const void *src, size_t bytes, int64_t off, IoPool::Batch *batch, uint8_t *map,
+                     uint64_t unit_base = 0)
 {
     const size_t piece = DeviceCtx::kIoPiece;
     const size_t pieces = (bytes + piece - 1) / piece;
@@ -466,7 +493,12 @@ int download_to_file(pss_writer *w, WDevice &d, const void *src, size_t bytes, i
     auto put = [&](size_t i) {          // piece i has landed in its staging buffer: to the pool
         const size_t o = i * piece, k = std::min(piece, bytes - o);
         if (drop) return;
-        if (map) pool.submit_copy(batch, map + o, w->stage[i % kWPieces], k, &done[i % kWPieces]);      // map: where `off` is mapped
+        if (w->stripes.S()) {             // striped layout: piece i is unit unit_base + i of the suffix arrays' files
+            const uint64_t u = unit_base + i;
+            const int S = w->stripes.S();
+            pool.submit(batch, w->stripes.fd[(size_t)(u % (uint64_t)S)], true, w->stage[i % kWPieces], k,
+                        (int64_t)((u / (uint64_t)S) * piece), &done[i % kWPieces]);
+        } else if (map) pool.submit_copy(batch, map + o, w->stage[i % kWPieces], k, &done[i % kWPieces]);      // map: where `off` is mapped
         else pool.submit(batch, w->fd, true, w->stage[i % kWPieces], k, off + (int64_t)o, &done[i % kWPieces]);
     };
     auto copies = [&]() -> int {
@@ -505,7 +537,10 @@ int write_record(pss_writer *w, const WJob &job)
     const size_t n = job.n;
     const size_t sa_bytes = n < 2 ? 4 * n : n * 4;
     const int64_t at = w->pos;
-    const int64_t total = (int64_t)(2 * hl + n + sa_bytes);
+    const bool striped = w->stripes.S() != 0;
+    const int64_t total = (int64_t)(2 * hl + n + (striped ? 0 : sa_bytes));
+    const uint64_t unit_base = w->stripes.next_unit;
+    if (striped) w->stripes.next_unit += (sa_bytes + DeviceCtx::kIoPiece - 1) / DeviceCtx::kIoPiece;
     w->pos += total;                    // whatever happens below, no later record may land here
     errno = 0;
     // On tmpfs large records go into the file through a shared MAPPING of their range: the blocks are reserved first
@@ -516,7 +551,7 @@ int write_record(pss_writer *w, const WJob &job)
     uint8_t *map = nullptr, *map_base = nullptr;
     size_t map_len = 0;
 #ifdef __linux__
-    if ((size_t)total >= w->mmap_min && !w->no_mmap && w->map_fd >= 0 && fallocate(w->fd, 0, (off_t)at, (off_t)total) == 0) {
+    if (!striped && (size_t)total >= w->mmap_min && !w->no_mmap && w->map_fd >= 0 && fallocate(w->fd, 0, (off_t)at, (off_t)total) == 0) {
         const int64_t pg = (int64_t)sysconf(_SC_PAGESIZE);
         const int64_t lo = at & ~(pg - 1);
         map_len = (size_t)(at + total - lo);
@@ -557,7 +592,10 @@ int write_record(pss_writer *w, const WJob &job)
     const int64_t sa_at = at + (int64_t)(2 * hl + n);
     if (rc == PSS_OK && n == 1) {              // libsais.c:6603-6607: n == 1 -> SA[0] = 0, no device involved
         const uint8_t zero[4] = {0, 0, 0, 0};
-        rc = pwrite_all(w->fd, zero, 4, sa_at);
+        if (striped) {
+            const int S = w->stripes.S();
+            rc = pwrite_all(w->stripes.fd[(size_t)(unit_base % (uint64_t)S)], zero, 4, (int64_t)((unit_base / (uint64_t)S) * DeviceCtx::kIoPiece));
+        } else rc = pwrite_all(w->fd, zero, 4, sa_at);
     }
     if (rc == PSS_OK && n >= 2) {
         // x86-64 / little-endian host: int32 in memory == i32le on disk (lib.rs:117-119)
@@ -566,7 +604,7 @@ int write_record(pss_writer *w, const WJob &job)
         WDevice &d = w->devs[job.seq % G];
         rc = guarded([&]() -> int {
             PSS_HIP(hipSetDevice(d.device));
-            return download_to_file(w, d, d.sa[(job.seq / G) & 1].p, n * 4, sa_at, &batch, map ? map + 2 * hl + n : nullptr);
+            return download_to_file(w, d, d.sa[(job.seq / G) & 1].p, n * 4, sa_at, &batch, map ? map + 2 * hl + n : nullptr, unit_base);
         });
     }
     const int err = IoPool::wait_all(&batch);      // the text pieces (and, after a failure above, whatever was in flight)
@@ -668,6 +706,7 @@ int w_report(pss_writer *w)              // with w->mu held: the sticky failure,
 // Blocks until every queued record is in the file; reports the first failure (every time).
 int io_wait(pss_writer *w)
 {
+    Phase ph("writer: wait for records");
     std::unique_lock<std::mutex> lk(w->mu);
     w->cv.wait(lk, [&] { return w->written == w->next_seq; });
     return w_report(w);
@@ -676,6 +715,7 @@ int io_wait(pss_writer *w)
 int pipe_start(pss_writer *w)
 {
     if (w->started) return PSS_OK;
+    Phase ph("writer: pipeline start");
     for (int i = 0; i < kWPieces; ++i)
         if (!w->stage[i] && !(w->stage[i] = stage_cache_take()))
             PSS_HIP(hipHostMalloc(&w->stage[i], DeviceCtx::kIoPiece, hipHostMallocPortable));
@@ -806,13 +846,18 @@ extern "C" int pss_writer_open_multi(const char *path, int64_t max_chunk_len, co
                                      int32_t format_version, pss_writer **out)
 {
     return guarded([&]() -> int {
-        if (!path || !out || (format_version != 1 && format_version != 2) || !devices || n_devices < 1 || n_devices > 64) {
-            set_error("pss_writer_open: bad arguments (format_version must be 1 or 2, 1..64 devices)");
+        const bool striped = (format_version & PSS_FORMAT_STRIPED) != 0;
+        format_version &= ~PSS_FORMAT_STRIPED;
+        if (!path || !out || (format_version != 1 && format_version != 2) || (striped && format_version != 2) || !devices ||
+            n_devices < 1 || n_devices > 64) {
+            set_error("pss_writer_open: bad arguments (format_version must be 1 or 2 -- 2 | PSS_FORMAT_STRIPED for the striped layout -- "
+                      "and 1..64 devices)");
             return PSS_EINVAL;
         }
         int32_t defaults[64];
         if (n_devices == 1 && devices[0] == -1) {      // the default list (PSS_DEVICES / a launcher's pin / every visible device)
             n_devices = pss_default_devices(defaults, 64);
+            if (n_devices < 1) return PSS_EINVAL;      // (a PSS_DEVICES that does not parse: the message is set)
             devices = defaults;
         }
         for (int i = 0; i < n_devices; ++i)
@@ -828,10 +873,27 @@ extern "C" int pss_writer_open_multi(const char *path, int64_t max_chunk_len, co
         const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);   // File::create truncates, lib.rs:55
         if (fd < 0) return io_error(path);
         int64_t pos = 0;
+        Stripes stripes;
+        if (striped) {
+            int S = 8;
+            if (const char *e = getenv("PSS_STRIPES")) S = std::min(64, std::max(1, atoi(e)));
+            for (int j = 0; j < S; ++j) {
+                const int sf = open(Stripes::name(path, j).c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+                if (sf < 0) {
+                    const int rc = io_error(Stripes::name(path, j).c_str());
+                    stripes.close_all();
+                    close(fd);
+                    return rc;
+                }
+                stripes.fd.push_back(sf);
+            }
+        }
         if (format_version == 2) {
             uint8_t hdr[kHeaderV2] = {};
             memcpy(hdr, kMagicV2, 8);
+            if (striped) put_u32le(hdr + 8, kStripedFlag | ((uint32_t)stripes.S() << 8) | ((uint32_t)kStripeUnitLog << 16));
             if (pwrite(fd, hdr, kHeaderV2, 0) != (ssize_t)kHeaderV2) {
+                stripes.close_all();
                 const int rc = io_error(path);
                 close(fd);
                 return rc;
@@ -841,6 +903,7 @@ extern "C" int pss_writer_open_multi(const char *path, int64_t max_chunk_len, co
         pss_writer *w = new pss_writer();
         w->fd = fd;
         w->pos = pos;
+        w->stripes = stripes;
         // Which way large records go into the page cache is a property of the file system (tests/tools/pagecache_micro.c
         // on the GPU box, 16 threads, one file): tmpfs takes 18.6 GB/s through a shared mapping and 5.8 through pwrite;
         // overlayfs / ext4 take 11 - 14 GB/s through pwrite -- the inode's lock lets one thread copy at a time -- and
@@ -1074,6 +1137,7 @@ extern "C" int pss_writer_close(pss_writer *w)
         const auto tc1 = std::chrono::steady_clock::now();
         errno = 0;
         if (w->map_fd >= 0) (void)close(w->map_fd);
+        w->stripes.close_all();
         const int crc = close(w->fd);
         if (getenv("PSS_TIMING"))
             fprintf(stderr, "[pss] writer close: threads and device buffers %.1f ms, close(fd) %.1f ms\n",
@@ -1348,27 +1412,35 @@ void reader_free(pss_reader *r)
 }
 
 // Reads `bytes` from fp's current position into host memory with the I/O pool (pieces of 16 MiB, several threads).
-int read_file_parallel(FILE *fp, void *dst, size_t bytes)
+// (stripes: the bytes are units unit_base, unit_base + 1, .. of the striped layout's files instead of fp's next bytes)
+int read_file_parallel(FILE *fp, void *dst, size_t bytes, const Stripes *stripes = nullptr, uint64_t unit_base = 0)
 {
     const int fd = fileno(fp);
     const int64_t base = (int64_t)ftello(fp);
     const size_t piece = DeviceCtx::kIoPiece;
     IoPool::Batch batch;
-    for (size_t o = 0; o < bytes; o += piece)
-        IoPool::get().submit(&batch, fd, false, static_cast<uint8_t *>(dst) + o, std::min(piece, bytes - o), base + (int64_t)o);
+    for (size_t o = 0; o < bytes; o += piece) {
+        if (stripes) {
+            const uint64_t u = unit_base + o / piece;
+            const uint64_t S = (uint64_t)stripes->S();
+            IoPool::get().submit(&batch, stripes->fd[(size_t)(u % S)], false, static_cast<uint8_t *>(dst) + o, std::min(piece, bytes - o),
+                                 (int64_t)((u / S) * piece));
+        } else
+            IoPool::get().submit(&batch, fd, false, static_cast<uint8_t *>(dst) + o, std::min(piece, bytes - o), base + (int64_t)o);
+    }
     const int err = IoPool::wait_all(&batch);
     if (err) {
         set_error("failed to fill whole buffer (truncated index file)");   // UnexpectedEof
         return PSS_EFORMAT;
     }
-    if (fseeko(fp, (off_t)(base + (int64_t)bytes), SEEK_SET) != 0) return io_error("seek");
+    if (!stripes && fseeko(fp, (off_t)(base + (int64_t)bytes), SEEK_SET) != 0) return io_error("seek");
     return PSS_OK;
 }
 
 // Reads `bytes` from fp's current position into device memory: the threads of the I/O pool pread pieces into a ring of
 // pinned buffers (up to kIoPieces reads in flight), the copy stream uploads every piece as soon as it has arrived --
 // reading, uploading and the page-cache copies of several pieces overlap (round 3: one thread's fread, then the copy).
-int upload_from_file(pss_reader *r, FILE *fp, void *dst, size_t bytes)
+int upload_from_file(pss_reader *r, FILE *fp, void *dst, size_t bytes, const Stripes *stripes = nullptr, uint64_t unit_base = 0)
 {
     DeviceCtx *ctx = r->ctx;
     PSS_TRY(ctx->ensure_io_ring());
@@ -1389,7 +1461,12 @@ int upload_from_file(pss_reader *r, FILE *fp, void *dst, size_t bytes)
                 const int slot = (int)(next % S);
                 if (next >= (size_t)S) PSS_HIP(hipEventSynchronize(ctx->io_ev[slot]));   // the upload of piece next - S is through
                 const size_t o = next * piece;
-                pool.submit(&batch, fd, false, ctx->io_ring[slot], std::min(piece, bytes - o), base + (int64_t)o, &done[slot]);
+                if (stripes) {
+                    const uint64_t u = unit_base + next, SS = (uint64_t)stripes->S();
+                    pool.submit(&batch, stripes->fd[(size_t)(u % SS)], false, ctx->io_ring[slot], std::min(piece, bytes - o),
+                                (int64_t)((u / SS) * piece), &done[slot]);
+                } else
+                    pool.submit(&batch, fd, false, ctx->io_ring[slot], std::min(piece, bytes - o), base + (int64_t)o, &done[slot]);
                 ++next;
             }
             const int slot = (int)(i % S);
@@ -1413,7 +1490,7 @@ int upload_from_file(pss_reader *r, FILE *fp, void *dst, size_t bytes)
         return PSS_EFORMAT;
     }
     PSS_HIP(he);
-    if (fseeko(fp, (off_t)(base + (int64_t)bytes), SEEK_SET) != 0) return io_error("seek");
+    if (!stripes && fseeko(fp, (off_t)(base + (int64_t)bytes), SEEK_SET) != 0) return io_error("seek");
     return PSS_OK;
 }
 
@@ -1464,6 +1541,7 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
         if (device == -1) {             // the default list (PSS_DEVICES / a launcher's pin / every visible device)
             int32_t defaults[64];
             const int32_t k = pss_default_devices(defaults, 64);
+            if (k < 1) return PSS_EINVAL;               // (a PSS_DEVICES that does not parse: the message is set)
             if (k > 1 && shard_count == 1) return pss_reader_open_multi(path, defaults, k, out);
             device = defaults[0];       // (a shard is one process's share: one device)
         }
@@ -1492,15 +1570,38 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
         // format 2 announces itself (a reference file starts with the u32 length of its first chunk,
         // < 2^30, which these bytes are not): 64-bit lengths, otherwise the same records
         bool v2 = false;
+        Stripes stripes;                       // striped layout: the suffix arrays' files
+        struct CloseStripes {
+            Stripes &s;
+            ~CloseStripes() { s.close_all(); }
+        } close_stripes{stripes};
         if (flen >= kHeaderV2) {
             uint8_t fh[kHeaderV2];
             if (fread(fh, 1, kHeaderV2, fp) == kHeaderV2 && memcmp(fh, kMagicV2, 8) == 0) {
                 v2 = true;
                 bytes_read = kHeaderV2;
+                const uint32_t fl = (uint32_t)fh[8] | ((uint32_t)fh[9] << 8) | ((uint32_t)fh[10] << 16) | ((uint32_t)fh[11] << 24);
+                if (fl & kStripedFlag) {
+                    const int S = (int)((fl >> 8) & 0xffu), ul = (int)((fl >> 16) & 0xffu);
+                    if (S < 1 || S > 64 || ul != kStripeUnitLog || (fl & ~0x00ffff01u)) {
+                        set_error("striped index: unknown header flags %#x", fl);
+                        return PSS_EFORMAT;
+                    }
+                    for (int j = 0; j < S; ++j) {
+                        errno = 0;
+                        const int sf = open(Stripes::name(path, j).c_str(), O_RDONLY | O_CLOEXEC);
+                        if (sf < 0) return io_error(Stripes::name(path, j).c_str());
+                        stripes.fd.push_back(sf);
+                    }
+                } else if (fl) {
+                    set_error("index file: unknown header flags %#x", fl);
+                    return PSS_EFORMAT;
+                }
             } else {
                 fseeko(fp, 0, SEEK_SET);
             }
         }
+        const bool striped = stripes.S() != 0;
         const size_t hl = v2 ? 8 : 4;
         auto get_len = [&](uint64_t *out_len) -> bool {
             uint8_t hdr[8];
@@ -1545,18 +1646,21 @@ extern "C" int pss_reader_open(const char *path, int32_t device, int32_t shard_i
                 rc = PSS_EFORMAT;
                 break;
             }
-            const uint64_t sa_bytes_file = (uint64_t)dlen * 4;
+            const uint64_t sa_bytes_all = (uint64_t)dlen * 4;
+            const uint64_t sa_bytes_file = striped ? 0 : sa_bytes_all;        // (striped: the array is not in this file)
             if (bytes_read + 2 * hl + dlen + sa_bytes_file > flen) { set_error("%s", kTrunc); rc = PSS_EFORMAT; break; }
+            const uint64_t unit_base = stripes.next_unit;
+            if (striped) stripes.next_unit += (sa_bytes_all + DeviceCtx::kIoPiece - 1) / DeviceCtx::kIoPiece;
             if (mine && dlen) {
                 if (cm.sa_host) {      // host tier: the file is read straight into the pinned buffer
-                    rc = read_file_parallel(fp, cm.sa, (size_t)sa_bytes_file);
+                    rc = read_file_parallel(fp, cm.sa, (size_t)sa_bytes_all, striped ? &stripes : nullptr, unit_base);
                 } else {
-                    rc = upload_from_file(r, fp, cm.sa, (size_t)sa_bytes_file);
+                    rc = upload_from_file(r, fp, cm.sa, (size_t)sa_bytes_all, striped ? &stripes : nullptr, unit_base);
                 }
                 if (rc) break;
                 rc = reader_sample_chunk(r, cd);     // uploads are complete (copy stream synchronised)
                 if (rc) break;
-            } else if (fseeko(fp, (off_t)sa_bytes_file, SEEK_CUR) != 0) { rc = io_error(path); break; }
+            } else if (sa_bytes_file && fseeko(fp, (off_t)sa_bytes_file, SEEK_CUR) != 0) { rc = io_error(path); break; }
             bytes_read += 2 * hl + (uint64_t)dlen + sa_bytes_file;   // lib.rs:184
             ++index;
         }

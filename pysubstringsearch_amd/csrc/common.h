@@ -91,8 +91,8 @@ struct ResidentMailbox {
     } post;
     uint8_t query[256 + 64];         // queries of more than sizeof(Post::bytes) bytes
     // kernel -> host, ONE 8-byte system-scope store: the sequence number of the last query answered (low word) and the
-    // checksum of the query bytes the workgroups worked on (high word, xor over them) -- a torn read of the posted line
-    // shows there
+    // checksum of the query bytes the workgroups worked on (high word, their sum mod 2^32) -- a torn or stale read of
+    // the posted line shows there, also when every workgroup read the same wrong bytes
     volatile uint64_t done_seq_echo;
     volatile uint32_t exited;        //                 1: the kernel has left (lease over, or told to)
     volatile uint32_t closing;       //                 1: the kernel is about to leave and looks once more
@@ -100,7 +100,7 @@ struct ResidentMailbox {
 };
 static_assert(offsetof(ResidentMailbox, done_seq_echo) % 8 == 0, "one aligned 8-byte store");
 // Checksum of a posted query (FNV-1a over the zero-padded 8-byte words and the length): what the host expects in `echo`
-// from ONE workgroup; an even number of workgroups cancels to 0, an odd number leaves it.
+// from ONE workgroup; W workgroups add up to W times it (mod 2^32).
 static inline uint32_t resident_query_checksum(const uint8_t *q, uint32_t plen)
 {
     uint32_t h = 0x811C9DC5u ^ plen;
@@ -168,6 +168,12 @@ struct DeviceCtx {
     uint32_t ss_plan_radix = 0;
     bool ss_refused_note = false;        // (the running build started over because the plan's sample was refused)
     uint32_t ss_plan_skip = 0, ss_plan_backoff = 0;      // builds that go by before the plan is tried again after a refusal
+    // ... and whether its anchors were sorted beside the text round (sa_build.hip, SideAnchors): the depth that side line
+    // was started for, the size class and the bits per symbol.  The next chunk of that kind starts its side line at once --
+    // beside the initial sort as well -- instead of waiting for a sample of its ties to show copies.
+    uint64_t side_plan_heff = 0;
+    uint32_t side_plan_logn = 0;
+    int side_plan_b = 0;
     double restart_ms = 0.0;             // device time of the attempts the running build gave up (sa_build.hip, start_over)
     int restart_depth = 0;
     // Two pinned staging buffers + a copy stream: file <-> HBM transfers are

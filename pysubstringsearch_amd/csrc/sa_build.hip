@@ -1153,9 +1153,21 @@ __global__ __launch_bounds__(256) void mid_collect_kernel(const u8 *big, const u
     }
 }
 
+// The group leaves the per-window tallies of flagged members / flagged heads (one thread).
+__device__ __forceinline__ void mid_untally(u32 gs, u32 size, u32 *blk_big, u32 *blk_heads)
+{
+    atomicSub(&blk_heads[gs / GS_T], 1u);
+    for (u32 w = gs / GS_T; w * GS_T < gs + size; ++w) {
+        const u32 a = max(gs, w * (u32)GS_T), b = min(gs + size, (w + 1) * (u32)GS_T);
+        atomicSub(&blk_big[w], b - a);
+    }
+}
+
+// fail_list / fail_count: the groups with a crowded bin (many equal keys -- copies of a stretch of text), for the merge
+// sort below (round 5; they used to stay flagged and take the chained radix sorts, a dozen global passes).
 __global__ __launch_bounds__(MID_BLOCK) void mid_sort_kernel(const u64 *key, const u32 *idx, const MidGroup *list, const u32 *count,
                                                                int key_bits, u64 *okey, u32 *oidx, u8 *big, u32 *blk_big,
-                                                               u32 *blk_heads)
+                                                               u32 *blk_heads, MidGroup *fail_list, u32 *fail_count)
 {
     __shared__ u64 s_key[MID_CAP];
     __shared__ u16 s_perm[MID_CAP];                    // slot (bin order) -> member
@@ -1195,6 +1207,14 @@ __global__ __launch_bounds__(MID_BLOCK) void mid_sort_kernel(const u64 *key, con
         if ((tid & 63u) == 0 && diff) atomicOr(reinterpret_cast<unsigned long long *>(&s_diff), (unsigned long long)diff);
         __syncthreads();
         const u64 dall = s_diff;
+        if (dall == 0) {
+            // every member carries the same key (copies of one stretch of text, h symbols on): the group is in order as
+            // it stands -- the pass-through copy of the LDS sort is its output -- and only leaves the flagged set
+            for (u32 p = tid; p < size; p += MID_BLOCK) big[gs + p] = 0;
+            if (tid == 0) mid_untally(gs, size, blk_big, blk_heads);
+            __syncthreads();
+            continue;
+        }
         const int top = dall ? 64 - __builtin_clzll(dall) : 0;          // bits [0, top) vary
         const int shift = top > 12 ? top - 12 : 0;
 #pragma unroll
@@ -1272,15 +1292,125 @@ __global__ __launch_bounds__(MID_BLOCK) void mid_sort_kernel(const u64 *key, con
                     big[gs + q0] = 0;
                 }
             }
-            if (tid == 0) {
-                // the group leaves the per-window tallies of flagged members / flagged heads
-                atomicSub(&blk_heads[gs / GS_T], 1u);
-                for (u32 w = gs / GS_T; w * GS_T < gs + size; ++w) {
-                    const u32 a = max(gs, w * (u32)GS_T), b = min(gs + size, (w + 1) * (u32)GS_T);
-                    atomicSub(&blk_big[w], b - a);
+            if (tid == 0) mid_untally(gs, size, blk_big, blk_heads);
+        } else if (tid == 0 && fail_list) {
+            fail_list[atomicAdd(fail_count, 1u)] = list[gi];
+        }
+        __syncthreads();
+    }
+}
+
+// ---- middle tier, second chance: a merge sort in LDS for the groups the counting scheme gave up ----------------------
+// Copies make keys EQUAL: a group of 600 .. 4096 suffixes of which most share the next symbols crowds one bin of
+// mid_sort_kernel, and the chained radix sorts it then fell to cost a dozen global passes per member (real files, first
+// text round: 111 M of 364 M members went that way; a third of the anchors' own text rounds).  A comparison sort does not
+// care: elements (key : 64, position in the group : 12), eight per thread through a sorting network, then merge rounds
+// with a merge-path search per thread -- the scheme of group_msort32_kernel and ss_local_kernel -- in 40 KiB of LDS.
+constexpr int MM_IPT = MID_CAP / MID_BLOCK;      // 8
+static_assert(MM_IPT == 8, "the register network below sorts eight elements");
+__device__ __forceinline__ u32 mm_slot(u32 p) { return p + (p >> 3); }
+// (keys and positions in separate scalars throughout: an array of {u64, u32} structs went to scratch memory -- 448 bytes
+// per lane -- and the kernel took 19 ms where 1 was expected)
+#define MM_LT(ak, ap, bk, bp) ((ak) < (bk) || ((ak) == (bk) && (ap) < (bp)))
+#define MM_CSWAP(i, j)                                                   \
+    {                                                                     \
+        const bool sw = MM_LT(vk[j], vp[j], vk[i], vp[i]);                \
+        const u64 xk = sw ? vk[j] : vk[i], yk = sw ? vk[i] : vk[j];       \
+        const u32 xp = sw ? vp[j] : vp[i], yp = sw ? vp[i] : vp[j];       \
+        vk[i] = xk; vk[j] = yk; vp[i] = xp; vp[j] = yp;                   \
+    }
+
+__global__ __launch_bounds__(MID_BLOCK) void mid_msort_kernel(const u64 *key, const u32 *idx, const MidGroup *list, const u32 *count,
+                                                                u64 *okey, u32 *oidx, u8 *big, u32 *blk_big, u32 *blk_heads)
+{
+    __shared__ u64 s_k[MID_CAP + MID_CAP / 8];
+    __shared__ u16 s_p[MID_CAP + MID_CAP / 8];
+    const u32 tid = threadIdx.x;
+    const u32 total = *count;
+    const u32 i0 = tid * MM_IPT;
+    for (u32 gi = blockIdx.x; gi < total; gi += gridDim.x) {
+        const u32 gs = list[gi].start, size = list[gi].size;
+        u64 vk[MM_IPT];
+        u32 vp[MM_IPT];
+        // coalesced load through LDS: position r of the group by thread r mod 512
+        for (u32 r = tid; r < (u32)MID_CAP; r += MID_BLOCK) {
+            s_k[mm_slot(r)] = r < size ? key[gs + r] : ~0ull;
+            s_p[mm_slot(r)] = (u16)(r < size ? r : 0xffffu);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < MM_IPT; ++q) {
+            vk[q] = s_k[mm_slot(i0 + q)];
+            vp[q] = s_p[mm_slot(i0 + q)];
+        }
+        MM_CSWAP(0, 1) MM_CSWAP(2, 3) MM_CSWAP(4, 5) MM_CSWAP(6, 7)
+        MM_CSWAP(0, 2) MM_CSWAP(1, 3) MM_CSWAP(4, 6) MM_CSWAP(5, 7)
+        MM_CSWAP(1, 2) MM_CSWAP(5, 6)
+        MM_CSWAP(0, 4) MM_CSWAP(1, 5) MM_CSWAP(2, 6) MM_CSWAP(3, 7)
+        MM_CSWAP(2, 4) MM_CSWAP(3, 5)
+        MM_CSWAP(1, 2) MM_CSWAP(3, 4) MM_CSWAP(5, 6)
+#pragma unroll
+        for (int q = 0; q < MM_IPT; ++q) {
+            s_k[mm_slot(i0 + q)] = vk[q];
+            s_p[mm_slot(i0 + q)] = (u16)vp[q];
+        }
+        __syncthreads();
+        const bool live = i0 < size;                  // the padding stays at the end of every run
+        for (u32 L = MM_IPT; L < MID_CAP; L <<= 1) {
+            if (L >= size) break;                     // (uniform: one run holds every element already)
+            const u32 pair0 = i0 & ~(2 * L - 1);
+            const u32 d = i0 - pair0;
+            const u32 A = pair0, B = pair0 + L;
+            const bool work = live && B < size;       // no element in the second run: the first is the merge
+            if (work) {
+                u32 lo = d > L ? d - L : 0, hi = d < L ? d : L;
+                while (lo < hi) {
+                    const u32 mid = (lo + hi) >> 1;
+                    const u32 sa = mm_slot(A + mid), sb = mm_slot(B + d - 1 - mid);
+                    const u64 xk = s_k[sa], yk = s_k[sb];
+                    const u32 xp = s_p[sa], yp = s_p[sb];
+                    if (MM_LT(xk, xp, yk, yp)) lo = mid + 1; else hi = mid;
+                }
+                u32 ai = lo, bi = d - lo;
+                u64 ak = ~0ull, bk = ~0ull;
+                u32 ap = 0xffffu, bp = 0xffffu;
+                if (ai < L) { ak = s_k[mm_slot(A + ai)]; ap = s_p[mm_slot(A + ai)]; }
+                if (bi < L) { bk = s_k[mm_slot(B + bi)]; bp = s_p[mm_slot(B + bi)]; }
+#pragma unroll
+                for (int q = 0; q < MM_IPT; ++q) {
+                    const bool ta = !MM_LT(bk, bp, ak, ap);
+                    vk[q] = ta ? ak : bk;
+                    vp[q] = ta ? ap : bp;
+                    ai += ta ? 1u : 0u;
+                    bi += ta ? 0u : 1u;
+                    if (q + 1 < MM_IPT) {
+                        const u32 ni = ta ? ai : bi;
+                        const u32 at = mm_slot((ta ? A : B) + min(ni, L - 1));
+                        const u64 nk = ni < L ? s_k[at] : ~0ull;
+                        const u32 np = ni < L ? (u32)s_p[at] : 0xffffu;
+                        ak = ta ? nk : ak;
+                        ap = ta ? np : ap;
+                        bk = ta ? bk : nk;
+                        bp = ta ? bp : np;
+                    }
                 }
             }
+            __syncthreads();
+            if (work) {
+#pragma unroll
+                for (int q = 0; q < MM_IPT; ++q) {
+                    s_k[mm_slot(i0 + q)] = vk[q];
+                    s_p[mm_slot(i0 + q)] = (u16)vp[q];
+                }
+            }
+            __syncthreads();
         }
+        for (u32 r = tid; r < size; r += MID_BLOCK) {
+            okey[gs + r] = s_k[mm_slot(r)];
+            oidx[gs + r] = idx[gs + s_p[mm_slot(r)]];
+            big[gs + r] = 0;
+        }
+        if (tid == 0) mid_untally(gs, size, blk_big, blk_heads);
         __syncthreads();
     }
 }
@@ -1744,6 +1874,7 @@ struct Knobs {
                                 //                unset: n >= 2^24 and the MSD sort did not take the text
     bool no_msd_fuse = false;   // PSS_MSD_NO_FUSE  MSD sort flags ties in the suffix array; the rerank kernels read them
     bool no_mid_tier = false;   // PSS_NO_MID_TIER  groups above 512 members all take the chained radix sorts
+    bool no_mid_merge = false;  // PSS_NO_MID_MERGE  groups of 513 .. 4096 members with a crowded bin take the chained sorts (no LDS merge sort)
     int period = -1;            // PSS_PERIOD     0: never the closed form for texts that repeat one word (rle_build.h)
     int rle = -1;               // PSS_RLE        0: never the run-length path, 1: always, unset: when runs average >= 8 bytes
     int anchor = -1;            // PSS_ANCHOR     0: never the anchor round for ties that outlive the text rounds (rank rounds over the
@@ -1778,6 +1909,7 @@ struct Knobs {
         k.no_front = getenv("PSS_NO_PLAN_FRONT") != nullptr;
         k.no_msd_fuse = getenv("PSS_MSD_NO_FUSE") != nullptr;
         k.no_mid_tier = getenv("PSS_NO_MID_TIER") != nullptr;
+        k.no_mid_merge = getenv("PSS_NO_MID_MERGE") != nullptr;
         if (const char *e = getenv("PSS_RLE")) k.rle = atoi(e);
         if (const char *e = getenv("PSS_PERIOD")) k.period = atoi(e);
         if (const char *e = getenv("PSS_ANCHOR")) k.anchor = atoi(e);
@@ -1879,6 +2011,7 @@ struct RoundsIO {
     u64 stop_text_h = 0;
     u32 *grp2 = nullptr;        // second group-rank buffer (nullptr: slot S_GRP2 of the context)
     int level = 0;              // 0: the text (or the run-length path's reduced string); k: the names of level k - 1's anchors
+    struct SideAnchors *side = nullptr;      // the side line of the build these rounds belong to (it may be under way already)
 };
 
 static int anchor_rank_keys(DeviceCtx *ctx, const Knobs &knobs, const RoundsIO &outer, u64 h, const u32 *syms,
@@ -1910,6 +2043,61 @@ struct SideAnchors {
     }
     ~SideAnchors() { join(); }
 };
+
+// Starts the side line: anchors of the text `codes` for windows that fit depth h_eff, sorted in ctx's helper context.
+// after (optional): an event on the main stream that the helper's stream waits for first (the codes are being written).
+// No room for the buffers is not an error: the anchors then wait their turn on the main line as before.
+static int side_start(DeviceCtx *ctx, const Knobs &knobs, SideAnchors &side, u32 n, const u8 *codes, int b, int plus_one, u64 h_eff,
+                      hipEvent_t after)
+{
+    if (side.started) return PSS_OK;
+    DeviceCtx *hc = nullptr;
+    const size_t sort_ws = radix_sort_workspace_bytes();
+    int rs = get_helper_ctx(ctx, &hc);
+    if (rs == PSS_OK) rs = hc->slot[S_K0].reserve((size_t)n * 8);
+    if (rs == PSS_OK) rs = hc->slot[S_K1].reserve((size_t)n * 8);
+    if (rs == PSS_OK) rs = hc->slot[S_ISA].reserve((size_t)n * 4 + 64);
+    if (rs == PSS_OK) rs = hc->slot[S_WORK].reserve(sort_ws + 65536);
+    if (rs != PSS_OK) {
+        (void)hipGetLastError();
+        set_error("%s", "");
+        return PSS_OK;
+    }
+    if (after) PSS_HIP(hipStreamWaitEvent(hc->stream, after, 0));
+    u8 *hw = hc->slot[S_WORK].as<u8>();
+    u8 *hsmall = hw + sort_ws;
+    RoundsIO o2;
+    memset(&o2, 0, sizeof o2);
+    o2.n = n;
+    o2.K[0] = hc->slot[S_K0].as<u64>();
+    o2.K[1] = hc->slot[S_K1].as<u64>();
+    o2.codes = codes;
+    o2.b = b;
+    o2.plus_one = plus_one;
+    o2.work = hw;
+    o2.d_agg_head = reinterpret_cast<u32 *>(hsmall + 4096);
+    o2.d_agg_cnt = reinterpret_cast<u32 *>(hsmall + 8192);
+    o2.d_red = reinterpret_cast<u64 *>(hsmall + 12288);
+    o2.d_counters = reinterpret_cast<u32 *>(hsmall + 12288 + 64);
+    o2.h_small = static_cast<u32 *>(hc->pinned);
+    o2.level = 0;
+    side.h_eff = h_eff;
+    side.akey = hc->slot[S_ISA].as<u32>();
+    memset(&side.st, 0, sizeof side.st);
+    side.started = true;
+    const int dev = ctx->device;
+    SideAnchors *sp = &side;
+    side.th = std::thread([hc, knobs, o2, h_eff, sp, dev]() {
+        if (hipSetDevice(dev) != hipSuccess) {
+            sp->rc = PSS_EDEVICE;
+            sp->err = "hipSetDevice failed in the anchors' side line";
+            return;
+        }
+        sp->rc = anchor_rank_keys(hc, knobs, o2, h_eff, nullptr, nullptr, sp->akey, sp->st, &sp->ok);
+        if (sp->rc != PSS_OK) sp->err = last_error();
+    });
+    return PSS_OK;
+}
 
 static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortStats &ss, pss_sa_stats &st)
 {
@@ -1973,7 +2161,8 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
     const u32 grid_all = (u32)grid_stream;
     // Integer strings (rank rounds only): the ranks the first round leaves ARE the string, up to renaming -- kept for the
     // minimizers of an anchor level on top of this one (anchor_impl.h), should the rounds reach depth 32 with much left tied.
-    SideAnchors side;
+    SideAnchors own_side;
+    SideAnchors &side = io.side ? *io.side : own_side;
     u32 *X0 = nullptr;
     const u32 *Xsym = nullptr;   // the same snapshot for the periodic keys of the rank rounds (per_*_kernel), never given up
     bool last_per = false;       // the last rank round met periodic runs among its large groups, or chains that will be
@@ -2078,7 +2267,7 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
             *bail = false;
             const u32 nblk = (m + GS_T - 1) / GS_T;
             PSS_TRY(ctx->slot[S_SCR].reserve((size_t)m + (size_t)nblk * 24 + (SC_MAX_BLOCKS + 8) * 8 + 4096 +
-                                             ((size_t)m / 2 + 16) * sizeof(MidGroup) + 256));
+                                             ((size_t)m / 2 + 16) * sizeof(MidGroup) + ((size_t)m / 512 + 16) * sizeof(MidGroup) + 512));
             u8 *scr = ctx->slot[S_SCR].as<u8>();
             size_t o = 0;
             auto carve = [&](size_t bytes) { u8 *p = scr + o; o = round_up(o + bytes, 64); return p; };
@@ -2110,12 +2299,16 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
                 // groups of up to MID_CAP members: one workgroup each, in LDS (no host round trip: the list and its
                 // length stay on the device, the workgroups persist and walk over it)
                 MidGroup *d_mid = reinterpret_cast<MidGroup *>(carve(((size_t)m / 2 + 16) * sizeof(MidGroup)));
+                MidGroup *d_mid_fail = reinterpret_cast<MidGroup *>(carve(((size_t)m / 512 + 16) * sizeof(MidGroup)));   // (groups of > 512 members)
                 u32 *d_mid_count = reinterpret_cast<u32 *>(carve(64));
-                PSS_HIP(hipMemsetAsync(d_mid_count, 0, 4, s));
+                PSS_HIP(hipMemsetAsync(d_mid_count, 0, 8, s));
                 hipLaunchKernelGGL(mid_collect_kernel, dim3(grid), dim3(256), 0, s, d_big, G[gcur], m, d_mid, d_mid_count);
                 hipLaunchKernelGGL(mid_sort_kernel, dim3((u32)ctx->num_cus * 4), dim3(MID_BLOCK), 0, s, K[src], V[src], d_mid,
                                    (const u32 *)d_mid_count, use_text ? kt * b : rank_bits, K[src ^ 1], V[src ^ 1], d_big, d_blk_big,
-                                   d_blk_heads);
+                                   d_blk_heads, knobs.no_mid_merge ? (MidGroup *)nullptr : d_mid_fail, d_mid_count + 1);
+                if (!knobs.no_mid_merge)
+                    hipLaunchKernelGGL(mid_msort_kernel, dim3((u32)ctx->num_cus * 3), dim3(MID_BLOCK), 0, s, K[src], V[src], d_mid_fail,
+                                       (const u32 *)(d_mid_count + 1), K[src ^ 1], V[src ^ 1], d_big, d_blk_big, d_blk_heads);
             }
             PSS_TRY(device_excl_scan(ctx, InU32{d_blk_big}, nblk, d_partial, d_total, d_off_big));
             PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
@@ -2254,54 +2447,9 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
                 if (knobs.timing) fprintf(stderr, "[pss] probe: %u of %u sampled pairs share 48 more symbols%s\n", h_small[1], h_small[0], skip_text ? ": no text rounds" : (side_wanted ? ": anchors beside the text round" : ""));
             }
             if (knobs.side == 1 && side_on && anchors_on && !anchored && text_rounds == 0 && !skip_text) side_wanted = true;
-            if (side_wanted && !side.started && text_rounds < text_rounds_max) {
+            if (side_wanted && !side.started && text_rounds < text_rounds_max)
                 // the depth the coming text round will reach decides the window; the anchors' sort starts now, on the side
-                DeviceCtx *hc = nullptr;
-                const u64 h_eff = h + (u64)kt;
-                const size_t sort_ws = radix_sort_workspace_bytes();
-                int rs = get_helper_ctx(ctx, &hc);
-                if (rs == PSS_OK) rs = hc->slot[S_K0].reserve((size_t)n * 8);
-                if (rs == PSS_OK) rs = hc->slot[S_K1].reserve((size_t)n * 8);
-                if (rs == PSS_OK) rs = hc->slot[S_ISA].reserve((size_t)n * 4 + 64);
-                if (rs == PSS_OK) rs = hc->slot[S_WORK].reserve(sort_ws + 65536);
-                if (rs == PSS_OK) {
-                    u8 *hw = hc->slot[S_WORK].as<u8>();
-                    u8 *hsmall = hw + sort_ws;
-                    RoundsIO o2;
-                    memset(&o2, 0, sizeof o2);
-                    o2.n = n;
-                    o2.K[0] = hc->slot[S_K0].as<u64>();
-                    o2.K[1] = hc->slot[S_K1].as<u64>();
-                    o2.codes = codes;
-                    o2.b = b;
-                    o2.plus_one = plus_one;
-                    o2.work = hw;
-                    o2.d_agg_head = reinterpret_cast<u32 *>(hsmall + 4096);
-                    o2.d_agg_cnt = reinterpret_cast<u32 *>(hsmall + 8192);
-                    o2.d_red = reinterpret_cast<u64 *>(hsmall + 12288);
-                    o2.d_counters = reinterpret_cast<u32 *>(hsmall + 12288 + 64);
-                    o2.h_small = static_cast<u32 *>(hc->pinned);
-                    o2.level = 0;
-                    side.h_eff = h_eff;
-                    side.akey = hc->slot[S_ISA].as<u32>();
-                    memset(&side.st, 0, sizeof side.st);
-                    side.started = true;
-                    const int dev = ctx->device;
-                    SideAnchors *sp = &side;
-                    side.th = std::thread([hc, knobs, o2, h_eff, sp, dev]() {
-                        if (hipSetDevice(dev) != hipSuccess) {
-                            sp->rc = PSS_EDEVICE;
-                            sp->err = "hipSetDevice failed in the anchors' side line";
-                            return;
-                        }
-                        sp->rc = anchor_rank_keys(hc, knobs, o2, h_eff, nullptr, nullptr, sp->akey, sp->st, &sp->ok);
-                        if (sp->rc != PSS_OK) sp->err = last_error();
-                    });
-                } else {
-                    (void)hipGetLastError();      // no room for the side line's buffers: the anchors wait their turn as before
-                    set_error("%s", "");
-                }
-            }
+                PSS_TRY(side_start(ctx, knobs, side, n, codes, b, plus_one, h + (u64)kt, nullptr));
             if (anchored) {
                 // cannot happen: the anchor round leaves no ties.  Counted (tests assert zero) and resolved by rank rounds.
                 st.anchor_left += m;
@@ -2709,6 +2857,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     if (flags & 8u) {                // a cold build: nothing of earlier builds on this device is used
         ctx->plan_path = 0;
         ctx->ss_plan_skip = ctx->ss_plan_backoff = 0;
+        ctx->side_plan_heff = 0;
         flags &= ~8u;                // (a restart of THIS build keeps what it has learnt)
     }
     const Knobs knobs = Knobs::read();
@@ -2761,7 +2910,9 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         ctx->restart_ms = 0.0;
         ctx->ss_refused_note = false;
     }
+    SideAnchors side;
     auto start_over = [&](uint32_t new_flags) -> int {
+        side.join();                         // (the next attempt has a side line of its own, in the same helper context)
         PSS_HIP(hipEventRecord(timer.ev1, s));
         PSS_HIP(hipStreamSynchronize(s));
         float gone = 0.f;
@@ -2915,6 +3066,20 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
         PSS_HIP(hipMemsetAsync(d_bad, 0, 4, s));
     } else {
         hipLaunchKernelGGL(sa_recode_kernel, dim3(grid_stream), dim3(256), 0, s, T, n, (u32)n_pad, d_lut, codes);
+        // The previous chunk on this device sorted its anchors beside its text round (text with copies in it), and this
+        // chunk will reach the same depth the same way (same size class, same bits per symbol, the sample sort's key of
+        // as many symbols): its side line starts NOW, beside the initial sort as well.  Should the build take another
+        // road -- no ties worth an anchor round, a shallower depth -- the result is thrown away (anchor_side = 2).
+        if (plain && knobs.side != 0 && knobs.anchor != 0 && ctx->side_plan_heff != 0 && ctx->side_plan_logn == logn &&
+            ctx->side_plan_b == b && n >= (1u << 24) && (flags & 2u) == 0) {
+            int kt0 = 64 / b;
+            if (kt0 > 16) kt0 = 16;
+            const int kc0 = ss_key_chars(n, plus_one ? 257u : sigma + 1u);
+            if (kc0 > 0 && (u64)kc0 + (u64)kt0 == ctx->side_plan_heff) {
+                PSS_HIP(hipEventRecord(timer.ev_mid, s));         // (recorded again below, where the initial sort ends)
+                PSS_TRY(side_start(ctx, knobs, side, n, codes, b, plus_one, ctx->side_plan_heff, timer.ev_mid));
+            }
+        }
     }
 
     // ---- 1. initial sort on the first key_chars symbols ----
@@ -3151,7 +3316,15 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     io.work = work;
     io.d_agg_head = d_agg_head; io.d_agg_cnt = d_agg_cnt; io.d_red = d_red; io.d_counters = d_counters; io.h_small = h_small;
     io.profile = profile;
+    io.side = &side;
     PSS_TRY(refine_rounds(ctx, knobs, io, ss, st));
+    side.join();
+    if (side.started && st.anchor_side == 0) st.anchor_side = 2;      // started for nothing
+    if (plain && n >= (1u << 24)) {
+        ctx->side_plan_heff = st.anchor_side == 1 ? side.h_eff : 0;
+        ctx->side_plan_logn = logn;
+        ctx->side_plan_b = b;
+    }
     PSS_HIP(hipEventRecord(timer.ev1, s));
     PSS_HIP(hipStreamSynchronize(s));
     float ms = 0.f;

@@ -821,7 +821,7 @@ constexpr u32 SM_MAX_PLEN = 256;       // longest query the path takes (kept in 
 struct SmallHeader {   // device memory; all zero between launches (the last wave to finish resets it)
     u32 ent_cursor, byte_cursor, done;
     u32 leave;          // resident kernel: its first workgroup tells the others to leave
-    u32 echo;           // resident kernel: xor of the workgroups' query checksums (ResidentMailbox::echo)
+    u32 echo;           // resident kernel: SUM (mod 2^32) of the workgroups' query checksums (ResidentMailbox::echo)
 };
 struct SmallRecord {
     u32 ent_start, ent_count;
@@ -1410,7 +1410,7 @@ __global__ __launch_bounds__(SM_BLOCK) void search_resident_kernel(const ChunkDe
             stores_done();
         }
 #endif
-        if (tid == 0 && nc * spread != 1) __hip_atomic_fetch_xor(&hdr->echo, ck, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && nc * spread != 1) __hip_atomic_fetch_add(&hdr->echo, ck, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0 && (nc * spread == 1 || atomicAdd(&hdr->done, 1u) == nc * spread - 1)) {
             if (nc * spread != 1) {          // (a workgroup on its own never moves the cursors)
                 ck = __hip_atomic_load(&hdr->echo, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1688,8 +1688,10 @@ static int resident_query(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, con
         if (answered) {
             // Did every workgroup work on the bytes that were posted?  (The two sequence numbers at the ends of the line
             // guard a read that the fabric splits in halves; a finer split could leave a stale word in the middle.)
+            // The workgroups' checksums are ADDED up (round 5; they used to be xor-ed, and an even number of workgroups that
+            // all read the same stale line -- the likely failure, they poll one cache line -- cancelled to the expected 0).
             const u32 one = resident_query_checksum(q, plen);
-            const u32 want = (nc * spread) % 2 ? one : 0u;
+            const u32 want = (u32)((u64)(nc * spread) * one);
             if ((u32)(done_pair >> 32) != want) {
                 ++R.torn;
                 return PSS_OK;                   // not served: the launch path answers this query

@@ -421,7 +421,7 @@ def test_default_device_list(monkeypatch):
     first, else the pin of a launcher (PSS_DEVICE / LOCAL_RANK), else every visible device (the reference's search
     fans over every core without being asked: src/lib.rs:205-207)."""
     import pysubstringsearch_amd as P
-    for var in ('PSS_DEVICES', 'PSS_DEVICE', 'LOCAL_RANK'):
+    for var in ('PSS_DEVICES', 'PSS_DEVICE', 'LOCAL_RANK', 'SLURM_LOCALID', 'OMPI_COMM_WORLD_LOCAL_RANK', 'MV2_COMM_WORLD_LOCAL_RANK'):
         monkeypatch.delenv(var, raising=False)
     n = P.device_count()
     assert P.default_devices() == (list(range(n)) if n else [0])
@@ -433,10 +433,62 @@ def test_default_device_list(monkeypatch):
     assert P.default_devices() == [0, 0, 0]                         # the list wins; an ordinal may repeat
     monkeypatch.setenv('PSS_DEVICES', 'all')
     assert P.default_devices() == (list(range(n)) if n else [0])
-    monkeypatch.setenv('PSS_DEVICES', '0,x')                        # malformed: as if unset (every visible device)
-    assert P.default_devices() == (list(range(n)) if n else [0])
+    # a list that does not parse is an error (round 5: it used to count as unset, and under a launcher every rank would
+    # have opened its handles on all visible GPUs); so is an ordinal beyond the device count
+    for bad in ('0,x', '0,,1', ',', '-1', 'every'):
+        monkeypatch.setenv('PSS_DEVICES', bad)
+        with pytest.raises(ValueError, match='PSS_DEVICES'):
+            P.default_devices()
+        with pytest.raises(ValueError, match='PSS_DEVICES'):
+            P.Reader('/nonexistent/never-opened.idx')
+    # set to nothing counts as unset -- and the launcher's pin is honoured then (it sat in the else-branch before)
+    monkeypatch.setenv('PSS_DEVICES', '')
+    assert P.default_devices() == [1 % n if n else 1]
+    monkeypatch.delenv('PSS_DEVICE')
+    monkeypatch.delenv('LOCAL_RANK')
+    monkeypatch.setenv('SLURM_LOCALID', '2')
+    assert P.default_devices() == [2 % n if n else 2]
+    monkeypatch.delenv('SLURM_LOCALID')
+    monkeypatch.setenv('OMPI_COMM_WORLD_LOCAL_RANK', '5')
+    assert P.default_devices() == [5 % n if n else 5]
     arr = (ctypes.c_int32 * 2)()
     from pysubstringsearch_amd import _ffi
     monkeypatch.setenv('PSS_DEVICES', '0,0,0')
     assert _ffi.lib.pss_default_devices(arr, 2) == 2                # never more than the caller's capacity
     assert _ffi.lib.pss_default_devices(None, 4) == 0
+    monkeypatch.setenv('PSS_DEVICES', 'x')
+    assert _ffi.lib.pss_default_devices(arr, 2) == -1 and 'PSS_DEVICES' in _ffi.last_error()
+
+
+def test_file_ingest_reads_straight_into_the_chunk(pss, tmp_path, monkeypatch):
+    """pss_writer_add_file_lines (src/lib.rs:67-86): a file of plain '\\n' lines is read straight into the chunk being
+    filled, block after block -- the unterminated tail of one read stays in place and the next read continues it (round 4
+    carried it over in a side buffer, which sent every later block through the copying path).  Lines with a '\\r' go
+    line by line through a block buffer.  No device is needed while nothing is flushed."""
+    import numpy as np
+    rng = np.random.default_rng(1)
+    lines = [bytes(rng.integers(97, 123, int(rng.integers(0, 90)), dtype=np.uint8)) for _ in range(40000)]
+    plain = b'\n'.join(lines) + b'\nlast line without a newline'
+    src = tmp_path / 'plain.txt'
+    src.write_bytes(plain)
+    monkeypatch.setenv('PSS_INGEST_BLOCK', '65536')            # many direct reads instead of one of 32 MiB
+    monkeypatch.setenv('PSS_INGEST_MIN_ROOM', '4096')
+    w = pss.Writer(str(tmp_path / 'a.idx'), 64 << 20, device=0)
+    w.add_entries_from_file_lines(str(src))
+    st = w.io_stats
+    assert st['ingest_copied_bytes'] == 0, st
+    assert st['ingest_direct_bytes'] == len(plain) - len(b'last line without a newline'), st
+    try:
+        w.close()                                               # (the flush needs a GPU: the container of the CPU suite has none)
+    except (RuntimeError, OSError, ValueError):
+        pass
+    crlf = tmp_path / 'crlf.txt'
+    crlf.write_bytes(b'\r\n'.join(lines[:5000]) + b'\r\n')
+    w = pss.Writer(str(tmp_path / 'b.idx'), 64 << 20, device=0)
+    w.add_entries_from_file_lines(str(crlf))
+    st = w.io_stats
+    assert st['ingest_direct_bytes'] == 0 and st['ingest_copied_bytes'] == crlf.stat().st_size, st
+    try:
+        w.close()
+    except (RuntimeError, OSError, ValueError):
+        pass

@@ -242,11 +242,16 @@ def test_sa_properties_at_scale():
             assert text[a:a + 64] <= text[b:b + 64]
 
 
-@pytest.mark.parametrize('seed', range(5))
-def test_file_ingest_fuzz(tmp_path, oracle, seed):
-    """add_entries_from_file_lines (bulk fast path + per-line path) vs the oracle's
-    line-by-line restatement: byte-identical .idx for random files and chunk limits."""
+@pytest.mark.parametrize('seed', range(8))
+def test_file_ingest_fuzz(tmp_path, oracle, seed, monkeypatch):
+    """add_entries_from_file_lines (direct reads into the chunk with the unterminated tail kept in place, bulk fast path,
+    per-line path) vs the oracle's line-by-line restatement: byte-identical .idx for random files and chunk limits.
+    Seeds 5 .. 7 shrink the direct reads to a few dozen bytes (PSS_INGEST_BLOCK / _MIN_ROOM), so that path -- which
+    otherwise wants a megabyte of room -- runs against limits of a few hundred bytes, tails longer than a block included."""
     rng = random.Random(100 + seed)
+    if seed >= 5:
+        monkeypatch.setenv('PSS_INGEST_BLOCK', str(rng.choice([16, 50, 700])))
+        monkeypatch.setenv('PSS_INGEST_MIN_ROOM', str(rng.choice([1, 16, 100])))
     parts = []
     for _ in range(rng.randint(1, 3000)):
         ln = rng.choice([0, 1, 2, 5, 17, 40, 80, 300])
@@ -272,6 +277,104 @@ def test_file_ingest_fuzz(tmp_path, oracle, seed):
         ow.add_entry('z')
         ow.close()
         assert open(p, 'rb').read() == open(q, 'rb').read(), (seed, limit)
+
+
+@pytest.mark.parametrize('stripes', [None, '3'])
+def test_striped_container(tmp_path, oracle, monkeypatch, stripes):
+    """Format 2 with the suffix arrays striped over files of their own (Writer(..., format_version=2, striped=True);
+    include/pss.h, PSS_FORMAT_STRIPED): the index file holds header and texts, `<path>.sa<j>` the arrays -- every chunk's
+    array starts a new 16 MiB unit, unit u in file u mod S.  Same chunks, same arrays (byte for byte against the
+    reference container of the same entries), same search results; a missing or short stripe file is an error like the
+    reference's UnexpectedEof; one, two and several devices write the same files."""
+    if stripes:
+        monkeypatch.setenv('PSS_STRIPES', stripes)
+    S = int(stripes) if stripes else 8
+    rng = random.Random(21)
+    entries = [''.join(rng.choice('abcdefg \t') for _ in range(rng.randint(0, 50))) for _ in range(9000)] + ['', 'x']
+    p1, p2 = str(tmp_path / 'v1.idx'), str(tmp_path / 'striped.idx')
+    b1 = build(p1, entries, 20000)
+    for devices in (None, [0, 0, 0]):
+        w = pysubstringsearch.Writer(p2, 20000, format_version=2, striped=True, **({'devices': devices} if devices else {}))
+        for e in entries:
+            w.add_entry(e)
+        w.close()
+        b2 = open(p2, 'rb').read()
+        assert b2[:8] == b'PSSIDX\x02\x00' and int.from_bytes(b2[8:12], 'little') == (1 | (S << 8) | (24 << 16))
+        files = [open(f'{p2}.sa{j}', 'rb').read() for j in range(S)]
+        assert not os.path.exists(f'{p2}.sa{S}')
+        unit = 1 << 24
+        o1, o2, chunks, u = 0, 16, 0, 0
+        while o1 < len(b1):
+            n = int.from_bytes(b1[o1:o1 + 4], 'little')
+            assert int.from_bytes(b2[o2:o2 + 8], 'little') == n and b1[o1 + 4:o1 + 4 + n] == b2[o2 + 8:o2 + 8 + n]
+            assert int.from_bytes(b2[o2 + 8 + n:o2 + 16 + n], 'little') == 4 * n
+            sa1 = b1[o1 + 8 + n:o1 + 8 + 5 * n]
+            f, off = files[u % S], (u // S) * unit                 # (chunks this small take one unit each)
+            assert f[off:off + 4 * n] == sa1, chunks
+            o1, o2, chunks, u = o1 + 8 + 5 * n, o2 + 16 + n, chunks + 1, u + 1
+        assert o2 == len(b2) and chunks > 5
+    text = '\n'.join(entries) + '\n'
+    qs = [text[s:s + rng.randint(1, 6)] for s in (rng.randrange(len(text)) for _ in range(300))] + ['', 'zz', '\n']
+    o = oracle.OracleReader(p1)
+    oe, oc = o.search_multiple_bytes([q.encode() for q in qs])
+    for kw in ({}, {'devices': [0, 0]}, {'shard': (1, 3)}):
+        with pysubstringsearch.Reader(p2, **kw) as r:
+            if 'shard' in kw:
+                assert r.num_chunks == len(range(1, chunks, 3))
+                continue
+            assert r.num_chunks == chunks
+            ents, counts = r.search_batch_raw([q.encode() for q in qs])
+            assert counts == oc.tolist() and sorted(ents) == sorted(oe)
+    os.truncate(f'{p2}.sa1', max(0, os.path.getsize(f'{p2}.sa1') - 3))
+    with pytest.raises(OSError):
+        pysubstringsearch.Reader(p2)
+    os.remove(f'{p2}.sa0')
+    with pytest.raises(FileNotFoundError):
+        pysubstringsearch.Reader(p2)
+    with pytest.raises(ValueError):
+        pysubstringsearch.Writer(str(tmp_path / 'bad.idx'), striped=True)          # the reference container has no flag
+
+
+def test_records_through_a_shared_mapping(oracle, monkeypatch):
+    """On tmpfs large records go into the index file through a shared mapping of their range (write_record, capi.cpp).
+    Round 4 opened the file write-only, like File::create does (src/lib.rs:55) -- and mmap(PROT_READ | PROT_WRITE,
+    MAP_SHARED) on a write-only descriptor fails with EACCES: the route never ran.  The mapping now has a descriptor of
+    its own (O_RDWR); pss_writer_io_stats says which way the records went, and the bytes are the pwrite route's."""
+    import shutil
+    import tempfile
+    if not os.path.isdir('/dev/shm') or not os.access('/dev/shm', os.W_OK):
+        pytest.skip('no tmpfs at /dev/shm')
+    d = tempfile.mkdtemp(prefix='pss_mmap_', dir='/dev/shm')
+    try:
+        rng = random.Random(3)
+        entries = [''.join(rng.choice('abcdefgh ') for _ in range(rng.randint(0, 60))) for _ in range(30000)]
+        files = {}
+        for route, env in (('map', {'PSS_WRITER_MMAP_MIN': '4096'}), ('pwrite', {'PSS_WRITER_MMAP': '0'})):
+            for k in ('PSS_WRITER_MMAP_MIN', 'PSS_WRITER_MMAP'):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            p = os.path.join(d, route + '.idx')
+            w = pysubstringsearch.Writer(p, 100000)
+            for e in entries:
+                w.add_entry(e)
+            w.finalize()
+            st = w.io_stats
+            w.close()
+            files[route] = open(p, 'rb').read()
+            if route == 'map':
+                assert st['records_mapped'] >= 5 and st['records_pwritten'] <= 1, st      # (the last record may be below the threshold)
+            else:
+                assert st['records_mapped'] == 0 and st['records_pwritten'] >= 5, st
+        assert files['map'] == files['pwrite']
+        q = os.path.join(d, 'oracle.idx')
+        ow = oracle.OracleWriter(q, 100000)
+        for e in entries:
+            ow.add_entry(e)
+        ow.close()
+        assert files['map'] == open(q, 'rb').read()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def test_real_files_through_the_file_api(tmp_path, oracle):

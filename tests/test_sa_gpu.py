@@ -709,6 +709,54 @@ def test_anchor_round_forced(oracle, monkeypatch, omega, count_sort):
     assert took >= (10 if omega != "9" else 4)      # (a window of 9 chooses about n / 5 anchors: the limit at which the path declines)
 
 
+@pytest.mark.parametrize('omega', [None, '12'])
+def test_anchors_sorted_beside_the_text_round(oracle, monkeypatch, omega):
+    """PSS_ANCHOR_SIDE=1 (round 5, SideAnchors in sa_build.hip): the anchors are selected and sorted by a second host
+    thread on a second stream, in the helper context, while the main line runs the text round that precedes the anchor
+    round -- at any size here (by default: texts of >= 2^24 bytes whose sampled ties show copies).  Same suffix arrays;
+    the side line's keys are used when the text round reached the depth they were made for (anchor_side = 1) and thrown
+    away when it gave up half-way (2); a second build of the same text starts its side line beside the initial sort
+    (the plan the first one left) and must agree as well."""
+    import ctypes
+    import random
+
+    import torch
+
+    from pysubstringsearch_amd import _ffi
+    monkeypatch.setenv('PSS_ANCHOR', '1')
+    monkeypatch.setenv('PSS_ANCHOR_SIDE', '1')
+    if omega:
+        monkeypatch.setenv('PSS_ANCHOR_OMEGA', omega)
+    rng = random.Random(7)
+    nrng = np.random.default_rng(7)
+    used = thrown = 0
+    cases = _repeat_cases(rng, nrng)[:14] + [gen_corpus(6, 1 << 20), gen_corpus(7, 1 << 21), gen_corpus(7, 3 << 20, 1), gen_corpus(5, 1 << 21)]
+    for t in cases:
+        t = np.ascontiguousarray(t)
+        want = oracle.sa(t)
+        dT = torch.from_numpy(t).cuda()
+        dSA = torch.empty(t.size, dtype=torch.int32, device='cuda')
+        st = _ffi.SaStats()
+        for again in range(2):
+            dSA.zero_()
+            _ffi.check(_ffi.lib.pss_sa_build_device(dT.data_ptr(), dSA.data_ptr(), t.size, 0, 8 if again == 0 else 0, ctypes.byref(st)))
+            assert st.anchor_left == 0
+            assert (dSA.cpu().numpy() == want).all(), (t.size, again, st.anchor_side)
+            used += int(st.anchor_side == 1)
+            thrown += int(st.anchor_side == 2)
+    assert used >= 6, (used, thrown)
+    # the default: small texts and natural text never start a side line
+    monkeypatch.delenv('PSS_ANCHOR_SIDE')
+    monkeypatch.delenv('PSS_ANCHOR')
+    for kind, n in ((1, 1 << 22), (7, 1 << 21)):
+        t = gen_corpus(kind, n)
+        dT = torch.from_numpy(t).cuda()
+        dSA = torch.empty(n, dtype=torch.int32, device='cuda')
+        st = _ffi.SaStats()
+        _ffi.check(_ffi.lib.pss_sa_build_device(dT.data_ptr(), dSA.data_ptr(), n, 0, 8, ctypes.byref(st)))
+        assert st.anchor_side == 0 and (dSA.cpu().numpy() == oracle.sa(t)).all()
+
+
 def test_anchor_round_is_chosen_for_long_repeats_only(oracle):
     """Default switches: texts of >= 2^20 bytes whose ties outlive the text rounds take the anchor round; natural text
     and high-entropy lines do not."""

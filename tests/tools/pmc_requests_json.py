@@ -5,6 +5,8 @@ the counter is wired) and the share that went to DRAM -- the calibration FETCH_S
 
     python tests/tools/pmc_requests_json.py <dir> <out json> <builds>
 """
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
 import csv
 import glob
 import json
@@ -30,7 +32,7 @@ for name, cs in sorted(agg.items(), key=lambda kv: -kv[1].get('TCC_EA0_RDREQ_sum
                  'BUBBLE_per_RDREQ': round(cs.get('TCC_BUBBLE_sum', 0.0) / rd, 4),
                  'DRAM_share': round(cs.get('TCC_EA0_RDREQ_DRAM_sum', 0.0) / rd, 4),
                  'bytes_at_64B_per_request': int(rd / builds * 64)}
-json.dump({'source': 'tests/tools/pmc_requests.sh (rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum '
+json.dump({**__import__('tree_hash').stamp(), 'source': 'tests/tools/pmc_requests.sh (rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum '
                      'TCC_EA0_RDREQ_DRAM_sum, one run)', 'kernels': res}, open(out, 'w'), indent=1)
 for k, v in list(res.items())[:12]:
     print(k, v)

@@ -4,6 +4,8 @@ on 15 resident chunks), FETCH x 2 for the streaming kernels only (hit_lines / em
 
     python tests/tools/pmc_search_json.py <dir with FETCH_SIZE/ and WRITE_SIZE/> <out json> [ms_device of the batch]
 """
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
 import csv
 import glob
 import json
@@ -47,5 +49,6 @@ if ms:
     res['ms_device_of_the_batch'] = ms
     res['achieved_gbs_raw'] = round(total_raw / ms / 1e6, 1)
     res['achieved_gbs_fetch_x2'] = round(total_x2 / ms / 1e6, 1)
+res.update(__import__('tree_hash').stamp())
 json.dump(res, open(out, 'w'), indent=1)
 print(json.dumps({k: v['bytes_fetch_raw_plus_write'] for k, v in kernels.items()}), res.get('achieved_gbs_raw'))

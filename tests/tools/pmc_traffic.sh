@@ -3,6 +3,8 @@
 #   tests/tools/pmc_traffic.sh <out dir> [corpus=lines] [builds=1]
 out=$1; corpus=${2:-lines}; builds=${3:-1}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/g1 -o pmc -- python3 tests/tools/sa_perf.py $corpus 29 $builds > $out.g1.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/g2 -o pmc -- python3 tests/tools/sa_perf.py $corpus 29 $builds > $out.g2.log 2>&1
+tool="tests/tools/sa_perf.py $corpus 29 $builds"
+[ "$corpus" = real ] && tool="tests/tools/real_text.py 29 $builds nocheck"      # real files found on the machine (one chunk of them)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/g1 -o pmc -- python3 $tool > $out.g1.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/g2 -o pmc -- python3 $tool > $out.g2.log 2>&1
 python tests/tools/pmc_summary.py $out scatter

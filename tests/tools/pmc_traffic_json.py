@@ -6,8 +6,10 @@ bytes = FETCH_SIZE_KB * 1024 * 2 (gfx950 correction, /opt/skills/guides/MI355X_M
 
 With a corpus other than lines only <out dir>/pmc_build_traffic_<corpus>.json is written.
 """
-import csv, glob, json, sys
+import csv, glob, json, os, sys
 from collections import defaultdict
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import tree_hash
 root, builds, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 corpus = sys.argv[4] if len(sys.argv) > 4 else 'lines'
 agg = defaultdict(lambda: defaultdict(list))
@@ -32,7 +34,7 @@ ALGO = {   # algorithmic bytes per element of the kernels of the initial sort (D
 # 16 B per lane, makes one request per 128 B).  Every other kernel reads wide and coalesced: FETCH x 2 (guide, "HBM").
 GATHER = ('text_keys_kernel', 'rank_keys_kernel', 'subset_keys_kernel', 'gather_names_kernel', 'build_keys_kernel',
           'probe_repeats_kernel', 'sample_keys_kernel', 'ss_sample_kernel')
-n = 1 << 29
+n = int(os.environ.get('PSS_PMC_BYTES', 1 << 29))     # bytes of text per build (real files: what real_text.py collected)
 kernels, total = {}, 0.0
 for name, cs in agg.items():
     short = name.replace('void ', '').replace('pss::', '').split('(')[0]
@@ -49,13 +51,13 @@ for name, cs in agg.items():
         e['ratio'] = round(per / (ALGO[short] * n), 3)
     kernels[short] = e
 src = ('tests/tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) around default-config '
-       f'pss_sa_build_device calls on the {corpus} corpus, n = 2^29')
+       f'pss_sa_build_device calls on the {corpus} corpus, {n} bytes')
 corr = ('bytes = FETCH_SIZE_KB * 1024 * 2 (gfx950 counts 64 B per 128-B request of a wide coalesced read) + WRITE_SIZE_KB * 1024; '
         'x 1 instead of x 2 for the gather kernels (' + ', '.join(GATHER) + '): their requests are 64 bytes, see profiles/pmc_requests_words.json')
 big = {k: v for k, v in kernels.items() if v['bytes_per_launch'] * v['launches_per_build'] > 50e6}
 if corpus == 'lines':
-    json.dump({'source': src, 'correction': corr, 'kernels': big}, open(f'{out}/pmc_traffic.json', 'w'), indent=1)
-json.dump({'source': src, 'correction': corr, 'total_bytes': int(total), 'bytes_per_suffix': round(total / n, 1),
-           'by_kernel': {k: int(v['bytes_per_launch'] * v['launches_per_build']) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['bytes_per_launch'] * kv[1]['launches_per_build'])[:16]}},
+    json.dump(dict(tree_hash.stamp(), **{'source': src, 'correction': corr, 'kernels': big}), open(f'{out}/pmc_traffic.json', 'w'), indent=1)
+json.dump(dict(tree_hash.stamp(), **{'source': src, 'correction': corr, 'text_bytes': n, 'total_bytes': int(total), 'bytes_per_suffix': round(total / n, 1),
+           'by_kernel': {k: int(v['bytes_per_launch'] * v['launches_per_build']) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['bytes_per_launch'] * kv[1]['launches_per_build'])[:16]}}),
           open(f'{out}/pmc_build_traffic.json' if corpus == 'lines' else f'{out}/pmc_build_traffic_{corpus}.json', 'w'), indent=1)
 print(json.dumps({k: v.get('ratio') for k, v in big.items()}))

@@ -104,6 +104,8 @@ def main():
               f'rounds={d["rounds"]} text_rounds={d["text_rounds"]} periodic={d["periodic_rounds"]}/{d["periodic_members"]} '
               f'sum_active={d["sum_active"]} plan={d["plan_hint"]} restarts={d["ms_restarts"]:.1f} ms | sigma={d["sigma"]} key_chars={d["key_chars"]} '
               f'initial {d["ms_initial"]:.1f} ms, ss buckets {d["ss_buckets"]} max {d["ss_max_bucket"]} samples {d["ss_samples"]} nomem {d["ss_declined_nomem"]} big_elems {d["big_elems"]}', flush=True)
+    if len(sys.argv) > 3 and sys.argv[3] == 'nocheck':
+        return
     got = dSA.cpu().numpy()
     from oracle import oracle as O
     t0 = time.time()
