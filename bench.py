@@ -234,13 +234,16 @@ def cpu_baseline_corpus(texts, sas, queries, sample_queries: int, want_disk: boo
            'sample': f'the first {len(qs)} queries of the batch, one at a time, fanned out over the {nchunks} chunks on '
                      f'{threads} threads (oracle/pss_oracle.c orc_bench_search: rayon par_iter_mut of src/lib.rs:207 restated)'}
     r = O.OracleReader.from_arrays(texts, sas)
+    r.bench_search(qs[:max(len(qs) // 10, 1)], threads)   # (warm-up: the first pass over a 37 GiB corpus pays for cold pages and TLBs)
     b = r.bench_search(qs, threads)                       # per-chunk dedupe by a hash set, like lib.rs:262
-    out['value'] = round(len(qs) / b['seconds'], 1)
-    out['value_is'] = ('suffix arrays in RAM (kinder than the reference, which probes them on disk); per-chunk dedupe by a hash set '
-                       'like the reference\'s AHashSet (src/lib.rs:262)')
     bs = r.bench_search(qs, threads, dedupe='sort')       # the checker's sorted scratch list (rounds 1-4 timed this one)
     assert np.array_equal(bs['counts'], b['counts'])
-    out['sort_dedupe_queries_per_sec'] = round(len(qs) / bs['seconds'], 1)
+    hash_qps, sort_qps = len(qs) / b['seconds'], len(qs) / bs['seconds']
+    out['value'] = round(max(hash_qps, sort_qps), 1)      # the better of the two: nothing here shall understate the CPU
+    out['value_is'] = ('suffix arrays in RAM (kinder than the reference, which probes them on disk); the faster of two per-chunk '
+                       'dedupes: a hash set like the reference\'s AHashSet (src/lib.rs:262) and the sorted scratch list of the checker')
+    out['hash_dedupe_queries_per_sec'] = round(hash_qps, 1)
+    out['sort_dedupe_queries_per_sec'] = round(sort_qps, 1)
     out['entries_per_query'] = round(b['entries'] / max(len(qs), 1), 2)
     b1 = r.bench_search(qs[:max(len(qs) // 10, 1)], 1)
     out['one_thread_queries_per_sec'] = round(max(len(qs) // 10, 1) / b1['seconds'], 1)

@@ -31,7 +31,8 @@ def _last_json(out):
 
 def test_bench_single_gpu_contract():
     r = subprocess.run([sys.executable, 'bench.py', '--steps', '2', '--warmup', '1', '--logn', '22', '--queries', '500',
-                        '--cpu-sample-logn', '20', '--chunks', '5', '--corpus15-queries', '3000', '--cpu-sample-queries', '300'],
+                        '--cpu-sample-logn', '20', '--chunks', '5', '--corpus15-queries', '3000', '--cpu-sample-queries', '300',
+                        '--real-files-logn', '24'],
                        cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
@@ -57,6 +58,11 @@ def test_bench_single_gpu_contract():
     assert c['config']['chunks'] == 5 and c['packed_queries_per_sec'] > 0 and c['single_query_us']['median'] > 0
     assert c['cpu_baseline']['value'] > 0 and c['cpu_baseline']['disk_queries_per_sec'] > 0
     assert c['roofline']['frac'] is None and len(c['per_rank_build_ms']) == 1
+    # round 5: real files, cold and warm, checked against libsais in the run; the striped container beside the reference's
+    rf = d['real_files']
+    assert rf and 'error' not in rf and rf['verified'] is True and rf['build_ms'] > 0 and rf['build_ms_cold'] > 0 and 'note' not in rf
+    assert d['e2e']['verified'] is True and d['e2e']['striped_format_2']['verified'] is True
+    assert any(a['corpus'] == 'source' and a['verified'] for a in d['adversarial'])
     ll = c['single_query_us']['low_latency_mode']                     # the resident search kernel: same results, no launch per query
     assert ll['same_results'] is True and ll['median'] > 0 and ll['queries_served'] >= 1000 and ll['kernels_started'] >= 1
 

@@ -33,6 +33,20 @@ void kasai(const uint8_t *T, const int32_t *SA, int32_t n, int32_t *lcp, int32_t
         } else { lcp[0] = 0; h = 0; }
     }
 }
+/* members of groups above `big` members at depth d0 that are still ONE group at depth d1 (every member's next d1 - d0
+ * symbols equal: a text round finds nothing to sort in them) */
+int64_t unsplit(const int32_t *lcp, int32_t n, int32_t d0, int32_t d1, int32_t big)
+{
+    int64_t run = 1, total = 0;
+    int32_t minl = 0x7fffffff;
+    for (int32_t i = 1; i <= n; ++i) {
+        if (i < n && lcp[i] >= d0) { ++run; if (lcp[i] < minl) minl = lcp[i]; continue; }
+        if (run > big && minl >= d1) total += run;
+        run = 1;
+        minl = 0x7fffffff;
+    }
+    return total;
+}
 /* members of groups (maximal runs of the suffix array sharing >= depth symbols) above each size in `sizes` */
 void groups(const int32_t *lcp, int32_t n, int32_t depth, const int32_t *sizes, int ns, int64_t *members, int64_t *tied)
 {
@@ -58,6 +72,8 @@ def helper():
         subprocess.run(['gcc', '-O2', '-shared', '-fPIC', '-o', so, c], check=True)
     lib = ctypes.CDLL(so)
     lib.kasai.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    lib.unsplit.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+    lib.unsplit.restype = ctypes.c_int64
     lib.groups.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     return lib
 
@@ -103,6 +119,9 @@ def main():
     sizes = np.array([1, 512, 4096, 65536], dtype=np.int32)
     mem = np.zeros(4, dtype=np.int64)
     tied = ctypes.c_int64()
+    for big in (512, 4096):
+        u = h.unsplit(lcp.ctypes.data, n, 12, 20, big)
+        print(f'  groups above {big} members at depth 12 that are still one group at depth 20: {100.0 * u / n:.1f} % of the suffixes')
     for depth in (12, 20, 28):
         h.groups(lcp.ctypes.data, n, depth, sizes.ctypes.data, 4, mem.ctypes.data, ctypes.byref(tied))
         print(f'  depth {depth}: in groups of > 1 / 512 / 4096 / 65536 members: ' + ' / '.join(f'{100.0 * m / n:.1f} %' for m in mem))

@@ -1,12 +1,14 @@
 #!/bin/bash
 # Everything profiles/ holds for a round, in one call on the GPU box (about 25 minutes):
-#   tests/tools/round_evidence.sh r04        -> gpurun_out/ev/*  (summaries only; copy what is to be kept into profiles/)
-tag=${1:-r04}
+#   PSS_TREE_COMMIT=$(git rev-parse --short HEAD) tests/tools/round_evidence.sh r05   -> gpurun_out/ev/*  (summaries only; copy what
+#   is to be kept into profiles/).  The counter files are stamped with a hash of the engine's sources (tree_hash.py) and with
+#   PSS_TREE_COMMIT (the box has no .git); the script ends with check_evidence.py on what it wrote.
+tag=${1:-r05}
 root=$GRAFT_REPO_ROOT; [ -z "$root" ] && root=$(pwd)
 ev=$root/gpurun_out/ev; mkdir -p $ev
 cd $root
 # 1. the GPU suite
-timeout 1200 python -m pytest tests -q -m gpu > $ev/${tag}_pytest_gpu.log 2>&1
+timeout 1700 python -m pytest tests -q -m gpu --durations=20 > $ev/${tag}_pytest_gpu.log 2>&1
 tail -3 $ev/${tag}_pytest_gpu.log
 # 2. the driver's command
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $ev/${tag}_bench_default.json 2> $ev/bench_default.err
@@ -14,18 +16,27 @@ timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $ev/${tag}_bench_de
 cd /tmp && export TMPDIR=/tmp; cd $root
 PSS_BENCH_NO_SECONDARY=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ev/prof_bench -o t -- python3 bench.py --no-cpu-baseline --no-corpus15 --no-e2e > $ev/${tag}_bench_under_rocprof.json 2>/dev/null
 cp $ev/prof_bench/t_kernel_stats.csv $ev/${tag}_bench_kernel_stats.csv
-for spec in lines:12 words:5 dup_blocks:3 mixed:3; do
+for spec in lines:12 words:5 dup_blocks:3 mixed:3 source:3 real:3; do
   c=${spec%%:*}; k=${spec#*:}
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ev/prof_$c -o t -- python3 tests/tools/sa_perf.py $c 29 $k > $ev/prof_$c.log 2>&1
-  cp $ev/prof_$c/t_kernel_stats.csv $ev/${tag}_sa_build_${c}_kernel_stats.csv
-  python tests/tools/timeline.py $ev/prof_$c/t_kernel_trace.csv 400 > $ev/${tag}_timeline_$c.txt 2>&1
+  tool="tests/tools/sa_perf.py $c 29 $k"
+  [ $c = real ] && tool="tests/tools/real_text.py 29 $k nocheck"
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ev/prof_$c -o t -- python3 $tool > $ev/prof_$c.log 2>&1
+  ks=$(ls $ev/prof_$c/t_kernel_stats.csv $ev/prof_$c/*/t_kernel_stats.csv 2>/dev/null | head -1)
+  kt=$(ls $ev/prof_$c/t_kernel_trace.csv $ev/prof_$c/*/t_kernel_trace.csv 2>/dev/null | head -1)
+  cp $ks $ev/${tag}_sa_build_${c}_kernel_stats.csv
+  python tests/tools/timeline.py $kt 400 > $ev/${tag}_timeline_$c.txt 2>&1
+  grep "build\|rep " $ev/prof_$c.log | tail -2 | cut -c1-200 >> $ev/${tag}_timeline_$c.txt
 done
+timeout 600 python tests/tools/real_text.py 29 3 > $ev/${tag}_real_files.txt 2>&1
+timeout 600 python tests/tools/real_e2e.py 29 2000 > $ev/real_e2e.log 2>&1; tail -1 $ev/real_e2e.log > $ev/${tag}_real_files_e2e.json
 # 4. HBM traffic by PMC (separate FETCH_SIZE / WRITE_SIZE passes)
 mkdir -p $ev/json
-for spec in lines:3 words:2 dup_blocks:2 mixed:2; do
+real_bytes=$(grep -o "^[0-9]* bytes of real files" $ev/${tag}_real_files.txt | head -1 | cut -d' ' -f1)
+for spec in lines:3 words:2 dup_blocks:2 mixed:2 source:2 real:2; do
   c=${spec%%:*}; k=${spec#*:}
   timeout 900 tests/tools/pmc_traffic.sh $ev/pmc_$c $c $k > /dev/null 2>&1
-  python tests/tools/pmc_traffic_json.py $ev/pmc_$c $k $ev/json $c > $ev/pmc_$c.ratios.txt 2>&1
+  if [ $c = real ]; then PSS_PMC_BYTES=$real_bytes python tests/tools/pmc_traffic_json.py $ev/pmc_$c $k $ev/json $c > $ev/pmc_$c.ratios.txt 2>&1
+  else python tests/tools/pmc_traffic_json.py $ev/pmc_$c $k $ev/json $c > $ev/pmc_$c.ratios.txt 2>&1; fi
 done
 timeout 600 tests/tools/pmc_requests.sh $ev/pmcreq_words words 1 > /dev/null 2>&1
 python tests/tools/pmc_requests_json.py $ev/pmcreq_words $ev/json/pmc_requests_words.json 1 > $ev/pmc_requests_words.txt 2>&1
@@ -52,5 +63,15 @@ python tests/tools/latency_hits.py 29 15 resident > $ev/lat15r.txt 2>&1; tail -1
 # 7. fuzzing of the final code
 (echo "# tests/tools/fuzz.py 300; FUZZ_BIG=1 fuzz.py 300; fuzz_search.py 200; anchor_check.py 150"; timeout 500 python tests/tools/fuzz.py 300 7001 2>&1 | tail -1; FUZZ_BIG=1 timeout 500 python tests/tools/fuzz.py 300 7002 2>&1 | tail -1; timeout 700 python tests/tools/fuzz_search.py 200 7003 2>&1 | tail -1; timeout 300 python tests/tools/anchor_check.py 150 7004 2>&1 | tail -1) > $ev/${tag}_fuzz.txt 2>&1
 # keep the summaries only
-rm -rf $ev/prof_* $ev/pmc_lines $ev/pmc_words $ev/pmc_dup_blocks $ev/pmc_mixed $ev/pmcreq_words $ev/pmc_search
+rm -rf $ev/prof_* $ev/pmc_lines $ev/pmc_words $ev/pmc_dup_blocks $ev/pmc_mixed $ev/pmc_source $ev/pmc_real $ev/pmcreq_words $ev/pmc_search
+# the counter files describe these sources?
+mkdir -p $ev/chk/profiles; cp $ev/json/*.json $ev/chk/profiles/ 2>/dev/null
+python - <<P
+import glob, json, sys
+sys.path.insert(0, 'tests/tools')
+import tree_hash
+now = tree_hash.csrc_hash()
+bad = [f for f in glob.glob('$ev/json/pmc_*.json') if json.load(open(f)).get('csrc_sha256_16') != now]
+print('evidence stamped with', now, '- stale:', bad)
+P
 ls -la $ev $ev/json
