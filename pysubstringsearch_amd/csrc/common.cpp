@@ -3,7 +3,6 @@
 
 #include <algorithm>
 #include <cerrno>
-#include <cstdlib>
 #include <unistd.h>
 
 #include <mutex>
@@ -279,21 +278,9 @@ static DeviceCtx g_ctx[kMaxDevices];        // reader side
 static DeviceCtx g_bctx[kMaxDevices];       // builder side
 static std::mutex g_ctx_mu;
 
-static int init_ctx(DeviceCtx &c, int device, bool high_priority = false)
+static int init_ctx(DeviceCtx &c, int device)
 {
-    // (a helper context -- the builder's side line, sa_build.hip -- asks for the highest stream priority the device has:
-    // its launches are many and small, they sit on the critical path, and they should not queue behind the workgroups of
-    // the main line's big kernels; PSS_HELPER_PRIORITY=0 keeps the default)
-    int least = 0, greatest = 0;
-    const char *hp = getenv("PSS_HELPER_PRIORITY");
-    if (high_priority && !(hp && atoi(hp) == 0) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
-        if (hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, greatest) != hipSuccess) {
-            (void)hipGetLastError();
-            c.stream = nullptr;
-        }
-    }
-    (void)hipGetLastError();
-    if (!c.stream) PSS_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    PSS_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     hipDeviceProp_t prop;
     PSS_HIP(hipGetDeviceProperties(&prop, device));
     c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -331,7 +318,7 @@ int get_helper_ctx(DeviceCtx *parent, DeviceCtx **out)
 {
     if (!parent->helper) {
         DeviceCtx *h = new DeviceCtx();
-        const int rc = init_ctx(*h, parent->device, true);
+        const int rc = init_ctx(*h, parent->device);
         if (rc != PSS_OK) {
             delete h;
             return rc;
