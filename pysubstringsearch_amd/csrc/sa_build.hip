@@ -1467,6 +1467,299 @@ __global__ __launch_bounds__(256) void big_writeback_kernel(const u32 *order, co
     }
 }
 
+
+// ---- large groups (beyond the LDS tiers): a segmented MERGE sort in global memory (round 5) ---------------------------
+// Groups of more than 4096 members went through two chained global radix sorts -- by key (eight passes for a 64-bit
+// text key), then by dense group number -- with the elements addressed through their list positions: ten to eleven
+// scatter passes and three random reads per element on the way back (real files: 98 M such elements per build, 65 GB of
+// radix passes, 19 GB of write-back gathers; `source`: 107 + 63 + 25 GB).  But the groups are CONTIGUOUS in the compacted
+// list and need sorting only inside themselves.  So: every 4096-element tile of a group is sorted in LDS (the merge
+// sort of the middle tier, on (key, suffix) pairs), then runs of L = 4096, 8192, ... are merged pairwise INSIDE their
+// group -- one workgroup per 4096 outputs: two merge-path searches in global memory give its share of both runs, the
+// share is merged in LDS and written out in order.  ceil(log2(size / 4096)) sequential passes of 12 bytes in / 12 out
+// per element instead of eleven scatter passes; no group keys, no positions, nothing gathered: the (key, suffix) pairs
+// ARE the payload, and the write-back is a sequential read.  Total order (key, then suffix index): no two elements are
+// equal, every phase uses the same comparison.
+// MEASURED AND LEFT OFF (PSS_BIG_MERGE=1 switches it on; test_large_groups_take_the_segmented_merge_sort runs it): a wash on
+// real files (111.8 / 112.7 ms against 112.6 / 113.5), 3 % on `source`, 4 % SLOWER on `mixed`, whose groups of millions
+// need twelve passes where 32-bit rank keys cost the radix sorts seven.  The passes are sequential but not fast -- a tile
+// is loaded, merged and stored behind three barriers by a workgroup that spends the first microseconds of each on two
+// searches in global memory -- and the traffic they save was not what bounded the build.
+constexpr u32 BG_TILE = 4096;
+struct BigTile {
+    u32 gstart, gsize, t;      // tile t of the group whose members are [gstart, gstart + gsize) of the compacted list
+};
+
+__global__ __launch_bounds__(256) void bg_gstart_kernel(const u32 *bgid, u32 nbig, u32 ngroups, u32 *gstart)
+{
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nbig; i += gridDim.x * blockDim.x)
+        if (i == 0 || bgid[i] != bgid[i - 1]) gstart[bgid[i]] = i;
+    if (blockIdx.x == 0 && threadIdx.x == 0) gstart[ngroups] = nbig;
+}
+struct InTileCount {
+    const u32 *gstart;
+    __device__ u64 operator()(u64 g) const { return (u64)((gstart[g + 1] - gstart[g] + BG_TILE - 1) / BG_TILE); }
+};
+__global__ __launch_bounds__(256) void bg_tiles_kernel(const u32 *gstart, const u64 *toff, u32 ngroups, BigTile *tiles)
+{
+    // one wave per group: lane l writes tiles l, l + 64, ...
+    const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    const u32 nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (u32 g = wave; g < ngroups; g += nwaves) {
+        const u32 s0 = gstart[g], size = gstart[g + 1] - s0;
+        const u32 nt = (size + BG_TILE - 1) / BG_TILE;
+        const u64 off = toff[g];
+        for (u32 t = lane; t < nt; t += 64) tiles[off + t] = BigTile{s0, size, t};
+    }
+}
+__global__ __launch_bounds__(256) void bg_gather_kernel(const u32 *bt, const u32 *idx, u32 nbig, u32 *out)
+{
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nbig; i += gridDim.x * blockDim.x) out[i] = idx[bt[i]];
+}
+
+#define BG_LT(ak, ai, bk, bi) ((ak) < (bk) || ((ak) == (bk) && (ai) < (bi)))
+#define BG_CSWAP(i, j)                                                   \
+    {                                                                     \
+        const bool sw = BG_LT(vk[j], vi[j], vk[i], vi[i]);                \
+        const u64 xk = sw ? vk[j] : vk[i], yk = sw ? vk[i] : vk[j];       \
+        const u32 xi = sw ? vi[j] : vi[i], yi = sw ? vi[i] : vi[j];       \
+        vk[i] = xk; vk[j] = yk; vi[i] = xi; vi[j] = yi;                   \
+    }
+constexpr int BG_BLOCK = 512, BG_IPT = BG_TILE / BG_BLOCK;
+static_assert(BG_IPT == 8, "eight elements per thread");
+__device__ __forceinline__ u32 bg_slot(u32 p) { return p + (p >> 3); }
+
+// Two sorted runs in LDS -- A = [0, na), B = [na, na + nb) of the slot space -- merged: thread t gets outputs 8 t .. 8 t + 7.
+__device__ __forceinline__ void bg_merge_lds(const u64 *s_k, const u32 *s_i, u32 na, u32 nb, u32 tid, u64 (&vk)[BG_IPT], u32 (&vi)[BG_IPT])
+{
+    const u32 d = tid * BG_IPT;
+    u32 lo = d > nb ? d - nb : 0, hi = d < na ? d : na;
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        const u32 sa = bg_slot(mid), sb = bg_slot(na + d - 1 - mid);
+        if (BG_LT(s_k[sa], s_i[sa], s_k[sb], s_i[sb])) lo = mid + 1; else hi = mid;
+    }
+    u32 ai = lo, bi = d - lo;
+    u64 ak = ~0ull, bk = ~0ull;
+    u32 ax = 0xffffffffu, bx = 0xffffffffu;
+    if (ai < na) { ak = s_k[bg_slot(ai)]; ax = s_i[bg_slot(ai)]; }
+    if (bi < nb) { bk = s_k[bg_slot(na + bi)]; bx = s_i[bg_slot(na + bi)]; }
+#pragma unroll
+    for (int q = 0; q < BG_IPT; ++q) {
+        const bool ta = !BG_LT(bk, bx, ak, ax);
+        vk[q] = ta ? ak : bk;
+        vi[q] = ta ? ax : bx;
+        ai += ta ? 1u : 0u;
+        bi += ta ? 0u : 1u;
+        if (q + 1 < BG_IPT) {
+            const u32 ni = ta ? ai : bi, lim = ta ? na : nb;
+            const u32 at = bg_slot((ta ? 0u : na) + min(ni, lim ? lim - 1 : 0u));
+            const u64 nk = ni < lim ? s_k[at] : ~0ull;
+            const u32 nx = ni < lim ? s_i[at] : 0xffffffffu;
+            ak = ta ? nk : ak;
+            ax = ta ? nx : ax;
+            bk = ta ? bk : nk;
+            bx = ta ? bx : nx;
+        }
+    }
+}
+
+// Every tile sorted by (key, suffix) in LDS: in -> out at the same positions.
+__global__ __launch_bounds__(BG_BLOCK) void bg_tile_sort_kernel(const u64 *ik, const u32 *ii, const BigTile *tiles, u32 bound, u64 *ok, u32 *oi)
+{
+    __shared__ u64 s_k[BG_TILE + BG_TILE / 8];
+    __shared__ u32 s_i[BG_TILE + BG_TILE / 8];
+    const u32 tid = threadIdx.x;
+    const u32 i0 = tid * BG_IPT;
+    for (u32 ti = blockIdx.x; ti < bound; ti += gridDim.x) {
+        const BigTile T = tiles[ti];
+        if (T.gsize == 0) continue;
+        const u32 start = T.gstart + T.t * BG_TILE;
+        const u32 size = min(BG_TILE, T.gsize - T.t * BG_TILE);
+        for (u32 r = tid; r < BG_TILE; r += BG_BLOCK) {
+            s_k[bg_slot(r)] = r < size ? ik[start + r] : ~0ull;
+            s_i[bg_slot(r)] = r < size ? ii[start + r] : 0xffffffffu;
+        }
+        __syncthreads();
+        u64 vk[BG_IPT];
+        u32 vi[BG_IPT];
+#pragma unroll
+        for (int q = 0; q < BG_IPT; ++q) {
+            vk[q] = s_k[bg_slot(i0 + q)];
+            vi[q] = s_i[bg_slot(i0 + q)];
+        }
+        BG_CSWAP(0, 1) BG_CSWAP(2, 3) BG_CSWAP(4, 5) BG_CSWAP(6, 7)
+        BG_CSWAP(0, 2) BG_CSWAP(1, 3) BG_CSWAP(4, 6) BG_CSWAP(5, 7)
+        BG_CSWAP(1, 2) BG_CSWAP(5, 6)
+        BG_CSWAP(0, 4) BG_CSWAP(1, 5) BG_CSWAP(2, 6) BG_CSWAP(3, 7)
+        BG_CSWAP(2, 4) BG_CSWAP(3, 5)
+        BG_CSWAP(1, 2) BG_CSWAP(3, 4) BG_CSWAP(5, 6)
+#pragma unroll
+        for (int q = 0; q < BG_IPT; ++q) {
+            s_k[bg_slot(i0 + q)] = vk[q];
+            s_i[bg_slot(i0 + q)] = vi[q];
+        }
+        __syncthreads();
+        const bool live = i0 < size;
+        for (u32 L = BG_IPT; L < BG_TILE; L <<= 1) {
+            if (L >= size) break;
+            const u32 pair0 = i0 & ~(2 * L - 1);
+            const u32 d = i0 - pair0;
+            const u32 A = pair0, B = pair0 + L;
+            const bool work = live && B < size;
+            if (work) {
+                u32 lo = d > L ? d - L : 0, hi = d < L ? d : L;
+                while (lo < hi) {
+                    const u32 mid = (lo + hi) >> 1;
+                    const u32 sa = bg_slot(A + mid), sb = bg_slot(B + d - 1 - mid);
+                    if (BG_LT(s_k[sa], s_i[sa], s_k[sb], s_i[sb])) lo = mid + 1; else hi = mid;
+                }
+                u32 ai = lo, bi = d - lo;
+                u64 ak = ~0ull, bk = ~0ull;
+                u32 ax = 0xffffffffu, bx = 0xffffffffu;
+                if (ai < L) { ak = s_k[bg_slot(A + ai)]; ax = s_i[bg_slot(A + ai)]; }
+                if (bi < L) { bk = s_k[bg_slot(B + bi)]; bx = s_i[bg_slot(B + bi)]; }
+#pragma unroll
+                for (int q = 0; q < BG_IPT; ++q) {
+                    const bool ta = !BG_LT(bk, bx, ak, ax);
+                    vk[q] = ta ? ak : bk;
+                    vi[q] = ta ? ax : bx;
+                    ai += ta ? 1u : 0u;
+                    bi += ta ? 0u : 1u;
+                    if (q + 1 < BG_IPT) {
+                        const u32 ni = ta ? ai : bi;
+                        const u32 at = bg_slot((ta ? A : B) + min(ni, L - 1));
+                        const u64 nk = ni < L ? s_k[at] : ~0ull;
+                        const u32 nx = ni < L ? s_i[at] : 0xffffffffu;
+                        ak = ta ? nk : ak;
+                        ax = ta ? nx : ax;
+                        bk = ta ? bk : nk;
+                        bx = ta ? bx : nx;
+                    }
+                }
+            }
+            __syncthreads();
+            if (work) {
+#pragma unroll
+                for (int q = 0; q < BG_IPT; ++q) {
+                    s_k[bg_slot(i0 + q)] = vk[q];
+                    s_i[bg_slot(i0 + q)] = vi[q];
+                }
+            }
+            __syncthreads();
+        }
+        for (u32 r = tid; r < size; r += BG_BLOCK) {
+            ok[start + r] = s_k[bg_slot(r)];
+            oi[start + r] = s_i[bg_slot(r)];
+        }
+        __syncthreads();
+    }
+}
+
+// One merge pass: runs of L elements (sorted, inside their group, counted from the group's start) become runs of 2 L.
+// Tile t of a group of more than L members = outputs [4096 (t mod R), + 4096) of pair t / R, R = 2 L / 4096.  A pair
+// without a second run is copied (the group changes buffers as a whole).
+__global__ __launch_bounds__(BG_BLOCK) void bg_merge_kernel(const u64 *sk, const u32 *si, u64 *dk, u32 *di, const BigTile *tiles, u32 bound, u32 L)
+{
+    __shared__ u64 s_k[BG_TILE + BG_TILE / 8];
+    __shared__ u32 s_i[BG_TILE + BG_TILE / 8];
+    __shared__ u32 s_part[2];
+    const u32 tid = threadIdx.x;
+    const u32 R = 2 * (L / BG_TILE);
+    for (u32 ti = blockIdx.x; ti < bound; ti += gridDim.x) {
+        const BigTile T = tiles[ti];
+        if (T.gsize <= L) continue;                        // (unused descriptor, or a group that is sorted already)
+        const u32 gend = T.gstart + T.gsize;
+        const u32 base = T.gstart + (T.t / R) * 2 * L;
+        const u32 left = gend - base;                      // elements of this pair of runs
+        const u32 lenA = min(L, left), lenB = left > L ? min(L, left - L) : 0u;
+        const u32 diag0 = (T.t % R) * BG_TILE, diag1 = min(diag0 + BG_TILE, lenA + lenB);
+        if (lenB == 0) {
+            for (u32 r = diag0 + tid; r < diag1; r += BG_BLOCK) {
+                dk[base + r] = sk[base + r];
+                di[base + r] = si[base + r];
+            }
+            continue;
+        }
+        if (tid < 128) {
+            // the two merge-path searches, one wave each, SIXTY-FOUR probes at a time (the predicate "A[mid] < B[d - 1 - mid]"
+            // is true up to the split and false from it on: a ballot over evenly spaced probes narrows the range 64-fold --
+            // three or four rounds of dependent global reads where a binary search by one thread made two dozen)
+            const u32 lane = tid & 63u;
+            const u32 d = tid < 64 ? diag0 : diag1;
+            u32 lo = d > lenB ? d - lenB : 0, hi = d < lenA ? d : lenA;
+            while (lo < hi) {
+                const u32 span = hi - lo, step = (span + 63u) / 64u;
+                const u32 mid = lo + lane * step;
+                bool pred = false;
+                if (mid < hi) {
+                    const u32 a = base + mid, b = base + L + d - 1 - mid;
+                    pred = BG_LT(sk[a], si[a], sk[b], si[b]);
+                }
+                const u32 ncand = (span + step - 1) / step;                 // probes inside [lo, hi)
+                const u32 cnt = (u32)__popcll(__ballot(pred));              // leading probes that are true
+                const u32 nlo = cnt ? lo + (cnt - 1) * step + 1 : lo;
+                const u32 nhi = cnt < ncand ? lo + cnt * step : hi;
+                lo = nlo;
+                hi = nhi;
+            }
+            if (lane == 0) s_part[tid < 64 ? 0 : 1] = lo;
+        }
+        __syncthreads();
+        const u32 a0 = s_part[0], a1 = s_part[1];
+        const u32 b0 = diag0 - a0, b1 = diag1 - a1;
+        const u32 na = a1 - a0, nb = b1 - b0;              // na + nb = diag1 - diag0 <= 4096
+        for (u32 r = tid; r < na + nb; r += BG_BLOCK) {
+            const u32 src = r < na ? base + a0 + r : base + L + b0 + (r - na);
+            s_k[bg_slot(r)] = sk[src];
+            s_i[bg_slot(r)] = si[src];
+        }
+        __syncthreads();
+        u64 vk[BG_IPT];
+        u32 vi[BG_IPT];
+        const bool live = tid * BG_IPT < na + nb;
+        if (live) bg_merge_lds(s_k, s_i, na, nb, tid, vk, vi);
+        __syncthreads();
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < BG_IPT; ++q) {
+                s_k[bg_slot(tid * BG_IPT + q)] = vk[q];
+                s_i[bg_slot(tid * BG_IPT + q)] = vi[q];
+            }
+        }
+        __syncthreads();
+        for (u32 r = tid; r < na + nb; r += BG_BLOCK) {
+            dk[base + diag0 + r] = s_k[bg_slot(r)];
+            di[base + diag0 + r] = s_i[bg_slot(r)];
+        }
+        __syncthreads();
+    }
+}
+
+// The sorted groups back into the round's output arrays: compacted element i of a group lives in the buffer its
+// number of merge passes left it in, and goes to list position bt[i].
+__global__ __launch_bounds__(256) void bg_writeback_kernel(const u64 *k0, const u32 *i0, const u64 *k1, const u32 *i1, const BigTile *tiles,
+                                                             u32 bound, const u32 *bt, u64 *okey, u32 *oidx)
+{
+    for (u32 ti = blockIdx.x; ti < bound; ti += gridDim.x) {
+        const BigTile T = tiles[ti];
+        if (T.gsize == 0) continue;
+        u32 passes = 0;
+        for (u64 L = BG_TILE; L < (u64)T.gsize; L <<= 1) ++passes;
+        const bool in1 = (passes & 1u) == 0;               // the tile sort wrote buffer 1, every pass changes sides
+        const u64 *k = in1 ? k1 : k0;
+        const u32 *x = in1 ? i1 : i0;
+        const u32 start = T.gstart + T.t * BG_TILE, size = min(BG_TILE, T.gsize - T.t * BG_TILE);
+        for (u32 r = threadIdx.x; r < size; r += blockDim.x) {
+            const u32 dst = bt[start + r];
+            okey[dst] = k[start + r];
+            oidx[dst] = x[start + r];
+        }
+    }
+}
+#undef BG_LT
+#undef BG_CSWAP
+
 // ---- periodic runs inside a rank round (round 4) ----------------------------------------------------------------
 // Prefix doubling resolves a run of period p and length L in log2(L / h) rounds, every one of them over nearly all of
 // the run: at depth h the suffixes of one phase form one group, their keys ISA[i + h] are the (equal) ranks of another
@@ -1826,7 +2119,7 @@ static void rerank_geometry(u32 m, RerankArgs &a)
     a.num_ranges = (a.num_tiles + a.tiles_per_range - 1) / a.tiles_per_range;
 }
 
-enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK, S_GRP2 = 26, S_BIG = 27, S_SCR = 29, S_SSA = 30, S_SSB = 31, S_ANC = 32 /* .. 38: one per level */, S_X0 = 39 /* .. 45 */, S_SSPLAN = 48, S_PER = 49, S_ANCW = 55 };      // (10 .. 23, 28: search.hip; 24, 25: capi.cpp)
+enum Slot { S_CODES = 0, S_K0, S_K1, S_V0, S_V1, S_ISA, S_P0, S_P1, S_GRP, S_WORK, S_GRP2 = 26, S_BIG = 27, S_SCR = 29, S_SSA = 30, S_SSB = 31, S_ANC = 32 /* .. 38: one per level */, S_X0 = 39 /* .. 45 */, S_SSPLAN = 48, S_PER = 49, S_BGT = 54, S_ANCW = 55 };      // (10 .. 23, 28: search.hip; 24, 25: capi.cpp)
 
 // Initial key width.  Model the text as i.i.d. with per-symbol collision
 // probability c = sum p_i^2 (from the sampled counts): two suffixes agree on k
@@ -1874,6 +2167,10 @@ struct Knobs {
                                 //                unset: n >= 2^24 and the MSD sort did not take the text
     bool no_msd_fuse = false;   // PSS_MSD_NO_FUSE  MSD sort flags ties in the suffix array; the rerank kernels read them
     bool no_mid_tier = false;   // PSS_NO_MID_TIER  groups above 512 members all take the chained radix sorts
+    int big_merge = 0;          // PSS_BIG_MERGE  1: groups above 4096 members through the segmented merge sort (bg_*_kernel) instead of the
+                                //                chained radix sorts, 2: in text rounds only.  Measured at 2^29 and left OFF: real files
+                                //                111.8 / 112.7 vs 112.6 / 113.5 ms, `source` 166.6 vs 171.5, `mixed` 90.7 vs 87.2 (its
+                                //                groups of millions take twelve merge passes where the radix sorts take seven)
     bool no_mid_merge = false;  // PSS_NO_MID_MERGE  groups of 513 .. 4096 members with a crowded bin take the chained sorts (no LDS merge sort)
     int period = -1;            // PSS_PERIOD     0: never the closed form for texts that repeat one word (rle_build.h)
     int rle = -1;               // PSS_RLE        0: never the run-length path, 1: always, unset: when runs average >= 8 bytes
@@ -1910,6 +2207,8 @@ struct Knobs {
         k.no_msd_fuse = getenv("PSS_MSD_NO_FUSE") != nullptr;
         k.no_mid_tier = getenv("PSS_NO_MID_TIER") != nullptr;
         k.no_mid_merge = getenv("PSS_NO_MID_MERGE") != nullptr;
+        if (const char *e = getenv("PSS_BIG_MERGE")) k.big_merge = atoi(e);
+        if (getenv("PSS_NO_BIG_MERGE")) k.big_merge = 0;
         if (const char *e = getenv("PSS_RLE")) k.rle = atoi(e);
         if (const char *e = getenv("PSS_PERIOD")) k.period = atoi(e);
         if (const char *e = getenv("PSS_ANCHOR")) k.anchor = atoi(e);
@@ -2401,6 +2700,35 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
                     (void)hipGetLastError();
                     set_error("%s", "");
                 }
+            }
+            if ((knobs.big_merge == 1 || (knobs.big_merge == 2 && use_text && big_key_bits > 32)) && nbig < 0x7fffffffu) {
+                // segmented merge sort of the large groups (bg_*_kernel): tiles in LDS, then merge passes inside every group
+                const u32 bound = nbig / BG_TILE + nbig_groups + 2;
+                const size_t g4 = round_up(((size_t)nbig_groups + 2) * 4, 64), g8 = round_up(((size_t)nbig_groups + 2) * 8, 64);
+                PSS_TRY(ctx->slot[S_BGT].reserve(g4 + g8 + round_up((size_t)bound * sizeof(BigTile), 64) + 256));
+                u8 *tb = ctx->slot[S_BGT].as<u8>();
+                u32 *d_gstart = reinterpret_cast<u32 *>(tb);
+                u64 *d_toff = reinterpret_cast<u64 *>(tb + g4);
+                BigTile *d_tiles = reinterpret_cast<BigTile *>(tb + g4 + g8);
+                const u32 eg = std::min<u32>((nbig + 255) / 256, (u32)ctx->num_cus * 16);
+                hipLaunchKernelGGL(bg_gstart_kernel, dim3(eg), dim3(256), 0, s, d_bgid, nbig, nbig_groups, d_gstart);
+                PSS_TRY(device_excl_scan(ctx, InTileCount{d_gstart}, nbig_groups, d_partial, d_total, d_toff));
+                PSS_HIP(hipMemsetAsync(d_tiles, 0, (size_t)bound * sizeof(BigTile), s));
+                hipLaunchKernelGGL(bg_tiles_kernel, dim3(std::min<u32>((nbig_groups + 3) / 4, (u32)ctx->num_cus * 8)), dim3(256), 0, s, d_gstart,
+                                   d_toff, nbig_groups, d_tiles);
+                hipLaunchKernelGGL(bg_gather_kernel, dim3(eg), dim3(256), 0, s, d_bt, V[src], nbig, BV[0]);
+                const u32 wg = std::min<u32>(bound, (u32)ctx->num_cus * 2);
+                hipLaunchKernelGGL(bg_tile_sort_kernel, dim3(wg), dim3(BG_BLOCK), 0, s, BK[0], BV[0], d_tiles, bound, BK[1], BV[1]);
+                int from = 1;
+                for (u64 L = BG_TILE; L < (u64)nbig; L <<= 1) {
+                    hipLaunchKernelGGL(bg_merge_kernel, dim3(wg), dim3(BG_BLOCK), 0, s, BK[from], BV[from], BK[from ^ 1], BV[from ^ 1], d_tiles,
+                                       bound, (u32)L);
+                    from ^= 1;
+                }
+                hipLaunchKernelGGL(bg_writeback_kernel, dim3(std::min<u32>(bound, (u32)ctx->num_cus * 8)), dim3(256), 0, s, BK[0], BV[0], BK[1], BV[1],
+                                   d_tiles, bound, d_bt, K[src ^ 1], V[src ^ 1]);
+                st.big_elems += nbig;
+                return PSS_OK;
             }
             hipLaunchKernelGGL(iota_kernel, dim3((nbig + 255) / 256), dim3(256), 0, s, BV[0], nbig);
             SortStats s1, s2;

@@ -757,6 +757,44 @@ def test_anchors_sorted_beside_the_text_round(oracle, monkeypatch, omega):
         assert st.anchor_side == 0 and (dSA.cpu().numpy() == oracle.sa(t)).all()
 
 
+@pytest.mark.parametrize('merge', ['1', '2', None])
+def test_large_groups_take_the_segmented_merge_sort(oracle, monkeypatch, merge):
+    """Groups of more than 4096 tied suffixes (bg_*_kernel in sa_build.hip, round 5): every 4096-element tile of a group
+    sorted in LDS, then merge passes inside the group -- for every round (PSS_BIG_MERGE=1), for text rounds only (2), and
+    the chained radix sorts that stayed the default (the merge sort measured no faster at full size) -- against libsais.  Texts made of a few lines written thousands of times in random order:
+    every position of a line is a group of as many suffixes as the line has copies -- 5 000 (one merge pass), 20 000
+    (three), 70 000 (five), with equal and unequal keys inside them, partial tiles at the ends, in text rounds (PSS_ANCHOR=0
+    keeps the rank rounds going instead of the anchor round) and rank rounds."""
+    import ctypes
+
+    import torch
+
+    from pysubstringsearch_amd import _ffi
+    if merge is not None:                      # (None: the default -- the chained radix sorts)
+        monkeypatch.setenv('PSS_BIG_MERGE', merge)
+    rng = np.random.default_rng(23)
+    cases = []
+    for nlines, copies, width in ((37, 5000, 24), (9, 20011, 17), (3, 70003, 11), (120, 4500, 9)):
+        pool = [bytes(rng.integers(97, 101, int(rng.integers(3, width)), dtype=np.uint8)) + b'\n' for _ in range(nlines)]
+        order = rng.integers(0, nlines, nlines * copies)
+        cases.append(np.frombuffer(b''.join(pool[int(i)] for i in order), dtype=np.uint8).copy())
+    big_seen = 0
+    for anchor in ('0', None):
+        if anchor is None:
+            monkeypatch.delenv('PSS_ANCHOR', raising=False)
+        else:
+            monkeypatch.setenv('PSS_ANCHOR', anchor)
+        for t in cases:
+            want = oracle.sa(t)
+            dT = torch.from_numpy(t).cuda()
+            dSA = torch.empty(t.size, dtype=torch.int32, device='cuda')
+            st = _ffi.SaStats()
+            _ffi.check(_ffi.lib.pss_sa_build_device(dT.data_ptr(), dSA.data_ptr(), t.size, 0, 8, ctypes.byref(st)))
+            assert (dSA.cpu().numpy() == want).all(), (t.size, anchor, merge)
+            big_seen += int(st.big_elems)
+    assert big_seen > 1000000
+
+
 def test_anchor_round_is_chosen_for_long_repeats_only(oracle):
     """Default switches: texts of >= 2^20 bytes whose ties outlive the text rounds take the anchor round; natural text
     and high-entropy lines do not."""
