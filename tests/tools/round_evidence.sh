@@ -32,7 +32,7 @@ timeout 600 python tests/tools/real_e2e.py 29 2000 > $ev/real_e2e.log 2>&1; tail
 # 4. HBM traffic by PMC (separate FETCH_SIZE / WRITE_SIZE passes)
 mkdir -p $ev/json
 real_bytes=$(grep -o "^[0-9]* bytes of real files" $ev/${tag}_real_files.txt | head -1 | cut -d' ' -f1)
-for spec in lines:3 words:2 dup_blocks:2 mixed:2 source:2 real:2; do
+for spec in lines:3 words:2 dup_blocks:2 mixed:2 source:2 real:2 runs:2; do
   c=${spec%%:*}; k=${spec#*:}
   timeout 900 tests/tools/pmc_traffic.sh $ev/pmc_$c $c $k > /dev/null 2>&1
   if [ $c = real ]; then PSS_PMC_BYTES=$real_bytes python tests/tools/pmc_traffic_json.py $ev/pmc_$c $k $ev/json $c > $ev/pmc_$c.ratios.txt 2>&1
@@ -63,7 +63,7 @@ python tests/tools/latency_hits.py 29 15 resident > $ev/lat15r.txt 2>&1; tail -1
 # 7. fuzzing of the final code
 (echo "# tests/tools/fuzz.py 300; FUZZ_BIG=1 fuzz.py 300; fuzz_search.py 200; anchor_check.py 150"; timeout 500 python tests/tools/fuzz.py 300 7001 2>&1 | tail -1; FUZZ_BIG=1 timeout 500 python tests/tools/fuzz.py 300 7002 2>&1 | tail -1; timeout 700 python tests/tools/fuzz_search.py 200 7003 2>&1 | tail -1; timeout 300 python tests/tools/anchor_check.py 150 7004 2>&1 | tail -1) > $ev/${tag}_fuzz.txt 2>&1
 # keep the summaries only
-rm -rf $ev/prof_* $ev/pmc_lines $ev/pmc_words $ev/pmc_dup_blocks $ev/pmc_mixed $ev/pmc_source $ev/pmc_real $ev/pmcreq_words $ev/pmc_search
+rm -rf $ev/prof_* $ev/pmc_runs $ev/pmc_lines $ev/pmc_words $ev/pmc_dup_blocks $ev/pmc_mixed $ev/pmc_source $ev/pmc_real $ev/pmcreq_words $ev/pmc_search
 # the counter files describe these sources?
 mkdir -p $ev/chk/profiles; cp $ev/json/*.json $ev/chk/profiles/ 2>/dev/null
 python - <<P
