@@ -2336,7 +2336,7 @@ struct SideAnchors {
     void join()
     {
         if (started && !joined) {
-            th.join();
+            if (th.joinable()) th.join();
             joined = true;
         }
     }
@@ -2383,18 +2383,28 @@ static int side_start(DeviceCtx *ctx, const Knobs &knobs, SideAnchors &side, u32
     side.h_eff = h_eff;
     side.akey = hc->slot[S_ISA].as<u32>();
     memset(&side.st, 0, sizeof side.st);
-    side.started = true;
     const int dev = ctx->device;
     SideAnchors *sp = &side;
+    // (std::thread's constructor may throw -- no more threads to be had: the flag goes up only once the thread exists, so
+    // that the destructor never joins what was never started; the exception travels to the C ABI's catch-all)
     side.th = std::thread([hc, knobs, o2, h_eff, sp, dev]() {
         if (hipSetDevice(dev) != hipSuccess) {
             sp->rc = PSS_EDEVICE;
             sp->err = "hipSetDevice failed in the anchors' side line";
             return;
         }
-        sp->rc = anchor_rank_keys(hc, knobs, o2, h_eff, nullptr, nullptr, sp->akey, sp->st, &sp->ok);
-        if (sp->rc != PSS_OK) sp->err = last_error();
+        try {
+            sp->rc = anchor_rank_keys(hc, knobs, o2, h_eff, nullptr, nullptr, sp->akey, sp->st, &sp->ok);
+            if (sp->rc != PSS_OK) sp->err = last_error();
+        } catch (const std::bad_alloc &) {
+            sp->rc = PSS_ENOMEM;
+            sp->err = "host allocation failed in the anchors' side line";
+        } catch (...) {                      // (nothing may leave a thread's function)
+            sp->rc = PSS_EDEVICE;
+            sp->err = "internal error in the anchors' side line";
+        }
     });
+    side.started = true;
     return PSS_OK;
 }
 

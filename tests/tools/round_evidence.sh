@@ -10,8 +10,7 @@ cd $root
 # 1. the GPU suite
 timeout 1700 python -m pytest tests -q -m gpu --durations=20 > $ev/${tag}_pytest_gpu.log 2>&1
 tail -3 $ev/${tag}_pytest_gpu.log
-# 2. the driver's command
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $ev/${tag}_bench_default.json 2> $ev/bench_default.err
+# 2. the driver's command: below, once the counter files of THIS tree exist (the line quotes them and says whether they are current)
 # 3. kernel stats under rocprofv3
 cd /tmp && export TMPDIR=/tmp; cd $root
 PSS_BENCH_NO_SECONDARY=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ev/prof_bench -o t -- python3 bench.py --no-cpu-baseline --no-corpus15 --no-e2e > $ev/${tag}_bench_under_rocprof.json 2>/dev/null
@@ -38,6 +37,8 @@ for spec in lines:3 words:2 dup_blocks:2 mixed:2 source:2 real:2 runs:2; do
   if [ $c = real ]; then PSS_PMC_BYTES=$real_bytes python tests/tools/pmc_traffic_json.py $ev/pmc_$c $k $ev/json $c > $ev/pmc_$c.ratios.txt 2>&1
   else python tests/tools/pmc_traffic_json.py $ev/pmc_$c $k $ev/json $c > $ev/pmc_$c.ratios.txt 2>&1; fi
 done
+cp $ev/json/*.json $root/profiles/ 2>/dev/null      # (on the box: the bench line below reads them)
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $ev/${tag}_bench_default.json 2> $ev/bench_default.err
 timeout 600 tests/tools/pmc_requests.sh $ev/pmcreq_words words 1 > /dev/null 2>&1
 python tests/tools/pmc_requests_json.py $ev/pmcreq_words $ev/json/pmc_requests_words.json 1 > $ev/pmc_requests_words.txt 2>&1
 timeout 1500 tests/tools/pmc_search.sh $ev/pmc_search > /dev/null 2>&1
