@@ -1,4 +1,4 @@
-"""Timeline of the last build in a rocprofv3 kernel trace: python tests/tools/timeline.py <kernel_trace.csv> [min_us=300]"""
+"""Timeline of the last build in a rocprofv3 kernel trace: python tests/tools/timeline.py <kernel_trace.csv> [min_us=300] [queues]"""
 import csv
 import sys
 
@@ -16,7 +16,8 @@ for r in last:
     a[0] += 1
     a[1] += d
     if d >= min_us:
-        print(f"{(int(r['Start_Timestamp']) - t0) / 1e6:8.2f} ms {d:9.1f} us  {name[:50]:50s} grid={r['Grid_Size_X']} lds={r['LDS_Block_Size']} vgpr={r['VGPR_Count']}")
+        q = f" q={r['Queue_Id']}" if len(sys.argv) > 3 and 'Queue_Id' in r else ''
+        print(f"{(int(r['Start_Timestamp']) - t0) / 1e6:8.2f} ms {d:9.1f} us  {name[:50]:50s} grid={r['Grid_Size_X']} lds={r['LDS_Block_Size']} vgpr={r['VGPR_Count']}{q}")
 print('--- per kernel (last build) ---')
 tot = 0.0
 for name, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
