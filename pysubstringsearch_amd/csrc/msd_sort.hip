@@ -1566,26 +1566,44 @@ int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t radix, uint32_
     if (maxb > SS_MAX_BUCKET) return PSS_OK;      // (a sampling accident, probability ~1e-10 per bucket: the caller falls back)
     hipLaunchKernelGGL(ss_scatter_kernel<false>, dim3((u32)max_ranges2), dim3(SS_SBLOCK), 0, s, a);
     PSS_TRY(mark());                                                                       // [3]
+    // bucket-by-bucket local sort (ss_local_seg_kernel): the plan counts every bucket's length rounded up to eight
+    const char *seg_env = getenv("PSS_SS_SEG");
+    const bool seg = !getenv("PSS_SS_WINDOW_PLAN") && !(seg_env && atoi(seg_env) == 0);
+    u32 *pstart = nullptr;
     if (getenv("PSS_SS_WINDOW_PLAN")) {
         const TilePlan tp{SS_WIN, SS_TILE_CAP};
         PSS_TRY(device_excl_scan(ctx, InTileHead{cstart, ne, n, tp}, ne, partial, d_total, ranks));
         hipLaunchKernelGGL(msd_tiles_kernel, dim3(1024), dim3(256), 0, s, cstart, ne, n, ranks, (const u64 *)d_total, tile_first, tp);
     } else {
         // greedy plan (ss_sort_impl.h); its tables live in the first element buffer, which the second scatter has read
-        const u32 nseg = (u32)(((u64)n + SS_PLAN_SEG - 1) / SS_PLAN_SEG);
+        const size_t row = (size_t)ne + 1;
+        u32 *pl = reinterpret_cast<u32 *>(buf.A[0]);
+        const u32 *starts = cstart;
+        u32 total = n, cap = SS_TILE_CAP;
+        if (seg) {
+            PSS_TRY(device_excl_scan(ctx, InPad8{cstart, ne, n}, ne, partial, d_total, ranks));
+            PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
+            pstart = pl;                                                  // the first row of the tables; read by the local sort too
+            hipLaunchKernelGGL(ss_pad_starts_kernel, dim3((u32)((row + 255) / 256)), dim3(256), 0, s, (const u64 *)ranks, (const u64 *)d_total, ne,
+                               pstart);
+            PSS_HIP(hipStreamSynchronize(s));
+            total = h_small[0];
+            starts = pstart;
+            cap = SS_TILE;
+            pl += round_up(row, 64);
+        }
+        const u32 nseg = (u32)(((u64)total + SS_PLAN_SEG - 1) / SS_PLAN_SEG);
         u32 levels = 0;
         while ((1u << levels) < nseg) ++levels;
-        u32 *pl = reinterpret_cast<u32 *>(buf.A[0]);
-        const size_t row = (size_t)ne + 1;
         u32 *nxt = pl, *heads = pl + row, *jumps = pl + 2 * row;          // jumps: `levels` rows (at least one)
         const u32 gb = (u32)((row + 255) / 256);
         PSS_HIP(hipMemsetAsync(heads, 0, row * 4, s));
-        hipLaunchKernelGGL(ss_plan_next_kernel, dim3(gb), dim3(256), 0, s, (const u32 *)cstart, ne, n, SS_TILE_CAP, nxt);
-        hipLaunchKernelGGL(ss_plan_exit_kernel, dim3(gb), dim3(256), 0, s, (const u32 *)cstart, ne, (const u32 *)nxt, jumps);
+        hipLaunchKernelGGL(ss_plan_next_kernel, dim3(gb), dim3(256), 0, s, starts, ne, total, cap, nxt);
+        hipLaunchKernelGGL(ss_plan_exit_kernel, dim3(gb), dim3(256), 0, s, starts, ne, (const u32 *)nxt, jumps);
         for (u32 i = 1; i < levels; ++i)
             hipLaunchKernelGGL(ss_plan_double_kernel, dim3(gb), dim3(256), 0, s, (const u32 *)(jumps + (size_t)(i - 1) * row), (u32)row,
                                jumps + (size_t)i * row);
-        hipLaunchKernelGGL(ss_plan_mark_kernel, dim3((nseg + 255) / 256), dim3(256), 0, s, (const u32 *)cstart, ne, (const u32 *)nxt,
+        hipLaunchKernelGGL(ss_plan_mark_kernel, dim3((nseg + 255) / 256), dim3(256), 0, s, starts, ne, (const u32 *)nxt,
                            (const u32 *)jumps, levels, nseg, heads);
         PSS_TRY(device_excl_scan(ctx, InU32{heads}, ne, partial, d_total, ranks));
         hipLaunchKernelGGL(ss_plan_tiles_kernel, dim3(1024), dim3(256), 0, s, (const u32 *)heads, ne, (const u64 *)ranks,
@@ -1606,8 +1624,12 @@ int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t radix, uint32_
     (void)blk_cnt;
     (void)dst_off;
     PSS_TRY(mark());                                                                       // [4]
-    hipLaunchKernelGGL(ss_local_kernel, dim3(nt), dim3(SL_BLOCK), 0, s, (const E16 *)buf.A[1], (const MsdTile *)tiles_all, nt, g.ib,
-                       sa_out);
+    if (pstart)
+        hipLaunchKernelGGL(ss_local_seg_kernel, dim3(nt), dim3(SL_BLOCK), 0, s, (const E16 *)buf.A[1], (const MsdTile *)tiles_all, nt, g.ib,
+                           (const u32 *)cstart, (const u32 *)pstart, (const u32 *)tile_first, ne, n, sa_out);
+    else
+        hipLaunchKernelGGL(ss_local_kernel, dim3(nt), dim3(SL_BLOCK), 0, s, (const E16 *)buf.A[1], (const MsdTile *)tiles_all, nt, g.ib,
+                           sa_out);
     PSS_TRY(mark());                                                                       // [5]
     hipLaunchKernelGGL(ss_boundary_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, (const MsdTile *)tiles_all, nt, tx, sa_out);
     PSS_HIP(hipGetLastError());

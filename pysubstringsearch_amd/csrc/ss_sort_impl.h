@@ -680,6 +680,166 @@ __global__ __launch_bounds__(SL_BLOCK, SL_BLOCK == 512 ? 4 : 8) void ss_local_ke
     }
 }
 
+// ---- local sort, bucket by bucket (round 5) --------------------------------------------------------------------------
+// A tile is a run of consecutive buckets, and the buckets are in order among themselves already (the splitters cut
+// [key | index] numbers: every element of a bucket is smaller than every element of the next).  Sorting the tile as one
+// array of 4096 slots takes nine merge rounds whatever it holds; sorting every bucket on its own takes log2 of the
+// bucket's length in runs of eight -- six rounds for the average bucket of 512 elements -- and the workgroup stops after
+// the rounds its LARGEST bucket needs.  For that every bucket starts at a multiple of eight slots (the plan counts
+// padded lengths: ss_pad_starts), so that a thread's eight outputs never straddle a border, the runs of a round are
+// counted from the bucket's start, and the last run of a bucket is simply shorter.  Threads of a bucket that is done
+// sit out the remaining rounds: the kernel is bound by VALU issue, and an idle wave leaves the issue slots to the others.
+constexpr u32 SL_MAXB = SS_TILE / 8;            // buckets of a tile at most (every bucket takes >= 8 slots)
+
+struct InPad8 {
+    const u32 *cstart;
+    u32 ne, n;
+    __device__ u64 operator()(u64 k) const
+    {
+        const u32 c = ((u32)k + 1 < ne ? cstart[k + 1] : n) - cstart[k];
+        return (u64)((c + 7u) & ~7u);
+    }
+};
+// padded starts as 32-bit numbers, ne + 1 of them (n + 7 ne < 2^32 is checked by the caller)
+__global__ __launch_bounds__(256) void ss_pad_starts_kernel(const u64 *scan, const u64 *total, u32 ne, u32 *pstart)
+{
+    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < ne) pstart[k] = (u32)scan[k];
+    else if (k == ne) pstart[ne] = (u32)*total;
+}
+
+__global__ __launch_bounds__(SL_BLOCK, SL_BLOCK == 512 ? 4 : 8) void ss_local_seg_kernel(const E16 *in, const MsdTile *tiles, u32 nt, int ib,
+                                                                                        const u32 *cstart, const u32 *pstart,
+                                                                                        const u32 *tile_first, u32 ne, u32 n, u32 *sa_out)
+{
+    static_assert(SL_IPT == 8, "runs of eight: the padding of the plan");
+    __shared__ E16 buf[SS_TILE];
+    __shared__ u32 s_bs[SL_MAXB + 1];            // element offset of bucket k inside the tile (k = nb: count)
+    __shared__ u32 s_ps[SL_MAXB + 1];            // slot offset of bucket k (k = nb: slots used)
+    __shared__ u32 s_pmax;
+    const u32 tid = threadIdx.x;
+    const u32 t = blockIdx.x;
+    if (t >= nt) return;
+    const u32 e0 = tiles[t].e0, count = tiles[t].count, nb = tiles[t].nb, k0 = tile_first[t];
+    if (tid == 0) s_pmax = 0;
+    const u32 p0 = pstart[k0];
+    for (u32 k = tid; k <= nb; k += SL_BLOCK) {
+        const u32 kk = k0 + k;
+        s_bs[k] = (kk < ne ? cstart[kk] : n) - e0;
+        s_ps[k] = pstart[kk] - p0;
+    }
+    __syncthreads();
+    for (u32 k = tid; k < nb; k += SL_BLOCK) atomicMax(&s_pmax, s_ps[k + 1] - s_ps[k]);
+    const u32 o0 = tid * SL_IPT;                 // this thread's slots, all of one bucket
+    const bool mine = o0 < s_ps[nb];
+    u32 b = 0;
+    if (mine) {
+        u32 lo = 0, hi = nb - 1;                 // the last bucket that starts at or before o0
+        while (lo < hi) {
+            const u32 mid = (lo + hi + 1) >> 1;
+            if (s_ps[mid] <= o0) lo = mid; else hi = mid - 1;
+        }
+        b = lo;
+    }
+    const u32 S = s_ps[b], P = s_ps[b + 1] - S;  // the bucket's slots: [S, S + P), P a multiple of eight
+    const u32 eb = s_bs[b], sz = s_bs[b + 1] - eb;
+    const u32 rel0 = o0 - S;                     // (meaningless unless mine)
+    E16 v[SL_IPT];
+#pragma unroll
+    for (int k = 0; k < SL_IPT; ++k) {
+        const u32 idx = rel0 + k;
+        const bool real = mine && idx < sz;
+        v[k] = e16_sel(real, e16_load(&in[e0 + (real ? eb + idx : 0u)]), e16_inf());
+    }
+    sl_cswap(v[0], v[1]); sl_cswap(v[2], v[3]); sl_cswap(v[4], v[5]); sl_cswap(v[6], v[7]);
+    sl_cswap(v[0], v[2]); sl_cswap(v[1], v[3]); sl_cswap(v[4], v[6]); sl_cswap(v[5], v[7]);
+    sl_cswap(v[1], v[2]); sl_cswap(v[5], v[6]);
+    sl_cswap(v[0], v[4]); sl_cswap(v[1], v[5]); sl_cswap(v[2], v[6]); sl_cswap(v[3], v[7]);
+    sl_cswap(v[2], v[4]); sl_cswap(v[3], v[5]);
+    sl_cswap(v[1], v[2]); sl_cswap(v[3], v[4]); sl_cswap(v[5], v[6]);
+#pragma unroll
+    for (int k = 0; k < SL_IPT; ++k) e16_store(&buf[sl_slot(o0 + k)], v[k]);
+    __syncthreads();
+    const u32 pmax = s_pmax;
+    for (u32 L = SL_IPT; L < pmax; L <<= 1) {
+        // runs of L slots counted from the bucket's start become runs of 2 L; the last run of a bucket may be short or missing
+        const u32 pr = rel0 & ~(2 * L - 1);      // first slot of my pair of runs, relative to the bucket
+        const u32 d = rel0 - pr;                 // outputs of the pair before mine
+        const u32 left = P - pr;                 // slots of the bucket from the pair's start on
+        const u32 lenA = min(L, left), lenB = left > L ? min(L, left - L) : 0u;
+        const bool live = mine && P > L && lenB != 0;      // (a run without a partner stays as it is: v[] holds it)
+        const u32 A = S + pr, B = A + L;
+        if (live) {
+            u32 lo = d > lenB ? d - lenB : 0, hi = min(d, lenA);
+            while (lo < hi) {
+                const u32 mid = (lo + hi) >> 1;
+                const E16 x = e16_load(&buf[sl_slot(A + mid)]), y = e16_load(&buf[sl_slot(B + d - 1 - mid)]);
+                if (e16_lt(x, y)) lo = mid + 1; else hi = mid;
+            }
+            u32 ai = lo, bi = d - lo;
+            E16 va = e16_sel(ai < lenA, e16_load(&buf[sl_slot(A + min(ai, lenA - 1))]), e16_inf());
+            E16 vb = e16_sel(bi < lenB, e16_load(&buf[sl_slot(B + min(bi, lenB - 1))]), e16_inf());
+#pragma unroll
+            for (int k = 0; k < SL_IPT; ++k) {
+                const bool ta = !e16_lt(vb, va);
+                v[k] = e16_sel(ta, va, vb);
+                ai += ta ? 1u : 0u;
+                bi += ta ? 0u : 1u;
+                if (k + 1 < SL_IPT) {
+                    const u32 ni = ta ? ai : bi, len = ta ? lenA : lenB;
+                    const E16 nx = e16_sel(ni < len, e16_load(&buf[sl_slot((ta ? A : B) + min(ni, len - 1))]), e16_inf());
+                    va = e16_sel(ta, nx, va);
+                    vb = e16_sel(ta, vb, nx);
+                }
+            }
+        }
+        __syncthreads();                         // every read of this round is done
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < SL_IPT; ++k) e16_store(&buf[sl_slot(o0 + k)], v[k]);
+        }
+        __syncthreads();
+    }
+    // v[] = my eight slots of the sorted bucket.  Suffix words (bit 31 = "same key as my predecessor") go through LDS so
+    // that the suffix array is written in order; the predecessor of a bucket's first element is the last real element
+    // of the bucket before it, the first element of the tile is looked at by ss_boundary_kernel.
+    const u32 imask = (u32)((1ull << ib) - 1ull);
+    u32 w[SL_IPT];
+    {
+        E16 prev = v[0];
+        bool have = false;
+        if (mine) {
+            if (rel0 != 0) {
+                prev = e16_load(&buf[sl_slot(o0 - 1)]);
+                have = true;
+            } else if (b != 0) {
+                prev = e16_load(&buf[sl_slot(s_ps[b - 1] + (eb - s_bs[b - 1]) - 1)]);
+                have = true;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < SL_IPT; ++k) {
+            const bool tie = have && e16_same_key(prev, v[k], ib);
+            w[k] = ((u32)v[k].lo & imask) | (tie ? 0x80000000u : 0u);
+            prev = v[k];
+            have = true;
+        }
+    }
+    __syncthreads();                             // the last reads of the elements are done: their LDS is the output stage now
+    u32 *s_out = reinterpret_cast<u32 *>(buf);
+    if (mine) {
+#pragma unroll
+        for (int k = 0; k < SL_IPT; ++k)
+            if (rel0 + k < sz) s_out[eb + rel0 + k] = w[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SL_IPT; ++k) {
+        const u32 p = k * SL_BLOCK + tid;
+        if (p < count) sa_out[e0 + p] = s_out[p];
+    }
+}
+
 // ---- greedy tile plan ----------------------------------------------------------------------------------------------
 // The merge sort costs per tile, so tiles should be as full as the buckets allow: tile = the longest run of consecutive
 // buckets that fits (SS_TILE_CAP).  That rule is a chain -- where a tile ends depends on where it began -- but every hop

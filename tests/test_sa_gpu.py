@@ -245,13 +245,20 @@ def test_msd_is_chosen_for_high_entropy_text_only(oracle):
 
 # ---- sample sort over 16-byte elements (ss_sort_impl.h) ----
 
-def test_sample_sort_forced_matches_libsais(oracle, monkeypatch):
+@pytest.mark.parametrize('local', ['buckets', 'tile', 'window'])
+def test_sample_sort_forced_matches_libsais(oracle, monkeypatch, local):
     """PSS_SS=1 sends every text of >= 2^16 bytes through the sample sort (splitters from a sorted sample, two partition
     passes over 16-byte [key | index] elements, merge sort of every tile in LDS, ties as flags + the tile-boundary pass):
     alphabets of 2 .. 256 symbols (keys of 11 .. 32 symbols), word-like repeats, long duplicated blocks (tie groups that
-    cross buckets and tiles), both bucket-count shapes (B1 = B2 and B1 = 2 B2), every tie-resolution mode afterwards."""
+    cross buckets and tiles), both bucket-count shapes (B1 = B2 and B1 = 2 B2), every tie-resolution mode afterwards.
+    The local sort in its three forms: bucket by bucket on a plan of padded lengths (round 5, the default), the whole
+    tile as one array (PSS_SS_SEG=0), and that on the window plan (PSS_SS_WINDOW_PLAN)."""
     monkeypatch.setenv('PSS_SS', '1')
     monkeypatch.setenv('PSS_MSD', '0')
+    if local == 'tile':
+        monkeypatch.setenv('PSS_SS_SEG', '0')
+    elif local == 'window':
+        monkeypatch.setenv('PSS_SS_WINDOW_PLAN', '1')
     rng = np.random.default_rng(3)
     took = 0
     for trial, n in enumerate((1 << 16, 70001, 100003, 300000, 1 << 20, (1 << 21) + 77, (1 << 22) + 5, 1 << 16, 200001, 1 << 19)):

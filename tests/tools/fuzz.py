@@ -84,7 +84,7 @@ def build(path, entries, limit, W):
 KNOBS = ('PSS_MODE', 'PSS_KEY_CHARS', 'PSS_KEY_DROP', 'PSS_TEXT_ROUNDS', 'PSS_NO_TIES_PASS', 'PSS_NO_SMALL_PATH', 'PSS_MSD',
          'PSS_MSD_NO_FUSE', 'PSS_MSD_SLOW_LOCAL', 'PSS_NO_PINNED_RESULTS', 'PSS_NO_MID_TIER', 'PSS_RLE', 'PSS_RLE_SORT', 'PSS_PERIOD', 'PSS_ANCHOR', 'PSS_ANCHOR_OMEGA',
          'PSS_COUNT_SORT', 'PSS_NO_PROBE', 'PSS_PERIODIC', 'PSS_PROBE_SKIP_PCT', 'PSS_ANCHOR_MIN_OMEGA', 'PSS_DEVICES', 'PSS_WRITER_MMAP', 'PSS_IO_THREADS',
-         'PSS_WRITER_MMAP_MIN', 'PSS_INGEST_BLOCK', 'PSS_INGEST_MIN_ROOM', 'PSS_ANCHOR_SIDE', 'PSS_BIG_MERGE', 'PSS_NO_MID_MERGE', 'PSS_RESULT_ORDER')
+         'PSS_WRITER_MMAP_MIN', 'PSS_INGEST_BLOCK', 'PSS_INGEST_MIN_ROOM', 'PSS_ANCHOR_SIDE', 'PSS_BIG_MERGE', 'PSS_NO_MID_MERGE', 'PSS_RESULT_ORDER', 'PSS_SS_SEG', 'PSS_SS')
 
 
 def random_knobs(rng):
@@ -147,6 +147,10 @@ def random_knobs(rng):
         os.environ['PSS_INGEST_MIN_ROOM'] = rng.choice(['1', '20'])
     if rng.random() < 0.3:
         os.environ['PSS_ANCHOR_SIDE'] = rng.choice(['0', '1', '1'])   # anchors sorted beside the text round (second stream / thread)
+    if rng.random() < 0.2:
+        os.environ['PSS_SS'] = '1'                               # the sample sort for every text of >= 2^16 bytes
+    if rng.random() < 0.2:
+        os.environ['PSS_SS_SEG'] = '0'                           # sample sort: every tile sorted as one array (the round-4 local sort)
     if rng.random() < 0.3:
         os.environ['PSS_BIG_MERGE'] = rng.choice(['1', '2'])     # groups above 4096 members through the segmented merge sort
     if rng.random() < 0.2:
