@@ -25,7 +25,7 @@ ALGO = {   # algorithmic bytes per element of the kernels of the initial sort (D
     'fs_scatter_kernel<0, 4>': 9, 'fs_scatter_kernel<4, 4>': 16, 'fs_scatter_kernel<4, 0>': 12,
     # sample sort over 16-byte elements (ss_sort_impl.h)
     'ss_digits1_kernel': 3, 'ss_scatter_kernel<true>': 19, 'ss_digits2_kernel': 18, 'ss_scatter_kernel<false>': 34,
-    'ss_local_kernel': 20,
+    'ss_local_kernel': 20, 'ss_local_seg_kernel': 20,
 }
 # Kernels whose reads are GATHERS (one 64-byte request per element: a random 4-byte rank, 32 bytes of text at a random
 # offset): for them FETCH_SIZE is what it says.  Calibrated in round 4 with the request counters themselves
