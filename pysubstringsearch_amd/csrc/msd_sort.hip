@@ -31,6 +31,27 @@
 // histogram.  The caller screens with the sorted key sample it already has; when the exact
 // check fails the caller falls back to the LSD path (G1 is lost, ~4 ms at n = 2^29).
 //
+// Round 6 -- the two digits in LSD ORDER, the second pass in ONE sweep (decoupled look-back).  The order above makes
+// the second pass wait for a histogram of its own: where bucket (b, d) starts inside G1 bucket b is only known once all
+// of b has been counted -- 8 n bytes read a second time (msd_hist_kernel<false>, 0.85 ms at n = 2^29).  Taken the other
+// way round the passes need the two 1024-bin histograms of the TEXT only, which one pass over its n bytes gives:
+//
+//   H   text          counts of the second digit d per range (the first pass's offsets) and of the first digit b
+//   P1  text -> A1    partition by d; the element keeps b: [ b | remaining key bits | suffix index ]
+//   P2  A1 -> A2      partition by b, tiles in order: a tile lies inside one d-region, so inside every b-bucket the tiles
+//                     arrive in d order and the joint buckets (b, d) come out contiguous whatever the order inside a tile
+//                     (still one returning LDS atomic per element).  Where (tile, b) goes = start of b + what the tiles
+//                     before it hold of b: every tile counts its own 16384 elements (it ranks them anyway), publishes
+//                     the 1024 counts and adds up what its predecessors published, back to the nearest tile that has
+//                     published its running total -- no second read, no table.  Tiles are handed out by an atomic ticket,
+//                     so every predecessor of a waiting tile is running.  The last tile of d-region d leaves the ends of
+//                     the buckets (b, d): the table of joint bucket starts falls out of the pass.
+//
+// The joint table only exists after P2, so P2 cannot tag an element with its bucket's number among the non-empty ones.
+// It tags with d mod 64 (a constant of the tile), the plan never lets a local-sort tile cross a multiple of 64 joint
+// buckets, and the local sort numbers a bucket by the non-empty ones below it in the tile's 64-bit map (a popcount).
+// Measured in isolation before it was built: tests/tools/lookback_micro.hip, profiles/r06_lookback_micro.txt.
+//
 // HBM-bound integer work: no MFMA anywhere by design.
 #include "msd_sort.h"
 
@@ -55,11 +76,19 @@ constexpr u32 MSD_MAX_BUCKET = 4088;                 // a bucket must fit a tile
                                                      // carry the fast kernel's scalars: MSD_TILE_CAP)
 constexpr int MSD_TAG_BITS = MSD_D + 1;              // an element entering the local sort carries the low 11 bits of its joint bucket number ...
 constexpr u32 MSD_TAG_SPAN = 1u << MSD_TAG_BITS;     // ... so a tile never crosses a multiple of 2048 buckets: inside it the tags only grow
+constexpr int MSD_RAW_TAG_BITS = 6;                  // LSD order: the tag is the joint bucket number mod 64 (= d mod 64) ...
+constexpr u32 MSD_RAW_TAG_SPAN = 1u << MSD_RAW_TAG_BITS;   // ... and a tile stays inside one aligned block of 64 joint buckets
 constexpr u32 MSD_G1_RANGES = 1024;
 constexpr u32 MSD_G2_RANGE = 16 * MSD_TILE;          // elements per G2 range (a piece of one G1 bucket)
 
 struct MsdRange {
     u32 seg, start, end;
+};
+
+// A tile of the look-back pass: a piece of one d-region (count 0: an empty region, which still owes its row of the
+// joint table), the region's digit, bit 31 = the region's last tile
+struct MsdTile2 {
+    u32 start, count, d_last;
 };
 
 struct MsdArgs {
@@ -81,6 +110,12 @@ struct MsdArgs {
     const u64 *dense;    // G2 scatter: [2^20] number of every joint bucket among the non-empty ones
     const u64 *in;
     u64 *out;
+    // LSD order (round 6): the first pass partitions by the SECOND digit, the second pass is the look-back kernel
+    int lsd;
+    u32 *T2;             // [1024][ranges] counts of the first digit per range (only their totals are used)
+    const u32 *Jb;       // [1025] starts of the first digit's buckets
+    const struct MsdTile2 *tiles2;
+    u32 *status;         // [tiles2][1024] look-back words
     // MsdFront: the first histogram pass recodes the raw text on its way through
     const u8 *raw;
     const u8 *lut;
@@ -130,6 +165,7 @@ template <bool FROM_TEXT>
 __global__ __launch_bounds__(MSD_BLOCK) void msd_hist_kernel(MsdArgs a)
 {
     __shared__ u32 hist[MSD_BINS];
+    __shared__ u32 histb[FROM_TEXT ? MSD_BINS : 1];      // LSD order: the first digit, counted in the same pass
     const u32 tid = threadIdx.x, r = blockIdx.x;
     u32 e0, e1;
     if (FROM_TEXT) {
@@ -142,16 +178,21 @@ __global__ __launch_bounds__(MSD_BLOCK) void msd_hist_kernel(MsdArgs a)
         e0 = a.ranges2[r].start;
         e1 = a.ranges2[r].end;
     }
-    for (u32 i = tid; i < MSD_BINS; i += MSD_BLOCK) hist[i] = 0;
+    for (u32 i = tid; i < MSD_BINS; i += MSD_BLOCK) {
+        hist[i] = 0;
+        if (FROM_TEXT) histb[i] = 0;
+    }
     __syncthreads();
     const int shift2 = a.idx_bits + a.key_bits - 2 * MSD_D;
     if (FROM_TEXT) {
         // the digit is the top 10 bits of the key: the first m = ceil(10 / b) symbols are all it takes -- a 32-bit
-        // sliding window instead of the 64-bit keys of text_keys16 (0.41 -> 0.16 ms at n = 2^29)
+        // sliding window instead of the 64-bit keys of text_keys16 (0.41 -> 0.16 ms at n = 2^29).  LSD order: the top
+        // 20 bits, m = ceil(20 / b) symbols (<= 24 bits), the pass's own digit is the LOWER ten of them.
         const int b = a.code_bits;
-        const int m = (MSD_D + b - 1) / b;
+        const int top = a.lsd ? 2 * MSD_D : MSD_D;
+        const int m = (top + b - 1) / b;
         const u32 wmask = (m * b >= 32) ? ~0u : ((1u << (m * b)) - 1u);
-        const int down = m * b - MSD_D;
+        const int down = m * b - top;
         // (the next tile's 32 bytes are loaded before this tile's atomics: two trips to HBM in flight per thread)
         uint4 nlo = make_uint4(0, 0, 0, 0), nhi = nlo;
         if (e0 + tid * MSD_IPT < e1) {
@@ -176,7 +217,11 @@ __global__ __launch_bounds__(MSD_BLOCK) void msd_hist_kernel(MsdArgs a)
 #pragma unroll
             for (int r = 0; r < MSD_IPT; ++r) {
                 if (r > 0) win = ((win << b) | sym((u32)(m - 1 + r))) & wmask;
-                if (i0 + r < e1) atomicAdd(&hist[win >> down], 1u);
+                if (i0 + r < e1) {
+                    const u32 tp = win >> down;
+                    atomicAdd(&hist[tp & (MSD_BINS - 1u)], 1u);
+                    if (a.lsd) atomicAdd(&histb[tp >> MSD_D], 1u);
+                }
             }
         }
     } else {
@@ -193,8 +238,12 @@ __global__ __launch_bounds__(MSD_BLOCK) void msd_hist_kernel(MsdArgs a)
     __syncthreads();
     // G1: digit-major (one row per digit: its offsets kernel scans rows); G2: range-major (one row per range)
     for (u32 i = tid; i < MSD_BINS; i += MSD_BLOCK) {
-        if (FROM_TEXT) a.T[(size_t)i * a.num_ranges1 + r] = hist[i];
-        else a.T[(size_t)r * MSD_BINS + i] = hist[i];
+        if (FROM_TEXT) {
+            a.T[(size_t)i * a.num_ranges1 + r] = hist[i];
+            if (a.lsd) a.T2[(size_t)i * a.num_ranges1 + r] = histb[i];
+        } else {
+            a.T[(size_t)r * MSD_BINS + i] = hist[i];
+        }
     }
 }
 
@@ -205,19 +254,21 @@ __global__ __launch_bounds__(MSD_BLOCK) void msd_hist_kernel(MsdArgs a)
 __global__ __launch_bounds__(MSD_BLOCK) void msd_hist_raw_kernel(MsdArgs a)
 {
     __shared__ u32 hist[MSD_BINS];
+    __shared__ u32 histb[MSD_BINS];      // LSD order: the first digit (see msd_hist_kernel)
     __shared__ u8 s_lut[256];
     const u32 tid = threadIdx.x, r = blockIdx.x;
     if (r >= a.num_ranges1) return;
     const u32 e0 = r * a.tiles_per_range1 * MSD_TILE;
     const u64 end = (u64)(r + 1) * a.tiles_per_range1 * MSD_TILE;
     const u32 e1 = end < a.n ? (u32)end : a.n;
-    for (u32 i = tid; i < MSD_BINS; i += MSD_BLOCK) hist[i] = 0;
+    for (u32 i = tid; i < MSD_BINS; i += MSD_BLOCK) hist[i] = histb[i] = 0;
     if (tid < 256) s_lut[tid] = a.lut[tid];
     __syncthreads();
     const int b = a.code_bits;
-    const int m = (MSD_D + b - 1) / b;
+    const int top = a.lsd ? 2 * MSD_D : MSD_D;
+    const int m = (top + b - 1) / b;
     const u32 wmask = (m * b >= 32) ? ~0u : ((1u << (m * b)) - 1u);
-    const int down = m * b - MSD_D;
+    const int down = m * b - top;
     auto tr = [&](u32 w) -> u32 {
         return (u32)s_lut[w & 0xffu] | ((u32)s_lut[(w >> 8) & 0xffu] << 8) | ((u32)s_lut[(w >> 16) & 0xffu] << 16) |
                ((u32)s_lut[w >> 24] << 24);
@@ -279,12 +330,19 @@ __global__ __launch_bounds__(MSD_BLOCK) void msd_hist_raw_kernel(MsdArgs a)
 #pragma unroll
         for (int k = 0; k < MSD_IPT; ++k) {
             if (k > 0) win = ((win << b) | sym((u32)(m - 1 + k))) & wmask;
-            if (i0 + k < e1) atomicAdd(&hist[win >> down], 1u);
+            if (i0 + k < e1) {
+                const u32 tp = win >> down;
+                atomicAdd(&hist[tp & (MSD_BINS - 1u)], 1u);
+                if (a.lsd) atomicAdd(&histb[tp >> MSD_D], 1u);
+            }
         }
     }
     if (__ballot(bad) && (tid & 63u) == 0) atomicOr(a.bad, 1u);
     __syncthreads();
-    for (u32 i = tid; i < MSD_BINS; i += MSD_BLOCK) a.T[(size_t)i * a.num_ranges1 + r] = hist[i];
+    for (u32 i = tid; i < MSD_BINS; i += MSD_BLOCK) {
+        a.T[(size_t)i * a.num_ranges1 + r] = hist[i];
+        if (a.lsd) a.T2[(size_t)i * a.num_ranges1 + r] = histb[i];
+    }
 }
 
 // G1 offsets, step 1: one workgroup per digit turns its row of per-range counts into exclusive prefixes
@@ -509,9 +567,18 @@ __global__ __launch_bounds__(BLOCK) void msd_scatter2_kernel(MsdArgs a)
                 if (i0 < a.n) text_keys16(a.codes, i0, a.code_bits, a.key_chars, a.plus_one, a.key_drop, a.n, key);
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
-                    const u32 d = (u32)(key[k] >> rest_bits) & (MSD_BINS - 1u), pos = tid * IPT + g * 16 + k;
+                    const u32 pos = tid * IPT + g * 16 + k;
+                    u32 d;
+                    u64 keep;                                   // the K - 10 key bits the element carries on
+                    if (a.lsd) {                                // the pass's digit is the SECOND ten bits; the first ten stay
+                        d = (u32)(key[k] >> (rest_bits - MSD_D)) & (MSD_BINS - 1u);
+                        keep = ((key[k] >> rest_bits) << (rest_bits - MSD_D)) | (key[k] & (rest_mask >> MSD_D));
+                    } else {
+                        d = (u32)(key[k] >> rest_bits) & (MSD_BINS - 1u);
+                        keep = key[k] & rest_mask;
+                    }
                     // through LDS: [key rest | digit | position in the tile]; the suffix index is base + position
-                    elem[g * 16 + k] = ((key[k] & rest_mask) << 24) | ((u64)d << 14) | (u64)pos;
+                    elem[g * 16 + k] = (keep << 24) | ((u64)d << 14) | (u64)pos;
                     lp[g * 16 + k] = pos < valid ? ((atomicAdd(&hist[d], 1u) & 0xffffu) | (d << 22)) : 0xffffffffu;
                 }
             }
@@ -582,6 +649,147 @@ __global__ __launch_bounds__(BLOCK) void msd_scatter2_kernel(MsdArgs a)
     }
 }
 
+// ---- second pass in one sweep: decoupled look-back (LSD order) ---------------------------------------
+
+// Tiles of the look-back pass: every d-region cut into pieces of MSD_TILE2 elements (an empty region still gets one
+// tile of nothing: it owes its row of the joint table).  One workgroup, thread = region.
+__global__ __launch_bounds__(MSD_BINS) void msd_tiles2_kernel(const u32 *J1, MsdTile2 *tiles, u32 *counters)
+{
+    __shared__ u32 scr[MSD_BINS / kWave + 1];
+    const u32 d = threadIdx.x;
+    const u32 s = J1[d], e = J1[d + 1];
+    const u32 nr = max(1u, (e - s + MSD_TILE2 - 1) / MSD_TILE2);
+    u32 total = 0;
+    const u32 first = block_excl_sum<MSD_BINS / kWave>(nr, scr, &total);
+    if (d == 0) counters[0] = total;
+    for (u32 k = 0; k < nr; ++k) {
+        const u32 ts = s + k * MSD_TILE2;
+        tiles[first + k] = MsdTile2{ts, min(MSD_TILE2, e - ts), d | (k + 1 == nr ? 0x80000000u : 0u)};
+    }
+}
+
+// A look-back word: two state bits over a 30-bit number (n < 2^30 on this path).  A: the tile's own count of the bin;
+// P: where the bin stands after the tile -- start of the bin's bucket + everything up to and including the tile.
+constexpr u32 LB_A = 1u << 30, LB_P = 2u << 30, LB_STATE = 3u << 30, LB_VALUE = LB_A - 1u;
+constexpr int LB_WINDOW = 4;                         // predecessors asked per trip (their loads are in flight together)
+
+// Persistent workgroups, tiles by ticket (a waiting tile's predecessors all hold earlier tickets, hence run).  Per tile:
+// load, rank with one returning LDS atomic per element, publish the 1024 counts, add up the predecessors' (thread =
+// bin; one 4-byte word per (tile, bin) carries state and number, so nothing needs ordering beyond the word itself:
+// relaxed device-scope accesses), publish the running totals, stage through LDS in two pieces, write.  Measured in
+// tests/tools/lookback_micro.hip at n = 2^29: 2.5 ms against 0.88 + 2.2 ms for histogram pass + scatter from a table;
+// a tile asks 5 trips of 4 rows on average (one chain over all tiles; 4 .. 64 chains side by side read fewer rows and
+// were no faster: neighbouring tiles then write to far-apart places).
+__global__ __launch_bounds__(1024) void msd_scatter_lb_kernel(MsdArgs a)
+{
+    constexpr int BLOCK = 1024;
+    constexpr int IPT = MSD_TILE2 / BLOCK;               // 16
+    __shared__ __attribute__((aligned(16))) u64 exch[MSD_TILE];
+    __shared__ u32 hist[MSD_BINS], s_delta[MSD_BINS];
+    __shared__ u16 s_start[MSD_BINS];
+    __shared__ u32 scr[BLOCK / kWave + 1];
+    __shared__ u32 s_ticket;
+    const u32 tid = threadIdx.x;
+    const u32 nt = a.counters[0];
+    const int shift2 = a.idx_bits + a.key_bits - 2 * MSD_D;      // the first digit sits right above [remaining key bits | index]
+    const u64 low_mask2 = (1ull << shift2) - 1ull;
+    hist[tid] = 0;
+    __syncthreads();
+    for (;;) {
+        if (tid == 0) s_ticket = atomicAdd(&a.counters[8], 1u);
+        __syncthreads();
+        const u32 t = s_ticket;
+        if (t >= nt) break;
+        const MsdTile2 td = a.tiles2[t];
+        const u32 base = td.start, valid = td.count;
+        u64 elem[IPT];
+        u32 lp[IPT];
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const u32 p = k * BLOCK + tid;
+            elem[k] = p < valid ? a.in[base + p] : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const u32 p = k * BLOCK + tid;
+            const u32 d = (u32)(elem[k] >> shift2) & (MSD_BINS - 1u);
+            lp[k] = p < valid ? (atomicAdd(&hist[d], 1u) | (d << 22)) : 0xffffffffu;
+        }
+        __syncthreads();                                    // (A) counts complete; previous tile fully written out
+        {
+            const u32 c = hist[tid];
+            u32 *row = a.status + (size_t)t * MSD_BINS;
+            u32 off;
+            if (t == 0) {
+                off = a.Jb[tid];
+                if (tid == 0) a.J[0] = 0;
+            } else {
+                __hip_atomic_store(&row[tid], LB_A | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                u32 sum = 0, p = t;                           // predecessors not yet added: the next one is p - 1
+                bool done = false;
+                while (!done) {
+                    const u32 p0 = p;
+                    u32 v[LB_WINDOW];
+#pragma unroll
+                    for (u32 w = 0; w < (u32)LB_WINDOW; ++w) {
+                        const u32 q = p0 > w ? p0 - 1 - w : 0u;
+                        v[w] = __hip_atomic_load(&a.status[(size_t)q * MSD_BINS + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    bool stop = false;
+#pragma unroll
+                    for (u32 w = 0; w < (u32)LB_WINDOW; ++w) {
+                        if (!stop && w < p0) {
+                            const u32 st = v[w] & LB_STATE;
+                            if (st == 0) {
+                                stop = true;                  // not published yet: ask again from here
+                            } else {
+                                sum += v[w] & LB_VALUE;
+                                --p;
+                                if (st == LB_P) done = stop = true;
+                            }
+                        }
+                    }
+                    if (p == 0) done = true;                  // (tile 0 publishes P: never the way out)
+                }
+                off = sum;
+            }
+            __hip_atomic_store(&row[tid], LB_P | (off + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the last tile of d-region d: where bin b stands now is the end of joint bucket (b, d)
+            if (td.d_last >> 31) a.J[(size_t)tid * MSD_BINS + (td.d_last & (MSD_BINS - 1u)) + 1u] = off + c;
+            const u32 ex = block_excl_sum<BLOCK / kWave>(c, scr, nullptr);
+            s_start[tid] = (u16)ex;
+            s_delta[tid] = off - ex;
+            hist[tid] = 0;
+        }
+        __syncthreads();                                    // (B) bin starts published
+        // what the element leaves as: [ tag | remaining key bits | index ], tag = joint bucket number mod 64 = d mod 64
+        const u64 tag = (u64)(td.d_last & (MSD_RAW_TAG_SPAN - 1u)) << shift2;
+#pragma unroll
+        for (int k = 0; k < IPT; ++k)
+            if (lp[k] != 0xffffffffu) lp[k] = (lp[k] & 0xffffu) + (u32)s_start[lp[k] >> 22];
+#pragma unroll
+        for (int h = 0; h < MSD_PIECES2; ++h) {
+            if (h * MSD_TILE >= valid) break;
+            if (h) __syncthreads();                         // the piece before this one is written out
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) {
+                const u32 q = lp[k] - h * MSD_TILE;
+                if (q < MSD_TILE) exch[q] = elem[k];
+            }
+            __syncthreads();                                // (C) the piece in bin order
+#pragma unroll
+            for (int k = 0; k < (int)(MSD_TILE / BLOCK); ++k) {
+                const u32 q = k * BLOCK + tid, p = h * MSD_TILE + q;
+                if (p < valid) {
+                    const u64 e = exch[q];
+                    const u32 d = (u32)(e >> shift2) & (MSD_BINS - 1u);
+                    a.out[s_delta[d] + p] = (e & low_mask2) | tag;
+                }
+            }
+        }
+    }
+}
+
 // ---- tile plan ---------------------------------------------------------------------------------
 
 struct InNonEmpty {
@@ -590,13 +798,15 @@ struct InNonEmpty {
 };
 
 // compact the starts of the non-empty joint buckets; largest bucket
-__global__ __launch_bounds__(256) void msd_compact_kernel(const u32 *J, u32 nb, const u64 *rank, u32 *cstart, u32 *counters)
+// (cj, LSD order: the joint bucket number of every non-empty bucket -- the tile rule and the tiles' bucket maps need it)
+__global__ __launch_bounds__(256) void msd_compact_kernel(const u32 *J, u32 nb, const u64 *rank, u32 *cstart, u32 *counters, u32 *cj)
 {
     u32 mx = 0;
     for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < nb; j += gridDim.x * blockDim.x) {
         const u32 s = J[j], e = J[j + 1];
         if (e > s) {
             cstart[rank[j]] = s;
+            if (cj) cj[rank[j]] = j;
             mx = max(mx, e - s);
         }
     }
@@ -611,10 +821,16 @@ __global__ __launch_bounds__(256) void msd_compact_kernel(const u32 *J, u32 nb, 
 // instead of the 4 096 of a plain "one tile per 4096-slot window" rule (a fifth fewer tiles).
 struct TilePlan {
     u32 win, cap;      // window of the rule above; elements a tile holds at most
+    const u32 *cj;     // LSD order: joint bucket numbers of the non-empty buckets -- a tile stays inside one aligned block of
+                       // MSD_RAW_TAG_SPAN joint buckets (else: of MSD_TAG_SPAN non-empty ones)
 };
 __device__ __forceinline__ bool msd_tile_head(const u32 *cstart, u32 ne, u32 n, u32 k, TilePlan tp)
 {
-    if ((k & (MSD_TAG_SPAN - 1u)) == 0) return true;
+    if (tp.cj) {
+        if (k == 0 || (tp.cj[k] >> MSD_RAW_TAG_BITS) != (tp.cj[k - 1] >> MSD_RAW_TAG_BITS)) return true;
+    } else if ((k & (MSD_TAG_SPAN - 1u)) == 0) {
+        return true;
+    }
     const u32 w = cstart[k] / tp.win;
     if (cstart[k - 1] / tp.win != w) return true;                        // first bucket of its window
     if (k + 1 < ne && cstart[k + 1] / tp.win == w) return false;         // neither first nor last
@@ -646,6 +862,7 @@ __global__ __launch_bounds__(256) void msd_tiles_kernel(const u32 *cstart, u32 n
 
 struct MsdTile {
     u32 e0, count, tag0, nb;      // first element, elements, tag of the first bucket, buckets
+    u64 map;                      // LSD order: bit i = joint bucket (block of 64) + i is one of the tile's buckets
 };
 
 // ---- output of a sorted tile ------------------------------------------------------------------------
@@ -763,6 +980,18 @@ __global__ __launch_bounds__(256) void msd_gather_kernel(const MsdTile *tiles, c
 // [ bucket number inside the tile | remaining key bits | suffix index ] -- stable 8-bit LSD passes
 // over the bucket and key bits (the index bits ride along), wave-ballot ranking as in radix_sort.hip.
 // This is the general (slower) form: it takes whatever the fast kernel below hands back.
+// RAW (LSD order): the element's tag is its joint bucket number mod 64; its bucket number inside the tile = non-empty
+// buckets of the tile below it, a popcount over the tile's map.
+template <bool RAW>
+__device__ __forceinline__ u64 msd_retag(u64 x, const MsdTile &td, u64 tag_base, int low_bits)
+{
+    if (!RAW) return x - tag_base;
+    const u32 tg = (u32)(x >> low_bits);
+    const u32 dn = (u32)__popcll(td.map & ((1ull << tg) - 1ull));
+    return (x & ((1ull << low_bits) - 1ull)) | ((u64)dn << low_bits);
+}
+
+template <bool RAW>
 __global__ __launch_bounds__(MSD_BLOCK) void msd_local_sort_kernel(const u64 *in, const MsdTile *tiles, int rem_bits, int idx_bits,
                                                                      u32 *sa_out, const u32 *tile_list, int fused, MsdEmit em_val)
 {
@@ -785,7 +1014,7 @@ __global__ __launch_bounds__(MSD_BLOCK) void msd_local_sort_kernel(const u64 *in
     for (int r = 0; r < MSD_IPT; ++r) {
         const u32 p = wave * (kWave * MSD_IPT) + r * kWave + lane;
         // [bucket inside the tile | remaining key bits | index] (G2 tagged the element with its bucket's number); ~0: padding
-        key[r] = p < count ? in[e0 + p] - tag_base : ~0ull;
+        key[r] = p < count ? msd_retag<RAW>(in[e0 + p], td, tag_base, rem_bits + idx_bits) : ~0ull;
     }
     const int sort_bits = rem_bits + seg_bits;
     for (int shift = idx_bits; shift < idx_bits + sort_bits; shift += 8) {
@@ -879,13 +1108,19 @@ constexpr int LS_GROUP = PSS_LS_GROUP;              // rows ranked / written out
 constexpr int LS_WINDOW = PSS_LS_WINDOW;                        // members of its bin every element reads unconditionally (bins average 1.3)
 
 __global__ __launch_bounds__(256) void msd_tile_desc_kernel(const u32 *cstart, const u32 *tile_first, u32 nt, u32 ne, u32 n,
-                                                              MsdTile *tiles)
+                                                              MsdTile *tiles, const u32 *cj)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt) return;
     const u32 k0 = tile_first[t], k1 = tile_first[t + 1];
     const u32 e0 = cstart[k0], e1 = k1 < ne ? cstart[k1] : n;
-    tiles[t] = MsdTile{e0, e1 - e0, k0 & (MSD_TAG_SPAN - 1u), k1 - k0};
+    if (cj) {
+        u64 map = 0;                                   // (<= 64 buckets: the tile lies inside one block of 64 joint buckets)
+        for (u32 k = k0; k < k1; ++k) map |= 1ull << (cj[k] & (MSD_RAW_TAG_SPAN - 1u));
+        tiles[t] = MsdTile{e0, e1 - e0, cj[k0] & (MSD_RAW_TAG_SPAN - 1u), k1 - k0, map};
+    } else {
+        tiles[t] = MsdTile{e0, e1 - e0, k0 & (MSD_TAG_SPAN - 1u), k1 - k0, 0ull};
+    }
 }
 
 // Workgroup barrier that waits for this wave's LDS traffic only: global loads issued before it (the
@@ -903,6 +1138,7 @@ __device__ __forceinline__ void lds_barrier()
 // memory most of the time.  The workgroups therefore persist (two per CU) and walk over the tiles with the
 // loads one tile ahead: descriptor two tiles ahead, bucket starts and elements of the next tile issued as
 // soon as the registers of the current one are free, landing while the current tile is being sorted.
+template <bool RAW>
 __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 *in, const MsdTile *tiles, u32 nt, int rem_bits,
                                                                      int idx_bits, u32 *sa_out, u32 *fail_list, u32 *fail_count,
                                                                      int fused, MsdEmit em_val)
@@ -921,7 +1157,7 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
     u32 t = blockIdx.x;
     if (t >= nt) return;
     MsdTile cur = tiles[t];
-    MsdTile nxt = t + stride < nt ? tiles[t + stride] : MsdTile{0, 0, 0, 0};
+    MsdTile nxt = t + stride < nt ? tiles[t + stride] : MsdTile{0, 0, 0, 0, 0};
     u64 pe[MSD_IPT];          // prefetched raw elements of the tile about to be sorted
     auto prefetch = [&](const MsdTile &d) {
 #pragma unroll
@@ -959,7 +1195,7 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
                 const u32 p = r * MSD_BLOCK + tid;
                 if (p < count) {
                     // the element carries its bucket (G2 put it there): [bucket inside the tile | remaining key bits | index]
-                    e[r] = pe[r] - tag_base;
+                    e[r] = msd_retag<RAW>(pe[r], cur, tag_base, rem_bits + idx_bits);
                     const u32 bin = (u32)(e[r] >> bin_shift);
                     atomicAdd(&hist[bin >> 1], 1u << (16u * (bin & 1u)));    // count now; the slot is taken after the scan
                 }
@@ -1132,7 +1368,7 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
         if (!more) break;
         t += stride;
         cur = nxt;
-        nxt = t + stride < nt ? tiles[t + stride] : MsdTile{0, 0, 0, 0};
+        nxt = t + stride < nt ? tiles[t + stride] : MsdTile{0, 0, 0, 0, 0};
     }
     if (em) {
         lds_barrier();
@@ -1145,10 +1381,21 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
 // ---- host --------------------------------------------------------------------------------------
 
 // Upper bound on the tiles of the plan: at most two per MSD_WIN window (msd_tile_head) plus one per aligned block
-// of MSD_TAG_SPAN joint buckets.
+// of MSD_TAG_SPAN non-empty / MSD_RAW_TAG_SPAN joint buckets.
 static size_t msd_max_tiles(uint32_t n)
 {
-    return (size_t)n / (SS_WIN / 2) + ((size_t)MSD_BINS * MSD_BINS) / MSD_TAG_SPAN + 8;      // (the smaller window of the two paths)
+    return (size_t)n / (SS_WIN / 2) + ((size_t)MSD_BINS * MSD_BINS) / MSD_RAW_TAG_SPAN + 8;  // (the smaller window of the two paths, the
+                                                                                             //  finer block rule: LSD order)
+}
+
+static size_t msd_max_tiles2(uint32_t n) { return (size_t)n / MSD_TILE2 + MSD_BINS + 8; }
+
+// LSD order + look-back: the default wherever its 30-bit look-back words hold the positions.  PSS_MSD_LSD=0: the two
+// passes in MSD order with the second histogram pass (rounds 2-5).
+static bool msd_use_lsd(uint32_t n)
+{
+    const char *e = getenv("PSS_MSD_LSD");
+    return !(e && atoi(e) == 0) && n < (1u << 30);
 }
 
 size_t msd_workspace_bytes(uint32_t n)
@@ -1164,14 +1411,19 @@ size_t msd_workspace_bytes(uint32_t n)
            + (msd_max_tiles(n) + 32) * 8              // tile_first, then the tiles left to the general kernel
            + (msd_max_tiles(n) + 32) * 16             // blocks of active records per tile + their final offsets
            + (msd_max_tiles(n) + 32) * sizeof(MsdTile)
-           + (SC_MAX_BLOCKS + 8) * 8 + 8192;
+           + (SC_MAX_BLOCKS + 8) * 8 + 8192
+           // LSD order: counts of the first digit per range, the look-back tiles and their words, joint numbers of the buckets
+           + (size_t)MSD_BINS * MSD_G1_RANGES * 4 + (MSD_BINS + 8) * 4
+           + msd_max_tiles2(n) * (sizeof(MsdTile2) + (size_t)MSD_BINS * 4)
+           + (nbk + 8) * 4 + 4096;
 }
 
 int msd_max_key_bits(uint32_t n)
 {
     int ib = 1;
     while ((1ull << ib) < (u64)n) ++ib;
-    return 64 + MSD_D - MSD_TAG_BITS - ib + MSD_D;      // [11-bit bucket tag | K - 20 key bits | ib index bits] must fit 64 bits after G2
+    // [bucket tag | K - 20 key bits | ib index bits] must fit 64 bits after the second pass: an 11-bit tag, or 6 bits in LSD order
+    return 64 + MSD_D - (msd_use_lsd(n) ? MSD_RAW_TAG_BITS : MSD_TAG_BITS) - ib + MSD_D;
 }
 
 int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bits, uint64_t *A[2], uint32_t *sa_out,
@@ -1206,6 +1458,17 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     u64 *dst_off = reinterpret_cast<u64 *>(carve((max_tiles + 8) * 8));
     u64 *partial = reinterpret_cast<u64 *>(carve((SC_MAX_BLOCKS + 8) * 8));
     u64 *d_total = partial + SC_MAX_BLOCKS;
+    const bool lsd = msd_use_lsd(n);
+    const size_t max_tiles2 = msd_max_tiles2(n);
+    u32 *T2 = nullptr, *Jb = nullptr, *status = nullptr, *cj = nullptr;
+    MsdTile2 *tiles2 = nullptr;
+    if (lsd) {
+        T2 = reinterpret_cast<u32 *>(carve((size_t)MSD_BINS * MSD_G1_RANGES * 4));
+        Jb = reinterpret_cast<u32 *>(carve((MSD_BINS + 8) * 4));
+        tiles2 = reinterpret_cast<MsdTile2 *>(carve(max_tiles2 * sizeof(MsdTile2)));
+        status = reinterpret_cast<u32 *>(carve(max_tiles2 * MSD_BINS * 4));
+        cj = reinterpret_cast<u32 *>(carve((nbk + 8) * 4));
+    }
 
     MsdArgs a;
     memset(&a, 0, sizeof a);
@@ -1226,6 +1489,11 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     a.ranges2 = ranges2;
     a.seg_first = seg_first;
     a.counters = counters;
+    a.lsd = lsd ? 1 : 0;
+    a.T2 = T2;
+    a.Jb = Jb;
+    a.tiles2 = tiles2;
+    a.status = status;
 
     hipEvent_t ev[8] = {};
     int nev = 0;
@@ -1261,25 +1529,41 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     static_assert(MSD_G1_RANGES <= 1024, "msd_offsets1_kernel takes four ranges per thread");
     hipLaunchKernelGGL(msd_offsets1_kernel, dim3(MSD_BINS), dim3(256), 0, s, T, a.num_ranges1, seg_first);   // totals: scratch
     hipLaunchKernelGGL(msd_offsets1b_kernel, dim3(1), dim3(MSD_BINS), 0, s, (const u32 *)seg_first, J1, n);
+    if (lsd) {
+        // the first digit's bucket starts from the same pass over the text (the per-range prefixes in T2 are not used)
+        hipLaunchKernelGGL(msd_offsets1_kernel, dim3(MSD_BINS), dim3(256), 0, s, T2, a.num_ranges1, seg_first);
+        hipLaunchKernelGGL(msd_offsets1b_kernel, dim3(1), dim3(MSD_BINS), 0, s, (const u32 *)seg_first, Jb, n);
+        // (the words of the look-back pass: zero = nothing published)
+        PSS_HIP(hipMemsetAsync(status, 0, max_tiles2 * MSD_BINS * 4, s));
+    }
     PSS_TRY(mark());
     // 16384-element scatter tiles (whole-line runs), 1024 threads: 2.2 -> 1.9 ms (from the text) and 2.8 -> 2.45 ms
     // (second pass, with its sixteen loads per thread issued before the ranking atomics) at 2^29; 512 threads x 32 elements
     // spill.  PSS_MSD_SCATTER=1: the 8192-element kernels.
-    const bool wide = !(getenv("PSS_MSD_SCATTER") && atoi(getenv("PSS_MSD_SCATTER")) == 1);
+    const bool wide = lsd || !(getenv("PSS_MSD_SCATTER") && atoi(getenv("PSS_MSD_SCATTER")) == 1);
     if (wide) hipLaunchKernelGGL((msd_scatter2_kernel<true, 1024>), dim3(a.num_ranges1), dim3(1024), 0, s, a);
     else hipLaunchKernelGGL(msd_scatter_kernel<true>, dim3(a.num_ranges1), dim3(MSD_BLOCK), 0, s, a);
     PSS_TRY(mark());
-    // ---- G2: A[0] -> A[1], every G1 bucket by the next 10 bits ----
-    hipLaunchKernelGGL(msd_ranges_kernel, dim3(1), dim3(MSD_BINS), 0, s, J1, ranges2, seg_first, counters);
     a.in = A[0];
     a.out = A[1];
-    a.dense = ranks;
-    hipLaunchKernelGGL(msd_hist_kernel<false>, dim3((u32)max_ranges2), dim3(MSD_BLOCK), 0, s, a);
-    hipLaunchKernelGGL(msd_offsets_kernel, dim3(MSD_BINS), dim3(MSD_BINS), 0, s, T, (const u32 *)seg_first, (const u32 *)J1, J,
-                       0u, n, MSD_BINS);
+    if (lsd) {
+        // ---- second pass in one sweep: A[0] -> A[1] by the first digit, tile order kept (look-back); leaves J ----
+        hipLaunchKernelGGL(msd_tiles2_kernel, dim3(1), dim3(MSD_BINS), 0, s, (const u32 *)J1, tiles2, counters);
+        PSS_TRY(mark());
+        const u32 grid2 = std::min<u32>((u32)max_tiles2, (u32)ctx->num_cus);      // one 1024-thread workgroup per CU (~100 VGPRs)
+        hipLaunchKernelGGL(msd_scatter_lb_kernel, dim3(grid2), dim3(1024), 0, s, a);
+        PSS_TRY(mark());
+    } else {
+        // ---- G2: A[0] -> A[1], every G1 bucket by the next 10 bits ----
+        hipLaunchKernelGGL(msd_ranges_kernel, dim3(1), dim3(MSD_BINS), 0, s, J1, ranges2, seg_first, counters);
+        a.dense = ranks;
+        hipLaunchKernelGGL(msd_hist_kernel<false>, dim3((u32)max_ranges2), dim3(MSD_BLOCK), 0, s, a);
+        hipLaunchKernelGGL(msd_offsets_kernel, dim3(MSD_BINS), dim3(MSD_BINS), 0, s, T, (const u32 *)seg_first, (const u32 *)J1, J,
+                           0u, n, MSD_BINS);
+    }
     // ---- plan: non-empty joint buckets, largest bucket, tiles ----
     PSS_TRY(device_excl_scan(ctx, InNonEmpty{J}, nbk, partial, d_total, ranks));
-    hipLaunchKernelGGL(msd_compact_kernel, dim3(1024), dim3(256), 0, s, J, (u32)nbk, ranks, cstart, counters);
+    hipLaunchKernelGGL(msd_compact_kernel, dim3(1024), dim3(256), 0, s, J, (u32)nbk, ranks, cstart, counters, cj);
     PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
     PSS_HIP(hipMemcpyAsync(h_small + 2, counters, 16, hipMemcpyDeviceToHost, s));
     if (front) PSS_HIP(hipMemcpyAsync(h_small + 6, front->bad, 4, hipMemcpyDeviceToHost, s));
@@ -1293,11 +1577,13 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     }
     if (front && h_small[6]) return PSS_OK;        // a byte the table has no code for: nothing of this sort can be used
     if (maxb > MSD_MAX_BUCKET) return PSS_OK;      // not this text: the caller takes the LSD path
-    PSS_TRY(mark());
-    if (wide) hipLaunchKernelGGL((msd_scatter2_kernel<false, 1024>), dim3((u32)max_ranges2), dim3(1024), 0, s, a);
-    else hipLaunchKernelGGL(msd_scatter_kernel<false>, dim3((u32)max_ranges2), dim3(MSD_BLOCK), 0, s, a);
-    PSS_TRY(mark());
-    const TilePlan tp{MSD_WIN, MSD_TILE_CAP};
+    if (!lsd) {
+        PSS_TRY(mark());
+        if (wide) hipLaunchKernelGGL((msd_scatter2_kernel<false, 1024>), dim3((u32)max_ranges2), dim3(1024), 0, s, a);
+        else hipLaunchKernelGGL(msd_scatter_kernel<false>, dim3((u32)max_ranges2), dim3(MSD_BLOCK), 0, s, a);
+        PSS_TRY(mark());
+    }
+    const TilePlan tp{MSD_WIN, MSD_TILE_CAP, cj};
     PSS_TRY(device_excl_scan(ctx, InTileHead{cstart, ne, n, tp}, ne, partial, d_total, ranks));
     hipLaunchKernelGGL(msd_tiles_kernel, dim3(1024), dim3(256), 0, s, cstart, ne, n, ranks, (const u64 *)d_total, tile_first, tp);
     PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
@@ -1314,14 +1600,17 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     const int fused = active != nullptr;
     if (fused) em = MsdEmit{active->st_pos, active->st_idx, blk_cnt};
     const int rem_bits = key_bits - 2 * MSD_D;
-    hipLaunchKernelGGL(msd_tile_desc_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, cstart, tile_first, nt, ne, n, tiles_all);
+    hipLaunchKernelGGL(msd_tile_desc_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, cstart, tile_first, nt, ne, n, tiles_all,
+                       (const u32 *)cj);
+    const auto local_sort = lsd ? msd_local_sort_kernel<true> : msd_local_sort_kernel<false>;
+    const auto local_fast = lsd ? msd_local_fast_kernel<true> : msd_local_fast_kernel<false>;
     if (getenv("PSS_MSD_SLOW_LOCAL")) {
-        hipLaunchKernelGGL(msd_local_sort_kernel, dim3(nt), dim3(MSD_BLOCK), 0, s, A[1], (const MsdTile *)tiles_all, rem_bits, ib,
+        hipLaunchKernelGGL(local_sort, dim3(nt), dim3(MSD_BLOCK), 0, s, A[1], (const MsdTile *)tiles_all, rem_bits, ib,
                            sa_out, (const u32 *)nullptr, fused, em);
     } else {
         MsdTile *tiles = tiles_all;
         const u32 grid = std::min<u32>(nt, 2u * (u32)ctx->num_cus);
-        hipLaunchKernelGGL(msd_local_fast_kernel, dim3(grid), dim3(MSD_BLOCK), 0, s, A[1], (const MsdTile *)tiles, nt, rem_bits, ib,
+        hipLaunchKernelGGL(local_fast, dim3(grid), dim3(MSD_BLOCK), 0, s, A[1], (const MsdTile *)tiles, nt, rem_bits, ib,
                            sa_out, fail_list, counters + 4, fused, em);
         PSS_TRY(mark());            // (profile mode) the events bracket this launch alone
         PSS_HIP(hipMemcpyAsync(h_small, counters + 4, 4, hipMemcpyDeviceToHost, s));
@@ -1329,7 +1618,7 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
         const u32 nfail = h_small[0];
         if (stats) stats->slow_tiles = nfail;
         if (nfail)
-            hipLaunchKernelGGL(msd_local_sort_kernel, dim3(nfail), dim3(MSD_BLOCK), 0, s, A[1], (const MsdTile *)tiles_all, rem_bits,
+            hipLaunchKernelGGL(local_sort, dim3(nfail), dim3(MSD_BLOCK), 0, s, A[1], (const MsdTile *)tiles_all, rem_bits,
                                ib, sa_out, (const u32 *)fail_list, fused, em);
     }
     if (getenv("PSS_MSD_SLOW_LOCAL")) PSS_TRY(mark());
@@ -1533,7 +1822,7 @@ int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t radix, uint32_
     hipLaunchKernelGGL(msd_offsets_kernel, dim3(MSD_BINS), dim3(MSD_BINS), 0, s, T, (const u32 *)seg_first, (const u32 *)J1, J,
                        0u, n, MSD_BINS);
     PSS_TRY(device_excl_scan(ctx, InNonEmpty{J}, nbk, partial, d_total, ranks));
-    hipLaunchKernelGGL(msd_compact_kernel, dim3(1024), dim3(256), 0, s, J, (u32)nbk, ranks, cstart, counters);
+    hipLaunchKernelGGL(msd_compact_kernel, dim3(1024), dim3(256), 0, s, J, (u32)nbk, ranks, cstart, counters, (u32 *)nullptr);
     PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
     PSS_HIP(hipMemcpyAsync(h_small + 2, counters, 16, hipMemcpyDeviceToHost, s));
     PSS_HIP(hipStreamSynchronize(s));
@@ -1571,7 +1860,7 @@ int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t radix, uint32_
     const bool seg = !getenv("PSS_SS_WINDOW_PLAN") && !(seg_env && atoi(seg_env) == 0);
     u32 *pstart = nullptr;
     if (getenv("PSS_SS_WINDOW_PLAN")) {
-        const TilePlan tp{SS_WIN, SS_TILE_CAP};
+        const TilePlan tp{SS_WIN, SS_TILE_CAP, nullptr};
         PSS_TRY(device_excl_scan(ctx, InTileHead{cstart, ne, n, tp}, ne, partial, d_total, ranks));
         hipLaunchKernelGGL(msd_tiles_kernel, dim3(1024), dim3(256), 0, s, cstart, ne, n, ranks, (const u64 *)d_total, tile_first, tp);
     } else {
@@ -1616,7 +1905,8 @@ int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t radix, uint32_
         set_error("ss_suffix_sort: %u tiles planned, tables hold %zu (internal error)", nt, max_tiles);
         return PSS_EDEVICE;
     }
-    hipLaunchKernelGGL(msd_tile_desc_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, cstart, tile_first, nt, ne, n, tiles_all);
+    hipLaunchKernelGGL(msd_tile_desc_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, cstart, tile_first, nt, ne, n, tiles_all,
+                       (const u32 *)nullptr);
     // Ties go out as flags (bit 31 = "same key as my predecessor", the contract of suffix_sort_flags), not as the records
     // of the fused first rerank: groups of equal keys cross tile boundaries here, and the flag of a tile's first element
     // takes a look at the tile before it (ss_boundary_kernel, once every tile is sorted).
