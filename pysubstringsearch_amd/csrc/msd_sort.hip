@@ -71,7 +71,9 @@ constexpr int MSD_WAVES = MSD_BLOCK / kWave;
 constexpr int MSD_IPT = 16;
 constexpr u32 MSD_TILE = MSD_BLOCK * MSD_IPT;        // 8192 elements
 constexpr u32 MSD_WIN = 6144;                        // buckets whose start falls into one window of this size share a tile ...
-constexpr u32 MSD_TILE_CAP = 8183;                   // ... unless that is more than a tile holds: then the window's last bucket goes alone
+constexpr u32 MSD_TILE_CAP = 8176;                   // ... unless that is more than a tile holds: then the window's last bucket goes alone
+                                                     // (8176: the eight slots behind a tile's last element hold the ranking's sentinels,
+                                                     //  the eight after those the fast kernel's scalars)
 constexpr u32 MSD_MAX_BUCKET = 4088;                 // a bucket must fit a tile on its own (the last eight slots of the LDS tile
                                                      // carry the fast kernel's scalars: MSD_TILE_CAP)
 constexpr int MSD_TAG_BITS = MSD_D + 1;              // an element entering the local sort carries the low 11 bits of its joint bucket number ...
@@ -295,7 +297,10 @@ __global__ __launch_bounds__(MSD_BLOCK) void msd_hist_raw_kernel(MsdArgs a)
         if ((u64)i0 + MSD_TILE < e1) load32(i0 + MSD_TILE, nlo, nhi);
         if (i0 >= e1) continue;
         lo = make_uint4(tr(lo.x), tr(lo.y), tr(lo.z), tr(lo.w));
-        hi = make_uint4(tr(hi.x), tr(hi.y), tr(hi.z), tr(hi.w));
+        // of the sixteen bytes after my own the windows read the first m - 1: one word of them when that is <= 4 symbols
+        // (every alphabet of >= 5 bits per symbol) -- the table lookups are what this pass spends its time on
+        if (m <= 5) hi = make_uint4(tr(hi.x), 0u, 0u, 0u);
+        else hi = make_uint4(tr(hi.x), tr(hi.y), tr(hi.z), tr(hi.w));
         // my own 16 bytes: codes out, and every one of them inside the text must have got a code
         const u32 own = min(16u, a.n - i0);
         if (own == 16) {
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_scatter_kernel(MsdArgs a)
 constexpr u32 MSD_TILE2 = 16384;
 constexpr int MSD_PIECES2 = MSD_TILE2 / MSD_TILE;    // 2
 
-template <bool FROM_TEXT, int BLOCK>
+template <bool FROM_TEXT, int BLOCK, bool LSD = false>
 __global__ __launch_bounds__(BLOCK) void msd_scatter2_kernel(MsdArgs a)
 {
     constexpr int IPT = MSD_TILE2 / BLOCK;               // 16 (1024 threads) or 32 (512)
@@ -570,7 +575,7 @@ __global__ __launch_bounds__(BLOCK) void msd_scatter2_kernel(MsdArgs a)
                     const u32 pos = tid * IPT + g * 16 + k;
                     u32 d;
                     u64 keep;                                   // the K - 10 key bits the element carries on
-                    if (a.lsd) {                                // the pass's digit is the SECOND ten bits; the first ten stay
+                    if (LSD) {                                  // the pass's digit is the SECOND ten bits; the first ten stay
                         d = (u32)(key[k] >> (rest_bits - MSD_D)) & (MSD_BINS - 1u);
                         keep = ((key[k] >> rest_bits) << (rest_bits - MSD_D)) | (key[k] & (rest_mask >> MSD_D));
                     } else {
@@ -649,29 +654,82 @@ __global__ __launch_bounds__(BLOCK) void msd_scatter2_kernel(MsdArgs a)
     }
 }
 
+// ---- decoupled look-back: where does (tile, bin) go? -------------------------------------------------------
+// A look-back word: two state bits over a 30-bit number (n < 2^30 on this path).  A: the tile's own count of the bin;
+// P: where the bin stands after the tile -- start of the bin's bucket + everything up to and including the tile.
+// One 4-byte word per (tile, bin) carries state and number, so nothing needs ordering beyond the word itself: relaxed
+// device-scope accesses.  Tiles are handed out by an atomic ticket: every predecessor of a waiting tile is running.
+constexpr u32 LB_A = 1u << 30, LB_P = 2u << 30, LB_STATE = 3u << 30, LB_VALUE = LB_A - 1u;
+constexpr int LB_WINDOW = 4;                         // predecessors asked per trip (their loads are in flight together)
+
+// thread = bin: publishes the tile's count c, adds up the predecessors' back to the nearest running total, publishes the
+// tile's own running total; returns where the tile's elements of the bin start.  first: the bin's bucket start (tile 0).
+__device__ __forceinline__ u32 lb_resolve(u32 *status, u32 t, u32 c, u32 first)
+{
+    const u32 tid = threadIdx.x;
+    u32 *row = status + (size_t)t * MSD_BINS;
+    u32 off = first;
+    if (t != 0) {
+        __hip_atomic_store(&row[tid], LB_A | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u32 sum = 0, p = t;                           // predecessors not yet added: the next one is p - 1
+        bool done = false;
+        while (!done) {
+            const u32 p0 = p;
+            u32 v[LB_WINDOW];
+#pragma unroll
+            for (u32 w = 0; w < (u32)LB_WINDOW; ++w) {
+                const u32 q = p0 > w ? p0 - 1 - w : 0u;
+                v[w] = __hip_atomic_load(&status[(size_t)q * MSD_BINS + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            bool stop = false;
+#pragma unroll
+            for (u32 w = 0; w < (u32)LB_WINDOW; ++w) {
+                if (!stop && w < p0) {
+                    const u32 st = v[w] & LB_STATE;
+                    if (st == 0) {
+                        stop = true;                  // not published yet: ask again from here
+                    } else {
+                        sum += v[w] & LB_VALUE;
+                        --p;
+                        if (st == LB_P) done = stop = true;
+                    }
+                }
+            }
+            if (p == 0) done = true;                  // (tile 0 publishes P: never the way out)
+        }
+        off = sum;
+    }
+    __hip_atomic_store(&row[tid], LB_P | (off + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return off;
+}
+
 // ---- second pass in one sweep: decoupled look-back (LSD order) ---------------------------------------
 
-// Tiles of the look-back pass: every d-region cut into pieces of MSD_TILE2 elements (an empty region still gets one
-// tile of nothing: it owes its row of the joint table).  One workgroup, thread = region.
+// Tiles of the look-back pass: every d-region cut into pieces of MSD_TILE2 elements.  The regions are RENUMBERED on the way:
+// the non-empty ones first, 0 .. D - 1 in digit order, then the empty ones (each still gets one tile of nothing: it owes
+// its row of the joint table).  From here on "d" is that number: a digit value that never occurs in the text (a quarter
+// of the 1024 for a 39-symbol alphabet in 6-bit codes) leaves no hole in the numbering of the joint buckets (b, d), which
+// is what lets the local sort take "tag - tag of the tile's first bucket" as the bucket's number inside its tile.
+// One workgroup, thread = region.
 __global__ __launch_bounds__(MSD_BINS) void msd_tiles2_kernel(const u32 *J1, MsdTile2 *tiles, u32 *counters)
 {
     __shared__ u32 scr[MSD_BINS / kWave + 1];
     const u32 d = threadIdx.x;
     const u32 s = J1[d], e = J1[d + 1];
-    const u32 nr = max(1u, (e - s + MSD_TILE2 - 1) / MSD_TILE2);
-    u32 total = 0;
+    const u32 nr = (e - s + MSD_TILE2 - 1) / MSD_TILE2;
+    u32 total = 0, D = 0;
     const u32 first = block_excl_sum<MSD_BINS / kWave>(nr, scr, &total);
-    if (d == 0) counters[0] = total;
+    const u32 dn = block_excl_sum<MSD_BINS / kWave>(nr ? 1u : 0u, scr, &D);      // non-empty regions below this one
+    if (d == 0) counters[0] = total + (MSD_BINS - D);
+    if (nr == 0) {
+        const u32 dd = D + (d - dn);                                               // (d - dn: empty regions below)
+        tiles[total + (d - dn)] = MsdTile2{s, 0u, dd | 0x80000000u};
+    }
     for (u32 k = 0; k < nr; ++k) {
         const u32 ts = s + k * MSD_TILE2;
-        tiles[first + k] = MsdTile2{ts, min(MSD_TILE2, e - ts), d | (k + 1 == nr ? 0x80000000u : 0u)};
+        tiles[first + k] = MsdTile2{ts, min(MSD_TILE2, e - ts), dn | (k + 1 == nr ? 0x80000000u : 0u)};
     }
 }
-
-// A look-back word: two state bits over a 30-bit number (n < 2^30 on this path).  A: the tile's own count of the bin;
-// P: where the bin stands after the tile -- start of the bin's bucket + everything up to and including the tile.
-constexpr u32 LB_A = 1u << 30, LB_P = 2u << 30, LB_STATE = 3u << 30, LB_VALUE = LB_A - 1u;
-constexpr int LB_WINDOW = 4;                         // predecessors asked per trip (their loads are in flight together)
 
 // Persistent workgroups, tiles by ticket (a waiting tile's predecessors all hold earlier tickets, hence run).  Per tile:
 // load, rank with one returning LDS atomic per element, publish the 1024 counts, add up the predecessors' (thread =
@@ -718,42 +776,8 @@ __global__ __launch_bounds__(1024) void msd_scatter_lb_kernel(MsdArgs a)
         __syncthreads();                                    // (A) counts complete; previous tile fully written out
         {
             const u32 c = hist[tid];
-            u32 *row = a.status + (size_t)t * MSD_BINS;
-            u32 off;
-            if (t == 0) {
-                off = a.Jb[tid];
-                if (tid == 0) a.J[0] = 0;
-            } else {
-                __hip_atomic_store(&row[tid], LB_A | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                u32 sum = 0, p = t;                           // predecessors not yet added: the next one is p - 1
-                bool done = false;
-                while (!done) {
-                    const u32 p0 = p;
-                    u32 v[LB_WINDOW];
-#pragma unroll
-                    for (u32 w = 0; w < (u32)LB_WINDOW; ++w) {
-                        const u32 q = p0 > w ? p0 - 1 - w : 0u;
-                        v[w] = __hip_atomic_load(&a.status[(size_t)q * MSD_BINS + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    bool stop = false;
-#pragma unroll
-                    for (u32 w = 0; w < (u32)LB_WINDOW; ++w) {
-                        if (!stop && w < p0) {
-                            const u32 st = v[w] & LB_STATE;
-                            if (st == 0) {
-                                stop = true;                  // not published yet: ask again from here
-                            } else {
-                                sum += v[w] & LB_VALUE;
-                                --p;
-                                if (st == LB_P) done = stop = true;
-                            }
-                        }
-                    }
-                    if (p == 0) done = true;                  // (tile 0 publishes P: never the way out)
-                }
-                off = sum;
-            }
-            __hip_atomic_store(&row[tid], LB_P | (off + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == 0 && tid == 0) a.J[0] = 0;
+            const u32 off = lb_resolve(a.status, t, c, a.Jb[tid]);
             // the last tile of d-region d: where bin b stands now is the end of joint bucket (b, d)
             if (td.d_last >> 31) a.J[(size_t)tid * MSD_BINS + (td.d_last & (MSD_BINS - 1u)) + 1u] = off + c;
             const u32 ex = block_excl_sum<BLOCK / kWave>(c, scr, nullptr);
@@ -862,7 +886,6 @@ __global__ __launch_bounds__(256) void msd_tiles_kernel(const u32 *cstart, u32 n
 
 struct MsdTile {
     u32 e0, count, tag0, nb;      // first element, elements, tag of the first bucket, buckets
-    u64 map;                      // LSD order: bit i = joint bucket (block of 64) + i is one of the tile's buckets
 };
 
 // ---- output of a sorted tile ------------------------------------------------------------------------
@@ -980,18 +1003,6 @@ __global__ __launch_bounds__(256) void msd_gather_kernel(const MsdTile *tiles, c
 // [ bucket number inside the tile | remaining key bits | suffix index ] -- stable 8-bit LSD passes
 // over the bucket and key bits (the index bits ride along), wave-ballot ranking as in radix_sort.hip.
 // This is the general (slower) form: it takes whatever the fast kernel below hands back.
-// RAW (LSD order): the element's tag is its joint bucket number mod 64; its bucket number inside the tile = non-empty
-// buckets of the tile below it, a popcount over the tile's map.
-template <bool RAW>
-__device__ __forceinline__ u64 msd_retag(u64 x, const MsdTile &td, u64 tag_base, int low_bits)
-{
-    if (!RAW) return x - tag_base;
-    const u32 tg = (u32)(x >> low_bits);
-    const u32 dn = (u32)__popcll(td.map & ((1ull << tg) - 1ull));
-    return (x & ((1ull << low_bits) - 1ull)) | ((u64)dn << low_bits);
-}
-
-template <bool RAW>
 __global__ __launch_bounds__(MSD_BLOCK) void msd_local_sort_kernel(const u64 *in, const MsdTile *tiles, int rem_bits, int idx_bits,
                                                                      u32 *sa_out, const u32 *tile_list, int fused, MsdEmit em_val)
 {
@@ -1014,7 +1025,7 @@ __global__ __launch_bounds__(MSD_BLOCK) void msd_local_sort_kernel(const u64 *in
     for (int r = 0; r < MSD_IPT; ++r) {
         const u32 p = wave * (kWave * MSD_IPT) + r * kWave + lane;
         // [bucket inside the tile | remaining key bits | index] (G2 tagged the element with its bucket's number); ~0: padding
-        key[r] = p < count ? msd_retag<RAW>(in[e0 + p], td, tag_base, rem_bits + idx_bits) : ~0ull;
+        key[r] = p < count ? in[e0 + p] - tag_base : ~0ull;
     }
     const int sort_bits = rem_bits + seg_bits;
     for (int shift = idx_bits; shift < idx_bits + sort_bits; shift += 8) {
@@ -1115,11 +1126,12 @@ __global__ __launch_bounds__(256) void msd_tile_desc_kernel(const u32 *cstart, c
     const u32 k0 = tile_first[t], k1 = tile_first[t + 1];
     const u32 e0 = cstart[k0], e1 = k1 < ne ? cstart[k1] : n;
     if (cj) {
-        u64 map = 0;                                   // (<= 64 buckets: the tile lies inside one block of 64 joint buckets)
-        for (u32 k = k0; k < k1; ++k) map |= 1ull << (cj[k] & (MSD_RAW_TAG_SPAN - 1u));
-        tiles[t] = MsdTile{e0, e1 - e0, cj[k0] & (MSD_RAW_TAG_SPAN - 1u), k1 - k0, map};
+        // LSD order: the tag is the joint bucket number mod 64, the tile lies inside one block of 64: "buckets" = the span of
+        // its tags (a joint bucket that is empty between two of them just takes a number)
+        const u32 t0 = cj[k0] & (MSD_RAW_TAG_SPAN - 1u), t1 = cj[k1 - 1] & (MSD_RAW_TAG_SPAN - 1u);
+        tiles[t] = MsdTile{e0, e1 - e0, t0, t1 - t0 + 1u};
     } else {
-        tiles[t] = MsdTile{e0, e1 - e0, k0 & (MSD_TAG_SPAN - 1u), k1 - k0, 0ull};
+        tiles[t] = MsdTile{e0, e1 - e0, k0 & (MSD_TAG_SPAN - 1u), k1 - k0};
     }
 }
 
@@ -1138,7 +1150,6 @@ __device__ __forceinline__ void lds_barrier()
 // memory most of the time.  The workgroups therefore persist (two per CU) and walk over the tiles with the
 // loads one tile ahead: descriptor two tiles ahead, bucket starts and elements of the next tile issued as
 // soon as the registers of the current one are free, landing while the current tile is being sorted.
-template <bool RAW>
 __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 *in, const MsdTile *tiles, u32 nt, int rem_bits,
                                                                      int idx_bits, u32 *sa_out, u32 *fail_list, u32 *fail_count,
                                                                      int fused, MsdEmit em_val)
@@ -1157,7 +1168,7 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
     u32 t = blockIdx.x;
     if (t >= nt) return;
     MsdTile cur = tiles[t];
-    MsdTile nxt = t + stride < nt ? tiles[t + stride] : MsdTile{0, 0, 0, 0, 0};
+    MsdTile nxt = t + stride < nt ? tiles[t + stride] : MsdTile{0, 0, 0, 0};
     u64 pe[MSD_IPT];          // prefetched raw elements of the tile about to be sorted
     auto prefetch = [&](const MsdTile &d) {
 #pragma unroll
@@ -1195,7 +1206,7 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
                 const u32 p = r * MSD_BLOCK + tid;
                 if (p < count) {
                     // the element carries its bucket (G2 put it there): [bucket inside the tile | remaining key bits | index]
-                    e[r] = msd_retag<RAW>(pe[r], cur, tag_base, rem_bits + idx_bits);
+                    e[r] = pe[r] - tag_base;
                     const u32 bin = (u32)(e[r] >> bin_shift);
                     atomicAdd(&hist[bin >> 1], 1u << (16u * (bin & 1u)));    // count now; the slot is taken after the scan
                 }
@@ -1248,6 +1259,8 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
                 }
             }
         }
+        // sentinels behind the tile: the ranking window of the last bins reads them (count + 7 < the scalars' slots: MSD_TILE_CAP)
+        if (tid < (u32)LS_WINDOW) exch[count + tid] = ~0ull;
         lds_barrier();
         // Place inside the bin = number of smaller elements there (thread <-> position: neighbours share the bin, their
         // reads are broadcasts).  The kernel is bound by the latency of dependent LDS reads, not by their number: every
@@ -1284,7 +1297,9 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
 #pragma unroll
                     for (int k = 0; k < LS_WINDOW; ++k) {
                         keep_load(y[j][k]);      // (or the compiler makes every read conditional on k < len: a branch and a wait per read)
-                        c += ((u32)k < len[j] ? 1u : 0u) & (y[j][k] < x[j] ? 1u : 0u);
+                        // (no "k < len": what lies behind my bin in the window belongs to LATER bins -- larger numbers, the
+                        // elements being in bin order -- or is a sentinel; eight compares and eight mask operations fewer per element)
+                        c += y[j][k] < x[j] ? 1u : 0u;
                     }
                     sm[j] = c;
                 }
@@ -1368,7 +1383,7 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
         if (!more) break;
         t += stride;
         cur = nxt;
-        nxt = t + stride < nt ? tiles[t + stride] : MsdTile{0, 0, 0, 0, 0};
+        nxt = t + stride < nt ? tiles[t + stride] : MsdTile{0, 0, 0, 0};
     }
     if (em) {
         lds_barrier();
@@ -1422,8 +1437,10 @@ int msd_max_key_bits(uint32_t n)
 {
     int ib = 1;
     while ((1ull << ib) < (u64)n) ++ib;
-    // [bucket tag | K - 20 key bits | ib index bits] must fit 64 bits after the second pass: an 11-bit tag, or 6 bits in LSD order
-    return 64 + MSD_D - (msd_use_lsd(n) ? MSD_RAW_TAG_BITS : MSD_TAG_BITS) - ib + MSD_D;
+    // [bucket tag | K - 20 key bits | ib index bits] must fit 64 bits after the second pass (an 11-bit tag, or 6 bits in LSD
+    // order), and [K - 10 key bits | ib index bits] after the first
+    const int after2 = 64 + MSD_D - (msd_use_lsd(n) ? MSD_RAW_TAG_BITS : MSD_TAG_BITS) - ib + MSD_D;
+    return std::min(after2, 64 + MSD_D - ib);
 }
 
 int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bits, uint64_t *A[2], uint32_t *sa_out,
@@ -1541,7 +1558,8 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     // (second pass, with its sixteen loads per thread issued before the ranking atomics) at 2^29; 512 threads x 32 elements
     // spill.  PSS_MSD_SCATTER=1: the 8192-element kernels.
     const bool wide = lsd || !(getenv("PSS_MSD_SCATTER") && atoi(getenv("PSS_MSD_SCATTER")) == 1);
-    if (wide) hipLaunchKernelGGL((msd_scatter2_kernel<true, 1024>), dim3(a.num_ranges1), dim3(1024), 0, s, a);
+    if (lsd) hipLaunchKernelGGL((msd_scatter2_kernel<true, 1024, true>), dim3(a.num_ranges1), dim3(1024), 0, s, a);
+    else if (wide) hipLaunchKernelGGL((msd_scatter2_kernel<true, 1024>), dim3(a.num_ranges1), dim3(1024), 0, s, a);
     else hipLaunchKernelGGL(msd_scatter_kernel<true>, dim3(a.num_ranges1), dim3(MSD_BLOCK), 0, s, a);
     PSS_TRY(mark());
     a.in = A[0];
@@ -1602,8 +1620,8 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     const int rem_bits = key_bits - 2 * MSD_D;
     hipLaunchKernelGGL(msd_tile_desc_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, cstart, tile_first, nt, ne, n, tiles_all,
                        (const u32 *)cj);
-    const auto local_sort = lsd ? msd_local_sort_kernel<true> : msd_local_sort_kernel<false>;
-    const auto local_fast = lsd ? msd_local_fast_kernel<true> : msd_local_fast_kernel<false>;
+    const auto local_sort = msd_local_sort_kernel;
+    const auto local_fast = msd_local_fast_kernel;
     if (getenv("PSS_MSD_SLOW_LOCAL")) {
         hipLaunchKernelGGL(local_sort, dim3(nt), dim3(MSD_BLOCK), 0, s, A[1], (const MsdTile *)tiles_all, rem_bits, ib,
                            sa_out, (const u32 *)nullptr, fused, em);

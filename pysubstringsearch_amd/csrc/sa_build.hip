@@ -3470,7 +3470,9 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     bool msd_done = false, msd_fused = false;
     u32 msd_active = 0;
     if (ties && knobs.msd != 0) {
-        int kb = std::min(msd_max_key_bits(n), 42);
+        // (at n = 2^29 an element holds 45 key bits after the first pass; smaller texts leave room for up to 48)
+        static const int key_cap = [] { const char *e = getenv("PSS_MSD_KEY_CAP"); return e ? atoi(e) : 48; }();
+        int kb = std::min(msd_max_key_bits(n), std::max(key_cap, 21));
         const int kc = std::min(kb / b, kmax);                   // whole symbols only
         kb = kc * b;
         const bool fits = kc >= 1 && kb >= 21 && !plus_one;

@@ -135,128 +135,113 @@ struct LbArgs {
 };
 
 // One tile: load, rank with returning LDS atomics, offsets (table or look-back), stage through LDS in two pieces, write.
-// WPE = waves per SIMD the register allocation aims at: 4 = one workgroup per CU (what the product's 1024-thread scatter
-// kernels get: ~100 VGPRs), 8 = two per CU (64 VGPRs: the sixteen elements and their ranks spill a little).
-// W = predecessors read per look-back trip.  PREFETCH: the next ticket is taken and its sixteen loads are issued before
-// this tile's look-back, so they land while it waits and writes (the ticket ORDER is what the chain relies on, and the
-// smallest unfinished ticket is always somebody's current tile: no deadlock).
-template <bool LOOKBACK, int WPE, int W, bool PREFETCH>
-__global__ __launch_bounds__(BLOCK, WPE) void scatter_kernel(LbArgs a)
+// W = predecessors read per look-back trip.  ORDER: where the look-back sits in the tile's schedule --
+//   0  publish, look back (all trips), then scan the bins and stage
+//   1  publish, first trip's loads issued, scan the bins, then the look-back consumes them (and goes on if it must)
+//   2  ... and the first piece is staged into LDS before the look-back is consumed (only the OUTPUT needs the offsets)
+// The ticket is taken right before the tile's loads (taking the next ticket early -- to prefetch its elements -- makes
+// the time between a ticket and its counts depend on how long the previous tile waited, and the chain behind it waits
+// for the slowest: measured, 2.77 vs 2.48 ms).
+template <bool LOOKBACK, int W, int ORDER>
+__global__ __launch_bounds__(BLOCK) void scatter_kernel(LbArgs a)
 {
     __shared__ __attribute__((aligned(16))) u64 exch[PIECE];
     __shared__ u32 hist[BINS], s_delta[BINS];
     __shared__ u16 s_start[BINS];
     __shared__ u32 scr[BLOCK / 64 + 1];
-    __shared__ u32 s_ticket[2];
+    __shared__ u32 s_ticket;
     const u32 tid = threadIdx.x;
-    // ticket -> tile (the chains advance side by side), position of the tile in its chain
-    auto tile_of = [&](u32 k, u32 &tc) -> u32 {
-        if (!LOOKBACK) { tc = 0; return k; }
-        const u32 c = k % a.chains;
-        tc = k / a.chains;
-        return c * a.tiles_per_chain + tc;
-    };
-    auto load = [&](u32 t, u64 (&e)[IPT]) {
+    hist[tid] = 0;
+    __syncthreads();
+    for (;;) {
+        if (tid == 0) s_ticket = atomicAdd(a.ticket, 1u);
+        __syncthreads();
+        const u32 k = s_ticket;
+        if (k >= a.nt) break;
+        u32 t = k, tc = k;
+        if (LOOKBACK) {
+            const u32 c = k % a.chains;
+            tc = k / a.chains;
+            t = c * a.tiles_per_chain + tc;
+        }
         const u32 base = t * TILE;
         const u32 valid = min(TILE, a.n - base);
+        u64 elem[IPT];
+        u32 lp[IPT];
 #pragma unroll
         for (u32 j = 0; j < IPT; ++j) {
             const u32 p = j * BLOCK + tid;
-            e[j] = p < valid ? a.in[base + p] : 0ull;
+            elem[j] = p < valid ? a.in[base + p] : 0ull;
         }
-    };
-    hist[tid] = 0;
-    if (tid == 0) s_ticket[0] = atomicAdd(a.ticket, 1u);
-    __syncthreads();
-    u32 k = s_ticket[0], par = 0;
-    if (k >= a.nt) return;
-    u32 tc;
-    u32 t = tile_of(k, tc);
-    u64 elem[IPT];
-    load(t, elem);
-    for (;;) {
-        const u32 base = t * TILE;
-        const u32 valid = min(TILE, a.n - base);
-        u32 lp[IPT];
 #pragma unroll
         for (u32 j = 0; j < IPT; ++j) {
             const u32 p = j * BLOCK + tid;
             const u32 d = (u32)(elem[j] >> SHIFT) & (BINS - 1u);
             lp[j] = p < valid ? (atomicAdd(&hist[d], 1u) | (d << 22)) : 0xffffffffu;
         }
-        if (tid == 0) s_ticket[par ^ 1u] = atomicAdd(a.ticket, 1u);
         __syncthreads();                                    // (A) counts complete; previous tile fully written out
-        const u32 kn = s_ticket[par ^ 1u];
-        u32 tcn = 0;
-        const u32 tn = kn < a.nt ? tile_of(kn, tcn) : 0u;
-        u64 nxt[IPT];
-        if (PREFETCH && kn < a.nt) load(tn, nxt);
-        {
-            const u32 c = hist[tid];
-            u32 off = 0;
-            u32 *row = a.status + (size_t)t * BINS;
-            u32 v[W];
-            u32 p = tc;                                     // predecessors of the chain not yet added: the next one is p - 1
-            if (LOOKBACK) {
-                if (tc == 0) {
-                    off = a.base[(size_t)(t / a.tiles_per_chain) * BINS + tid];
-                } else {
-                    __hip_atomic_store(&row[tid], ST_A | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u32 c = hist[tid];
+        u32 *row = a.status + (size_t)t * BINS;
+        u32 off = 0, rows = 0;
+        u32 v[W];
+        u32 p = tc;                                         // predecessors of the chain not yet added: the next one is p - 1
+        auto ask = [&]() {
 #pragma unroll
-                    for (u32 w = 0; w < (u32)W; ++w) {        // the first trip is on its way while the bins are scanned
-                        const u32 q = p > w ? p - 1 - w : 0u;
-                        v[w] = __hip_atomic_load(&a.status[(size_t)(t - tc + q) * BINS + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            } else {
-                off = a.T[(size_t)t * BINS + tid];
+            for (u32 w = 0; w < (u32)W; ++w) {
+                const u32 q = p > w ? p - 1 - w : 0u;
+                v[w] = __hip_atomic_load(&a.status[(size_t)(t - tc + q) * BINS + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            const u32 ex = block_excl_sum(c, scr);
-            s_start[tid] = (u16)ex;
-            hist[tid] = 0;
-            if (LOOKBACK) {
-                u32 rows = 0;
-                if (tc != 0) {
-                    u32 sum = 0;
-                    bool done = false;
-                    for (;;) {
-                        const u32 p0 = p;
-                        ++rows;
-                        bool stop = false;
+        };
+        auto lookback = [&](bool asked) {
+            if (tc == 0) {
+                off = a.base[(size_t)(t / a.tiles_per_chain) * BINS + tid];
+            } else {
+                u32 sum = 0;
+                for (;;) {
+                    if (!asked) ask();
+                    asked = false;
+                    const u32 p0 = p;
+                    ++rows;
+                    bool stop = false, done = false;
 #pragma unroll
-                        for (u32 w = 0; w < (u32)W; ++w) {
-                            if (!stop && w < p0) {
-                                const u32 st = v[w] & ST_MASK;
-                                if (st == 0) {
-                                    stop = true;              // not published yet: ask again from here
-                                } else {
-                                    sum += v[w] & VAL_MASK;
-                                    --p;
-                                    if (st == ST_P) done = stop = true;
-                                }
+                    for (u32 w = 0; w < (u32)W; ++w) {
+                        if (!stop && w < p0) {
+                            const u32 st = v[w] & ST_MASK;
+                            if (st == 0) {
+                                stop = true;              // not published yet: ask again from here
+                            } else {
+                                sum += v[w] & VAL_MASK;
+                                --p;
+                                if (st == ST_P) done = stop = true;
                             }
                         }
-                        if (done || p == 0) break;            // (the chain's first tile publishes P: p == 0 is never the way out)
-#pragma unroll
-                        for (u32 w = 0; w < (u32)W; ++w) {
-                            const u32 q = p > w ? p - 1 - w : 0u;
-                            v[w] = __hip_atomic_load(&a.status[(size_t)(t - tc + q) * BINS + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
                     }
-                    off = sum;
+                    if (done || p == 0) break;
                 }
-                __hip_atomic_store(&row[tid], ST_P | (off + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (a.depth) {
-                    u32 m = rows;                             // the slowest lane of the tile
-#pragma unroll
-                    for (int o = 32; o; o >>= 1) m = max(m, (u32)__shfl_xor((int)m, o));
-                    if ((tid & 63u) == 0) atomicMax(&a.depth[t], m);
-                }
-                // the last tile of a d-region: its inclusive prefixes are the ends of the joint buckets (b, d)
-                if ((t + 1) % a.tiles_per_region == 0) a.J[(size_t)tid * BINS + t / a.tiles_per_region] = off + c;
+                off = sum;
             }
-            s_delta[tid] = off - ex;
+            __hip_atomic_store(&row[tid], ST_P | (off + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.depth) {
+                u32 m = rows;                             // the slowest lane of the tile
+#pragma unroll
+                for (int o = 32; o; o >>= 1) m = max(m, (u32)__shfl_xor((int)m, o));
+                if ((tid & 63u) == 0) atomicMax(&a.depth[t], m);
+            }
+            // the last tile of a d-region: its inclusive prefixes are the ends of the joint buckets (b, d)
+            if ((t + 1) % a.tiles_per_region == 0) a.J[(size_t)tid * BINS + t / a.tiles_per_region] = off + c;
+        };
+        if (LOOKBACK) {
+            if (tc != 0) __hip_atomic_store(&row[tid], ST_A | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ORDER == 0) lookback(false);
+            else if (tc != 0) ask();
+        } else {
+            off = a.T[(size_t)t * BINS + tid];
         }
+        const u32 ex = block_excl_sum(c, scr);
+        s_start[tid] = (u16)ex;
+        hist[tid] = 0;
+        if (LOOKBACK && ORDER == 1) lookback(true);
+        if (!LOOKBACK || ORDER != 2) s_delta[tid] = off - ex;
         __syncthreads();                                    // (B) bin starts published
 #pragma unroll
         for (u32 j = 0; j < IPT; ++j)
@@ -270,6 +255,10 @@ __global__ __launch_bounds__(BLOCK, WPE) void scatter_kernel(LbArgs a)
                 const u32 q = lp[j] - h * PIECE;
                 if (q < PIECE) exch[q] = elem[j];
             }
+            if (LOOKBACK && ORDER == 2 && h == 0) {
+                lookback(true);
+                s_delta[tid] = off - ex;
+            }
             __syncthreads();                                // (C) the piece in bin order
 #pragma unroll
             for (u32 j = 0; j < PIECE / BLOCK; ++j) {
@@ -280,17 +269,6 @@ __global__ __launch_bounds__(BLOCK, WPE) void scatter_kernel(LbArgs a)
                     a.out[s_delta[d] + pp] = e;
                 }
             }
-        }
-        if (kn >= a.nt) break;
-        k = kn;
-        t = tn;
-        tc = tcn;
-        par ^= 1u;
-        if (PREFETCH) {
-#pragma unroll
-            for (u32 j = 0; j < IPT; ++j) elem[j] = nxt[j];
-        } else {
-            load(t, elem);
         }
     }
 }
@@ -363,11 +341,11 @@ int main(int argc, char **argv)
     typedef void (*Kern)(LbArgs);
     struct Variant { const char *name; Kern table, lb; u32 wgs_per_cu; };
     const Variant variants[] = {
-        {"1 wg/CU, window 4", scatter_kernel<false, 4, 4, false>, scatter_kernel<true, 4, 4, false>, 1},
-        {"1 wg/CU, window 8", scatter_kernel<false, 4, 4, false>, scatter_kernel<true, 4, 8, false>, 1},
-        {"1 wg/CU, window 4, next tile prefetched", scatter_kernel<false, 4, 4, true>, scatter_kernel<true, 4, 4, true>, 1},
-        {"1 wg/CU, window 8, next tile prefetched", scatter_kernel<false, 4, 4, true>, scatter_kernel<true, 4, 8, true>, 1},
-        {"2 wg/CU (64 VGPRs, spills), window 4", scatter_kernel<false, 8, 4, false>, scatter_kernel<true, 8, 4, false>, 2},
+        {"window 4, look back then scan", scatter_kernel<false, 4, 0>, scatter_kernel<true, 4, 0>, 1},
+        {"window 8, look back then scan", scatter_kernel<false, 4, 0>, scatter_kernel<true, 8, 0>, 1},
+        {"window 4, asked before the scan", scatter_kernel<false, 4, 0>, scatter_kernel<true, 4, 1>, 1},
+        {"window 4, asked before the scan, consumed after the first piece is staged", scatter_kernel<false, 4, 0>, scatter_kernel<true, 4, 2>, 1},
+        {"window 8, asked before the scan, consumed after the first piece is staged", scatter_kernel<false, 4, 0>, scatter_kernel<true, 8, 2>, 1},
     };
     float ms_h = 0;
     for (int r = 0; r < reps; ++r) {
@@ -406,7 +384,7 @@ int main(int argc, char **argv)
         if (check("table", &ref_sum)) return 1;
     }
     // ---- look-back modes ----
-    const u32 chain_counts[] = {1, 4, 16, 64};
+    const u32 chain_counts[] = {1, 8};
     for (u32 C : chain_counts) {
         const u32 tiles_per_chain = nt / C;
         if (tiles_per_chain % tiles_per_region) { printf("lb%u: chains do not end at region borders, skipped\n", C); continue; }
