@@ -33,7 +33,7 @@ int msd_max_key_bits(uint32_t n);
 // of (packed text key >> text->drop), bit 31 = "same key as my predecessor".  The order among equal
 // keys is unspecified (suffix_sort_flags leaves them by index; nothing downstream relies on that).
 // *accepted = false (and sa_out untouched) when some joint bucket exceeds what a workgroup sorts in
-// LDS: the caller then uses suffix_sort_flags.  h_small: >= 32 bytes of pinned host memory.
+// LDS: the caller then uses suffix_sort_flags.  h_small: >= 64 bytes of pinned host memory.
 // `front` (optional): the codes do not exist yet -- the first histogram pass makes them on its way through the raw text
 // (codes[i] = lut[T[i]], the buffer behind text->codes is written; its padding past n must be zero already) and raises
 // *bad when a byte has no code in `lut` (then the sort declines: *accepted = false, stats->bad_symbol = 1).

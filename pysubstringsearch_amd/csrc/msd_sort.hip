@@ -875,6 +875,29 @@ struct InTileHead {
     __device__ u64 operator()(u64 k) const { return msd_tile_head(cstart, ne, n, (u32)k, tp) ? 1u : 0u; }
 };
 
+// The same with the number of non-empty buckets read on the device (LSD order: the whole plan is launched without a
+// host round trip; the scan runs over all 2^20 bucket numbers, those from *nep on count nothing).
+struct InTileHeadDev {
+    const u32 *cstart;
+    const u64 *nep;
+    u32 n;
+    TilePlan tp;
+    __device__ u64 operator()(u64 k) const
+    {
+        const u32 ne = (u32)*nep;
+        return (k < ne && msd_tile_head(cstart, ne, n, (u32)k, tp)) ? 1u : 0u;
+    }
+};
+__global__ __launch_bounds__(256) void msd_tiles_dev_kernel(const u32 *cstart, const u64 *nep, u32 n, const u64 *rank, const u64 *total,
+                                                              u32 *tile_first, TilePlan tp)
+{
+    const u32 ne = (u32)*nep;
+    if (blockIdx.x == 0 && threadIdx.x == 0) tile_first[*total] = ne;      // sentinel behind the last tile
+    for (u32 k = blockIdx.x * blockDim.x + threadIdx.x; k < ne; k += gridDim.x * blockDim.x) {
+        if (msd_tile_head(cstart, ne, n, k, tp)) tile_first[rank[k]] = k;
+    }
+}
+
 __global__ __launch_bounds__(256) void msd_tiles_kernel(const u32 *cstart, u32 ne, u32 n, const u64 *rank, const u64 *total,
                                                           u32 *tile_first, TilePlan tp)
 {
@@ -1119,9 +1142,13 @@ constexpr int LS_GROUP = PSS_LS_GROUP;              // rows ranked / written out
 constexpr int LS_WINDOW = PSS_LS_WINDOW;                        // members of its bin every element reads unconditionally (bins average 1.3)
 
 __global__ __launch_bounds__(256) void msd_tile_desc_kernel(const u32 *cstart, const u32 *tile_first, u32 nt, u32 ne, u32 n,
-                                                              MsdTile *tiles, const u32 *cj)
+                                                              MsdTile *tiles, const u32 *cj, const u64 *ntp, const u64 *nep)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ntp) {                     // (counts on the device: see InTileHeadDev)
+        nt = (u32)*ntp;
+        ne = (u32)*nep;
+    }
     if (t >= nt) return;
     const u32 k0 = tile_first[t], k1 = tile_first[t + 1];
     const u32 e0 = cstart[k0], e1 = k1 < ne ? cstart[k1] : n;
@@ -1150,10 +1177,18 @@ __device__ __forceinline__ void lds_barrier()
 // memory most of the time.  The workgroups therefore persist (two per CU) and walk over the tiles with the
 // loads one tile ahead: descriptor two tiles ahead, bucket starts and elements of the next tile issued as
 // soon as the registers of the current one are free, landing while the current tile is being sorted.
+// nt_dev (optional): the number of tiles is read on the device, and the kernel does nothing when the plan it would run on
+// is not to be used -- a bucket beyond a tile (counters[1]) or a byte without a code (*bad_dev): the host learns both after
+// the launch, in the one round trip of the sort.
 __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 *in, const MsdTile *tiles, u32 nt, int rem_bits,
                                                                      int idx_bits, u32 *sa_out, u32 *fail_list, u32 *fail_count,
-                                                                     int fused, MsdEmit em_val)
+                                                                     int fused, MsdEmit em_val, const u64 *nt_dev,
+                                                                     const u32 *counters_dev, const u32 *bad_dev)
 {
+    if (nt_dev) {
+        if (counters_dev[1] > MSD_MAX_BUCKET || (bad_dev && *bad_dev)) return;
+        nt = (u32)*nt_dev;
+    }
     const MsdEmit *em = fused ? &em_val : nullptr;
     // 80 KiB of LDS to the byte: two workgroups per CU.  One array: the tile, then the counters -- the ranking below reads
     // up to LS_WINDOW - 1 elements past the tile's last slot (masked out afterwards), and those reads must stay inside it.
@@ -1273,17 +1308,13 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
         for (int g = 0; g < MSD_IPT; g += LS_GROUP) {
             if ((u32)g < rows) {
                 u64 x[LS_GROUP];
-                u32 s0[LS_GROUP], len[LS_GROUP], sm[LS_GROUP];
+                u32 s0[LS_GROUP], sm[LS_GROUP];
 #pragma unroll
                 for (int j = 0; j < LS_GROUP; ++j) x[j] = exch[(g + j) * MSD_BLOCK + tid];
 #pragma unroll
                 for (int j = 0; j < LS_GROUP; ++j) {
-                    const u32 p = (g + j) * MSD_BLOCK + tid;
                     const u32 bin = (u32)(x[j] >> bin_shift) & (LS_BINS - 1u);      // (a slot past the tile holds anything)
                     s0[j] = starts16[bin];
-                    const u32 nx = starts16[min(bin + 1u, LS_BINS - 1u)];
-                    const u32 s1 = bin + 1u < LS_BINS ? nx : count;
-                    len[j] = p < count ? s1 - s0[j] : 0u;
                 }
                 u64 y[LS_GROUP][LS_WINDOW];
 #pragma unroll
@@ -1305,11 +1336,17 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_local_fast_kernel(const u64 
                 }
 #pragma unroll
                 for (int j = 0; j < LS_GROUP; ++j) {
-                    if (len[j] > (u32)LS_WINDOW) {
-                        if (len[j] > LS_KMAX) {
+                    // the window's last member still in my bin: the bin may go on (rare: bins average 1.3 elements) -- only then
+                    // is its length looked up (the bin's end = the next bin's start)
+                    const u32 p = (g + j) * MSD_BLOCK + tid;
+                    if (p < count && ((y[j][LS_WINDOW - 1] ^ x[j]) >> bin_shift) == 0) {
+                        const u32 bin = (u32)(x[j] >> bin_shift) & (LS_BINS - 1u);
+                        const u32 s1 = bin + 1u < LS_BINS ? (u32)starts16[min(bin + 1u, LS_BINS - 1u)] : count;
+                        const u32 len = s1 - s0[j];
+                        if (len > LS_KMAX) {
                             s_fail = 1;
                         } else {
-                            for (u32 q = s0[j] + LS_WINDOW; q < s0[j] + len[j]; ++q) sm[j] += exch[q] < x[j] ? 1u : 0u;
+                            for (u32 q = s0[j] + LS_WINDOW; q < s0[j] + len; ++q) sm[j] += exch[q] < x[j] ? 1u : 0u;
                         }
                     }
                     e[g + j] = x[j];
@@ -1582,6 +1619,31 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     // ---- plan: non-empty joint buckets, largest bucket, tiles ----
     PSS_TRY(device_excl_scan(ctx, InNonEmpty{J}, nbk, partial, d_total, ranks));
     hipLaunchKernelGGL(msd_compact_kernel, dim3(1024), dim3(256), 0, s, J, (u32)nbk, ranks, cstart, counters, cj);
+    const int rem_bits = key_bits - 2 * MSD_D;
+    MsdEmit em{};
+    const int fused = active != nullptr;
+    if (fused) em = MsdEmit{active->st_pos, active->st_idx, blk_cnt};
+    // LSD order: nothing between here and the local sort needs the host -- the counts stay on the device (the scans run
+    // over all 2^20 bucket numbers), the local sort checks the plan's verdict itself, ONE round trip afterwards tells the
+    // host everything (rounds 2-5: three, ~0.1 ms of idle GPU each at n = 2^29).
+    const bool one_trip = lsd && !getenv("PSS_MSD_SLOW_LOCAL");
+    u64 *d_total2 = d_total + 1;
+    u32 *const fail_list_dev = tile_first + max_tiles + 16;      // (tile_first has 2 (max_tiles + 16) slots)
+    if (one_trip) {
+        const TilePlan tpd{MSD_WIN, MSD_TILE_CAP, cj};
+        PSS_TRY(device_excl_scan(ctx, InTileHeadDev{cstart, d_total, n, tpd}, nbk, partial, d_total2, ranks));
+        hipLaunchKernelGGL(msd_tiles_dev_kernel, dim3(1024), dim3(256), 0, s, cstart, (const u64 *)d_total, n, ranks, (const u64 *)d_total2,
+                           tile_first, tpd);
+        hipLaunchKernelGGL(msd_tile_desc_kernel, dim3((u32)((max_tiles + 255) / 256)), dim3(256), 0, s, cstart, tile_first, 0u, 0u, n,
+                           tiles_all, (const u32 *)cj, (const u64 *)d_total2, (const u64 *)d_total);
+        PSS_TRY(mark());            // (events 2 .. 5: second pass, then the local sort)
+        hipLaunchKernelGGL(msd_local_fast_kernel, dim3(2u * (u32)ctx->num_cus), dim3(MSD_BLOCK), 0, s, A[1], (const MsdTile *)tiles_all, 0u,
+                           rem_bits, ib, sa_out, fail_list_dev, counters + 4, fused, em, (const u64 *)d_total2, (const u32 *)counters,
+                           front ? (const u32 *)front->bad : (const u32 *)nullptr);
+        PSS_TRY(mark());
+        PSS_HIP(hipMemcpyAsync(h_small + 8, d_total2, 8, hipMemcpyDeviceToHost, s));
+        PSS_HIP(hipMemcpyAsync(h_small + 10, counters + 4, 4, hipMemcpyDeviceToHost, s));
+    }
     PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
     PSS_HIP(hipMemcpyAsync(h_small + 2, counters, 16, hipMemcpyDeviceToHost, s));
     if (front) PSS_HIP(hipMemcpyAsync(h_small + 6, front->bad, 4, hipMemcpyDeviceToHost, s));
@@ -1601,27 +1663,37 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
         else hipLaunchKernelGGL(msd_scatter_kernel<false>, dim3((u32)max_ranges2), dim3(MSD_BLOCK), 0, s, a);
         PSS_TRY(mark());
     }
+    const auto local_sort = msd_local_sort_kernel;
+    const auto local_fast = msd_local_fast_kernel;
+    u32 nt = 0;
+    u32 *fail_list = fail_list_dev;
+    if (one_trip) {
+        nt = h_small[8];
+        if ((size_t)nt > max_tiles) {
+            set_error("msd_suffix_sort: %u tiles planned, tables hold %zu (internal error)", nt, max_tiles);
+            return PSS_EDEVICE;
+        }
+        const u32 nfail = h_small[10];
+        if (stats) stats->slow_tiles = nfail;
+        if (nfail)
+            hipLaunchKernelGGL(local_sort, dim3(nfail), dim3(MSD_BLOCK), 0, s, A[1], (const MsdTile *)tiles_all, rem_bits,
+                               ib, sa_out, (const u32 *)fail_list, fused, em);
+    } else {
     const TilePlan tp{MSD_WIN, MSD_TILE_CAP, cj};
     PSS_TRY(device_excl_scan(ctx, InTileHead{cstart, ne, n, tp}, ne, partial, d_total, ranks));
     hipLaunchKernelGGL(msd_tiles_kernel, dim3(1024), dim3(256), 0, s, cstart, ne, n, ranks, (const u64 *)d_total, tile_first, tp);
     PSS_HIP(hipMemcpyAsync(h_small, d_total, 8, hipMemcpyDeviceToHost, s));
     PSS_HIP(hipStreamSynchronize(s));
-    const u32 nt = h_small[0];
+    nt = h_small[0];
     if ((size_t)nt > max_tiles) {       // cannot happen (msd_max_tiles is an upper bound of the plan): never run past the tables
         set_error("msd_suffix_sort: %u tiles planned, tables hold %zu (internal error)", nt, max_tiles);
         return PSS_EDEVICE;
     }
     PSS_TRY(mark());
     // counters[4] = tiles the fast kernel declined (their numbers go behind the tile table), [5] = active records
-    u32 *fail_list = tile_first + nt + 8;
-    MsdEmit em{};
-    const int fused = active != nullptr;
-    if (fused) em = MsdEmit{active->st_pos, active->st_idx, blk_cnt};
-    const int rem_bits = key_bits - 2 * MSD_D;
+    fail_list = tile_first + nt + 8;
     hipLaunchKernelGGL(msd_tile_desc_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, cstart, tile_first, nt, ne, n, tiles_all,
-                       (const u32 *)cj);
-    const auto local_sort = msd_local_sort_kernel;
-    const auto local_fast = msd_local_fast_kernel;
+                       (const u32 *)cj, (const u64 *)nullptr, (const u64 *)nullptr);
     if (getenv("PSS_MSD_SLOW_LOCAL")) {
         hipLaunchKernelGGL(local_sort, dim3(nt), dim3(MSD_BLOCK), 0, s, A[1], (const MsdTile *)tiles_all, rem_bits, ib,
                            sa_out, (const u32 *)nullptr, fused, em);
@@ -1629,7 +1701,7 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
         MsdTile *tiles = tiles_all;
         const u32 grid = std::min<u32>(nt, 2u * (u32)ctx->num_cus);
         hipLaunchKernelGGL(local_fast, dim3(grid), dim3(MSD_BLOCK), 0, s, A[1], (const MsdTile *)tiles, nt, rem_bits, ib,
-                           sa_out, fail_list, counters + 4, fused, em);
+                           sa_out, fail_list, counters + 4, fused, em, (const u64 *)nullptr, (const u32 *)nullptr, (const u32 *)nullptr);
         PSS_TRY(mark());            // (profile mode) the events bracket this launch alone
         PSS_HIP(hipMemcpyAsync(h_small, counters + 4, 4, hipMemcpyDeviceToHost, s));
         PSS_HIP(hipStreamSynchronize(s));
@@ -1640,6 +1712,7 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
                                ib, sa_out, (const u32 *)fail_list, fused, em);
     }
     if (getenv("PSS_MSD_SLOW_LOCAL")) PSS_TRY(mark());
+    }
     if (fused) {
         PSS_TRY(device_excl_scan(ctx, InBlkCnt{blk_cnt}, nt, partial, d_total, dst_off));
         hipLaunchKernelGGL(msd_gather_kernel, dim3((nt + 3) / 4), dim3(256), 0, s, (const MsdTile *)tiles_all, blk_cnt, dst_off, nt,
@@ -1924,7 +1997,7 @@ int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t radix, uint32_
         return PSS_EDEVICE;
     }
     hipLaunchKernelGGL(msd_tile_desc_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, cstart, tile_first, nt, ne, n, tiles_all,
-                       (const u32 *)nullptr);
+                       (const u32 *)nullptr, (const u64 *)nullptr, (const u64 *)nullptr);
     // Ties go out as flags (bit 31 = "same key as my predecessor", the contract of suffix_sort_flags), not as the records
     // of the fused first rerank: groups of equal keys cross tile boundaries here, and the flag of a tile's first element
     // takes a look at the tile before it (ss_boundary_kernel, once every tile is sorted).
