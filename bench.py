@@ -917,8 +917,9 @@ def run_chunk(args, D):
         if prof['msd']:
             # hybrid MSD initial sort (msd_sort.hip): partition from the text (1 B in, 8 B out per suffix), partition of
             # the 8-byte elements (8 in, 8 out), LDS-resident local sort (8 in, 4 out)
-            cands.append((prof['msd_ms_g1'], 'msd_scatter2_kernel<true, 1024>', 1, n, 9))
-            cands.append((prof['msd_ms_g2'], 'msd_scatter2_kernel<false, 1024>', 1, n, 16))
+            lb = bool(prof.get('msd_lookback'))      # round 6: digits in LSD order, the second pass in one sweep (look-back)
+            cands.append((prof['msd_ms_g1'], 'msd_scatter2_kernel<true, 1024, true>' if lb else 'msd_scatter2_kernel<true, 1024>', 1, n, 9))
+            cands.append((prof['msd_ms_g2'], 'msd_scatter_lb_kernel' if lb else 'msd_scatter2_kernel<false, 1024>', 1, n, 16))
             cands.append((prof['msd_ms_local'], 'msd_local_fast_kernel', 1, n, 12))
         roof = None
         if cands:
@@ -955,8 +956,9 @@ def run_chunk(args, D):
         a_model = 3 * n + 8 * n + a_sort + 80 * sa_stats['sum_active']
         if sa_stats['msd']:
             # MSD initial sort: (1 hist + 1 + 8) + (8 hist + 8 + 8) + (8 + 4) bytes per suffix; the first rerank is fused
-            # into the local sort (no pass over the flagged array)
-            a_model = 3 * n + 46 * n + 80 * sa_stats['sum_active']
+            # into the local sort (no pass over the flagged array).  With the look-back pass (round 6) the second
+            # histogram read is gone: (1 + 1 + 8) + (8 + 8) + (8 + 4) = 38
+            a_model = 3 * n + (38 if sa_stats.get('msd_lookback') else 46) * n + 80 * sa_stats['sum_active']
         measured, m_stamp = None, None
         if args.corpus == 'lines' and args.logn == 29:
             mj, m_stamp = evidence('pmc_build_traffic.json')
@@ -1033,10 +1035,13 @@ def run_chunk(args, D):
             'search_stats': last.get('search_stats'),
             'sa_stats': {k: sa_stats[k] for k in ('sigma', 'code_bits', 'key_chars', 'initial_passes', 'rounds',
                                                   'round_passes', 'sum_active', 'sort_launches', 'mode', 'key_bits', 'ms_total',
-                                                  'msd', 'msd_buckets', 'msd_max_bucket', 'msd_tiles', 'msd_slow_tiles')},
-            'initial_sort': 'hybrid MSD (2 partition passes over 8-byte [key|index] elements + LDS local sort)' if sa_stats['msd']
+                                                  'msd', 'msd_buckets', 'msd_max_bucket', 'msd_tiles', 'msd_slow_tiles', 'msd_lookback')},
+            'initial_sort': ('hybrid MSD (2 partition passes over 8-byte [key|index] elements, the second in one sweep by decoupled '
+                             'look-back, + LDS local sort)' if sa_stats.get('msd_lookback') else
+                             'hybrid MSD (2 partition passes over 8-byte [key|index] elements + LDS local sort)') if sa_stats['msd']
                             else 'LSD passes with shrinking keys',
-            'kernel_ms': ({'msd_scatter2_kernel<true, 1024>': round(prof['msd_ms_g1'], 3), 'msd_scatter2_kernel<false, 1024>': round(prof['msd_ms_g2'], 3),
+            'kernel_ms': ({('msd_scatter2_kernel<true, 1024, true>' if prof.get('msd_lookback') else 'msd_scatter2_kernel<true, 1024>'): round(prof['msd_ms_g1'], 3),
+                           ('msd_scatter_lb_kernel' if prof.get('msd_lookback') else 'msd_scatter2_kernel<false, 1024>'): round(prof['msd_ms_g2'], 3),
                            'msd_local_fast_kernel': round(prof['msd_ms_local'], 3)} if prof['msd'] else None),
             'roofline': roof,
             'build_roofline': build_roof,

@@ -181,6 +181,8 @@ typedef struct pss_sa_stats {
     double anchor_ms;          /* device time of the anchors' selection and sort */
     double ms_restarts;        /* part of ms_total: attempts given up (a remembered plan, or the shortcut of a first chunk, that
                                   this text did not fit -- the build started over without it) */
+    uint64_t msd_lookback;     /* 1: the MSD sort took its two digits in LSD order and partitioned the second pass in one sweep
+                                  (decoupled look-back, no second histogram pass: round 6; texts below 2^30 bytes) */
 } pss_sa_stats;
 
 /*
@@ -282,6 +284,10 @@ int pss_reader_open(const char *path, int32_t device, int32_t shard_index, int32
  * ("virtual devices": the parts then take turns on that GPU).  pss_reader_search_batch / count_batch / residency /
  * evict / promote work on such a reader; the device-resident result and the chunk hand-off calls do not. */
 int pss_reader_open_multi(const char *path, const int32_t *devices, int32_t n_devices, pss_reader **out);
+/* Observer of the placement above: the number of parts of the reader (1 for a single-device reader) and, in counts[0 .. cap),
+ * how many chunks each part holds -- chunk c of the file lives in part c % G, so 15 chunks over 8 devices read
+ * 2,2,2,2,2,2,2,1 ("report this imbalance").  No reference counterpart. */
+uint64_t pss_reader_part_chunks(const pss_reader *r, uint64_t *counts, uint64_t cap);
 
 /* Residency manager ("LRU when index > HBM"; the reference keeps every suffix array on disk,
  * src/lib.rs:179-189).  A reader whose suffix arrays do not all fit the HBM budget keeps a decayed per-chunk count of the

@@ -276,6 +276,15 @@ class Reader:
         return _lib.pss_reader_num_chunks(self._handle())
 
     @property
+    def chunks_per_device(self) -> typing.List[int]:
+        """Extension: how many chunks every part of the reader holds -- chunk c of the file lives on ``devices[c % G]``
+        (SURVEY 8(e)), so 15 chunks over 8 devices read ``[2, 2, 2, 2, 2, 2, 2, 1]``; one number for a single-device reader."""
+        g = int(_lib.pss_reader_part_chunks(self._handle(), None, 0))
+        buf = (ctypes.c_uint64 * max(g, 1))()
+        _lib.pss_reader_part_chunks(self._handle(), buf, g)
+        return [int(buf[i]) for i in range(g)]
+
+    @property
     def residency(self) -> dict:
         """Extension: where the resident index lives -- bytes in HBM, bytes of suffix arrays kept in
         pinned host memory (chunks beyond the HBM budget) and how many chunks that concerns."""

@@ -91,6 +91,7 @@ class SaStats(ctypes.Structure):
         ('anchor_side', ctypes.c_uint64),
         ('anchor_ms', ctypes.c_double),
         ('ms_restarts', ctypes.c_double),
+        ('msd_lookback', ctypes.c_uint64),
     ]
 
     def as_dict(self):
@@ -236,6 +237,7 @@ def _load() -> ctypes.CDLL:
         'pss_reader_add_chunk_device': (ctypes.c_int, [vp, vp, vp, u32]),
         'pss_reader_set_chunk_device': (ctypes.c_int, [vp, u64, vp, vp, u32]),
         'pss_reader_num_chunks': (u64, [vp]),
+        'pss_reader_part_chunks': (u64, [vp, ctypes.POINTER(u64), u64]),
         'pss_reader_residency': (ctypes.c_int, [vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64)]),
         'pss_reader_search_batch': (ctypes.c_int, [vp, vp, vp, u32, pvp]),
         'pss_reader_count_batch': (ctypes.c_int, [vp, vp, vp, u32, vp]),

@@ -2059,6 +2059,18 @@ extern "C" int pss_reader_chunk_tiers(const pss_reader *r, uint8_t *tiers, uint6
     return PSS_OK;
 }
 
+extern "C" uint64_t pss_reader_part_chunks(const pss_reader *r, uint64_t *counts, uint64_t cap)
+{
+    if (!r) return 0;
+    if (r->parts.empty()) {
+        if (counts && cap) counts[0] = r->chunks.size();
+        return 1;
+    }
+    for (size_t g = 0; g < r->parts.size() && g < cap; ++g)
+        if (counts) counts[g] = r->parts[g]->reader->chunks.size();
+    return r->parts.size();
+}
+
 extern "C" uint64_t pss_reader_num_chunks(const pss_reader *r)
 {
     if (!r) return 0;

@@ -11,6 +11,7 @@ struct MsdStats {
     uint32_t tiles = 0;        // local-sort workgroups
     uint32_t slow_tiles = 0;   // of them, tiles the counting kernel handed to the general (ballot LSD) kernel
     uint32_t bad_symbol = 0;   // MsdFront: a byte of the text had no code in the table it was given
+    uint32_t lookback = 0;     // digits in LSD order, second pass in one sweep (look-back)
     double ms_g1 = 0, ms_g2 = 0, ms_local = 0;   // profile mode: the two partition scatters and the local sort
 };
 

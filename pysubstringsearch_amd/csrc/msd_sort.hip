@@ -1736,7 +1736,10 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
         active->count = h_small[0];
     }
     PSS_HIP(hipGetLastError());
-    if (stats) stats->tiles = nt;
+    if (stats) {
+        stats->tiles = nt;
+        stats->lookback = lsd ? 1u : 0u;
+    }
     if (profile && nev >= 6) {
         PSS_HIP(hipStreamSynchronize(s));
         float ms = 0.f;

@@ -3514,6 +3514,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
                 st.msd = 1;
                 st.msd_tiles = ms.tiles;
                 st.msd_slow_tiles = ms.slow_tiles;
+                st.msd_lookback = ms.lookback;
                 st.msd_ms_g1 = ms.ms_g1;
                 st.msd_ms_g2 = ms.ms_g2;
                 st.msd_ms_local = ms.ms_local;

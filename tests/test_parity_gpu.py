@@ -644,6 +644,45 @@ def test_multi_device_reader_in_one_process(tmp_path, oracle):
         pysubstringsearch.Reader(p, devices=[0], device=0)
 
 
+def test_eight_way_placement_of_fifteen_chunks(tmp_path, oracle):
+    """BASELINE configs[2] / [3] shape on the one GPU of the box: a 15-chunk index opened over EIGHT parts ([0] * 8) -- chunk
+    c on part c mod 8, hence 2,2,2,2,2,2,2,1 chunks (best case 7.5 x at 8 GPUs) -- with every API answering
+    what the oracle answers.  No multi-GPU box has run this build; the first 8-GPU run shall not also be the first 8-way run."""
+    from tests.util import gen_corpus
+    src = tmp_path / 'c.txt'
+    text = gen_corpus(0, 15 << 15).tobytes()
+    src.write_bytes(text)
+    p = str(tmp_path / 'c.idx')
+    w = pysubstringsearch.Writer(p, 1 << 15)
+    w.add_entries_from_file_lines(str(src))
+    w.close()
+    o = oracle.OracleReader(p)
+    rng = np.random.default_rng(8)
+    qs = [b'', b'e', b'zzzzzz', b'a\n']
+    while len(qs) < 1500:
+        s0 = int(rng.integers(0, len(text) - 20))
+        qs.append(text[s0:s0 + int(rng.integers(1, 14))])
+    with pysubstringsearch.Reader(p, devices=[0] * 8) as r:
+        nc = r.num_chunks
+        assert nc >= 15
+        assert r.chunks_per_device == [len(range(g, nc, 8)) for g in range(8)]
+        if nc == 15:
+            assert r.chunks_per_device == [2, 2, 2, 2, 2, 2, 2, 1]
+        for batch in (qs[:1], qs[:40], qs):
+            ents, counts = r.search_batch_raw(batch)
+            oe, oc = o.search_multiple_bytes(batch)
+            assert counts == oc.tolist()
+            pos = 0
+            for c in counts:
+                assert sorted(ents[pos:pos + c]) == sorted(oe[pos:pos + c])
+                pos += c
+        assert r.count_multiple_bytes(qs[:100]) == o.search_multiple_bytes(qs[:100])[1].tolist()
+        for q in qs[4:24]:                                  # configs[2]: one query at a time over all parts
+            assert sorted(r.search_batch_raw([q])[0]) == sorted(o.search_multiple_bytes([q])[0])
+    with pysubstringsearch.Reader(p) as single:
+        assert single.chunks_per_device == [nc]
+
+
 def test_unchanged_call_uses_the_default_device_list(tmp_path, oracle, monkeypatch):
     """`Reader(path)` / `Writer(path)` exactly as a user of the reference writes them: with PSS_DEVICES set (or more
     than one GPU visible) they fan out over the device list without a `devices=` argument -- the reference's search
