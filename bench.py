@@ -756,6 +756,40 @@ def run_chunk(args, D):
         sized_ms = st.ms_total if sized_ms is None else min(sized_ms, st.ms_total)
         cold_hint = int(st.plan_hint)
 
+    # What the builder's workspace holds after the builds above (grow-only slots: the high-water mark of this corpus'
+    # route), and Seam 1: the libsais-shaped call with HOST pointers, which pays the text up (n bytes) and
+    # the suffix array down (4 n bytes) around the build -- outside the timed region, rank 0, N = 1
+    workspace = {'lines' if args.corpus == 'lines' else args.corpus: int(lib.pss_workspace_bytes(dev))}
+    seam1 = None
+    if world == 1 and not os.environ.get('PSS_BENCH_NO_SECONDARY'):
+        def host_build(t_ptr, sa_ptr):
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                rc = lib.pss_sa_build(t_ptr, sa_ptr, n, dev)
+                dt = (time.perf_counter() - t0) * 1e3
+                _ffi.check(rc)
+                best = dt if best is None else min(best, dt)
+            return best
+        try:
+            h_sa = np.empty(n, dtype=np.int32)
+            ms_pageable = host_build(host.ctypes.data, h_sa.ctypes.data)
+            ok_page = bool(sa_poly64_torch(torch.from_numpy(h_sa[:n]).cuda()) == sa_poly64_torch(dSA)) if verified is not False else None
+            del h_sa
+            p_t = torch.from_numpy(host).pin_memory()
+            p_sa = torch.empty(n, dtype=torch.int32).pin_memory()
+            ms_pinned = host_build(p_t.data_ptr(), p_sa.data_ptr())
+            del p_t, p_sa
+            seam1 = {'call': 'pss_sa_build(T, SA, n, device) with host pointers (the drop-in for libsais(T, SA, n, 0, NULL), src/lib.rs:30-36)',
+                     'build_ms_host_pointers_pageable': round(ms_pageable, 2), 'build_ms_host_pointers_pinned': round(ms_pinned, 2),
+                     'same_suffix_array_as_the_device_call': ok_page,
+                     'bytes_over_pcie': 5 * n,
+                     'pcie_gbs_pinned': round(5 * n / max(ms_pinned - build_s / args.steps * 1e3, 1e-3) / 1e6, 1),
+                     'note': 'n bytes up + 4 n bytes down around a build of build_ms_warm: the call is bound by the host link '
+                             '(2.68 GB per 512 MiB chunk), not by the build; the Writer hides it behind the next chunk (e2e leg)'}
+        except Exception as e:                       # (no room for 2 GiB of pinned memory: the figure is simply absent)
+            seam1 = {'error': repr(e)[:200]}
+
     # secondary corpus (natural-text-like LCP), outside the timed region, N = 1 only
     secondary = None
     if world == 1 and args.corpus == 'lines' and not os.environ.get('PSS_BENCH_NO_SECONDARY'):
@@ -783,6 +817,7 @@ def run_chunk(args, D):
                 ok_i, w_how = verify_sa(dSA, w_hosts[ci], 'words', ci, load_big_goldens(), want_sha=False)
                 w_ok = None if (ok_i is None or w_ok is None) else (w_ok and ok_i)
         best = sum(w_ms) / len(w_ms)
+        workspace['words'] = int(lib.pss_workspace_bytes(dev))
         del w_dTs, w_hosts
         wd = wst.as_dict()
         w_traffic, w_stamp = None, None
@@ -818,6 +853,7 @@ def run_chunk(args, D):
                 _ffi.check(lib.pss_sa_build_device(a_dT.data_ptr(), dSA.data_ptr(), n, dev, 0, ctypes.byref(ast)))
                 best = ast.ms_total if best is None else min(best, ast.ms_total)
             ad = ast.as_dict()
+            workspace[kind] = int(lib.pss_workspace_bytes(dev))
             a_ok, a_how = verify_sa(dSA, a_host, kind, 0, load_big_goldens(), want_sha=False)
             if kind in ('repeat_line', 'dup_blocks', 'mixed', 'source'):
                 # repeats that are not runs of one byte: one word repeated (closed form), duplicated blocks, natural
@@ -1009,7 +1045,13 @@ def run_chunk(args, D):
                 'source_build_ms': pick(adversarial, 'source', 'build_ms'),
                 'real_files_build_gbs': pick(real_files, 'index_build_gbs') if real_files and 'error' not in real_files else None,
                 'real_files_bytes': pick(real_files, 'bytes') if real_files and 'error' not in real_files else None,
+                'build_ms_host_pointers_pinned': pick(seam1, 'build_ms_host_pointers_pinned') if seam1 and 'error' not in seam1 else None,
+                'build_ms_host_pointers_pageable': pick(seam1, 'build_ms_host_pointers_pageable') if seam1 and 'error' not in seam1 else None,
+                'workspace_bytes': workspace,
+                'workspace_bytes_is': 'pss_workspace_bytes(device) after the builds of each corpus, in the order they ran in this '
+                                      'process (grow-only slots: a later figure includes what the earlier routes reserved)',
             },
+            'seam1_host_pointers': seam1,
             'value_cold': value_cold,
             'value_is_warm': 'steady state of a Writer: %d distinct chunks rotate through the timed loop, every build after '
                              'the first runs under the remembered plan (alphabet + choice of sort); value_cold = a build with '

@@ -65,6 +65,12 @@ int pss_reload_env(void);
  * bytes around for reuse; resident Reader chunks are not touched). */
 int pss_release_workspace(void);
 
+/* HBM (bytes) the grow-only workspaces of `device` hold right now: the suffix-array builder's buffers (~45 n bytes after a
+ * build of an n-byte chunk, more for natural text: DESIGN.md 3), its helper line's, and the scratch of the search path.
+ * Resident indexes are not counted (pss_reader_residency).  A Writer that shares a GPU with a resident Reader can see
+ * what one chunk in flight costs and give it back (pss_release_workspace).  No reference counterpart. */
+uint64_t pss_workspace_bytes(int32_t device);
+
 /* sizeof(pss_sa_stats) / sizeof(pss_search_stats) as the library was built: a binding that declares the structs itself
  * (ctypes, cgo, JNI) compares them with its own before the first call that fills one. */
 uint64_t pss_sa_stats_size(void);

@@ -26,7 +26,7 @@ try:   # C loop for result lists (csrc/pyglue.c); plain Python slicing if it was
 except ImportError:   # pragma: no cover
     _pssglue = None
 
-__all__ = ['Writer', 'Reader', 'PackedResult', 'DeviceResult', 'device_count', 'default_devices', 'release_workspace']
+__all__ = ['Writer', 'Reader', 'PackedResult', 'DeviceResult', 'device_count', 'default_devices', 'release_workspace', 'workspace_bytes']
 
 
 def device_count() -> int:
@@ -37,6 +37,12 @@ def release_workspace() -> None:
     """Free the engine's grow-only HBM workspace (suffix-array build buffers, search
     scratch) on every device; resident Reader chunks stay."""
     _ffi.check(_lib.pss_release_workspace())
+
+
+def workspace_bytes(device: int = 0) -> int:
+    """HBM the engine's grow-only workspaces of ``device`` hold right now (include/pss.h, pss_workspace_bytes): what a
+    chunk in flight costs next to a resident Reader; ``release_workspace()`` gives it back."""
+    return int(_lib.pss_workspace_bytes(int(device)))
 
 
 def default_devices() -> typing.List[int]:

@@ -100,3 +100,4 @@ def device_count() -> int: ...
 
 
 def release_workspace() -> None: ...
+def workspace_bytes(device: int = ...) -> int: ...

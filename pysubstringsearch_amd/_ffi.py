@@ -236,6 +236,7 @@ def _load() -> ctypes.CDLL:
         'pss_reader_create': (ctypes.c_int, [i32, pvp]),
         'pss_reader_add_chunk_device': (ctypes.c_int, [vp, vp, vp, u32]),
         'pss_reader_set_chunk_device': (ctypes.c_int, [vp, u64, vp, vp, u32]),
+        'pss_workspace_bytes': (u64, [i32]),
         'pss_reader_num_chunks': (u64, [vp]),
         'pss_reader_part_chunks': (u64, [vp, ctypes.POINTER(u64), u64]),
         'pss_reader_residency': (ctypes.c_int, [vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64)]),

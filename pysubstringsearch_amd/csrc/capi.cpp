@@ -242,6 +242,8 @@ extern "C" int pss_release_workspace(void)
     });
 }
 
+extern "C" uint64_t pss_workspace_bytes(int32_t device) { return workspace_bytes(device); }
+
 extern "C" uint64_t pss_sa_stats_size(void) { return sizeof(pss_sa_stats); }
 extern "C" uint64_t pss_search_stats_size(void) { return sizeof(pss_search_stats); }
 

@@ -368,6 +368,23 @@ void DeviceCtx::stop_resident()
     resident.running = false;
 }
 
+// HBM the grow-only workspaces of one device hold right now: the builder's context (and its helper line's), and the
+// search scratch of the reader side's context -- resident indexes are not workspace (pss_reader_residency reports those).
+uint64_t workspace_bytes(int device)
+{
+    if (device < 0 || device >= kMaxDevices) return 0;
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    uint64_t total = 0;
+    for (DeviceCtx *table : {g_ctx, g_bctx}) {
+        DeviceCtx &c = table[device];
+        if (c.device < 0) continue;
+        for (auto &s : c.slot) total += s.cap;
+        if (c.helper)
+            for (auto &s : c.helper->slot) total += s.cap;
+    }
+    return total;
+}
+
 void trim_all()
 {
     std::lock_guard<std::mutex> lk(g_ctx_mu);

@@ -250,6 +250,8 @@ int get_ctx(int device, DeviceCtx **out);
 int get_build_ctx(int device, DeviceCtx **out);
 // Frees every workspace slot of every context (memory pressure relief).
 void trim_all();
+// Bytes of HBM the workspace slots of one device's contexts hold right now (builder, its helper line, search scratch).
+uint64_t workspace_bytes(int device);
 
 static inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
