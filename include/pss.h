@@ -71,6 +71,12 @@ int pss_release_workspace(void);
  * what one chunk in flight costs and give it back (pss_release_workspace).  No reference counterpart. */
 uint64_t pss_workspace_bytes(int32_t device);
 
+/* The environment switches the library reads (csrc/knobs.h: one registry, every read goes through it): how many there
+ * are, and for switch i its name, what an unset switch means, the values a fuzzer may set (separated by '|'; empty: not
+ * drawn) and what it does.  The strings are static.  None of the switches changes a result.  No reference counterpart. */
+int32_t pss_knob_count(void);
+int pss_knob_info(int32_t i, const char **name, const char **dflt, const char **fuzz, const char **what);
+
 /* sizeof(pss_sa_stats) / sizeof(pss_search_stats) as the library was built: a binding that declares the structs itself
  * (ctypes, cgo, JNI) compares them with its own before the first call that fills one. */
 uint64_t pss_sa_stats_size(void);

@@ -101,6 +101,17 @@ class SaStats(ctypes.Structure):
         return d
 
 
+def knobs():
+    """The library's environment switches (csrc/knobs.h) as a list of dicts: name, default, fuzz (values a fuzzer may set), what."""
+    out = []
+    for i in range(lib.pss_knob_count()):
+        f = [ctypes.c_char_p() for _ in range(4)]
+        check(lib.pss_knob_info(i, *[ctypes.byref(x) for x in f]))
+        name, dflt, fuzz, what = [x.value.decode() for x in f]
+        out.append({'name': name, 'default': dflt, 'fuzz': [v for v in fuzz.split('|') if v], 'what': what})
+    return out
+
+
 class SearchStats(ctypes.Structure):
     _fields_ = [
         ('queries', ctypes.c_uint64),
@@ -185,7 +196,9 @@ class RcclApiTable(ctypes.Structure):
     SEND = ctypes.CFUNCTYPE(_i, _vp, _sz, _i, _i, _vp, _vp)
     RECV = ctypes.CFUNCTYPE(_i, _vp, _sz, _i, _i, _vp, _vp)
     ALL_GATHER = ctypes.CFUNCTYPE(_i, _vp, _vp, _sz, _i, _vp, _vp)
-    ERROR_STRING = ctypes.CFUNCTYPE(ctypes.c_char_p, _i)
+    # (the C side sees `const char *(*)(int)`; a c_void_p result lets a Python callback hand back the address of a buffer it
+    #  keeps alive -- a c_char_p result makes ctypes warn "memory leak in callback function" on every call)
+    ERROR_STRING = ctypes.CFUNCTYPE(ctypes.c_void_p, _i)
     _fields_ = [('get_unique_id', GET_UNIQUE_ID), ('comm_init_rank', COMM_INIT_RANK), ('comm_destroy', COMM_FN),
                 ('comm_abort', COMM_FN), ('comm_get_async_error', ASYNC_ERROR), ('group_start', GROUP_FN),
                 ('group_end', GROUP_FN), ('send', SEND), ('recv', RECV), ('all_gather', ALL_GATHER),
@@ -237,6 +250,9 @@ def _load() -> ctypes.CDLL:
         'pss_reader_add_chunk_device': (ctypes.c_int, [vp, vp, vp, u32]),
         'pss_reader_set_chunk_device': (ctypes.c_int, [vp, u64, vp, vp, u32]),
         'pss_workspace_bytes': (u64, [i32]),
+        'pss_knob_count': (i32, []),
+        'pss_knob_info': (ctypes.c_int, [i32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p),
+                                           ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p)]),
         'pss_reader_num_chunks': (u64, [vp]),
         'pss_reader_part_chunks': (u64, [vp, ctypes.POINTER(u64), u64]),
         'pss_reader_residency': (ctypes.c_int, [vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64)]),

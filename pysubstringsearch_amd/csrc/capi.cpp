@@ -32,7 +32,7 @@ constexpr int W_TEXT = 24, W_SA = 25;
 struct Phase {
     const char *name;
     std::chrono::steady_clock::time_point t0;
-    static bool on() { static const bool v = getenv("PSS_TIMING") != nullptr; return v; }
+    static bool on() { static const bool v = knob("PSS_TIMING") != nullptr; return v; }
     explicit Phase(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {}
     ~Phase()
     {
@@ -110,7 +110,7 @@ extern "C" int32_t pss_default_devices(int32_t *out, int32_t cap)
             if (*c < '0' || *c > '9') return false;
         return true;
     };
-    const char *e = getenv("PSS_DEVICES");
+    const char *e = knob("PSS_DEVICES");
     if (e && *e) {
         if (strcmp(e, "all") == 0) {
             int32_t k = 0;
@@ -139,7 +139,7 @@ extern "C" int32_t pss_default_devices(int32_t *out, int32_t cap)
     }
     // unset (or set to nothing): one process per GPU under a launcher -- ours, torchrun's, Slurm's, Open MPI's, MVAPICH's
     for (const char *var : {"PSS_DEVICE", "LOCAL_RANK", "SLURM_LOCALID", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK"}) {
-        const char *v = getenv(var);
+        const char *v = getenv(var);      // (launchers' variables, read as they are: not switches of this library)
         if (digits(v)) {
             const long d = strtol(v, nullptr, 10);
             out[0] = (int32_t)(count > 0 ? d % count : d);
@@ -243,6 +243,17 @@ extern "C" int pss_release_workspace(void)
 }
 
 extern "C" uint64_t pss_workspace_bytes(int32_t device) { return workspace_bytes(device); }
+
+extern "C" int32_t pss_knob_count(void) { return kNumKnobs; }
+extern "C" int pss_knob_info(int32_t i, const char **name, const char **dflt, const char **fuzz, const char **what)
+{
+    if (i < 0 || i >= kNumKnobs) return PSS_EINVAL;
+    if (name) *name = kKnobs[i].name;
+    if (dflt) *dflt = kKnobs[i].dflt;
+    if (fuzz) *fuzz = kKnobs[i].fuzz;
+    if (what) *what = kKnobs[i].what;
+    return PSS_OK;
+}
 
 extern "C" uint64_t pss_sa_stats_size(void) { return sizeof(pss_sa_stats); }
 extern "C" uint64_t pss_search_stats_size(void) { return sizeof(pss_search_stats); }
@@ -491,7 +502,7 @@ int download_to_file(pss_writer *w, WDevice &d, const void *src, size_t bytes, i
     IoPool &pool = IoPool::get();
     std::atomic<int> done[kWPieces];
     for (auto &x : done) x.store(1);
-    static const bool drop = getenv("PSS_EXPERIMENT_NO_FILE") != nullptr;     // measurement only: the copies without the file
+    static const bool drop = knob("PSS_EXPERIMENT_NO_FILE") != nullptr;     // measurement only: the copies without the file
     auto put = [&](size_t i) {          // piece i has landed in its staging buffer: to the pool
         const size_t o = i * piece, k = std::min(piece, bytes - o);
         if (drop) return;
@@ -878,7 +889,7 @@ extern "C" int pss_writer_open_multi(const char *path, int64_t max_chunk_len, co
         Stripes stripes;
         if (striped) {
             int S = 8;
-            if (const char *e = getenv("PSS_STRIPES")) S = std::min(64, std::max(1, atoi(e)));
+            if (const char *e = knob("PSS_STRIPES")) S = std::min(64, std::max(1, atoi(e)));
             for (int j = 0; j < S; ++j) {
                 const int sf = open(Stripes::name(path, j).c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
                 if (sf < 0) {
@@ -913,8 +924,8 @@ extern "C" int pss_writer_open_multi(const char *path, int64_t max_chunk_len, co
         {
             struct statfs sf;
             w->no_mmap = !(fstatfs(fd, &sf) == 0 && (unsigned long)sf.f_type == 0x01021994ul /* TMPFS_MAGIC */);
-            if (const char *e = getenv("PSS_WRITER_MMAP")) w->no_mmap = atoi(e) == 0;
-            if (const char *e = getenv("PSS_WRITER_MMAP_MIN")) w->mmap_min = (size_t)strtoull(e, nullptr, 0);
+            if (const char *e = knob("PSS_WRITER_MMAP")) w->no_mmap = atoi(e) == 0;
+            if (const char *e = knob("PSS_WRITER_MMAP_MIN")) w->mmap_min = (size_t)strtoull(e, nullptr, 0);
             if (!w->no_mmap) {
                 w->map_fd = open(path, O_RDWR | O_CLOEXEC);       // (a file this user may not read: records are pwritten)
                 if (w->map_fd < 0) w->no_mmap = true;
@@ -925,7 +936,7 @@ extern "C" int pss_writer_open_multi(const char *path, int64_t max_chunk_len, co
         w->devs.resize((size_t)n_devices);
         for (int i = 0; i < n_devices; ++i) w->devs[(size_t)i].device = devices[i];
         w->version = format_version;
-        if (const char *ev = getenv("PSS_WRITER_HOST_BUDGET")) w->text_budget = (size_t)strtoull(ev, nullptr, 0);
+        if (const char *ev = knob("PSS_WRITER_HOST_BUDGET")) w->text_budget = (size_t)strtoull(ev, nullptr, 0);
         *out = w;
         return PSS_OK;
     });
@@ -1057,8 +1068,8 @@ extern "C" int pss_writer_add_file_lines(pss_writer *w, const char *path)
         // finishes where it lies.
         size_t pend = 0;
         size_t direct_block = (size_t)32 << 20, direct_min_room = (size_t)1 << 20;     // tests shrink both: PSS_INGEST_BLOCK, _MIN_ROOM
-        if (const char *e = getenv("PSS_INGEST_BLOCK")) direct_block = std::max<size_t>(16, (size_t)strtoull(e, nullptr, 0));
-        if (const char *e = getenv("PSS_INGEST_MIN_ROOM")) direct_min_room = std::max<size_t>(1, (size_t)strtoull(e, nullptr, 0));
+        if (const char *e = knob("PSS_INGEST_BLOCK")) direct_block = std::max<size_t>(16, (size_t)strtoull(e, nullptr, 0));
+        if (const char *e = knob("PSS_INGEST_MIN_ROOM")) direct_min_room = std::max<size_t>(1, (size_t)strtoull(e, nullptr, 0));
         auto pend_to_line = [&]() {
             if (pend) line.assign(w->buf + w->len, w->buf + w->len + pend);
             pend = 0;
@@ -1141,7 +1152,7 @@ extern "C" int pss_writer_close(pss_writer *w)
         if (w->map_fd >= 0) (void)close(w->map_fd);
         w->stripes.close_all();
         const int crc = close(w->fd);
-        if (getenv("PSS_TIMING"))
+        if (knob("PSS_TIMING"))
             fprintf(stderr, "[pss] writer close: threads and device buffers %.1f ms, close(fd) %.1f ms\n",
                     std::chrono::duration<double, std::milli>(tc1 - tc0).count(),
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc1).count());
@@ -1191,7 +1202,7 @@ struct pss_reader {
     bool low_latency = false;            // single queries through the resident kernel (pss_reader_set_low_latency)
     // entries of one chunk in the reference's order (suffix-array order of their first hit, src/lib.rs:262-276) instead of
     // the order of their leftmost match: pss_reader_set_result_order, PSS_RESULT_ORDER=sa
-    bool order_sa = getenv("PSS_RESULT_ORDER") != nullptr && strcmp(getenv("PSS_RESULT_ORDER"), "sa") == 0;
+    bool order_sa = knob("PSS_RESULT_ORDER") != nullptr && strcmp(knob("PSS_RESULT_ORDER"), "sa") == 0;
     // Residency manager ("LRU when index > HBM").  A reader with suffix arrays on the host tier keeps,
     // per chunk, a decayed count of the hits its batches found there and the number of the last batch that touched it;
     // between batches the hottest host-tier suffix array changes places with the coldest one in HBM when it is more than
@@ -1199,7 +1210,7 @@ struct pss_reader {
     std::vector<uint64_t> heat, last_touch, batch_hits;
     std::vector<uint8_t> manual;         // chunks the caller placed by hand (evict / promote): the manager leaves them alone
     uint64_t batch_seq = 0, auto_moves = 0;
-    bool auto_residency = getenv("PSS_READER_AUTO_RESIDENCY") == nullptr || atoi(getenv("PSS_READER_AUTO_RESIDENCY")) != 0;
+    bool auto_residency = knob("PSS_READER_AUTO_RESIDENCY") == nullptr || atoi(knob("PSS_READER_AUTO_RESIDENCY")) != 0;
     pss_search_stats last{};
     // A reader over several devices (pss_reader_open_multi) is a front for one reader per device -- part k holds the
     // chunks c with c % G == k on devices[k] -- each with a worker thread that answers the batch for its chunks; the
@@ -1257,9 +1268,9 @@ int reader_alloc_chunk(pss_reader *r, uint32_t n, ChunkDesc *out, pss_reader::Me
     PSS_HIP(hipSetDevice(r->device));
     pss_reader::Mem m;
     const size_t sa_bytes = round_up((size_t)n * 4 + 16, 8);
-    const bool samples = getenv("PSS_NO_KEY_SAMPLES") == nullptr;
+    const bool samples = knob("PSS_NO_KEY_SAMPLES") == nullptr;
     uint32_t shift = kSampleShift;
-    if (const char *ev = getenv("PSS_SAMPLE_SHIFT")) {      // tests: dense tables on small chunks
+    if (const char *ev = knob("PSS_SAMPLE_SHIFT")) {      // tests: dense tables on small chunks
         const int v = atoi(ev);
         if (v >= 0 && v <= 20) shift = (uint32_t)v;
     }
@@ -1275,7 +1286,7 @@ int reader_alloc_chunk(pss_reader *r, uint32_t n, ChunkDesc *out, pss_reader::Me
     uint64_t used = 0;
     for (const auto &x : r->mem) used += x.hbm_bytes;
     bool want_hbm = true;
-    if (const char *ev = getenv("PSS_READER_HBM_BUDGET"))
+    if (const char *ev = knob("PSS_READER_HBM_BUDGET"))
         want_hbm = used + m.hbm_bytes + sa_bytes + sk_bytes <= strtoull(ev, nullptr, 0);
     // (second attempt: the grow-only workspace of the builder on this device -- up to 80 bytes per byte of the largest
     // chunk it has built, the sample sort's element buffers alone 32 -- goes back before a suffix array settles for the
@@ -1299,7 +1310,7 @@ int reader_alloc_chunk(pss_reader *r, uint32_t n, ChunkDesc *out, pss_reader::Me
         e = hipMalloc(&m.sa, sa_bytes + sk_bytes);
         if (e == hipSuccess) {
             size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < kHbmReserve && !getenv("PSS_READER_HBM_BUDGET")) {
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < kHbmReserve && !knob("PSS_READER_HBM_BUDGET")) {
                 (void)hipFree(m.sa);                  // it fits, but would starve the workspaces
                 m.sa = nullptr;
             }
@@ -1941,7 +1952,7 @@ int reader_move_sa(pss_reader *r, uint64_t index, bool to_host)
 // ---- residency manager ----------------------------------------------------------------------------------------
 bool reader_hbm_room(pss_reader *r, size_t bytes)
 {
-    if (const char *ev = getenv("PSS_READER_HBM_BUDGET")) {
+    if (const char *ev = knob("PSS_READER_HBM_BUDGET")) {
         uint64_t used = 0;
         for (const auto &x : r->mem) used += x.hbm_bytes;
         return used + bytes <= strtoull(ev, nullptr, 0);
@@ -2352,7 +2363,7 @@ RcclApi &rccl_lookup()
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char *names[] = {getenv("PSS_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        const char *names[] = {knob("PSS_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
         for (const char *nm : names) {
             if (!nm || !*nm) continue;
             api.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);               // the copy the process already has (torch's), if any
@@ -2398,7 +2409,7 @@ int rccl_check(const RcclApi &a, int rc, const char *what)
 
 uint32_t rccl_default_timeout_ms()
 {
-    if (const char *e = getenv("PSS_RCCL_TIMEOUT_MS")) {
+    if (const char *e = knob("PSS_RCCL_TIMEOUT_MS")) {
         const long v = atol(e);
         if (v > 0) return (uint32_t)std::min<long>(v, 3600 * 1000L);
     }

@@ -1,6 +1,11 @@
 // common.cpp -- error state and per-device contexts.
 #include "common.h"
+#include "knobs.h"
 
+#include <atomic>
+#include <cstring>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cerrno>
 #include <unistd.h>
@@ -82,7 +87,7 @@ IoPool &IoPool::get()
 IoPool::IoPool()
 {
     int k = 0;
-    if (const char *e = getenv("PSS_IO_THREADS")) k = atoi(e);
+    if (const char *e = knob("PSS_IO_THREADS")) k = atoi(e);
     if (k <= 0) {
         const unsigned hw = std::thread::hardware_concurrency();
         k = (int)std::min<unsigned>(16u, std::max<unsigned>(8u, hw / 8));
@@ -186,17 +191,17 @@ int DeviceCtx::ensure_search_stage()
 void SearchKnobs::load()
 {
     *this = SearchKnobs{};
-    no_small_path = getenv("PSS_NO_SMALL_PATH") != nullptr;
-    no_block_path = getenv("PSS_NO_BLOCK_PATH") != nullptr;
-    no_search_stage = getenv("PSS_NO_SEARCH_STAGE") != nullptr;
-    wave_search = getenv("PSS_WAVE_SEARCH") != nullptr;
-    no_group_search = getenv("PSS_NO_GROUP_SEARCH") != nullptr;
-    no_mid_pipeline = getenv("PSS_NO_MID_PIPELINE") != nullptr;
-    no_pinned_results = getenv("PSS_NO_PINNED_RESULTS") != nullptr;
-    small_path_events = getenv("PSS_SEARCH_EVENTS") != nullptr;
-    if (const char *e = getenv("PSS_LANE_SEARCH_MIN")) lane_search_min = strtoull(e, nullptr, 0);
-    if (const char *e = getenv("PSS_RESIDENT_IDLE_US")) resident_idle_us = (uint32_t)strtoul(e, nullptr, 0);
-    if (const char *e = getenv("PSS_RESIDENT_LIFE_US")) resident_life_us = (uint32_t)strtoul(e, nullptr, 0);
+    no_small_path = knob("PSS_NO_SMALL_PATH") != nullptr;
+    no_block_path = knob("PSS_NO_BLOCK_PATH") != nullptr;
+    no_search_stage = knob("PSS_NO_SEARCH_STAGE") != nullptr;
+    wave_search = knob("PSS_WAVE_SEARCH") != nullptr;
+    no_group_search = knob("PSS_NO_GROUP_SEARCH") != nullptr;
+    no_mid_pipeline = knob("PSS_NO_MID_PIPELINE") != nullptr;
+    no_pinned_results = knob("PSS_NO_PINNED_RESULTS") != nullptr;
+    small_path_events = knob("PSS_SEARCH_EVENTS") != nullptr;
+    if (const char *e = knob("PSS_LANE_SEARCH_MIN")) lane_search_min = strtoull(e, nullptr, 0);
+    if (const char *e = knob("PSS_RESIDENT_IDLE_US")) resident_idle_us = (uint32_t)strtoul(e, nullptr, 0);
+    if (const char *e = knob("PSS_RESIDENT_LIFE_US")) resident_life_us = (uint32_t)strtoul(e, nullptr, 0);
 }
 
 static SearchKnobs g_knobs;
@@ -366,6 +371,85 @@ void DeviceCtx::stop_resident()
     resident.post(nullptr, kResidentStop);
     (void)hipStreamSynchronize(resident.stream);
     resident.running = false;
+}
+
+// ---- environment switches: the registry (knobs.h) -------------------------------------------------------------------
+const KnobDef kKnobs[] = {
+    {"PSS_KEY_CHARS", "0 (chosen)", "1|2|3|5|8|12|16", "builder: force the symbols packed into the initial sort key"},
+    {"PSS_KEY_DROP", "-1 (chosen)", "0|1|3|7", "builder: force the low bits of the last key symbol that are left out"},
+    {"PSS_NO_SAMPLE", "unset", "1", "builder: size the initial key from symbol counts even for large texts (no sizing sample)"},
+    {"PSS_NO_TIES_PASS", "unset", "1", "builder: plain 8-byte-key LSD passes and key comparison in the rerank (no tie flags)"},
+    {"PSS_MODE", "chosen", "dense|sparse|text", "builder: how ties are resolved -- doubling over an inverse suffix array, sparse (hash), text rounds"},
+    {"PSS_TEXT_ROUNDS", "5", "0|1|2|3", "builder: text rounds at most before the rank rounds"},
+    {"PSS_MSD", "-1 (screened)", "0|1|1", "initial sort: never / whenever the key fits the hybrid MSD radix sort (msd_sort.hip)"},
+    {"PSS_MSD_LSD", "1", "0|1", "MSD sort: 0 = digits in MSD order with a second histogram pass (rounds 2-5); else LSD order, second pass by look-back"},
+    {"PSS_MSD_KEY_CAP", "48", "", "MSD sort: largest key width tried (bits; the element format bounds it further)"},
+    {"PSS_MSD_NO_FUSE", "unset", "1", "MSD sort: ties flagged in the suffix array instead of emitted from the local sort"},
+    {"PSS_MSD_SLOW_LOCAL", "unset", "1", "MSD sort: the general (ballot LSD) local-sort kernel for every tile"},
+    {"PSS_MSD_SCATTER", "unset", "1", "MSD sort in MSD order: the 8192-element partition kernels of round 2"},
+    {"PSS_SS", "-1 (n >= 2^24, MSD declined)", "0|1", "initial sort: never / whenever the text has the size for it the sample sort over 16-byte elements"},
+    {"PSS_SS_SEG", "1", "0", "sample sort: 0 = every tile merge-sorted as one array instead of bucket by bucket"},
+    {"PSS_SS_WINDOW_PLAN", "unset", "1", "sample sort: tiles by the window rule of the MSD sort instead of the greedy plan"},
+    {"PSS_SS_DEBUG", "unset", "", "sample sort: print where a bucket beyond a tile came from (diagnostic)"},
+    {"PSS_NO_PLAN_CACHE", "unset", "1", "builder: forget between chunks which initial sort and alphabet the previous chunk took"},
+    {"PSS_NO_PLAN_FRONT", "unset", "1", "builder: remember the sort but not the alphabet (separate alphabet and recode passes)"},
+    {"PSS_RLE", "-1 (runs average >= 8 bytes)", "0|1|1", "builder: never / always the run-length path (rle_build.hip)"},
+    {"PSS_RLE_SORT", "unset", "1", "run-length path: expansion by the stable radix sort instead of the matrix walk"},
+    {"PSS_PERIOD", "-1 (when the text repeats one word)", "0", "builder: 0 = never the closed form for a text that repeats one word"},
+    {"PSS_ANCHOR", "-1 (texts of >= 2^20 bytes)", "0|1|1", "builder: never / whenever ties outlive the text rounds the anchor round (anchor_impl.h)"},
+    {"PSS_ANCHOR_OMEGA", "0 (as wide as the common prefix allows)", "9|12|17|33", "anchor round: force the window of the minimizers"},
+    {"PSS_ANCHOR_MIN_OMEGA", "11", "3|7|9", "anchor round: narrowest window it accepts by itself"},
+    {"PSS_ANCHOR_SIDE", "-1 (>= 2^24 bytes, sampled ties show copies)", "0|1", "anchor round: never / always sort the anchors beside the text round (second stream)"},
+    {"PSS_ANCHOR_SIDE_PCT", "8", "", "anchor round: share of sampled tied pairs that must be copies for the side line"},
+    {"PSS_ANCHOR_CAP_DIV", "5", "3|4", "anchor round: declines above n / this many anchors"},
+    {"PSS_NO_PROBE", "unset", "1", "builder: always a text round before the anchor round (no sampling of the ties)"},
+    {"PSS_PROBE_SKIP_PCT", "50", "0|20|90", "builder: no text rounds when more than this share of the sampled tied pairs are repeats"},
+    {"PSS_NO_MID_TIER", "unset", "1", "rounds: groups above 512 members all take the chained radix sorts"},
+    {"PSS_NO_MID_MERGE", "unset", "1", "rounds: groups of 513 .. 4096 members with a crowded bin take the chained sorts (no LDS merge sort)"},
+    {"PSS_BIG_MERGE", "0", "1|2", "rounds: groups above 4096 members through the segmented merge sort (2: in text rounds only)"},
+    {"PSS_NO_BIG_MERGE", "unset", "", "rounds: overrides PSS_BIG_MERGE"},
+    {"PSS_COUNT_SORT", "unset", "1", "rank rounds: groups ranked by counting instead of the merge sort"},
+    {"PSS_PERIODIC", "1", "0", "rank rounds: 0 = no periodic keys for the large groups"},
+    {"PSS_TIMING", "unset", "", "builder / Writer: per-round and per-stage trace on stderr"},
+    {"PSS_DEVICES", "all visible", "0|0,0|0,0,0|all", "devices of Reader(path) / Writer(path) without a device argument: all | comma-separated ordinals"},
+    {"PSS_DEVICE", "unset", "", "default device of a process (launchers' LOCAL_RANK etc. are honoured the same way)"},
+    {"PSS_IO_THREADS", "8 .. 16 by core count", "2|5", "file path: threads of the I/O pool"},
+    {"PSS_INGEST_BLOCK", "32 MiB", "16|40|300", "Writer: size of the direct reads of add_entries_from_file_lines"},
+    {"PSS_INGEST_MIN_ROOM", "1 MiB", "1|20", "Writer: room a chunk must have left for one direct read"},
+    {"PSS_WRITER_MMAP", "tmpfs: 1, else 0", "0|1", "Writer: records through a shared mapping (1) or pwrite (0)"},
+    {"PSS_WRITER_MMAP_MIN", "1 MiB", "16", "Writer: smallest record that goes through the mapping"},
+    {"PSS_WRITER_HOST_BUDGET", "8 GiB", "", "multi-device Writer: host text of the chunks in flight (one chunk always goes through)"},
+    {"PSS_STRIPES", "8", "", "striped container format 2: stripe files of a Writer"},
+    {"PSS_EXPERIMENT_NO_FILE", "unset", "", "measurement only: the record thread copies without writing the file"},
+    {"PSS_RESULT_ORDER", "text", "sa", "Reader: 'sa' = the reference's order inside a chunk (suffix-array order of every entry's first hit)"},
+    {"PSS_READER_HBM_BUDGET", "whatever hipMalloc grants minus 2 GiB", "", "Reader: suffix arrays beyond this many bytes of HBM stay in pinned host memory"},
+    {"PSS_READER_AUTO_RESIDENCY", "1", "", "Reader: 0 = the residency manager never moves a suffix array by itself"},
+    {"PSS_NO_KEY_SAMPLES", "unset", "", "Reader: no key-sample table"},
+    {"PSS_SAMPLE_SHIFT", "11", "", "Reader: one key sample per 2^shift suffixes"},
+    {"PSS_NO_SMALL_PATH", "unset", "1", "search: no fused single-query kernels"},
+    {"PSS_NO_BLOCK_PATH", "unset", "1", "search: small batches one wave per pair instead of one workgroup"},
+    {"PSS_NO_SEARCH_STAGE", "unset", "1", "search: no pinned staging of queries and results"},
+    {"PSS_WAVE_SEARCH", "unset", "1", "search: interval kernel one wave per pair at every batch size"},
+    {"PSS_NO_GROUP_SEARCH", "unset", "1", "search: never 16 lanes per pair"},
+    {"PSS_NO_MID_PIPELINE", "unset", "1", "search: always the general multi-kernel pipeline"},
+    {"PSS_NO_PINNED_RESULTS", "unset", "1", "search: large results into pageable memory"},
+    {"PSS_LANE_SEARCH_MIN", "8192", "1|100000", "search: pairs from which one lane per pair searches"},
+    {"PSS_SEARCH_EVENTS", "unset", "", "single-query path: HIP events around the fused kernel (fills ms_device; ~4 us per query)"},
+    {"PSS_RESIDENT_IDLE_US", "1000", "", "low-latency mode: the resident kernel leaves after this long without a query"},
+    {"PSS_RESIDENT_LIFE_US", "50000", "", "low-latency mode: ... and after this long in any case"},
+    {"PSS_TRACE_RESIDENT", "unset", "", "libpss_trace.so only: print the resident kernel's phase stamps"},
+    {"PSS_RCCL_LIB", "librccl.so of the process", "", "gather inside the C ABI: the RCCL library to load"},
+    {"PSS_RCCL_TIMEOUT_MS", "60000", "", "gather inside the C ABI: bound of every wait for the peers"},
+};
+const int kNumKnobs = (int)(sizeof(kKnobs) / sizeof(kKnobs[0]));
+
+const char *knob(const char *name)
+{
+    for (int i = 0; i < kNumKnobs; ++i)
+        if (strcmp(kKnobs[i].name, name) == 0) return getenv(name);
+    static std::atomic<bool> said{false};
+    if (!said.exchange(true)) fprintf(stderr, "[pss] %s is not in the switch registry (knobs.h): treated as unset\n", name);
+    return nullptr;
 }
 
 // HBM the grow-only workspaces of one device hold right now: the builder's context (and its helper line's), and the

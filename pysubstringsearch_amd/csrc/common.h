@@ -19,6 +19,8 @@
 
 #include "../../include/pss.h"
 
+#include "knobs.h"
+
 namespace pss {
 
 void set_error(const char *fmt, ...);

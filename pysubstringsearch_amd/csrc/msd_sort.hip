@@ -1460,7 +1460,7 @@ static size_t msd_max_tiles2(uint32_t n) { return (size_t)n / MSD_TILE2 + MSD_BI
 // passes in MSD order with the second histogram pass (rounds 2-5).
 static bool msd_use_lsd(uint32_t n)
 {
-    const char *e = getenv("PSS_MSD_LSD");
+    const char *e = knob("PSS_MSD_LSD");
     return !(e && atoi(e) == 0) && n < (1u << 30);
 }
 
@@ -1608,7 +1608,7 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     // 16384-element scatter tiles (whole-line runs), 1024 threads: 2.2 -> 1.9 ms (from the text) and 2.8 -> 2.45 ms
     // (second pass, with its sixteen loads per thread issued before the ranking atomics) at 2^29; 512 threads x 32 elements
     // spill.  PSS_MSD_SCATTER=1: the 8192-element kernels.
-    const bool wide = lsd || !(getenv("PSS_MSD_SCATTER") && atoi(getenv("PSS_MSD_SCATTER")) == 1);
+    const bool wide = lsd || !(knob("PSS_MSD_SCATTER") && atoi(knob("PSS_MSD_SCATTER")) == 1);
     if (lsd) hipLaunchKernelGGL((msd_scatter2_kernel<true, 1024, true>), dim3(a.num_ranges1), dim3(1024), 0, s, a);
     else if (wide) hipLaunchKernelGGL((msd_scatter2_kernel<true, 1024>), dim3(a.num_ranges1), dim3(1024), 0, s, a);
     else hipLaunchKernelGGL(msd_scatter_kernel<true>, dim3(a.num_ranges1), dim3(MSD_BLOCK), 0, s, a);
@@ -1640,7 +1640,7 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     // LSD order: nothing between here and the local sort needs the host -- the counts stay on the device (the scans run
     // over all 2^20 bucket numbers), the local sort checks the plan's verdict itself, ONE round trip afterwards tells the
     // host everything (rounds 2-5: three, ~0.1 ms of idle GPU each at n = 2^29).
-    const bool one_trip = lsd && !getenv("PSS_MSD_SLOW_LOCAL");
+    const bool one_trip = lsd && !knob("PSS_MSD_SLOW_LOCAL");
     u64 *d_total2 = d_total + 1;
     u32 *const fail_list_dev = tile_first + max_tiles + 16;      // (tile_first has 2 (max_tiles + 16) slots)
     if (one_trip) {
@@ -1708,7 +1708,7 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
     fail_list = tile_first + nt + 8;
     hipLaunchKernelGGL(msd_tile_desc_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, cstart, tile_first, nt, ne, n, tiles_all,
                        (const u32 *)cj, (const u64 *)nullptr, (const u64 *)nullptr);
-    if (getenv("PSS_MSD_SLOW_LOCAL")) {
+    if (knob("PSS_MSD_SLOW_LOCAL")) {
         hipLaunchKernelGGL(local_sort, dim3(nt), dim3(MSD_BLOCK), 0, s, A[1], (const MsdTile *)tiles_all, rem_bits, ib,
                            sa_out, (const u32 *)nullptr, fused, em);
     } else {
@@ -1725,7 +1725,7 @@ int msd_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t n, int key_bi
             hipLaunchKernelGGL(local_sort, dim3(nfail), dim3(MSD_BLOCK), 0, s, A[1], (const MsdTile *)tiles_all, rem_bits,
                                ib, sa_out, (const u32 *)fail_list, fused, em);
     }
-    if (getenv("PSS_MSD_SLOW_LOCAL")) PSS_TRY(mark());
+    if (knob("PSS_MSD_SLOW_LOCAL")) PSS_TRY(mark());
     }
     if (fused) {
         PSS_TRY(device_excl_scan(ctx, InBlkCnt{blk_cnt}, nt, partial, d_total, dst_off));
@@ -1944,7 +1944,7 @@ int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t radix, uint32_
         stats->samples = S;
         stats->key_chars = g.kc;
     }
-    if (maxb > SS_MAX_BUCKET && getenv("PSS_SS_DEBUG")) {
+    if (maxb > SS_MAX_BUCKET && knob("PSS_SS_DEBUG")) {
         // diagnostic: where did the crowded bucket come from?  (first-level bucket sizes, the largest joint buckets)
         std::vector<u32> hj1(MSD_BINS + 1), hj((size_t)nbk + 1);
         (void)hipMemcpy(hj1.data(), J1, (MSD_BINS + 1) * 4, hipMemcpyDeviceToHost);
@@ -1964,10 +1964,10 @@ int ss_suffix_sort(DeviceCtx *ctx, const TextKeys *text, uint32_t radix, uint32_
     hipLaunchKernelGGL(ss_scatter_kernel<false>, dim3((u32)max_ranges2), dim3(SS_SBLOCK), 0, s, a);
     PSS_TRY(mark());                                                                       // [3]
     // bucket-by-bucket local sort (ss_local_seg_kernel): the plan counts every bucket's length rounded up to eight
-    const char *seg_env = getenv("PSS_SS_SEG");
-    const bool seg = !getenv("PSS_SS_WINDOW_PLAN") && !(seg_env && atoi(seg_env) == 0);
+    const char *seg_env = knob("PSS_SS_SEG");
+    const bool seg = !knob("PSS_SS_WINDOW_PLAN") && !(seg_env && atoi(seg_env) == 0);
     u32 *pstart = nullptr;
-    if (getenv("PSS_SS_WINDOW_PLAN")) {
+    if (knob("PSS_SS_WINDOW_PLAN")) {
         const TilePlan tp{SS_WIN, SS_TILE_CAP, nullptr};
         PSS_TRY(device_excl_scan(ctx, InTileHead{cstart, ne, n, tp}, ne, partial, d_total, ranks));
         hipLaunchKernelGGL(msd_tiles_kernel, dim3(1024), dim3(256), 0, s, cstart, ne, n, ranks, (const u64 *)d_total, tile_first, tp);

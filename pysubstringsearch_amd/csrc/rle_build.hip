@@ -446,7 +446,7 @@ int rle_suffix_array(DeviceCtx *ctx, const uint8_t *T, uint32_t n, uint32_t S, u
     const u32 NB = (S + CB - 1) / CB, idpad = (u32)round_up((size_t)num_ids, 64), nchunks = idpad / 64u;
     const u32 nseg = (NB + CSEG - 1) / CSEG;
     // (the bounds keep the table inside the first key buffer and everything else inside the second)
-    const bool columns = !getenv("PSS_RLE_SORT") && n >= 4096u && (u64)S * 4 <= (u64)n && (u64)idpad * 4 <= (u64)n &&
+    const bool columns = !knob("PSS_RLE_SORT") && n >= 4096u && (u64)S * 4 <= (u64)n && (u64)idpad * 4 <= (u64)n &&
                          (u64)NB * idpad * 4 <= (u64)n * 8 && (u64)NB * nchunks < (1ull << 31);
     if (columns) {
         // matrix walk: table in the first key buffer, everything else in the second

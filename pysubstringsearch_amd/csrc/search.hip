@@ -1700,7 +1700,7 @@ static int resident_query(DeviceCtx *ctx, const ChunkDesc *d_chunks, u32 nc, con
             st->ms_device = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_post).count();
             st->ms_interval = st->ms_device;
 #ifdef PSS_TRACE_RESIDENT
-            if (getenv("PSS_TRACE_RESIDENT")) {
+            if (knob("PSS_TRACE_RESIDENT")) {
                 u32 t[8];
                 for (int i = 0; i < 8; ++i) t[i] = mb->pad2[i];
                 fprintf(stderr, "[pss] resident trace (10 ns ticks): host %.1f us | interval %u, bounds %u, sums %u, pack %u, copy %u, drain %u, fence %u\n",

@@ -169,6 +169,28 @@ def test_product_never_imports_oracle():
                 assert 'oracle' not in src.replace('oracle restatement', ''), f'{f} mentions the oracle'
 
 
+def test_every_environment_switch_is_in_the_one_registry():
+    """csrc/knobs.h: every switch the engine reads goes through knob("PSS_..."), and knob() only answers for names in the
+    registry -- so the registry (which the C ABI lists, and which tests/tools/fuzz.py draws from) is complete by
+    construction.  The sources may not call getenv("PSS_...") directly, may not ask knob() for a name the table lacks,
+    and the table lists nothing the sources never read (PSS_DEVICE is read through the launchers' loop in capi.cpp)."""
+    import re
+    from pysubstringsearch_amd import _ffi
+    table = _ffi.knobs()
+    names = [k['name'] for k in table]
+    assert len(names) == len(set(names)) >= 60
+    assert all(k['what'] and k['default'] for k in table)
+    read = set()
+    csrc = os.path.join(ROOT, 'pysubstringsearch_amd', 'csrc')
+    for f in os.listdir(csrc):
+        if f.endswith(('.cpp', '.hip', '.h')):
+            src = open(os.path.join(csrc, f), encoding='utf-8').read()
+            assert not re.search(r'getenv\("PSS_', src), f'{f} reads a switch behind the registry'
+            read |= set(re.findall(r'knob\("(PSS_[A-Z0-9_]+)"\)', src))
+    assert read - set(names) == set(), f'not registered: {sorted(read - set(names))}'
+    assert set(names) - read == {'PSS_DEVICE'}, f'registered but never read: {sorted(set(names) - read)}'
+
+
 # ---- corpus generators: C++ (libpss) vs an independent Python restatement of SURVEY 8(d) ----
 
 M64 = (1 << 64) - 1

@@ -68,8 +68,10 @@ class FakePeer:
                        T.ALL_GATHER(self._all_gather), T.ERROR_STRING(self._errstr))
 
     # -- table entries --------------------------------------------------------------------------------------------
+    _ERRSTR = ctypes.create_string_buffer(b'injected failure')
+
     def _errstr(self, rc):
-        return b'injected failure'
+        return ctypes.addressof(self._ERRSTR)
 
     def _group_start(self):
         self.calls['group_start'] += 1

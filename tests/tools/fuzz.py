@@ -81,82 +81,20 @@ def build(path, entries, limit, W):
     return open(path, 'rb').read()
 
 
-KNOBS = ('PSS_MODE', 'PSS_KEY_CHARS', 'PSS_KEY_DROP', 'PSS_TEXT_ROUNDS', 'PSS_NO_TIES_PASS', 'PSS_NO_SMALL_PATH', 'PSS_MSD',
-         'PSS_MSD_NO_FUSE', 'PSS_MSD_SLOW_LOCAL', 'PSS_NO_PINNED_RESULTS', 'PSS_NO_MID_TIER', 'PSS_RLE', 'PSS_RLE_SORT', 'PSS_PERIOD', 'PSS_ANCHOR', 'PSS_ANCHOR_OMEGA',
-         'PSS_COUNT_SORT', 'PSS_NO_PROBE', 'PSS_PERIODIC', 'PSS_PROBE_SKIP_PCT', 'PSS_ANCHOR_MIN_OMEGA', 'PSS_DEVICES', 'PSS_WRITER_MMAP', 'PSS_IO_THREADS',
-         'PSS_WRITER_MMAP_MIN', 'PSS_INGEST_BLOCK', 'PSS_INGEST_MIN_ROOM', 'PSS_ANCHOR_SIDE', 'PSS_BIG_MERGE', 'PSS_NO_MID_MERGE', 'PSS_RESULT_ORDER', 'PSS_SS_SEG', 'PSS_SS')
-
-
 def random_knobs(rng):
-    """Builder / search switches that must never change a result."""
+    """Builder / search / file-path switches that must never change a result -- drawn mechanically from the library's own
+    registry (csrc/knobs.h through pss_knob_info): every switch with a `fuzz` column, each with probability 1/4, any
+    combination on any input.  A switch added to the registry is fuzzed from then on without a line here."""
     from pysubstringsearch_amd import _ffi
-    for k in KNOBS:
-        os.environ.pop(k, None)
+    table = _ffi.knobs()
+    for k in table:
+        os.environ.pop(k['name'], None)
     _ffi.lib.pss_reload_env()        # the search switches are read once, not per call
     if rng.random() < 0.5:
         return
-    if rng.random() < 0.5:
-        os.environ['PSS_MODE'] = rng.choice(['dense', 'sparse', 'text'])
-    if rng.random() < 0.5:
-        os.environ['PSS_KEY_CHARS'] = str(rng.randint(1, 16))
-        if rng.random() < 0.6:
-            os.environ['PSS_KEY_DROP'] = str(rng.randint(0, 8))
-    if rng.random() < 0.3:
-        os.environ['PSS_TEXT_ROUNDS'] = str(rng.randint(0, 3))
-    if rng.random() < 0.15:
-        os.environ['PSS_NO_TIES_PASS'] = '1'
-    if rng.random() < 0.5:
-        os.environ['PSS_NO_SMALL_PATH'] = '1'
-    if rng.random() < 0.6:
-        os.environ['PSS_MSD'] = rng.choice(['0', '1', '1'])      # hybrid MSD initial sort forced on / off
-        if rng.random() < 0.3:
-            os.environ['PSS_MSD_NO_FUSE'] = '1'
-        if rng.random() < 0.3:
-            os.environ['PSS_MSD_SLOW_LOCAL'] = '1'
-    if rng.random() < 0.3:
-        os.environ['PSS_NO_PINNED_RESULTS'] = '1'
-    if rng.random() < 0.3:
-        os.environ['PSS_NO_MID_TIER'] = '1'
-    if rng.random() < 0.5:
-        os.environ['PSS_RLE'] = rng.choice(['0', '1', '1'])      # run-length path forced on / off
-        if rng.random() < 0.4:
-            os.environ['PSS_RLE_SORT'] = '1'                     # ... with the radix-sort expansion
-    if rng.random() < 0.3:
-        os.environ['PSS_PERIOD'] = '0'                           # never the closed form for one repeated word
-    if rng.random() < 0.6:                                       # round 4: the anchor round forced on / off, narrow windows
-        os.environ['PSS_ANCHOR'] = rng.choice(['0', '1', '1'])
-        if rng.random() < 0.5:
-            os.environ['PSS_ANCHOR_OMEGA'] = str(rng.choice([9, 12, 17, 33]))
-        if rng.random() < 0.3:
-            os.environ['PSS_NO_PROBE'] = '1'
-        if rng.random() < 0.3:
-            os.environ['PSS_PROBE_SKIP_PCT'] = rng.choice(['0', '20', '90'])      # when the probe sends the ties straight to the anchors
-        if rng.random() < 0.3:
-            os.environ['PSS_ANCHOR_MIN_OMEGA'] = rng.choice(['3', '7', '9'])      # narrowest window taken without PSS_ANCHOR=1
-    if rng.random() < 0.3:
-        os.environ['PSS_COUNT_SORT'] = '1'                       # rank rounds: counting instead of the segmented merge sort
-    if rng.random() < 0.2:
-        os.environ['PSS_PERIODIC'] = '0'                         # rank rounds: no periodic keys for the large groups
-    if rng.random() < 0.3:
-        os.environ['PSS_DEVICES'] = rng.choice(['0', '0,0', '0,0,0', 'all'])      # the default device list of Writer / Reader
-    if rng.random() < 0.3:
-        os.environ['PSS_WRITER_MMAP'] = rng.choice(['0', '1'])   # records through a shared mapping / pwrite
-        os.environ['PSS_WRITER_MMAP_MIN'] = '16'                 # ... whatever their size (round 5: the route never ran before)
-    if rng.random() < 0.3:                                       # direct file ingest on tiny chunks, tails longer than a block
-        os.environ['PSS_INGEST_BLOCK'] = rng.choice(['16', '40', '300'])
-        os.environ['PSS_INGEST_MIN_ROOM'] = rng.choice(['1', '20'])
-    if rng.random() < 0.3:
-        os.environ['PSS_ANCHOR_SIDE'] = rng.choice(['0', '1', '1'])   # anchors sorted beside the text round (second stream / thread)
-    if rng.random() < 0.2:
-        os.environ['PSS_SS'] = '1'                               # the sample sort for every text of >= 2^16 bytes
-    if rng.random() < 0.2:
-        os.environ['PSS_SS_SEG'] = '0'                           # sample sort: every tile sorted as one array (the round-4 local sort)
-    if rng.random() < 0.3:
-        os.environ['PSS_BIG_MERGE'] = rng.choice(['1', '2'])     # groups above 4096 members through the segmented merge sort
-    if rng.random() < 0.2:
-        os.environ['PSS_NO_MID_MERGE'] = '1'
-    if rng.random() < 0.2:
-        os.environ['PSS_RESULT_ORDER'] = 'sa'                    # (multisets are compared: the order must not matter)
+    for k in table:
+        if k['fuzz'] and rng.random() < 0.25:
+            os.environ[k['name']] = rng.choice(k['fuzz'])
     _ffi.lib.pss_reload_env()
 
 
