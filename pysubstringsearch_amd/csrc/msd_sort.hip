@@ -517,7 +517,7 @@ __global__ __launch_bounds__(MSD_BLOCK, 4) void msd_scatter_kernel(MsdArgs a)
 
 // The same pass over tiles of 16384 elements (1024 threads x 16): twice as many elements per bin and tile, so the runs
 // the output loop writes are 16 x 8 = 128 bytes on average -- whole lines instead of half lines; the pass is bound by
-// the 128-byte lines it touches.  LDS stages 8192 elements at a time: the tile goes through in two
+// the 128-byte lines it touches (docs/history 4.3).  LDS stages 8192 elements at a time: the tile goes through in two
 // pieces by destination position.
 constexpr u32 MSD_TILE2 = 16384;
 constexpr int MSD_PIECES2 = MSD_TILE2 / MSD_TILE;    // 2

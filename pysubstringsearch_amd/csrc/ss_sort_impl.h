@@ -454,7 +454,7 @@ __global__ __launch_bounds__(SS_DBLOCK) void ss_digits2_kernel(SsArgs a)
 #endif
 // A scatter tile is larger than what LDS can stage at once: it goes through in pieces by destination position
 // (positions [0, 2048), [2048, 4096), ...), 32 KiB of staging whatever the tile size.  What the tile size buys is the
-// length of the runs the output loop writes: the pass is bound by the 128-byte lines it touches, and 8192
+// length of the runs the output loop writes: the pass is bound by the 128-byte lines it touches (docs/history 4.3), and 8192
 // elements over 1024 bins are runs of 8 x 16 bytes -- whole lines -- where 4096 gave half lines.
 constexpr u32 SS_STILE = PSS_SS_STILE;
 constexpr int SS_SIPT2 = SS_STILE / SS_SBLOCK;      // elements per thread and tile

@@ -1,4 +1,4 @@
-// Micro-benchmark behind DESIGN 13 item 10 (round-4 review: "accumulate the joint 20-bit histogram while G1 scatters").
+// Micro-benchmark behind docs/history/DESIGN_rounds_1-5.md 13 item 10 (round-4 review: "accumulate the joint 20-bit histogram while G1 scatters").
 // What would be ADDED to the first scatter pass of the `lines` build is one atomic per element into a table of 2^20
 // 32-bit counters (4 MiB, L2-resident); what would be SAVED is msd_hist_kernel<false> (0.84 ms at n = 2^29).  This
 // program times exactly that addition in isolation, the cheapest way it can be done:

@@ -1,4 +1,4 @@
-// Micro-benchmark behind DESIGN 4.2f (round-5 review, item 1: "single-pass partition primitive, decoupled look-back").
+// Micro-benchmark behind DESIGN 4.2 (round-5 review, item 1: "single-pass partition primitive, decoupled look-back").
 //
 // What it models: the SECOND partition pass of the `lines` build in LSD order -- the input is already grouped by the
 // second 10-bit digit d (1024 "d-regions"), the pass partitions by the FIRST digit b, and tiles must arrive in every
