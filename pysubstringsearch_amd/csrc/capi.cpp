@@ -357,11 +357,15 @@ struct Stripes {
     std::vector<int> fd;
     uint64_t next_unit = 0;                            // first unit of the next chunk's suffix array
     int S() const { return (int)fd.size(); }
-    void close_all()
+    // closes every stripe file; returns the errno of the first close() that failed (0: none) -- four fifths of a striped
+    // index's bytes live in these files, their close is where a full disk or a lost NFS write shows up
+    int close_all()
     {
+        int first = 0;
         for (int f : fd)
-            if (f >= 0) (void)close(f);
+            if (f >= 0 && close(f) != 0 && first == 0) first = errno ? errno : EIO;
         fd.clear();
+        return first;
     }
     static std::string name(const char *path, int j) { return std::string(path) + ".sa" + std::to_string(j); }
 };
@@ -887,6 +891,16 @@ extern "C" int pss_writer_open_multi(const char *path, int64_t max_chunk_len, co
         if (fd < 0) return io_error(path);
         int64_t pos = 0;
         Stripes stripes;
+        // stripe files an earlier striped Writer left beside this path and this one will not rewrite (it has fewer stripes,
+        // or none): a Reader must never find arrays that belong to another index there
+        {
+            int keep = 0;
+            if (striped) {
+                keep = 8;
+                if (const char *e = knob("PSS_STRIPES")) keep = std::min(64, std::max(1, atoi(e)));
+            }
+            for (int j = keep; j < 64; ++j) (void)unlink(Stripes::name(path, j).c_str());
+        }
         if (striped) {
             int S = 8;
             if (const char *e = knob("PSS_STRIPES")) S = std::min(64, std::max(1, atoi(e)));
@@ -1150,8 +1164,12 @@ extern "C" int pss_writer_close(pss_writer *w)
         const auto tc1 = std::chrono::steady_clock::now();
         errno = 0;
         if (w->map_fd >= 0) (void)close(w->map_fd);
-        w->stripes.close_all();
-        const int crc = close(w->fd);
+        const int serr = w->stripes.close_all();
+        int crc = close(w->fd);
+        if (crc == 0 && serr != 0) {        // (a stripe file's close failed: reported like the index file's own)
+            errno = serr;
+            crc = -1;
+        }
         if (knob("PSS_TIMING"))
             fprintf(stderr, "[pss] writer close: threads and device buffers %.1f ms, close(fd) %.1f ms\n",
                     std::chrono::duration<double, std::milli>(tc1 - tc0).count(),
@@ -2464,8 +2482,10 @@ void comm_abort(pss_comm *c, const char *why)
     c->dead = true;
     ++c->aborts;
     if (c->comm) {
+        // Without ncclCommAbort in the table the communicator is marked dead and LEFT: ncclCommDestroy waits for outstanding
+        // work, and the work of a communicator that is being aborted is exactly what does not finish --
+        // a leak in a path that runs once per broken peer, against a call that may never return.
         if (c->api.CommAbort) (void)c->api.CommAbort(c->comm);
-        else if (!c->adopted) (void)c->api.CommDestroy(c->comm);
         c->comm = nullptr;
     }
     // what the abort releases drains now; a stream that still does not (no ncclCommAbort in this library) is left alone

@@ -471,11 +471,19 @@ uint64_t workspace_bytes(int device)
 
 void trim_all()
 {
-    std::lock_guard<std::mutex> lk(g_ctx_mu);
-    for (DeviceCtx *table : {g_ctx, g_bctx})
-        for (int d = 0; d < kMaxDevices; ++d) {
-            DeviceCtx &c = table[d];
-            if (c.device < 0) continue;
+    // The contexts that exist, listed under the table's lock; every one is then locked WITHOUT it: a reader that runs out
+    // of HBM inside its own context's lock asks for the builder's context (get_build_ctx takes the table's lock) -- the
+    // two orders must not cross.  Contexts are never destroyed, so the pointers stay good.
+    std::vector<DeviceCtx *> live;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        for (DeviceCtx *table : {g_ctx, g_bctx})
+            for (int d = 0; d < kMaxDevices; ++d)
+                if (table[d].device >= 0) live.push_back(&table[d]);
+    }
+    for (DeviceCtx *cp : live) {
+        {
+            DeviceCtx &c = *cp;
             std::lock_guard<std::recursive_mutex> lk2(c.mu);
             (void)hipSetDevice(c.device);
             c.stop_resident();               // (it works in one of the slots)
@@ -486,6 +494,7 @@ void trim_all()
             // arena's address changes: a fresh allocation may come back at the old address with garbage in it
             c.small_hdr_ready = nullptr;
         }
+    }
     pinned_pool_trim();
 }
 

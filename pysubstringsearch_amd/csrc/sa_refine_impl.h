@@ -534,7 +534,16 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
                 const u32 *akey = ISA;
                 if (side.started) {
                     side.join();
-                    if (side.rc != PSS_OK) {
+                    if (side.rc == PSS_ENOMEM) {
+                        // no room for the side line's buffers is not an error of the build (side_start says so about its own
+                        // reservations; the same holds for what the helper context grows later): give its slots back and let
+                        // the anchors wait their turn on the main line
+                        if (ctx->helper)
+                            for (auto &sl : ctx->helper->slot) sl.release();
+                        (void)hipGetLastError();
+                        set_error("%s", "");
+                        side.ok = false;
+                    } else if (side.rc != PSS_OK) {
                         set_error("%s", side.err.c_str());
                         return side.rc;
                     }
