@@ -384,6 +384,7 @@ const KnobDef kKnobs[] = {
     {"PSS_MSD", "-1 (screened)", "0|1|1", "initial sort: never / whenever the key fits the hybrid MSD radix sort (msd_sort.hip)"},
     {"PSS_MSD_LSD", "1", "0|1", "MSD sort: 0 = digits in MSD order with a second histogram pass (rounds 2-5); else LSD order, second pass by look-back"},
     {"PSS_MSD_KEY_CAP", "48", "", "MSD sort: largest key width tried (bits; the element format bounds it further)"},
+    {"PSS_MSD_PARTIAL_SYMBOL", "unset", "1", "MSD sort: fill the element with the high bits of one more symbol than fits whole (fewer ties; measured slower on lines)"},
     {"PSS_MSD_NO_FUSE", "unset", "1", "MSD sort: ties flagged in the suffix array instead of emitted from the local sort"},
     {"PSS_MSD_SLOW_LOCAL", "unset", "1", "MSD sort: the general (ballot LSD) local-sort kernel for every tile"},
     {"PSS_MSD_SCATTER", "unset", "1", "MSD sort in MSD order: the 8192-element partition kernels of round 2"},

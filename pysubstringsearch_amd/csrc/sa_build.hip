@@ -538,14 +538,25 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
     u32 msd_active = 0;
     if (ties && knobs.msd != 0) {
         // (at n = 2^29 an element holds 45 key bits after the first pass; smaller texts leave room for up to 48)
-        static const int key_cap = [] { const char *e = knob("PSS_MSD_KEY_CAP"); return e ? atoi(e) : 48; }();
+        const char *cap_env = knob("PSS_MSD_KEY_CAP");
+        const int key_cap = cap_env ? atoi(cap_env) : 48;
+        // Whole symbols by default.  PSS_MSD_PARTIAL_SYMBOL=1 fills the element with the high bits of one more symbol (a monotone
+        // coarsening, like the LSD path's; the depth the rounds start from counts the whole symbols only): `lines` at 2^29 then
+        // sorts by 45 bits = 7 symbols + 3 bits of the 8th and leaves 0.42 M suffixes tied instead of 2.09 M -- which sends
+        // them to the sparse mode's global passes (<= n / 1024 ties: eight launch-bound radix passes, 0.7 ms) where the text
+        // round took 0.3 ms for five times as many: 8.55 vs 8.02 ms, measured in round 6 and left off.
+        const bool whole = knob("PSS_MSD_PARTIAL_SYMBOL") == nullptr;
         int kb = std::min(msd_max_key_bits(n), std::max(key_cap, 21));
-        const int kc = std::min(kb / b, kmax);                   // whole symbols only
-        kb = kc * b;
+        int kc = std::min(whole ? kb / b : (kb + b - 1) / b, kmax);
+        int mdrop = kc * b - kb;
+        if (mdrop < 0 || kc <= 1) {                               // (kmax symbols do not fill the element: all of their bits)
+            kb = kc * b;
+            mdrop = 0;
+        }
         const bool fits = kc >= 1 && kb >= 21 && !plus_one;
         const bool auto_ok = sampled && msd_screen_ok && (hint == 1 || (key_bits0 <= 48 && kb + 8 >= key_bits0));
         if (fits && (knobs.msd == 1 || (knobs.msd < 0 && auto_ok))) {
-            TextKeys mk{codes, b, kc, plus_one, 0};
+            TextKeys mk{codes, b, kc, plus_one, mdrop};
             MsdStats ms;
             bool accepted = false;
             // The local sort hands over the active list of the first rerank (SA slot, suffix, group rank of every
@@ -575,7 +586,7 @@ int sa_build_device(DeviceCtx *ctx, const void *d_T, void *d_SA, int32_t n_in, u
             if (accepted) {
                 msd_done = true;
                 key_chars = kc;
-                key_drop = 0;
+                key_drop = mdrop;
                 st.key_chars = (u32)kc;
                 st.key_bits = (u64)kb;
                 st.msd = 1;
