@@ -1608,6 +1608,24 @@ def main():
                     'corpus15_single_query_us_low_latency': (lat.get('low_latency_mode') or {}).get('median'),
                     'corpus15_verified': out2.get('verified'),
                 })
+                # configs[2] / [3] on NATURAL-TEXT-LIKE chunks ("run on lines and words"): a leg of its own
+                # (python bench.py --config corpus15 --corpus words --qmin 16: 15 words builds, 259 M result entries per batch,
+                # minutes with its CPU baselines) -- quoted here from the committed run, not measured in this one
+                try:
+                    wl = json.loads(open(os.path.join(ROOT, 'profiles', 'r06_bench_corpus15_words.json')).read().strip().splitlines()[-1])
+                    wc = wl.get('cpu_baseline') or {}
+                    out['summary'].update({
+                        'corpus15_words_packed_api_queries_per_sec': wl.get('packed_queries_per_sec'),
+                        'corpus15_words_list_api_queries_per_sec': wl.get('value'),
+                        'corpus15_words_entries_per_batch': wl.get('entries_per_batch'),
+                        'corpus15_words_cpu_ram_queries_per_sec': wc.get('value'),
+                        'corpus15_words_cpu_disk_queries_per_sec': wc.get('disk_queries_per_sec'),
+                        'corpus15_words_verified': wl.get('verified'),
+                        'corpus15_words_is': 'profiles/r06_bench_corpus15_words.json (committed run of --config corpus15 --corpus words '
+                                             '--qmin 16 on one MI355X; NOT measured in this run)',
+                    })
+                except Exception:
+                    pass
     else:
         rc, out = run_corpus(args, D)
     if out is not None:

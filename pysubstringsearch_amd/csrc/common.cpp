@@ -226,7 +226,17 @@ struct PinnedBlock {
 std::mutex g_pool_mu;
 std::vector<PinnedBlock> g_pool;            // free blocks
 constexpr size_t kPoolMaxBlocks = 4;
-constexpr size_t kPoolMaxBytes = (size_t)12 << 30;
+// Pinned memory the pool keeps between batches.  Round 6: 12 -> 40 GiB (PSS_PINNED_POOL_BYTES): a batch on natural text
+// returns 18 GB of entries (100 000 queries of 16..32 bytes on 15 chunks of `words`, 259 M entries), and a block the pool
+// would not keep was pinned and unpinned on EVERY batch -- 1.8 s + 1 s around 0.06 s of kernels and 0.36 s of PCIe.
+size_t pool_max_bytes()
+{
+    static const size_t v = [] {
+        const char *e = knob("PSS_PINNED_POOL_BYTES");
+        return e ? (size_t)strtoull(e, nullptr, 0) : ((size_t)40 << 30);
+    }();
+    return v;
+}
 }  // namespace
 
 void *pinned_pool_alloc(size_t bytes, size_t *granted)
@@ -256,16 +266,28 @@ void *pinned_pool_alloc(size_t bytes, size_t *granted)
 void pinned_pool_free(void *p, size_t granted)
 {
     if (!p) return;
+    std::vector<PinnedBlock> drop;
+    bool kept = false;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         size_t held = 0;
         for (const auto &b : g_pool) held += b.bytes;
-        if (g_pool.size() < kPoolMaxBlocks && held + granted <= kPoolMaxBytes) {
+        if (granted <= pool_max_bytes()) {
+            // the block just used says most about the next batch: smaller ones make room for it
+            while (!g_pool.empty() && (g_pool.size() >= kPoolMaxBlocks || held + granted > pool_max_bytes())) {
+                size_t k = 0;
+                for (size_t i = 1; i < g_pool.size(); ++i)
+                    if (g_pool[i].bytes < g_pool[k].bytes) k = i;
+                held -= g_pool[k].bytes;
+                drop.push_back(g_pool[k]);
+                g_pool.erase(g_pool.begin() + (long)k);
+            }
             g_pool.push_back({p, granted});
-            return;
+            kept = true;
         }
     }
-    (void)hipHostFree(p);
+    for (auto &b : drop) (void)hipHostFree(b.p);
+    if (!kept) (void)hipHostFree(p);
 }
 
 void pinned_pool_trim()
@@ -433,6 +455,7 @@ const KnobDef kKnobs[] = {
     {"PSS_WAVE_SEARCH", "unset", "1", "search: interval kernel one wave per pair at every batch size"},
     {"PSS_NO_GROUP_SEARCH", "unset", "1", "search: never 16 lanes per pair"},
     {"PSS_NO_MID_PIPELINE", "unset", "1", "search: always the general multi-kernel pipeline"},
+    {"PSS_PINNED_POOL_BYTES", "40 GiB", "", "search: pinned host memory the result pool keeps between batches"},
     {"PSS_NO_PINNED_RESULTS", "unset", "1", "search: large results into pageable memory"},
     {"PSS_LANE_SEARCH_MIN", "8192", "1|100000", "search: pairs from which one lane per pair searches"},
     {"PSS_SEARCH_EVENTS", "unset", "", "single-query path: HIP events around the fused kernel (fills ms_device; ~4 us per query)"},
