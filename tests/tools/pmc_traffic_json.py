@@ -17,9 +17,10 @@ for f in sorted(glob.glob(f'{root}/g*/*counter_collection.csv')):
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE'):
             agg[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
-ALGO = {   # algorithmic bytes per element of the kernels of the initial sort (DESIGN.md 4.2)
+ALGO = {   # algorithmic bytes per element of the kernels of the initial sort (DESIGN.md 4.2, 4.3)
     'msd_scatter_kernel<true>': 9, 'msd_scatter_kernel<false>': 16, 'msd_local_fast_kernel': 12,
     'msd_scatter2_kernel<true, 1024>': 9, 'msd_scatter2_kernel<false, 1024>': 16,
+    'msd_scatter2_kernel<true, 1024, true>': 9, 'msd_scatter_lb_kernel': 16,      # round 6: LSD order, second pass by look-back
     'msd_hist_raw_kernel': 2,
     'msd_hist_kernel<true>': 1, 'msd_hist_kernel<false>': 8,
     'fs_scatter_kernel<0, 4>': 9, 'fs_scatter_kernel<4, 4>': 16, 'fs_scatter_kernel<4, 0>': 12,

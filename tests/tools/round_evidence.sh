@@ -1,14 +1,14 @@
 #!/bin/bash
 # Everything profiles/ holds for a round, in one call on the GPU box (about 25 minutes):
-#   PSS_TREE_COMMIT=$(git rev-parse --short HEAD) tests/tools/round_evidence.sh r05   -> gpurun_out/ev/*  (summaries only; copy what
+#   PSS_TREE_COMMIT=$(git rev-parse --short HEAD) tests/tools/round_evidence.sh r06   -> gpurun_out/ev/*  (summaries only; copy what
 #   is to be kept into profiles/).  The counter files are stamped with a hash of the engine's sources (tree_hash.py) and with
 #   PSS_TREE_COMMIT (the box has no .git); the script ends with check_evidence.py on what it wrote.
-tag=${1:-r05}
+tag=${1:-r06}
 root=$GRAFT_REPO_ROOT; [ -z "$root" ] && root=$(pwd)
 ev=$root/gpurun_out/ev; mkdir -p $ev
 cd $root
 # 1. the GPU suite
-timeout 1700 python -m pytest tests -q -m gpu --durations=20 > $ev/${tag}_pytest_gpu.log 2>&1
+timeout 2400 python -m pytest tests -q -m gpu -W error --durations=20 > $ev/${tag}_pytest_gpu.log 2>&1
 tail -3 $ev/${tag}_pytest_gpu.log
 # 2. the driver's command: below, once the counter files of THIS tree exist (the line quotes them and says whether they are current)
 # 3. kernel stats under rocprofv3
@@ -38,6 +38,12 @@ for spec in lines:3 words:2 dup_blocks:2 mixed:2 source:2 real:2 runs:2; do
   else python tests/tools/pmc_traffic_json.py $ev/pmc_$c $k $ev/json $c > $ev/pmc_$c.ratios.txt 2>&1; fi
 done
 cp $ev/json/*.json $root/profiles/ 2>/dev/null      # (on the box: the bench line below reads them)
+# 4b. configs[2] / [3] on natural-text-like chunks, and the look-back micro-benchmark behind DESIGN 4.2
+timeout 1500 python bench.py --config corpus15 --corpus words --qmin 16 --steps 2 --warmup 1 > $ev/${tag}_bench_corpus15_words.json 2> $ev/bench_corpus15_words.err
+[ -x tests/tools/bin/lookback_micro ] && timeout 240 tests/tools/bin/lookback_micro > $ev/${tag}_lookback_micro_final.txt 2>&1
+mkdir -p $ev/pmc_sq; tests/tools/pmc.sh $ev/pmc_sq/p -- python3 tests/tools/sa_perf.py lines 29 3 > /dev/null 2>&1
+python tests/tools/pmc_summary.py $ev/pmc_sq/p msd_ > $ev/${tag}_pmc_sq_lines_kernels.txt 2>&1; rm -rf $ev/pmc_sq
+cp $ev/${tag}_bench_corpus15_words.json $root/profiles/ 2>/dev/null
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $ev/${tag}_bench_default.json 2> $ev/bench_default.err
 timeout 600 tests/tools/pmc_requests.sh $ev/pmcreq_words words 1 > /dev/null 2>&1
 python tests/tools/pmc_requests_json.py $ev/pmcreq_words $ev/json/pmc_requests_words.json 1 > $ev/pmc_requests_words.txt 2>&1
