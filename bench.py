@@ -51,6 +51,7 @@
                        one at a time, one thread per chunk, suffix arrays in RAM and -- like
                        the reference -- probed on disk with lseek + read(8 KiB)
 """
+import pathlib
 import argparse
 import ctypes
 import hashlib
@@ -82,7 +83,7 @@ def evidence(name: str):
     if not os.path.exists(p):
         return None, None
     try:
-        d = json.load(open(p))
+        d = json.loads(pathlib.Path(p).read_text())
     except Exception:
         return None, None
     try:
@@ -103,7 +104,7 @@ def load_big_goldens():
     p = os.path.join(ROOT, 'tests', 'golden', 'sa_big.json')
     if not os.path.exists(p):
         return {}
-    return {(r['kind'], r['chunk_index'], r['n']): r for r in json.load(open(p))['chunks']}
+    return {(r['kind'], r['chunk_index'], r['n']): r for r in json.loads(pathlib.Path(p).read_text())['chunks']}
 
 
 def sa_poly64_torch(d_sa) -> int:
@@ -462,7 +463,7 @@ def run_inproc(args):
             w.add_entries_from_file_lines(src)
             w.close()
             t_w = time.perf_counter() - t0
-            same_bytes = open(one, 'rb').read() == open(many, 'rb').read()
+            same_bytes = pathlib.Path(one).read_bytes() == pathlib.Path(many).read_bytes()
             qs = make_queries(np.fromfile(src, dtype=np.uint8, count=cn), 3000, args.qlen)
             with pysubstringsearch.Reader(one, device=devs[0]) as r1, pysubstringsearch.Reader(many, devices=devs) as rn:
                 e1, c1 = r1.search_batch_raw(qs)
@@ -1240,7 +1241,7 @@ def run_corpus(args, D, steps=None, warmup=None):
         pmcs = os.path.join(ROOT, 'profiles', 'pmc_search_corpus15.json')
         if os.path.exists(pmcs) and world == 1 and chunks == 15 and args.logn == 29 and len(queries) == 100000:
             try:
-                traffic = json.load(open(pmcs)).get('total_bytes_raw')
+                traffic = json.loads(pathlib.Path(pmcs).read_text()).get('total_bytes_raw')
                 achieved = round(traffic / ms_dev / 1e6, 1) if traffic and ms_dev else None
             except Exception:
                 traffic = achieved = None
@@ -1572,7 +1573,7 @@ def main():
                         time.sleep(0.25)
                         if os.path.exists(flag):
                             try:
-                                why = open(flag).read()[:300]
+                                why = pathlib.Path(flag).read_text()[:300]
                             except OSError:
                                 why = 'another rank gave up'
                             bail(why, tell=False)
@@ -1612,7 +1613,7 @@ def main():
                 # (python bench.py --config corpus15 --corpus words --qmin 16: 15 words builds, 259 M result entries per batch,
                 # minutes with its CPU baselines) -- quoted here from the committed run, not measured in this one
                 try:
-                    wl = json.loads(open(os.path.join(ROOT, 'profiles', 'r06_bench_corpus15_words.json')).read().strip().splitlines()[-1])
+                    wl = json.loads(pathlib.Path(os.path.join(ROOT, 'profiles', 'r06_bench_corpus15_words.json')).read_text().strip().splitlines()[-1])
                     wc = wl.get('cpu_baseline') or {}
                     out['summary'].update({
                         'corpus15_words_packed_api_queries_per_sec': wl.get('packed_queries_per_sec'),

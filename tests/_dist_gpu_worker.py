@@ -1,5 +1,6 @@
 """world_size-2 RCCL worker for tests/test_dist_gpu.py: one process per GPU, each a Reader over its shard of the index,
 the packed results gathered device to device and merged on the collecting rank's GPU."""
+import pathlib
 import json
 import os
 import sys
@@ -19,7 +20,7 @@ def main():
     dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world,
                             device_id=torch.device('cuda', rank))
     r = pdist.ShardedReader(idx, device=rank)
-    queries = json.load(open(idx + '.queries.json'))
+    queries = json.loads(pathlib.Path(idx + '.queries.json').read_text())
     qs = [q.encode('latin-1') for q in queries]
     res = {}
     for name, batch in (('one', qs[:1]), ('few', qs[:40]), ('all', qs)):
@@ -48,8 +49,8 @@ def main():
         w = Writer(idx + '.multi', 1 << 16, devices=[0, 1])
         w.add_entries_from_file_lines(idx + '.txt')
         w.close()
-        res['multi_writer_identical'] = open(idx + '.multi', 'rb').read() == open(idx, 'rb').read()
-        json.dump(res, open(out, 'w'))
+        res['multi_writer_identical'] = pathlib.Path(idx + '.multi').read_bytes() == pathlib.Path(idx).read_bytes()
+        pathlib.Path(out).write_text(json.dumps(res))
     dist.barrier()
     dist.destroy_process_group()
 

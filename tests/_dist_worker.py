@@ -1,4 +1,5 @@
 """world_size-2 gloo worker for tests/test_host.py::test_sharded_gather_gloo."""
+import pathlib
 import json
 import os
 import sys
@@ -53,7 +54,7 @@ def main():
     empty = rp.search_multiple_bytes([b'zzz'])
     assert (empty is None) if rank else (empty[0] == [] and empty[1].tolist() == [0])
     if rank == 0:
-        json.dump({'got': got, 'counts': raw[1].tolist(), 'raw': [e.decode() for e in raw[0]]}, open(out, 'w'))
+        pathlib.Path(out).write_text(json.dumps({'got': got, 'counts': raw[1].tolist(), 'raw': [e.decode() for e in raw[0]]}))
     else:
         assert got is None and raw is None
     dist.barrier()

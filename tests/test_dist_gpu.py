@@ -2,6 +2,7 @@
 test boxes); everything they would exercise on one GPU is covered with virtual devices / gloo elsewhere
 (test_multi_device_reader_in_one_process, test_device_merge_equals_host_merge, test_sharded_gather_gloo,
 test_bench_two_ranks_self_launch)."""
+import pathlib
 import json
 import os
 import socket
@@ -37,7 +38,7 @@ def test_rccl_gather_and_multi_device_handles(tmp_path, oracle):
         s = int(rng.integers(0, len(text) - 20))
         cand = text[s:s + int(rng.integers(1, 14))]
         qs.append(cand)
-    json.dump([q.decode('latin-1') for q in qs], open(idx + '.queries.json', 'w'))
+    pathlib.Path(idx + '.queries.json').write_text(json.dumps([q.decode('latin-1') for q in qs]))
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
@@ -47,7 +48,7 @@ def test_rccl_gather_and_multi_device_handles(tmp_path, oracle):
                               env=env) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=600) == 0
-    got = json.load(open(out))
+    got = json.loads(pathlib.Path(out).read_text())
     o = oracle.OracleReader(idx)
     for name, batch in (('one', qs[:1]), ('few', qs[:40]), ('all', qs)):
         oe, oc = o.search_multiple_bytes(batch)

@@ -1,6 +1,7 @@
 """CPU tests of the host side: the C ABI surface, the Python mirror of the
 reference API, the corpus generators and the multi-process result gather.
 No compute call needs a GPU here (the engine has no CPU fallback)."""
+import pathlib
 import ctypes
 import hashlib
 import inspect
@@ -18,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_cabi_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, 'include', 'pss.h')).read()
+    hdr = pathlib.Path(os.path.join(ROOT, 'include', 'pss.h')).read_text()
     hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
     names = sorted(set(re.findall(r'\b(pss_[a-z0-9_]+)\s*\(', hdr)))
     assert len(names) >= 25
@@ -31,7 +32,7 @@ def test_stats_structs_are_declared_alike_on_both_sides():
     """pss_sa_stats / pss_search_stats exist twice -- include/pss.h and the ctypes classes of _ffi.py: same fields in the same
     order with the same types, and the library reports the size its build had (the binding refuses to load otherwise)."""
     from pysubstringsearch_amd import _ffi
-    hdr = open(os.path.join(ROOT, 'include', 'pss.h')).read()
+    hdr = pathlib.Path(os.path.join(ROOT, 'include', 'pss.h')).read_text()
     hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
     ctype = {'uint64_t': ctypes.c_uint64, 'uint32_t': ctypes.c_uint32, 'int32_t': ctypes.c_int32, 'double': ctypes.c_double,
              'float': ctypes.c_float, 'int64_t': ctypes.c_int64}
@@ -137,7 +138,7 @@ def test_chunk_limit_growth_rule(pss, tmp_path):
     with pytest.raises(RuntimeError, match='no usable HIP device') if not pss.device_count() else _noraise():
         w.close()
     w2.close()               # a one-byte chunk has the suffix array [0] by contract (libsais.c:6603-6607): no device
-    assert open(str(tmp_path / 'z.idx'), 'rb').read().hex() == '010000000a0400000000000000'
+    assert pathlib.Path(str(tmp_path / 'z.idx')).read_bytes().hex() == '010000000a0400000000000000'
 
 
 class _noraise:
@@ -165,7 +166,7 @@ def test_product_never_imports_oracle():
     for dirpath, _, files in os.walk(pkg):
         for f in files:
             if f.endswith(('.py', '.cpp', '.hip', '.h')):
-                src = open(os.path.join(dirpath, f), encoding='utf-8').read()
+                src = pathlib.Path(os.path.join(dirpath, f)).read_text(encoding='utf-8')
                 assert 'oracle' not in src.replace('oracle restatement', ''), f'{f} mentions the oracle'
 
 
@@ -184,7 +185,7 @@ def test_every_environment_switch_is_in_the_one_registry():
     csrc = os.path.join(ROOT, 'pysubstringsearch_amd', 'csrc')
     for f in os.listdir(csrc):
         if f.endswith(('.cpp', '.hip', '.h')):
-            src = open(os.path.join(csrc, f), encoding='utf-8').read()
+            src = pathlib.Path(os.path.join(csrc, f)).read_text(encoding='utf-8')
             assert not re.search(r'getenv\("PSS_', src), f'{f} reads a switch behind the registry'
             read |= set(re.findall(r'knob\("(PSS_[A-Z0-9_]+)"\)', src))
     assert read - set(names) == set(), f'not registered: {sorted(read - set(names))}'
@@ -293,7 +294,7 @@ def test_generators_match_python_spec():
     runs = gen_corpus(2, 50000).tobytes()
     assert set(runs) <= {97, 98, 10} and runs[-1:] == b'\n'
     assert all(len(set(line)) <= 1 and len(line) <= 8192 for line in runs.split(b'\n'))
-    kats = {k['name']: k for k in json.load(open(os.path.join(ROOT, 'tests', 'golden', 'sa_kats.json')))['kats']}
+    kats = {k['name']: k for k in json.loads(pathlib.Path(os.path.join(ROOT, 'tests', 'golden', 'sa_kats.json')).read_text())['kats']}
     for kind, name in [(0, 'lines_1MiB'), (1, 'words_1MiB'), (2, 'runs_1MiB'), (3, 'periodic_1MiB')]:
         assert hashlib.sha256(gen_corpus(kind, 1 << 20).tobytes()).hexdigest() == kats[name]['text_sha256']
 
@@ -319,7 +320,7 @@ def test_sharded_gather_gloo(tmp_path):
                               env=env) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=180) == 0
-    got = json.load(open(out))
+    got = json.loads(pathlib.Path(out).read_text())
     # query-major; inside a query rank 0's entries then rank 1's; duplicates across queries kept
     assert got['got'] == ['ten', 'tenten', 'ten', 'x', 'one', 'three', 'ten', 'tenten', 'ten']
     assert got['counts'] == [2, 3] and got['raw'] == ['one', 'three', 'ten', 'tenten', 'ten']
@@ -385,14 +386,14 @@ def test_tools_compile():
     files = sorted(glob.glob(os.path.join(root, '*.py')))
     assert len(files) > 10
     for f in files:
-        compile(open(f, encoding='utf-8').read(), f, 'exec')
+        compile(pathlib.Path(f).read_text(encoding='utf-8'), f, 'exec')
 
 
 def test_drop_in_name_ships_type_stubs():
     """The reference ships pysubstringsearch/pysubstringsearch.pyi and py.typed beside its __init__.py."""
     pkg = os.path.join(ROOT, 'pysubstringsearch')
     assert os.path.exists(os.path.join(pkg, 'py.typed')) and os.path.exists(os.path.join(pkg, '__init__.pyi'))
-    stub = open(os.path.join(ROOT, 'pysubstringsearch_amd', '__init__.pyi')).read()
+    stub = pathlib.Path(os.path.join(ROOT, 'pysubstringsearch_amd', '__init__.pyi')).read_text()
     for name in ('add_entries_from_file_lines', 'add_entry', 'dump_data', 'finalize', 'search', 'search_multiple'):
         assert f'def {name}(' in stub, name
 

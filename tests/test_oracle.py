@@ -1,5 +1,6 @@
 """CPU tests: the oracle restatement against the committed golden vectors
 (reference tests re-expressed as data, libsais-generated SAs and .idx bytes)."""
+import pathlib
 import hashlib
 import json
 import os
@@ -13,7 +14,7 @@ GOLD = os.path.join(HERE, 'golden')
 
 
 def load(name):
-    return json.load(open(os.path.join(GOLD, name), encoding='utf-8'))
+    return json.loads(pathlib.Path(os.path.join(GOLD, name)).read_text(encoding='utf-8'))
 
 
 def build_idx(W, path, entries, max_chunk_len=None, dump_after=()):
@@ -24,7 +25,7 @@ def build_idx(W, path, entries, max_chunk_len=None, dump_after=()):
             w.dump_data()
     w.finalize()
     w.close()
-    return open(path, 'rb').read()
+    return pathlib.Path(path).read_bytes()
 
 
 def test_little_endian_host():
@@ -69,7 +70,7 @@ def test_container_cases(oracle, tmp_path):
         w = oracle.OracleWriter(p, case.get('max_chunk_len'))
         w.add_entries_from_file_lines(str(src))
         w.close()
-        assert open(p, 'rb').read().hex() == case['idx_hex'], case['name']
+        assert pathlib.Path(p).read_bytes().hex() == case['idx_hex'], case['name']
 
 
 def test_known_multi_chunk_layout(oracle, tmp_path):

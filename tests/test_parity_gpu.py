@@ -3,6 +3,7 @@ the reference's own tests re-expressed as data, the container goldens, and
 fuzzing against the CPU oracle.  Result lists are compared as multisets
 (assertCountEqual in the reference, tests/test_pysubstringsearch.py:32-37);
 .idx files byte for byte."""
+import pathlib
 import hashlib
 import json
 import os
@@ -20,7 +21,7 @@ GOLD = os.path.join(HERE, 'golden')
 
 
 def load(name):
-    return json.load(open(os.path.join(GOLD, name), encoding='utf-8'))
+    return json.loads(pathlib.Path(os.path.join(GOLD, name)).read_text(encoding='utf-8'))
 
 
 def build(path, entries, max_chunk_len=None, dump_after=(), W=None):
@@ -31,7 +32,7 @@ def build(path, entries, max_chunk_len=None, dump_after=(), W=None):
             w.dump_data()
     w.finalize()
     w.close()
-    return open(path, 'rb').read()
+    return pathlib.Path(path).read_bytes()
 
 
 def test_reference_tests_as_data(tmp_path):
@@ -45,7 +46,7 @@ def test_reference_tests_as_data(tmp_path):
         for s in case['entries']:
             writer.add_entry(text=s)
         writer.finalize()
-        idx = open(p, 'rb').read()
+        idx = pathlib.Path(p).read_bytes()
         assert hashlib.sha256(idx).hexdigest() == case['idx_sha256'], case['name']
         reader = pysubstringsearch.Reader(index_file_path=p)
         for s in case['searches']:
@@ -72,7 +73,7 @@ def test_container_goldens(tmp_path):
         w = pysubstringsearch.Writer(p, case.get('max_chunk_len'))
         w.add_entries_from_file_lines(str(src))
         w.close()
-        assert open(p, 'rb').read().hex() == case['idx_hex'], case['name']
+        assert pathlib.Path(p).read_bytes().hex() == case['idx_hex'], case['name']
 
 
 def test_writer_reuse_after_finalize_and_truncation(tmp_path, oracle):
@@ -87,7 +88,7 @@ def test_writer_reuse_after_finalize_and_truncation(tmp_path, oracle):
         assert r.num_chunks == 2 and sorted(r.search('a')) == ['alpha', 'beta']
     o = oracle.OracleReader(p)
     assert sorted(o.search('a')) == ['alpha', 'beta']
-    data = open(p, 'rb').read()
+    data = pathlib.Path(p).read_bytes()
     t = tmp_path / 't.idx'
     t.write_bytes(data[:-3])          # truncated SA -> UnexpectedEof -> OSError
     with pytest.raises(OSError):
@@ -174,8 +175,8 @@ def test_one_mib_chunks_batch(tmp_path, oracle):
     ow.add_entries_from_file_lines(str(src))
     ow.close()
     oracle.use_reference_sa(False)
-    assert hashlib.sha256(open(p, 'rb').read()).hexdigest() == hashlib.sha256(open(q, 'rb').read()).hexdigest()
-    text = open(src, 'rb').read()
+    assert hashlib.sha256(pathlib.Path(p).read_bytes()).hexdigest() == hashlib.sha256(pathlib.Path(q).read_bytes()).hexdigest()
+    text = pathlib.Path(src).read_bytes()
     rng = np.random.default_rng(1)
     qs = []
     while len(qs) < 1000:
@@ -276,7 +277,7 @@ def test_file_ingest_fuzz(tmp_path, oracle, seed, monkeypatch):
         ow.add_entries_from_file_lines(str(src))
         ow.add_entry('z')
         ow.close()
-        assert open(p, 'rb').read() == open(q, 'rb').read(), (seed, limit)
+        assert pathlib.Path(p).read_bytes() == pathlib.Path(q).read_bytes(), (seed, limit)
 
 
 @pytest.mark.parametrize('stripes', [None, '3'])
@@ -298,9 +299,9 @@ def test_striped_container(tmp_path, oracle, monkeypatch, stripes):
         for e in entries:
             w.add_entry(e)
         w.close()
-        b2 = open(p2, 'rb').read()
+        b2 = pathlib.Path(p2).read_bytes()
         assert b2[:8] == b'PSSIDX\x02\x00' and int.from_bytes(b2[8:12], 'little') == (1 | (S << 8) | (24 << 16))
-        files = [open(f'{p2}.sa{j}', 'rb').read() for j in range(S)]
+        files = [pathlib.Path(f'{p2}.sa{j}').read_bytes() for j in range(S)]
         assert not os.path.exists(f'{p2}.sa{S}')
         unit = 1 << 24
         o1, o2, chunks, u = 0, 16, 0, 0
@@ -361,7 +362,7 @@ def test_records_through_a_shared_mapping(oracle, monkeypatch):
             w.finalize()
             st = w.io_stats
             w.close()
-            files[route] = open(p, 'rb').read()
+            files[route] = pathlib.Path(p).read_bytes()
             if route == 'map':
                 assert st['records_mapped'] >= 5 and st['records_pwritten'] <= 1, st      # (the last record may be below the threshold)
             else:
@@ -372,7 +373,7 @@ def test_records_through_a_shared_mapping(oracle, monkeypatch):
         for e in entries:
             ow.add_entry(e)
         ow.close()
-        assert files['map'] == open(q, 'rb').read()
+        assert files['map'] == pathlib.Path(q).read_bytes()
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
@@ -401,7 +402,7 @@ def test_real_files_through_the_file_api(tmp_path, oracle):
     ow.add_entries_from_file_lines(str(src))
     ow.close()
     oracle.use_reference_sa(False)
-    assert open(p, 'rb').read() == open(q, 'rb').read()
+    assert pathlib.Path(p).read_bytes() == pathlib.Path(q).read_bytes()
     rng = np.random.default_rng(3)
     qs = []
     for s0, k in zip(rng.integers(0, len(raw) - 64, 150), rng.integers(2, 40, 150)):
@@ -472,7 +473,7 @@ def test_concurrent_handles_from_threads(tmp_path, oracle):
             q = str(tmp_path / f'w{k}.idx')      # and a Writer in the same thread
             build(q, entries, 1500)
             oracle.use_reference_sa(False)
-            assert open(q, 'rb').read() == build(str(tmp_path / f'ow{k}.idx'), entries, 1500, W=oracle.OracleWriter)
+            assert pathlib.Path(q).read_bytes() == build(str(tmp_path / f'ow{k}.idx'), entries, 1500, W=oracle.OracleWriter)
         except Exception as e:   # noqa: BLE001
             errors.append((k, repr(e)))
 
@@ -704,7 +705,7 @@ def test_unchanged_call_uses_the_default_device_list(tmp_path, oracle, monkeypat
     assert w.devices == [0, 0, 0]
     w.add_entries_from_file_lines(str(src))
     w.close()
-    assert open(p1, 'rb').read() == open(p3, 'rb').read()
+    assert pathlib.Path(p1).read_bytes() == pathlib.Path(p3).read_bytes()
     o = oracle.OracleReader(p1)
     text = src.read_bytes()
     rng = np.random.default_rng(2)
@@ -914,7 +915,7 @@ def test_container_format_2(tmp_path, oracle):
     for e in entries:
         w.add_entry(e)
     w.close()
-    b2 = open(p2, 'rb').read()
+    b2 = pathlib.Path(p2).read_bytes()
     assert b2[:8] == b'PSSIDX\x02\x00' and b2[8:16] == bytes(8)
     # walk both files: identical text and suffix array bytes, chunk by chunk
     o1, o2, chunks = 0, 16, 0
@@ -937,7 +938,7 @@ def test_container_format_2(tmp_path, oracle):
         assert counts == oc.tolist() and sorted(ents) == sorted(oe)
     with pysubstringsearch.Reader(p2, shard=(1, 3)) as r:
         assert r.num_chunks == len(range(1, chunks, 3))
-    open(str(tmp_path / 'cut.idx'), 'wb').write(b2[:len(b2) - 5])
+    pathlib.Path(str(tmp_path / 'cut.idx')).write_bytes(b2[:len(b2) - 5])
     with pytest.raises(OSError):
         pysubstringsearch.Reader(str(tmp_path / 'cut.idx'))
     with pytest.raises(ValueError):
@@ -982,13 +983,13 @@ def test_multi_device_writer_is_byte_identical(tmp_path, oracle, devices):
         w.finalize()
         w.add_entry('after finalize')
         w.close()
-        assert open(multi, 'rb').read() == open(single + '2', 'rb').read(), (limit, devices)
+        assert pathlib.Path(multi).read_bytes() == pathlib.Path(single + '2').read_bytes(), (limit, devices)
         oracle.use_reference_sa(True if oracle.have_reference() else False)
         ow = oracle.OracleWriter(orc, limit)
         fill(ow)
         ow.close()
         oracle.use_reference_sa(False)
-        assert open(single, 'rb').read() == open(orc, 'rb').read(), limit
+        assert pathlib.Path(single).read_bytes() == pathlib.Path(orc).read_bytes(), limit
     with pysubstringsearch.Reader(multi) as r:
         assert r.num_chunks >= 4 and r.search('after finalize') == ['after finalize']
     # the host text of the chunks in flight is bounded by bytes too (PSS_WRITER_HOST_BUDGET): with room for one chunk
@@ -1002,7 +1003,7 @@ def test_multi_device_writer_is_byte_identical(tmp_path, oracle, devices):
         w.close()
     finally:
         del os.environ['PSS_WRITER_HOST_BUDGET']
-    assert open(multi + '3', 'rb').read() == open(single + '2', 'rb').read()
+    assert pathlib.Path(multi + '3').read_bytes() == pathlib.Path(single + '2').read_bytes()
     with pytest.raises(ValueError):
         pysubstringsearch.Writer(multi, devices=[])
     with pytest.raises(ValueError):
@@ -1090,7 +1091,7 @@ def test_dropped_writer_flushes_at_once(pss, oracle, tmp_path):
             ow.add_entry(e)
         ow.close()
         del w
-        assert open(p, 'rb').read() == open(q, 'rb').read()
+        assert pathlib.Path(p).read_bytes() == pathlib.Path(q).read_bytes()
         r = pss.Reader(p)
         assert sorted(r.search('ten')) == ['ten', 'tenten']
         ref = weakref.ref(r)

@@ -1,5 +1,6 @@
 """Property tests (hypothesis): the oracle against brute force on CPU; the HIP engine
 against the oracle on the GPU, over arbitrary byte strings and entry lists."""
+import pathlib
 import os
 
 import numpy as np
@@ -100,7 +101,7 @@ def test_gpu_container_and_search_match_oracle(oracle, tmp_path_factory, entries
         ow.add_entry(e)
     w.close()
     ow.close()
-    assert open(p, 'rb').read() == open(q, 'rb').read()
+    assert pathlib.Path(p).read_bytes() == pathlib.Path(q).read_bytes()
     o = oracle.OracleReader(q)
     with pysubstringsearch.Reader(p) as r:
         assert sorted(r.search_multiple(patterns)) == sorted(o.search_multiple(patterns))
