@@ -71,9 +71,12 @@ constexpr int MSD_WAVES = MSD_BLOCK / kWave;
 constexpr int MSD_IPT = 16;
 constexpr u32 MSD_TILE = MSD_BLOCK * MSD_IPT;        // 8192 elements
 constexpr u32 MSD_WIN = 6144;                        // buckets whose start falls into one window of this size share a tile ...
-constexpr u32 MSD_TILE_CAP = 8176;                   // ... unless that is more than a tile holds: then the window's last bucket goes alone
-                                                     // (8176: the eight slots behind a tile's last element hold the ranking's sentinels,
-                                                     //  the eight after those the fast kernel's scalars)
+#ifndef PSS_LS_WINDOW
+#define PSS_LS_WINDOW 8                              // (members of its bin every element of the local sort reads unconditionally)
+#endif
+constexpr u32 MSD_TILE_CAP = 8184 - PSS_LS_WINDOW;   // ... unless that is more than a tile holds: then the window's last bucket goes alone
+                                                     // (the window's worth of slots behind a tile's last element hold the ranking's
+                                                     //  sentinels, the eight after those the fast kernel's scalars)
 constexpr u32 MSD_MAX_BUCKET = 4088;                 // a bucket must fit a tile on its own (the last eight slots of the LDS tile
                                                      // carry the fast kernel's scalars: MSD_TILE_CAP)
 constexpr int MSD_TAG_BITS = MSD_D + 1;              // an element entering the local sort carries the low 11 bits of its joint bucket number ...
@@ -1150,9 +1153,6 @@ constexpr u32 LS_KMAX = 64;
 #define PSS_LS_GROUP 1
 #endif
 constexpr int LS_GROUP = PSS_LS_GROUP;              // rows ranked / written out together: their LDS reads are issued back to back
-#ifndef PSS_LS_WINDOW
-#define PSS_LS_WINDOW 8
-#endif
 constexpr int LS_WINDOW = PSS_LS_WINDOW;                        // members of its bin every element reads unconditionally (bins average 1.3)
 
 __global__ __launch_bounds__(256) void msd_tile_desc_kernel(const u32 *cstart, const u32 *tile_first, u32 nt, u32 ne, u32 n,

@@ -20,6 +20,7 @@ Outputs (data only: inputs + expected outputs):
                          and generated inputs (sha256 of the i32le SA; full SA
                          for the small ones).
 """
+import pathlib
 import hashlib
 import json
 import os
@@ -80,13 +81,13 @@ def build_idx(entries, max_chunk_len=None, dump_after=()):
                 w.dump_data()
         w.finalize()
         w.close()
-        return open(p, 'rb').read()
+        return pathlib.Path(p).read_bytes()
 
 
 def search_idx(idx_bytes, queries):
     with tempfile.TemporaryDirectory() as d:
         p = os.path.join(d, 'o.idx')
-        open(p, 'wb').write(idx_bytes)
+        pathlib.Path(p).write_bytes(idx_bytes)
         r = O.OracleReader(p)
         out = {q: sorted(r.search(q)) for q in queries}
         r.close()
@@ -145,23 +146,23 @@ def main():
                       ('only_newline', b'\n'), ('non_utf8', b'\xff\xfe\n\x80abc\n')]:
         with tempfile.TemporaryDirectory() as d:
             src = os.path.join(d, 'in.txt')
-            open(src, 'wb').write(raw)
+            pathlib.Path(src).write_bytes(raw)
             p = os.path.join(d, 'o.idx')
             w = O.OracleWriter(p)
             w.add_entries_from_file_lines(src)
             w.close()
-            idx = open(p, 'rb').read()
+            idx = pathlib.Path(p).read_bytes()
         ingest.append({'name': name, 'input_hex': raw.hex(), 'idx_hex': idx.hex()})
     with tempfile.TemporaryDirectory() as d:   # chunk overflow during ingest
         raw = b''.join(b'line%03d\n' % i for i in range(40))
         src = os.path.join(d, 'in.txt')
-        open(src, 'wb').write(raw)
+        pathlib.Path(src).write_bytes(raw)
         p = os.path.join(d, 'o.idx')
         w = O.OracleWriter(p, 50)
         w.add_entries_from_file_lines(src)
         w.close()
         ingest.append({'name': 'overflow_50', 'input_hex': raw.hex(), 'max_chunk_len': 50,
-                       'idx_hex': open(p, 'rb').read().hex()})
+                       'idx_hex': pathlib.Path(p).read_bytes().hex()})
     json.dump({'note': 'parity unpinned by the reference tests: produced by oracle/pss_oracle.c with libsais SAs',
                'cases': cc, 'file_ingest': ingest},
               open(os.path.join(HERE, 'container_cases.json'), 'w'), ensure_ascii=False, indent=1)

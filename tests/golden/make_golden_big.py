@@ -15,6 +15,7 @@ Per (corpus kind, chunk_index):
 
 Data only: inputs are regenerated from the corpus specification, outputs are hashes.
 """
+import pathlib
 import argparse
 import hashlib
 import json
@@ -94,7 +95,7 @@ def main():
         jobs += [('lines', 0, BIG_N), ('words', 0, BIG_N), ('mixed', 0, BIG_N), ('runs', 0, BIG_N), ('source', 0, BIG_N), ('words', 0, FORMAT2_N)]
     done = {}
     if os.path.exists(args.out):
-        for r in json.load(open(args.out))['chunks']:
+        for r in json.loads(pathlib.Path(args.out).read_text())['chunks']:
             done[(r['kind'], r['chunk_index'], r['n'])] = r
     if args.only:
         jobs = [j for j in jobs if j[0] in args.only.split(',')]

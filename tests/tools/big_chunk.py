@@ -3,6 +3,7 @@
 every sampled query must return exactly the lines of the text that contain it.
 
     python tests/tools/big_chunk.py [bytes=1342177280]"""
+import pathlib
 import os
 import sys
 import tempfile
@@ -21,7 +22,7 @@ buf = np.empty(n, dtype=np.uint8)
 _ffi.check(_ffi.lib.pss_gen_corpus(0, buf.ctypes.data, n, 7))
 text = buf.tobytes()
 del buf
-open(src, 'wb').write(text)
+pathlib.Path(src).write_bytes(text)
 t0 = time.perf_counter()
 w = pysubstringsearch.Writer(idx, n, format_version=2)
 w.add_entries_from_file_lines(src)

@@ -4,6 +4,7 @@ current sources -- or that carries none -- is stale.
 
     python tests/tools/check_evidence.py [--strict]     exit 1 when a file is stale (--strict: also for files without a hash)
 """
+import pathlib
 import glob
 import json
 import os
@@ -17,7 +18,7 @@ strict = '--strict' in sys.argv
 bad = 0
 for f in sorted(glob.glob(os.path.join(tree_hash.ROOT, 'profiles', 'pmc_*.json'))):
     try:
-        d = json.load(open(f))
+        d = json.loads(pathlib.Path(f).read_text())
     except Exception as e:                      # noqa: BLE001
         print(f'{os.path.basename(f)}: unreadable ({e})')
         bad += 1

@@ -5,6 +5,7 @@ reference's Writer / Reader): random alphabets, repeat structure, chunk limits a
 
 Every case checks (1) the suffix array of the raw text, (2) the .idx container byte for byte,
 (3) search / search_multiple multisets and per-query counts.  Prints the failing seed and stops."""
+import pathlib
 import os
 import random
 import sys
@@ -78,7 +79,7 @@ def build(path, entries, limit, W):
     w.finalize()
     if hasattr(w, 'close'):
         w.close()
-    return open(path, 'rb').read()
+    return pathlib.Path(path).read_bytes()
 
 
 def random_knobs(rng):
@@ -108,7 +109,7 @@ def file_case(rng, tmp):
     if rng.random() < 0.5 and blob.endswith(b'\n'):
         blob = blob[:-1]
     src = os.path.join(tmp, 'in.txt')
-    open(src, 'wb').write(blob)
+    pathlib.Path(src).write_bytes(blob)
     limit = rng.choice([None, 40, 100, 1000])
     tail = rng.random() < 0.3
     out = []
@@ -121,7 +122,7 @@ def file_case(rng, tmp):
         w.finalize()
         if hasattr(w, 'close'):
             w.close()
-        out.append(open(path, 'rb').read())
+        out.append(pathlib.Path(path).read_bytes())
     return out
 
 

@@ -4,6 +4,7 @@ search, arena overflow, > 1024 hits per (query, chunk)), long and newline-crossi
 sharded readers.  Everything is compared with the oracle's restatement of Reader::search.
 
     python tests/tools/fuzz_search.py [seconds=120] [seed0=<time>]"""
+import pathlib
 import os
 import random
 import sys
@@ -34,7 +35,7 @@ def one_case(seed, tmp):
         w.finalize()
         if hasattr(w, 'close'):
             w.close()
-    assert open(p, 'rb').read() == open(q, 'rb').read(), 'container differs'
+    assert pathlib.Path(p).read_bytes() == pathlib.Path(q).read_bytes(), 'container differs'
     text = '\n'.join(entries) + '\n'
     nq = rng.choice([1, 3, 50, 1500, 40000 if total < 300000 else 3000])
     queries = []

@@ -6,6 +6,7 @@ after k symbols, how large the tied groups are -- the figures the `source` corpu
 
 CPU only; minutes at logn = 26.
 """
+import pathlib
 import ctypes
 import os
 import subprocess
@@ -68,7 +69,7 @@ def helper():
     so = os.path.join(d, 'pss_lcp_stats.so')
     if not os.path.exists(so):
         c = os.path.join(d, 'pss_lcp_stats.c')
-        open(c, 'w').write(SRC)
+        pathlib.Path(c).write_text(SRC)
         subprocess.run(['gcc', '-O2', '-shared', '-fPIC', '-o', so, c], check=True)
     lib = ctypes.CDLL(so)
     lib.kasai.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]

@@ -4,6 +4,7 @@ the oracle's Reader on the same .idx.
 
     python tests/tools/real_e2e.py [logn=29] [queries=20000]
 """
+import pathlib
 import importlib.util
 import json
 import os
@@ -25,7 +26,7 @@ def main():
     nq = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
     raw = rt.collect(1 << logn)
     src, idx = '/tmp/real_e2e.txt', '/tmp/real_e2e.idx'
-    open(src, 'wb').write(raw)
+    pathlib.Path(src).write_bytes(raw)
     out = {'text_bytes': len(raw)}
     # (round 4 reused the path between the two repetitions: the second Writer then TRUNCATES a 2 GB file and rewrites it, and
     # ext4 answers that pattern -- replace-via-truncate -- by flushing the new blocks when the file is closed: 207 ms of

@@ -4,6 +4,7 @@ tables of numbers, bytes above 127 -- built on the GPU and compared with libsais
 
     python tests/tools/real_text.py [logn=26] [reps=3]
 """
+import pathlib
 import ctypes
 import hashlib
 import os
@@ -33,7 +34,7 @@ def collect(limit):
                 try:
                     if os.path.islink(p) or os.path.getsize(p) > (8 << 20):
                         continue
-                    b = open(p, 'rb').read()
+                    b = pathlib.Path(p).read_bytes()
                 except OSError:
                     continue
                 if not b:
@@ -83,10 +84,10 @@ def main():
     t0 = time.time()
     cache = f'/tmp/real_text_{logn}.bin'
     if os.path.exists(cache):
-        raw = open(cache, 'rb').read()
+        raw = pathlib.Path(cache).read_bytes()
     else:
         raw = collect(n)
-        open(cache, 'wb').write(raw)
+        pathlib.Path(cache).write_bytes(raw)
     t = np.frombuffer(raw, dtype=np.uint8).copy()
     if t.size and t[-1] != 10:
         t[-1] = 10

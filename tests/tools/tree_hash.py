@@ -4,6 +4,7 @@ the files themselves can, and bench.py / check_evidence.py recompute it to say w
 
     python tests/tools/tree_hash.py            prints the hash (and the commit given in PSS_TREE_COMMIT, if any)
 """
+import pathlib
 import glob
 import hashlib
 import os
@@ -19,7 +20,7 @@ def csrc_hash() -> str:
     h = hashlib.sha256()
     for f in sorted(files):
         h.update(os.path.relpath(f, ROOT).encode() + b'\0')
-        h.update(open(f, 'rb').read())
+        h.update(pathlib.Path(f).read_bytes())
         h.update(b'\0')
     return h.hexdigest()[:16]
 
