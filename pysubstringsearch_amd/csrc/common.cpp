@@ -429,7 +429,7 @@ const KnobDef kKnobs[] = {
     {"PSS_PROBE_SKIP_PCT", "50", "0|20|90", "builder: no text rounds when more than this share of the sampled tied pairs are repeats"},
     {"PSS_NO_MID_TIER", "unset", "1", "rounds: groups above 512 members all take the chained radix sorts"},
     {"PSS_NO_MID_MERGE", "unset", "1", "rounds: groups of 513 .. 4096 members with a crowded bin take the chained sorts (no LDS merge sort)"},
-    {"PSS_BIG_MERGE", "0", "1|2", "rounds: groups above 4096 members through the segmented merge sort (2: in text rounds only)"},
+    {"PSS_BIG_MERGE", "-1 (by the average size of the large groups)", "0|1|2", "rounds: groups above 4096 members through the segmented merge sort (2: in text rounds only)"},
     {"PSS_NO_BIG_MERGE", "unset", "", "rounds: overrides PSS_BIG_MERGE"},
     {"PSS_COUNT_SORT", "unset", "1", "rank rounds: groups ranked by counting instead of the merge sort"},
     {"PSS_PERIODIC", "1", "0", "rank rounds: 0 = no periodic keys for the large groups"},

@@ -119,7 +119,8 @@ struct Knobs {
                                 //                unset: n >= 2^24 and the MSD sort did not take the text
     bool no_msd_fuse = false;   // PSS_MSD_NO_FUSE  MSD sort flags ties in the suffix array; the rerank kernels read them
     bool no_mid_tier = false;   // PSS_NO_MID_TIER  groups above 512 members all take the chained radix sorts
-    int big_merge = 0;          // PSS_BIG_MERGE  1: groups above 4096 members through the segmented merge sort (bg_*_kernel) instead of the
+    int big_merge = -1;         // PSS_BIG_MERGE  unset: by the average size of the large groups (sa_refine_impl.h); 0: never;
+                                //                1: groups above 4096 members through the segmented merge sort (bg_*_kernel) instead of the
                                 //                chained radix sorts, 2: in text rounds only.  Measured at 2^29 and left OFF: real files
                                 //                111.8 / 112.7 vs 112.6 / 113.5 ms, `source` 166.6 vs 171.5, `mixed` 90.7 vs 87.2 (its
                                 //                groups of millions take twelve merge passes where the radix sorts take seven)

@@ -439,7 +439,13 @@ static int refine_rounds(DeviceCtx *ctx, const Knobs &knobs, RoundsIO &io, SortS
                     set_error("%s", "");
                 }
             }
-            if ((knobs.big_merge == 1 || (knobs.big_merge == 2 && use_text && big_key_bits > 32)) && nbig < 0x7fffffffu) {
+            // Default (round 6): the merge sort where the large groups are small on average (<= 2^16 members: `words`,
+            // source-like text -- a handful of tile sorts and merge passes inside every group against 8 + 3 chained radix
+            // passes over all of them), the chained sorts where a few groups hold millions (`mixed`: twelve merge passes
+            // against seven).  Measured: words 35.5-36.0 -> 35.2-35.4 ms, `source` 3-6 ms on one box and within the noise on
+            // another, mixed / dup_blocks / real files unchanged (forced on everywhere: mixed 88 -> 91).
+            const bool merge_auto = knobs.big_merge < 0 && (u64)nbig <= ((u64)nbig_groups << 16);
+            if ((knobs.big_merge == 1 || merge_auto || (knobs.big_merge == 2 && use_text && big_key_bits > 32)) && nbig < 0x7fffffffu) {
                 // segmented merge sort of the large groups (bg_*_kernel): tiles in LDS, then merge passes inside every group
                 const u32 bound = nbig / BG_TILE + nbig_groups + 2;
                 const size_t g4 = round_up(((size_t)nbig_groups + 2) * 4, 64), g8 = round_up(((size_t)nbig_groups + 2) * 8, 64);
