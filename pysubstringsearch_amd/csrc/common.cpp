@@ -225,7 +225,7 @@ struct PinnedBlock {
 };
 std::mutex g_pool_mu;
 std::vector<PinnedBlock> g_pool;            // free blocks
-constexpr size_t kPoolMaxBlocks = 4;
+constexpr size_t kPoolMaxBlocks = 24;      // (a reader over eight devices returns eight blocks and a merged one per batch)
 // Pinned memory the pool keeps between batches.  Round 6: 12 -> 40 GiB (PSS_PINNED_POOL_BYTES): a batch on natural text
 // returns 18 GB of entries (100 000 queries of 16..32 bytes on 15 chunks of `words`, 259 M entries), and a block the pool
 // would not keep was pinned and unpinned on EVERY batch -- 1.8 s + 1 s around 0.06 s of kernels and 0.36 s of PCIe.
