@@ -48,8 +48,10 @@
 //                     the buckets (b, d): the table of joint bucket starts falls out of the pass.
 //
 // The joint table only exists after P2, so P2 cannot tag an element with its bucket's number among the non-empty ones.
-// It tags with d mod 64 (a constant of the tile), the plan never lets a local-sort tile cross a multiple of 64 joint
-// buckets, and the local sort numbers a bucket by the non-empty ones below it in the tile's 64-bit map (a popcount).
+// The d-regions are renumbered first (msd_tiles2_kernel: the non-empty ones 0 .. D - 1 in digit order -- a digit value
+// that never occurs leaves no hole), P2 tags with that number mod 64 (a constant of the tile), the plan never lets a
+// local-sort tile cross a multiple of 64 joint buckets, and the local sort takes "tag - tag of the tile's first bucket"
+// as the bucket's number inside its tile: one subtraction.
 // Measured in isolation before it was built: tests/tools/lookback_micro.hip, profiles/r06_lookback_micro.txt.
 //
 // HBM-bound integer work: no MFMA anywhere by design.
@@ -839,7 +841,7 @@ struct InNonEmpty {
 };
 
 // compact the starts of the non-empty joint buckets; largest bucket
-// (cj, LSD order: the joint bucket number of every non-empty bucket -- the tile rule and the tiles' bucket maps need it)
+// (cj, LSD order: the joint bucket number of every non-empty bucket -- the tile rule and the tiles' tags need it)
 __global__ __launch_bounds__(256) void msd_compact_kernel(const u32 *J, u32 nb, const u64 *rank, u32 *cstart, u32 *counters, u32 *cj)
 {
     u32 mx = 0;
