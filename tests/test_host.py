@@ -343,6 +343,12 @@ def test_cabi_argument_contract_without_gpu():
     assert lib.pss_reader_open(b'x', 0, 2, 2, ctypes.byref(h)) == _ffi.PSS_EINVAL      # shard index out of range
     assert lib.pss_gen_corpus(99, t.ctypes.data, 1, 0) == _ffi.PSS_EINVAL
     assert lib.pss_result_num_entries(None) == 0 and lib.pss_reader_num_chunks(None) == 0
+    # the observers of round 6: a null reader has no parts, a device nobody used holds no workspace, knob indices are checked
+    assert lib.pss_reader_part_chunks(None, None, 0) == 0
+    assert lib.pss_workspace_bytes(-1) == 0 and lib.pss_workspace_bytes(63) == 0 and lib.pss_workspace_bytes(1 << 20) == 0
+    assert lib.pss_knob_info(-1, None, None, None, None) == _ffi.PSS_EINVAL
+    assert lib.pss_knob_info(lib.pss_knob_count(), None, None, None, None) == _ffi.PSS_EINVAL
+    assert lib.pss_knob_info(0, None, None, None, None) == _ffi.PSS_OK
     assert lib.pss_reader_set_low_latency(None, 1) == _ffi.PSS_EINVAL
     assert lib.pss_reader_low_latency_stats(None, None, None) == _ffi.PSS_EINVAL
     assert lib.pss_reader_evict_chunk(None, 0) == _ffi.PSS_EINVAL
