@@ -684,6 +684,59 @@ def test_eight_way_placement_of_fifteen_chunks(tmp_path, oracle):
         assert single.chunks_per_device == [nc]
 
 
+def test_multi_device_results_merged_by_several_threads(tmp_path, oracle):
+    """The host merge of a multi-device reader splits the batch into ranges of queries that several threads merge side by
+    side once the result is large (>= 2^18 entries or 32 MB: capi.cpp multi_batch, round 6).  A batch whose queries return
+    hundreds of thousands of entries each -- single letters on 15 chunks of 1 MiB -- next to queries that return nothing:
+    every API equal to the one-device reader and, on a sample, to the oracle."""
+    from tests.util import gen_corpus
+    src = tmp_path / 'c.txt'
+    text = gen_corpus(0, 15 << 20).tobytes()
+    src.write_bytes(text)
+    p = str(tmp_path / 'c.idx')
+    w = pysubstringsearch.Writer(p, 1 << 20)
+    w.add_entries_from_file_lines(str(src))
+    w.close()
+    rng = np.random.default_rng(3)
+    qs = [b'e', b'zzzzzzzz', b'a', b' ', b'qx', b'', b'.', b'0']
+    while len(qs) < 400:
+        s0 = int(rng.integers(0, len(text) - 20))
+        qs.append(text[s0:s0 + int(rng.integers(2, 9))])
+    order = rng.permutation(len(qs))
+    qs = [qs[i] for i in order]
+    with pysubstringsearch.Reader(p) as single:
+        se, sc = single.search_batch_raw(qs)
+        assert len(se) >= (1 << 20)                          # well beyond the threshold of the threaded merge
+        starts = np.zeros(len(sc) + 1, dtype=np.int64)
+        np.cumsum(sc, out=starts[1:])
+        for devs in ([0, 0], [0] * 8):
+            with pysubstringsearch.Reader(p, devices=devs) as r:
+                ents, counts = r.search_batch_raw(qs)
+                assert counts == sc and len(ents) == len(se)
+                for i, c in enumerate(counts):
+                    if c and c < 20000:                      # (the big ones: by length and a checksum of their bytes below)
+                        assert sorted(ents[starts[i]:starts[i] + c]) == sorted(se[starts[i]:starts[i] + c]), qs[i]
+                pk, spk = r.search_batch_packed(qs), single.search_batch_packed(qs)
+                assert pk.counts.tolist() == spk.counts.tolist() and int(pk.offsets[-1]) == int(spk.offsets[-1])
+                po, so = np.asarray(pk.offsets), np.asarray(spk.offsets)
+                for i, c in enumerate(counts):               # per query: the same multiset of entry lengths, the same bytes in sum
+                    a, b = int(starts[i]), int(starts[i] + c)
+                    assert np.array_equal(np.sort(np.diff(po[a:b + 1])), np.sort(np.diff(so[a:b + 1])))
+                    assert int(np.asarray(pk.data[int(po[a]):int(po[b])], dtype=np.uint64).sum()) == \
+                        int(np.asarray(spk.data[int(so[a]):int(so[b])], dtype=np.uint64).sum())
+                del pk, spk
+    o = oracle.OracleReader(p)
+    sample = [q for q in qs if q not in (b'e', b'a', b' ', b'', b'.', b'0')][:60]
+    with pysubstringsearch.Reader(p, devices=[0] * 8) as r:
+        ents, counts = r.search_batch_raw(sample)
+        oe, oc = o.search_multiple_bytes(sample)
+        assert counts == oc.tolist()
+        pos = 0
+        for c in counts:
+            assert sorted(ents[pos:pos + c]) == sorted(oe[pos:pos + c])
+            pos += c
+
+
 def test_unchanged_call_uses_the_default_device_list(tmp_path, oracle, monkeypatch):
     """`Reader(path)` / `Writer(path)` exactly as a user of the reference writes them: with PSS_DEVICES set (or more
     than one GPU visible) they fan out over the device list without a `devices=` argument -- the reference's search
