@@ -337,7 +337,7 @@ def test_striped_container(tmp_path, oracle, monkeypatch, stripes):
 
 
 def test_records_through_a_shared_mapping(oracle, monkeypatch):
-    """On tmpfs large records go into the index file through a shared mapping of their range (write_record, capi.cpp).
+    """On tmpfs large records go into the index file through a shared mapping of their range (write_record, capi_writer_impl.h).
     Round 4 opened the file write-only, like File::create does (src/lib.rs:55) -- and mmap(PROT_READ | PROT_WRITE,
     MAP_SHARED) on a write-only descriptor fails with EACCES: the route never ran.  The mapping now has a descriptor of
     its own (O_RDWR); pss_writer_io_stats says which way the records went, and the bytes are the pwrite route's."""
@@ -686,7 +686,7 @@ def test_eight_way_placement_of_fifteen_chunks(tmp_path, oracle):
 
 def test_multi_device_results_merged_by_several_threads(tmp_path, oracle):
     """The host merge of a multi-device reader splits the batch into ranges of queries that several threads merge side by
-    side once the result is large (>= 2^18 entries or 32 MB: capi.cpp multi_batch, round 6).  A batch whose queries return
+    side once the result is large (>= 2^18 entries or 32 MB: capi_reader_impl.h multi_batch, round 6).  A batch whose queries return
     hundreds of thousands of entries each -- single letters on 15 chunks of 1 MiB -- next to queries that return nothing:
     every API equal to the one-device reader and, on a sample, to the oracle."""
     from tests.util import gen_corpus
