@@ -159,12 +159,18 @@ void IoPool::run()
             at += (size_t)k;
         }
         {
+            // The notification goes out UNDER the batch's lock: a Batch lives on its waiter's stack (write_record,
+            // the reader's load paths), and a waiter that another worker's notification (or a spurious wake-up) lets
+            // see finished == submitted returns and ends the Batch.  Notifying after the unlock touched a condition
+            // variable in a dead stack frame -- once in some thousands of Writers it found other data there and
+            // rewrote it (fuzz campaign of round 6: "stack smashing detected" in the record thread, a hang at exit).
+            // With the lock held the waiter cannot leave wait() before this worker is done with the Batch.
             std::lock_guard<std::mutex> lk(t.b->mu);
             if (err && !t.b->err) t.b->err = err;
             t.b->finished += 1;
             if (t.done) t.done->store(1, std::memory_order_release);
+            t.b->cv.notify_all();
         }
-        t.b->cv.notify_all();
     }
 }
 

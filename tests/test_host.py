@@ -417,6 +417,24 @@ def test_merge_packed_c_helper_rejects_inconsistent_input():
     assert rc == _ffi.PSS_EINVAL
 
 
+def test_io_pool_is_done_with_a_batch_before_its_waiter_returns(tmp_path):
+    """A Batch of the I/O pool lives on its waiter's stack (the Writer's record thread, the Reader's load paths): the worker
+    that finishes its last piece must not touch it once the waiter can run on.  tests/native/io_pool_stack_batch.cpp
+    repeats the record thread's pattern 40 000 times and watches the stack frame that follows; the version that notified
+    after unlocking (found by round 6's fuzz campaign as a stack-smashing abort on the GPU box) rewrites words of that
+    frame or hangs here within a few thousand rounds.  Host code only: common.cpp built with g++, no device touched."""
+    csrc = os.path.join(ROOT, 'pysubstringsearch_amd', 'csrc')
+    exe = str(tmp_path / 'io_pool_stack_batch')
+    r = subprocess.run(['g++', '-O1', '-std=c++17', '-D__HIP_PLATFORM_AMD__', '-I/opt/rocm/include', '-I' + csrc,
+                        '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'native', 'io_pool_stack_batch.cpp'),
+                        os.path.join(csrc, 'common.cpp'), '-o', exe, '-L/opt/rocm/lib', '-lamdhip64', '-lpthread'],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, LD_LIBRARY_PATH='/opt/rocm/lib:' + os.environ.get('LD_LIBRARY_PATH', ''))
+    r = subprocess.run([exe, '40000'], capture_output=True, text=True, env=env, timeout=180)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-1000:]
+
+
 def test_host_logic_under_sanitizers(tmp_path):
     """The host side of the library (capi.cpp: container writer / reader, argument checks, packed-result merge;
     common.cpp; corpus.cpp) rebuilt with -fsanitize=address,undefined (`make asan`) and driven through the host tests of
