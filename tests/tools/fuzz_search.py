@@ -116,6 +116,40 @@ def one_case(seed, tmp):
                 assert c1 == [counts[i]] and sorted(e1) == sorted(oe[starts[i]:starts[i] + counts[i]]), ('single query differs', mode)
         r.set_low_latency(False)
         os.environ.pop('PSS_RESIDENT_IDLE_US', None)
+    # several lanes in one process (round 6: added to the campaign after it found the I/O-pool race): a Writer whose
+    # chunks go round-robin to k builder lanes of this GPU must write the same bytes, in format 1 and -- format 2, striped
+    # or not -- an index that reads back equal; a Reader over k lanes (host merge of the lanes' results, by several
+    # threads when large) must return what the one-lane reader returned
+    if rng.random() < 0.5:
+        k = rng.choice([2, 3, 8])
+        fmt = rng.choice([1, 1, 2])
+        striped = fmt == 2 and rng.random() < 0.5
+        pm = os.path.join(tmp, 'm.idx')
+        kw = dict(devices=[0] * k)
+        if fmt == 2:
+            kw.update(format_version=2, striped=striped)
+        w = pysubstringsearch.Writer(pm, limit, **kw)
+        for e in entries:
+            w.add_entry(e)
+        w.finalize()
+        w.close()
+        if fmt == 1:
+            assert pathlib.Path(pm).read_bytes() == pathlib.Path(q).read_bytes(), 'container of a %d-lane writer differs' % k
+        nsub = min(len(qb), 2000)
+        want = sum(oc.tolist()[:nsub])
+        for path, devs in ((pm, None), (p, [0] * rng.choice([2, 5, 8])), (pm, [0] * k)):
+            with (Reader(path, devices=devs) if devs else Reader(path)) as r:
+                e, c = r.search_batch_raw(qb[:nsub])
+                assert c == oc.tolist()[:nsub], ('lanes: counts differ', fmt, striped, devs)
+                pos = 0
+                for cc in c:
+                    assert sorted(e[pos:pos + cc]) == sorted(oe[pos:pos + cc]), ('lanes: multiset differs', fmt, striped, devs)
+                    pos += cc
+                assert pos == want
+                assert r.count_multiple_bytes(qb[:nsub]) == c, ('lanes: count API differs', fmt, striped, devs)
+        for f in os.listdir(tmp):
+            if f.startswith('m.idx'):
+                os.remove(os.path.join(tmp, f))
     # shards: the union over ranks is the whole result, per query
     k = rng.choice([2, 3, 8])
     per = [0] * len(qb)
