@@ -1,7 +1,8 @@
 """Time-boxed fuzzing of the search path on mid-size multi-chunk indexes: batch sizes from 1 to
 tens of thousands of queries (fused small-batch kernel, wave-per-pair and lane-per-pair interval
 search, arena overflow, > 1024 hits per (query, chunk)), long and newline-crossing patterns,
-sharded readers.  Everything is compared with the oracle's restatement of Reader::search.
+sharded readers, Writers and Readers over several lanes of one GPU (container formats 1, 2, striped).  Everything is
+compared with the oracle's restatement of Reader::search.
 
     python tests/tools/fuzz_search.py [seconds=120] [seed0=<time>]"""
 import pathlib
