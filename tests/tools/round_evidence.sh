@@ -68,7 +68,14 @@ python tests/tools/latency_hits.py 29 1 resident > $ev/lat1r.txt 2>&1; tail -1 $
 python tests/tools/latency_hits.py 29 15 > $ev/lat15.txt 2>&1; tail -1 $ev/lat15.txt > $ev/${tag}_latency_vs_results_15chunks.json
 python tests/tools/latency_hits.py 29 15 resident > $ev/lat15r.txt 2>&1; tail -1 $ev/lat15r.txt > $ev/${tag}_latency_vs_results_15chunks_low_latency.json
 # 7. fuzzing of the final code
-(echo "# tests/tools/fuzz.py 300; FUZZ_BIG=1 fuzz.py 300; fuzz_search.py 200; anchor_check.py 150"; timeout 500 python tests/tools/fuzz.py 300 7001 2>&1 | tail -1; FUZZ_BIG=1 timeout 500 python tests/tools/fuzz.py 300 7002 2>&1 | tail -1; timeout 700 python tests/tools/fuzz_search.py 200 7003 2>&1 | tail -1; timeout 300 python tests/tools/anchor_check.py 150 7004 2>&1 | tail -1) > $ev/${tag}_fuzz.txt 2>&1
+# (every leg prints its exit code: a campaign must also END -- round 6's first final campaign aborted inside glibc and
+#  `| tail -1` showed only the line of `timeout`)
+leg() { "$@" 2>&1 | grep -v amdgpu.ids | tail -2; echo "exit ${PIPESTATUS[0]}"; }
+(echo "# tests/tools/fuzz.py 300; FUZZ_BIG=1 fuzz.py 300; fuzz_search.py 200; anchor_check.py 150"
+ leg timeout 500 python tests/tools/fuzz.py 300 7001
+ FUZZ_BIG=1 leg timeout 500 python tests/tools/fuzz.py 300 7002
+ leg timeout 900 python tests/tools/fuzz_search.py 200 7003
+ leg timeout 300 python tests/tools/anchor_check.py 150 7004) > $ev/${tag}_fuzz.txt 2>&1
 # keep the summaries only
 rm -rf $ev/prof_* $ev/pmc_runs $ev/pmc_lines $ev/pmc_words $ev/pmc_dup_blocks $ev/pmc_mixed $ev/pmc_source $ev/pmc_real $ev/pmcreq_words $ev/pmc_search
 # the counter files describe these sources?
